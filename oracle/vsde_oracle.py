@@ -1,0 +1,269 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy/ctypes front end of the CPU oracle.
+
+The arithmetic lives in ``vsde_oracle_impl.h`` (plain C, each function cites the
+reference lines it restates).  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; the shipped package
+(``viforsdes_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity pin: ``tests/test_oracle_golden.py`` checks every function here against the
+golden vectors in ``tests/golden/`` that were produced by importing the reference
+itself (``tests/golden/make_golden.py``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvsde_oracle.so")
+DIAG_MIN = 1e-2  # reference: inference/constants.py:6
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (``make -C oracle``)."""
+    src_newer = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("vsde_oracle.c", "vsde_oracle_impl.h")
+    )
+    if force or src_newer:
+        subprocess.run(["make", "-C", _HERE, "-B", "libvsde_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+class HeadWeights(NamedTuple):
+    """nn.GRU-native layout, as passed to ``_SDEFunction.apply`` (kernels/autograd.py:46-56)."""
+
+    W_ih_l0: np.ndarray    # [3H, S+C+P]
+    W_hh_l0: np.ndarray    # [3H, H]
+    b_ih_l0: np.ndarray    # [3H]
+    b_hh_l0: np.ndarray    # [3H]
+    W_ih_stack: np.ndarray  # [L-1, 3H, H]
+    W_hh_stack: np.ndarray  # [L-1, 3H, H]
+    b_ih_stack: np.ndarray  # [L-1, 3H]
+    b_hh_stack: np.ndarray  # [L-1, 3H]
+    out_weight: np.ndarray  # [S+ntril, H]
+    out_bias: np.ndarray    # [S+ntril]
+
+
+def _dt(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "_f32", ctypes.c_float
+    if dtype == np.float64:
+        return "_f64", ctypes.c_double
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _dims(x0, ctx, theta, w: HeadWeights):
+    B, S = x0.shape
+    T, C = ctx.shape[1], ctx.shape[2]
+    P = theta.shape[1]
+    H = w.W_hh_l0.shape[1]
+    L = 1 + (w.W_ih_stack.shape[0] if w.W_ih_stack.size else 0)
+    assert w.W_ih_l0.shape == (3 * H, S + C + P), (w.W_ih_l0.shape, (3 * H, S + C + P))
+    return B, T, S, P, C, H, L
+
+
+def _ctx_arg(ctx: np.ndarray, dtype):
+    """Accept the strided ``context[:, :-1]`` view without copying when possible."""
+    item = np.dtype(dtype).itemsize
+    if ctx.dtype == dtype and ctx.strides[2] == item and ctx.strides[1] == ctx.shape[2] * item \
+            and ctx.strides[0] % item == 0:
+        return ctx, ctx.strides[0] // item
+    c = _c(ctx, dtype)
+    return c, c.shape[1] * c.shape[2]
+
+
+def _wargs(w: HeadWeights, dtype):
+    return [_c(a, dtype) for a in w]
+
+
+class FwdResult(NamedTuple):
+    paths: np.ndarray       # [B, T+1, S]
+    means: np.ndarray       # [B, T, S]
+    chol: np.ndarray        # [B, T, S, S]
+    chol_raw: Optional[np.ndarray]  # [B, T, ntril]
+    acts: Optional[np.ndarray]      # [B, T, L, 5, H]  (h, r, u, n, c_n)
+
+
+def head_forward(x0, ctx, theta, eps, w: HeadWeights, dt: float, save: bool = True,
+                 dtype=np.float32, diag_min: float = DIAG_MIN) -> FwdResult:
+    """launch_fwd restated (kernels/forward.py:378-563)."""
+    sfx, _ = _dt(dtype)
+    x0 = _c(x0, dtype); theta = _c(theta, dtype); eps = _c(eps, dtype)
+    ctx, bstride = _ctx_arg(np.asarray(ctx), dtype)
+    B, T, S, P, C, H, L = _dims(x0, ctx, theta, w)
+    ntril = S * (S + 1) // 2
+    ws = _wargs(w, dtype)
+    paths = np.empty((B, T + 1, S), dtype)
+    means = np.empty((B, T, S), dtype)
+    chol = np.empty((B, T, S, S), dtype)
+    chol_raw = np.empty((B, T, ntril), dtype) if save else None
+    acts = np.empty((B, T, L, 5, H), dtype) if save else None
+    fn = getattr(lib(), "vsde_oracle_fwd" + sfx)
+    fn.restype = None
+    fn(*(ctypes.c_int(v) for v in (B, T, S, P, C, H, L)),
+       _p(x0), _p(ctx), ctypes.c_long(bstride), _p(theta), _p(eps),
+       *(_p(a) for a in ws), ctypes.c_double(dt), ctypes.c_double(diag_min),
+       _p(paths), _p(means), _p(chol), _p(chol_raw), _p(acts))
+    return FwdResult(paths, means, chol, chol_raw, acts)
+
+
+class BwdResult(NamedTuple):
+    """Same order as launch_bwd's 13-tuple (kernels/backward.py:766-784)."""
+
+    x0: np.ndarray
+    context: np.ndarray
+    sde_parameters: np.ndarray
+    W_ih_l0: np.ndarray
+    W_hh_l0: np.ndarray
+    b_ih_l0: np.ndarray
+    b_hh_l0: np.ndarray
+    W_ih_stack: np.ndarray
+    W_hh_stack: np.ndarray
+    b_ih_stack: np.ndarray
+    b_hh_stack: np.ndarray
+    out_weight: np.ndarray
+    out_bias: np.ndarray
+
+
+def head_backward(g_paths, g_means, g_chol, ctx, theta, eps, fwd: FwdResult, w: HeadWeights,
+                  dt: float, dtype=np.float32, diag_min: float = DIAG_MIN) -> BwdResult:
+    """launch_bwd restated (kernels/backward.py:627-784)."""
+    sfx, _ = _dt(dtype)
+    theta = _c(theta, dtype); eps = _c(eps, dtype)
+    ctx, bstride = _ctx_arg(np.asarray(ctx), dtype)
+    B, T, C = ctx.shape
+    S = fwd.paths.shape[2]
+    P = theta.shape[1]
+    H = w.W_hh_l0.shape[1]
+    L = fwd.acts.shape[2]
+    ntril = S * (S + 1) // 2
+    ws = _wargs(w, dtype)
+    g = BwdResult(
+        np.empty((B, S), dtype), np.empty((B, T, C), dtype), np.empty((B, P), dtype),
+        np.empty((3 * H, S + C + P), dtype), np.empty((3 * H, H), dtype),
+        np.empty((3 * H,), dtype), np.empty((3 * H,), dtype),
+        np.zeros((L - 1, 3 * H, H), dtype), np.zeros((L - 1, 3 * H, H), dtype),
+        np.zeros((L - 1, 3 * H), dtype), np.zeros((L - 1, 3 * H), dtype),
+        np.empty((S + ntril, H), dtype), np.empty((S + ntril,), dtype))
+    fn = getattr(lib(), "vsde_oracle_bwd" + sfx)
+    fn.restype = None
+    fn(*(ctypes.c_int(v) for v in (B, T, S, P, C, H, L)),
+       _p(_c(g_paths, dtype)), _p(_c(g_means, dtype)), _p(_c(g_chol, dtype)),
+       _p(ctx), ctypes.c_long(bstride), _p(theta), _p(eps),
+       _p(_c(fwd.paths, dtype)), _p(_c(fwd.chol_raw, dtype)), _p(_c(fwd.acts, dtype)),
+       _p(ws[0]), _p(ws[1]), _p(ws[4]), _p(ws[5]), _p(ws[8]),
+       ctypes.c_double(dt), ctypes.c_double(diag_min),
+       *(_p(a) for a in g))
+    return g
+
+
+def _mask(pos_dims, n):
+    m = np.zeros((n,), np.uint8)
+    for d in pos_dims or []:
+        m[d] = 1
+    return m
+
+
+def to_state(z, positive_dims, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    z = _c(z, dtype)
+    S = z.shape[-1]
+    x = np.empty_like(z)
+    fn = getattr(lib(), "vsde_oracle_to_state" + sfx); fn.restype = None
+    fn(ctypes.c_long(z.size // S), ctypes.c_int(S), _p(z), _p(_mask(positive_dims, S)), _p(x))
+    return x
+
+
+def to_latent(x, positive_dims, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    x = _c(x, dtype)
+    S = x.shape[-1]
+    z = np.empty_like(x)
+    fn = getattr(lib(), "vsde_oracle_to_latent" + sfx); fn.restype = None
+    fn(ctypes.c_long(x.size // S), ctypes.c_int(S), _p(x), _p(_mask(positive_dims, S)), _p(z))
+    return z
+
+
+def elbo_path_terms(z, x, means, chol, drift, diffusion, positive_dims, dt, dtype=np.float32):
+    """(sde_log_prob[B], gen_log_prob[B], log_jacobian[B]) -- evidence_lower_bound.py:42-50."""
+    sfx, _ = _dt(dtype)
+    z = _c(z, dtype); x = _c(x, dtype); means = _c(means, dtype); chol = _c(chol, dtype)
+    drift = _c(drift, dtype); diffusion = _c(diffusion, dtype)
+    B, T1, S = z.shape
+    T = T1 - 1
+    assert S <= 64
+    out = [np.empty((B,), dtype) for _ in range(3)]
+    fn = getattr(lib(), "vsde_oracle_elbo_path_terms" + sfx); fn.restype = None
+    fn(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S), _p(z), _p(x), _p(means), _p(chol),
+       _p(drift), _p(diffusion), _p(_mask(positive_dims, S)), ctypes.c_double(dt), *(_p(o) for o in out))
+    return tuple(out)
+
+
+def elbo_path_terms_bwd(z, x, means, chol, drift, diffusion, positive_dims, dt,
+                        g_sde, g_gen, g_jac, dtype=np.float32):
+    """Gradients (z, x, means, chol, drift, diffusion) of the three path terms."""
+    sfx, _ = _dt(dtype)
+    z = _c(z, dtype); x = _c(x, dtype); means = _c(means, dtype); chol = _c(chol, dtype)
+    drift = _c(drift, dtype); diffusion = _c(diffusion, dtype)
+    B, T1, S = z.shape
+    T = T1 - 1
+    outs = [np.zeros_like(z), np.zeros_like(x), np.zeros_like(means), np.zeros_like(chol),
+            np.zeros_like(drift), np.zeros_like(diffusion)]
+    fn = getattr(lib(), "vsde_oracle_elbo_path_terms_bwd" + sfx); fn.restype = None
+    fn(ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S), _p(z), _p(x), _p(means), _p(chol),
+       _p(drift), _p(diffusion), _p(_mask(positive_dims, S)), ctypes.c_double(dt),
+       _p(_c(g_sde, dtype)), _p(_c(g_gen, dtype)), _p(_c(g_jac, dtype)), *(_p(o) for o in outs))
+    return tuple(outs)
+
+
+def obs_log_prob(x, obs_idx, obs_values, variance, obs_matrix=None, dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    x = _c(x, dtype); obs_values = _c(obs_values, dtype)
+    obs_idx = np.ascontiguousarray(obs_idx, dtype=np.int64)
+    B, T1, S = x.shape
+    n_obs, obs_dim = obs_values.shape
+    om = None if obs_matrix is None else _c(obs_matrix, dtype)
+    out = np.empty((B,), dtype)
+    fn = getattr(lib(), "vsde_oracle_obs_log_prob" + sfx); fn.restype = None
+    fn(ctypes.c_int(B), ctypes.c_int(T1 - 1), ctypes.c_int(S), ctypes.c_int(n_obs), ctypes.c_int(obs_dim),
+       _p(x), _p(obs_idx), _p(obs_values), _p(om), ctypes.c_double(variance), _p(out))
+    return out
+
+
+def theta_log_probs(theta, q_mean, q_log_std, positive_dims, prior_is_lognormal, prior_mean, prior_std,
+                    dtype=np.float32):
+    sfx, _ = _dt(dtype)
+    theta = _c(theta, dtype)
+    B, P = theta.shape
+    prior_lp = np.empty((B,), dtype); post_lp = np.empty((B,), dtype)
+    fn = getattr(lib(), "vsde_oracle_theta_log_probs" + sfx); fn.restype = None
+    fn(ctypes.c_int(B), ctypes.c_int(P), _p(theta), _p(_c(q_mean, dtype)), _p(_c(q_log_std, dtype)),
+       _p(_mask(positive_dims, P)), ctypes.c_int(int(bool(prior_is_lognormal))),
+       ctypes.c_double(prior_mean), ctypes.c_double(prior_std), _p(prior_lp), _p(post_lp))
+    return prior_lp, post_lp

@@ -1,0 +1,395 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference lives read-only at /root/reference and
+never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is recorded (inputs and expected outputs only -- no reference source text):
+
+* head_*.npz      fused-head forward/backward cases.  Expected values come from the
+                  reference's own eager single-step definition
+                  ``DiffusionTransitionHead.forward`` (models/head.py:68-97) looped over
+                  time with the Euler-Maruyama update of kernels/forward.py:365, and its
+                  autograd (this is oracle "O1" of SURVEY.md section 8c).  For the tiny cases the
+                  reference's Triton kernels themselves are also run under
+                  TRITON_INTERPRET=1 ("O2") and stored next to O1.
+* elbo_*.npz      ``compute_evidence_lower_bound`` (inference/evidence_lower_bound.py:19-74)
+                  with the example OU / Lotka-Volterra SDEs: per-sample terms, components,
+                  scalar and autograd gradients.
+* encoder_tiny.npz  ``ObservationContextEncoder`` forward + gradients for a tiny config.
+* state_dict_manifest.json  key -> [shape, dtype] of ``VariationalSDEPosterior.state_dict()``.
+* trajectory_tiny.npz  a K-step ``VariationalInferenceTrainer`` run on CPU with the head's
+                  kernel call replaced by O1 and every ``torch.randn`` draw recorded.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import typing
+
+import numpy as np
+import typing_extensions
+
+typing.Self = typing_extensions.Self  # reference needs py>=3.11 (config.py:5)
+os.environ.setdefault("TRITON_INTERPRET", "1")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/src")
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from variational_sde.config import EncoderConfig, HeadConfig, TrainingConfig  # noqa: E402
+from variational_sde.core.observations import GaussianObservationLikelihood, Observations  # noqa: E402
+from variational_sde.core.priors import Prior, PriorType  # noqa: E402
+from variational_sde.inference.evidence_lower_bound import compute_evidence_lower_bound  # noqa: E402
+from variational_sde.inference.state_space import StateSpace  # noqa: E402
+from variational_sde.inference.types import DiffusionPathSample  # noqa: E402
+from variational_sde.models.head import DiffusionTransitionHead  # noqa: E402
+from variational_sde.models.encoder import ObservationContextEncoder  # noqa: E402
+from variational_sde.models.sde_parameter_posterior import SDEParameterPosterior  # noqa: E402
+from variational_sde.models.variational_sde_posterior import VariationalSDEPosterior  # noqa: E402
+
+
+def o1(head, z0, ctx, theta, eps, dt):
+    """Loop the reference's eager step (head.py:68-86) with the update of forward.py:365."""
+    h = head.init_hidden(z0.shape[0], z0.device, z0.dtype)
+    z, P, M, Ls = z0, [z0], [], []
+    for t in range(ctx.shape[1]):
+        mu, L, h = head(z, ctx[:, t], theta, h)
+        z = z + mu * dt + torch.einsum("bij,bj->bi", L, eps[:, t]) * dt ** 0.5
+        P.append(z); M.append(mu); Ls.append(L)
+    return torch.stack(P, 1), torch.stack(M, 1), torch.stack(Ls, 1)
+
+
+def head_weights(head):
+    ws = head._extract_gru_weights()
+    return list(ws) + [head.out_proj.weight, head.out_proj.bias]
+
+
+W_NAMES = ["W_ih_l0", "W_hh_l0", "b_ih_l0", "b_hh_l0", "W_ih_stack", "W_hh_stack",
+           "b_ih_stack", "b_hh_stack", "out_weight", "out_bias"]
+G_NAMES = ["x0", "context", "sde_parameters"] + W_NAMES
+
+
+def make_head_case(name, B, T, S, C, P, H, L, seed, with_o2, with_f64=True, clamp_stress=False):
+    g = torch.Generator().manual_seed(seed)
+    head = DiffusionTransitionHead(S, C, P, HeadConfig(hidden_dim=H, num_layers=L))
+    with torch.no_grad():
+        for p in head.gru.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.35)
+        head.out_proj.weight.copy_(torch.randn(head.out_proj.weight.shape, generator=g) * 0.3)
+        bias = torch.randn(head.out_proj.bias.shape, generator=g) * 0.1
+        for k in range(S):
+            # default init puts 1.0 on the diagonal entries (head.py:60-66); the stress case
+            # straddles DIAG_MIN=0.01 so that both branches of the clamp gradient rule fire.
+            bias[S + k * (k + 3) // 2] += 0.02 if clamp_stress else 0.6
+        head.out_proj.bias.copy_(bias)
+    dt = 0.05
+    x0 = torch.randn(B, S, generator=g)
+    ctx_full = torch.randn(B, T + 1, C, generator=g)
+    theta = torch.randn(B, P, generator=g).abs() + 0.1
+    eps = torch.randn(B, T, S, generator=g)
+    gp = torch.randn(B, T + 1, S, generator=g)
+    gm = torch.randn(B, T, S, generator=g)
+    gl = torch.randn(B, T, S, S, generator=g)
+
+    rec = {"dims": np.array([B, T, S, C, P, H, L]), "dt": np.array(dt), "x0": x0.numpy(),
+           "context_full": ctx_full.numpy(), "sde_parameters": theta.numpy(), "eps": eps.numpy(),
+           "g_paths": gp.numpy(), "g_means": gm.numpy(), "g_chol": gl.numpy()}
+    for n, w in zip(W_NAMES, head_weights(head)):
+        rec["w_" + n] = w.detach().numpy().copy()
+
+    def run(dtype, tag):
+        hd = head.double() if dtype == torch.float64 else head.float()
+        ins = [t.to(dtype).clone().requires_grad_(True) for t in (x0, ctx_full, theta)]
+        ws = head_weights(hd)
+        paths, means, chol = o1(hd, ins[0], ins[1][:, :-1], ins[2], eps.to(dtype), dt)
+        rec[f"{tag}_paths"] = paths.detach().numpy().copy()
+        rec[f"{tag}_means"] = means.detach().numpy().copy()
+        rec[f"{tag}_chol"] = chol.detach().numpy().copy()
+        loss = (paths * gp.to(dtype)).sum() + (means * gm.to(dtype)).sum() + (chol * gl.to(dtype)).sum()
+        params = [hd.gru.weight_ih_l0, hd.gru.weight_hh_l0, hd.gru.bias_ih_l0, hd.gru.bias_hh_l0]
+        stacks = [[getattr(hd.gru, f"{k}_l{l}") for l in range(1, L)]
+                  for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        flat = params + [p for st in stacks for p in st] + [hd.out_proj.weight, hd.out_proj.bias]
+        grads = torch.autograd.grad(loss, ins + flat)
+        gx0, gctx, gth = grads[:3]
+        rec[f"{tag}_grad_x0"] = gx0.numpy().copy()
+        rec[f"{tag}_grad_context"] = gctx[:, :-1].numpy().copy()  # grad wrt context[:, :-1]
+        rec[f"{tag}_grad_sde_parameters"] = gth.numpy().copy()
+        gi = 3
+        for n in W_NAMES[:4]:
+            rec[f"{tag}_grad_{n}"] = grads[gi].numpy().copy(); gi += 1
+        for n in W_NAMES[4:8]:
+            if L > 1:
+                rec[f"{tag}_grad_{n}"] = torch.stack(list(grads[gi:gi + L - 1])).numpy().copy()
+            else:
+                rec[f"{tag}_grad_{n}"] = np.zeros((0,) + tuple(ws[W_NAMES.index(n)].shape[1:]))
+            gi += L - 1
+        rec[f"{tag}_grad_out_weight"] = grads[gi].numpy().copy()
+        rec[f"{tag}_grad_out_bias"] = grads[gi + 1].numpy().copy()
+
+    run(torch.float32, "o1f32")
+    if with_f64:
+        run(torch.float64, "o1f64")
+    head.float()
+
+    if with_o2:
+        # The reference's Triton kernels under the interpreter.
+        import triton.language as tl
+        from triton.language.extra import libdevice
+        libdevice.tanh = lambda x: 1.0 - 2.0 / (tl.exp(2.0 * x) + 1.0)
+        import variational_sde.kernels.forward as kf
+        kf.libdevice = libdevice
+        head.train()
+        ins = [t.clone().requires_grad_(True) for t in (x0, ctx_full, theta)]
+        paths, means, chol = head.sample_diffusion_paths(ins[0], ins[1][:, :-1], ins[2], eps, dt)
+        rec["o2_paths"] = paths.detach().numpy().copy()
+        rec["o2_means"] = means.detach().numpy().copy()
+        rec["o2_chol"] = chol.detach().numpy().copy()
+        loss = (paths * gp).sum() + (means * gm).sum() + (chol * gl).sum()
+        flat = [head.gru.weight_ih_l0, head.gru.weight_hh_l0, head.gru.bias_ih_l0, head.gru.bias_hh_l0,
+                head.out_proj.weight, head.out_proj.bias]
+        grads = torch.autograd.grad(loss, ins + flat)
+        rec["o2_grad_x0"] = grads[0].numpy().copy()
+        rec["o2_grad_context"] = grads[1][:, :-1].numpy().copy()
+        rec["o2_grad_sde_parameters"] = grads[2].numpy().copy()
+        rec["o2_grad_W_ih_l0"] = grads[3].numpy().copy()
+        rec["o2_grad_W_hh_l0"] = grads[4].numpy().copy()
+        rec["o2_grad_b_ih_l0"] = grads[5].numpy().copy()
+        rec["o2_grad_b_hh_l0"] = grads[6].numpy().copy()
+        rec["o2_grad_out_weight"] = grads[7].numpy().copy()
+        rec["o2_grad_out_bias"] = grads[8].numpy().copy()
+        d = max(float(np.abs(rec["o2_" + k] - rec["o1f32_" + k]).max()) for k in
+                ("paths", "means", "chol", "grad_x0", "grad_context", "grad_W_ih_l0", "grad_out_weight"))
+        print(f"  {name}: max |O2 - O1| = {d:.3e}")
+    np.savez_compressed(os.path.join(OUT, f"head_{name}.npz"), **rec)
+    print("wrote", f"head_{name}.npz")
+
+
+# ----------------------------------------------------------------------------- ELBO
+def example_sdes():
+    from examples.ornstein_uhlenbeck import OrnsteinUhlenbeck
+    from examples.lotka_volterra import LotkaVolterra
+    return OrnsteinUhlenbeck(), LotkaVolterra()
+
+
+def make_elbo_case(name, sde, obs_times, obs_values, var, prior, state_pos, theta_pos, B, T, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    S, P = sde.state_dim, sde.sde_param_dim
+    space = StateSpace(S, state_pos)
+    post = SDEParameterPosterior(P, theta_pos)
+    with torch.no_grad():
+        post.mean.copy_(torch.randn(P, generator=g) * 0.3)
+        post.log_std.copy_(torch.randn(P, generator=g) * 0.2 - 0.5)
+    eps_theta = torch.randn(B, P, generator=g)
+    std = post.log_std.exp()
+    theta = post.mean + std * eps_theta
+    theta = torch.where(post.positive_mask, theta.exp(), theta).detach().requires_grad_(True)
+    observations = Observations(times=torch.tensor(obs_times), values=torch.tensor(obs_values))
+    x0 = observations.values[0].expand(B, -1)
+    z0 = space.to_latent(x0)
+    # a plausible random path in latent space + random transition params
+    incr = torch.randn(B, T, S, generator=g) * (dt ** 0.5) * 0.8
+    z = torch.cat([z0[:, None], z0[:, None] + incr.cumsum(1)], 1).detach().requires_grad_(True)
+    means = (torch.randn(B, T, S, generator=g) * 0.5).requires_grad_(True)
+    Lm = torch.randn(B, T, S, S, generator=g) * 0.3
+    Lm = torch.tril(Lm, -1) + torch.diag_embed(torch.rand(B, T, S, generator=g) + 0.3)
+    chol = Lm.detach().requires_grad_(True)
+    like = GaussianObservationLikelihood(variance=var)
+    sample = DiffusionPathSample(z=z, transition_means=means, transition_cholesky=chol, state_space=space)
+
+    # per-sample terms, recomputed exactly as evidence_lower_bound.py:29-61 does
+    res = compute_evidence_lower_bound(sde, observations, like, prior, post, theta, sample, dt)
+    grads = torch.autograd.grad(res.evidence_lower_bound, [z, means, chol, theta, post.mean, post.log_std])
+    from variational_sde.inference.evidence_lower_bound import _gaussian_log_prob
+    from einops import rearrange, repeat
+    with torch.no_grad():
+        x = sample.x
+        xt = rearrange(x[:, :-1], "b t d -> (b t) d")
+        th = repeat(theta, "b d -> (b t) d", t=T)
+        drift = rearrange(sde.drift(xt, th), "(b t) d -> b t d", b=B)
+        diff = rearrange(sde.diffusion(xt, th), "(b t) d e -> b t d e", b=B)
+        sde_lp = _gaussian_log_prob(x[:, 1:], x[:, :-1] + drift * dt, diff * dt ** 0.5)
+        gen_lp = _gaussian_log_prob(z[:, 1:], z[:, :-1] + means * dt, chol * dt ** 0.5)
+        jac = sample.log_jacobian()
+        idx = torch.clamp(torch.round(observations.times / dt).long(), max=T)
+        obs_lp = like.log_prob(repeat(observations.values, "t d -> b t d", b=B), x[:, idx]).sum(-1)
+        prior_lp = prior.log_prob(theta)
+        post_lp = post.log_prob(theta)
+    c = res.components
+    rec = dict(
+        dims=np.array([B, T, S, P]), dt=np.array(dt), variance=np.array(var),
+        state_positive_dims=np.array(state_pos, dtype=np.int64), theta_positive_dims=np.array(theta_pos, dtype=np.int64),
+        prior_type=np.array(1 if prior.type == PriorType.LOG_NORMAL else 0), prior_mean=np.array(prior.mean),
+        prior_std=np.array(prior.std), obs_times=np.array(obs_times, dtype=np.float32),
+        obs_values=np.array(obs_values, dtype=np.float32), obs_idx=idx,
+        q_mean=post.mean, q_log_std=post.log_std, eps_theta=eps_theta,
+        theta=theta, z=z, x=x, z0=z0, x0=x0,
+        means=means, chol=chol, drift=drift, diffusion=diff,
+        sde_lp=sde_lp, gen_lp=gen_lp, jac=jac, obs_lp=obs_lp,
+        prior_lp=prior_lp, post_lp=post_lp, elbo=res.evidence_lower_bound,
+        comp_obs=c.observation_log_prob, comp_sde=c.sde_log_prob,
+        comp_gen=c.generative_log_prob, comp_prior=c.prior_log_prob,
+        comp_post=c.posterior_log_prob, expected_value=post.expected_value,
+        grad_z=grads[0], grad_means=grads[1], grad_chol=grads[2],
+        grad_theta=grads[3], grad_q_mean=grads[4], grad_q_log_std=grads[5])
+    rec = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in rec.items()}
+    np.savez_compressed(os.path.join(OUT, f"elbo_{name}.npz"), **rec)
+    print("wrote", f"elbo_{name}.npz", "elbo =", float(res.evidence_lower_bound))
+
+
+# -------------------------------------------------------------------------- encoder
+def randomize_(module, gen, scale=0.05):
+    """Give zero-initialised modulators/gates non-trivial values so the test sees them."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if not p.requires_grad:
+                continue
+            if p.abs().sum() == 0 or "v_residual_lambda" in n:
+                p.add_(torch.randn(p.shape, generator=gen) * scale)
+
+
+def make_encoder_case():
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    cfg = EncoderConfig(hidden_dim=32, cond_dim=16, num_heads=4, depth=3, mlp_ratio=8 / 3)
+    enc = ObservationContextEncoder(observation_dim=2, sde_param_dim=3, config=cfg)
+    randomize_(enc, g, 0.2)
+    obs_t = torch.tensor([0.0, 0.5, 1.0, 1.5])
+    obs_v = torch.randn(4, 2, generator=g)
+    theta = (torch.randn(5, 3, generator=g).abs() + 0.2).requires_grad_(True)
+    ctx = enc(obs_v, obs_t, theta, 1.5, 0.1)
+    gout = torch.randn(ctx.shape, generator=g)
+    names = [n for n, p in enc.named_parameters() if p.requires_grad]
+    params = [p for n, p in enc.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad((ctx * gout).sum(), [theta] + params)
+    rec = {"obs_times": obs_t.numpy(), "obs_values": obs_v.numpy(), "theta": theta.detach().numpy(),
+           "time_horizon": np.array(1.5), "time_step": np.array(0.1), "context": ctx.detach().numpy(),
+           "g_context": gout.numpy(), "grad_theta": grads[0].numpy(),
+           "cfg": np.array([cfg.hidden_dim, cfg.cond_dim, cfg.num_heads, cfg.depth])}
+    for k, v in enc.state_dict().items():
+        rec["sd::" + k] = torch.view_as_real(v).numpy() if v.is_complex() else v.numpy()
+    for n, gr in zip(names, grads[1:]):
+        rec["grad::" + n] = gr.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder_tiny.npz"), **rec)
+    print("wrote encoder_tiny.npz", tuple(ctx.shape))
+
+
+def make_manifest():
+    out = {}
+    for depth in (2, 8):
+        m = VariationalSDEPosterior(2, 2, 3, EncoderConfig(hidden_dim=256, num_heads=4, depth=depth),
+                                    HeadConfig(hidden_dim=64, num_layers=2), [0, 1, 2])
+        out[f"lv_depth{depth}"] = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        out[f"lv_depth{depth}_params"] = [n for n, _ in m.named_parameters()]
+    m = VariationalSDEPosterior(1, 1, 3, EncoderConfig(), HeadConfig(hidden_dim=32, num_layers=3), [0, 2])
+    out["ou_default_l3"] = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote state_dict_manifest.json")
+
+
+# ----------------------------------------------------------------------- trajectory
+def make_trajectory():
+    """K optimizer steps of the reference trainer on CPU (mixed precision off, compile off)
+    with the Triton call replaced by O1 and every torch.randn draw recorded in order."""
+    from variational_sde.inference.trainer import VariationalInferenceTrainer
+    from variational_sde.console import Console
+    _, lv = example_sdes()
+    K, B, dt, horizon = 12, 6, 0.1, 1.0
+    obs = Observations(times=torch.tensor([0.0, 0.5, 1.0]),
+                       values=torch.tensor([[1.2, 0.7], [0.9, 1.1], [0.6, 1.4]]))
+    prior = Prior(type=PriorType.LOG_NORMAL, mean=0.0, std=1.5, dim=3)
+
+    def patched(self, x0, context, sde_parameters, standard_noise, time_step):
+        return o1(self, x0, context, sde_parameters, standard_noise, time_step)
+
+    DiffusionTransitionHead.sample_diffusion_paths = patched
+    torch.manual_seed(2024)
+    tr = VariationalInferenceTrainer(
+        sde=lv, observations=obs, observation_likelihood=GaussianObservationLikelihood(variance=0.25),
+        prior=prior, time_horizon=horizon,
+        config=TrainingConfig(time_step=dt, batch_size=B, n_iterations=K, learning_rate=1e-3, sde_param_lr=1e-2),
+        encoder_config=EncoderConfig(hidden_dim=32, cond_dim=16, num_heads=4, depth=2),
+        head_config=HeadConfig(hidden_dim=16, num_layers=2),
+        state_positive_dims=[0, 1], sde_param_positive_dims=[0, 1, 2], device="cpu",
+        mixed_precision=False, console=Console(enabled=False), accelerator=None)
+    model = tr.ctx.model
+    g = torch.Generator().manual_seed(5)
+    randomize_(model.encoder, g, 0.1)
+    with torch.no_grad():
+        model.head.out_proj.weight.add_(torch.randn(model.head.out_proj.weight.shape, generator=g) * 0.2)
+    tr.ctx.ema._init_shadow()
+    rec = {}
+    for k, v in model.state_dict().items():
+        rec["init::" + k] = torch.view_as_real(v).numpy().copy() if v.is_complex() else v.numpy().copy()
+    draws = []
+    real_randn = torch.randn
+
+    def rec_randn(*a, **kw):
+        t = real_randn(*a, **kw)
+        draws.append(t.detach().clone())
+        return t
+
+    torch.randn = rec_randn
+    elbos, comps, gnorms = [], [], []
+    try:
+        model.train()
+        for step in range(K):
+            r = tr._train_step(model)
+            tr.ctx.ema.update()
+            elbos.append(r.elbo_result.evidence_lower_bound.item())
+            c = r.elbo_result.components
+            comps.append([c.observation_log_prob.item(), c.sde_log_prob.item(), c.generative_log_prob.item(),
+                          c.prior_log_prob.item(), c.posterior_log_prob.item()])
+            gnorms.append(r.grad_norm)
+    finally:
+        torch.randn = real_randn
+    assert len(draws) == 2 * K
+    rec["theta_eps"] = torch.stack(draws[0::2]).numpy()
+    rec["path_noise"] = torch.stack(draws[1::2]).numpy()
+    rec["elbo"] = np.array(elbos); rec["components"] = np.array(comps); rec["grad_norm"] = np.array(gnorms)
+    post = model.sde_parameter_posterior
+    rec["final_mean"] = post.mean.detach().numpy().copy()
+    rec["final_log_std"] = post.log_std.detach().numpy().copy()
+    rec["final_expected_value"] = post.expected_value.detach().numpy().copy()
+    rec["ema_mean"] = tr.ctx.ema.shadow["sde_parameter_posterior.mean"].numpy().copy()
+    rec["ema_log_std"] = tr.ctx.ema.shadow["sde_parameter_posterior.log_std"].numpy().copy()
+    rec["final::head.out_proj.bias"] = model.head.out_proj.bias.detach().numpy().copy()
+    rec["final::encoder.bridge_token"] = model.encoder.bridge_token.detach().numpy().copy()
+    rec["cfg"] = np.array([K, B]); rec["dt"] = np.array(dt); rec["horizon"] = np.array(horizon)
+    rec["obs_times"] = obs.times.numpy(); rec["obs_values"] = obs.values.numpy()
+    np.savez_compressed(os.path.join(OUT, "trajectory_tiny.npz"), **rec)
+    print("wrote trajectory_tiny.npz; elbo[0], elbo[-1] =", elbos[0], elbos[-1])
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:]) or {"head", "elbo", "encoder", "manifest", "trajectory"}
+    if "head" in which:
+        make_head_case("tiny_l2", 4, 7, 2, 16, 3, 8, 2, seed=11, with_o2=True)
+        make_head_case("tiny_l1_odd", 3, 5, 3, 10, 2, 12, 1, seed=12, with_o2=True)
+        make_head_case("tiny_l4", 2, 4, 1, 6, 3, 16, 4, seed=13, with_o2=False)
+        make_head_case("s8_h64", 2, 6, 8, 16, 8, 64, 2, seed=14, with_o2=False)
+        make_head_case("clamp", 4, 9, 3, 8, 2, 24, 2, seed=15, with_o2=False, clamp_stress=True)
+        make_head_case("ou_dims", 3, 10, 1, 64, 3, 64, 2, seed=16, with_o2=False)
+        make_head_case("lv_dims", 2, 12, 2, 256, 3, 64, 2, seed=17, with_o2=False, with_f64=False)
+    ou, lv = example_sdes()
+    if "elbo" in which:
+        make_elbo_case("ou", ou, [0.0, 1.0, 2.0, 3.0, 4.0, 5.0], [[2.0], [1.5], [0.8], [1.2], [0.9], [1.1]],
+                       0.1, Prior(type=PriorType.NORMAL, mean=0.0, std=1.0, dim=3), [], [0, 2], 6, 100, 0.05, 21)
+        make_elbo_case("lv", lv, [0.0, 1.0, 2.0, 3.0, 4.0],
+                       [[71.0, 79.0], [47.61225908, 447.20971405], [80.53119269, 50.26254069],
+                        [23.10087379, 339.40432691], [158.05238324, 66.79611979]],
+                       1.0, Prior(type=PriorType.LOG_NORMAL, mean=0.0, std=1.5, dim=3), [0, 1], [0, 1, 2],
+                       5, 40, 0.1, 22)
+    if "encoder" in which:
+        make_encoder_case()
+    if "manifest" in which:
+        make_manifest()
+    if "trajectory" in which:
+        make_trajectory()
