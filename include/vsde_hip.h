@@ -1,0 +1,152 @@
+/*
+ * vsde_hip.h -- C ABI of libvsde_hip.so, the MI355X (gfx950) implementation of the
+ * variational-SDE hot path.  Plain pointers and sizes only; every pointer is a DEVICE
+ * pointer unless stated otherwise; `stream` is a hipStream_t passed as void*.
+ *
+ * Each entry point replaces one interface of the reference (Tom-Ryder/VIforSDEs):
+ *
+ *   vsde_head_forward        launch_fwd + sde_fwd_kernel   src/variational_sde/kernels/forward.py:378-563
+ *                            (called from _SDEFunction.forward, kernels/autograd.py:79-87, and from
+ *                             kernels.autograd.sample_diffusion_paths, autograd.py:244-268)
+ *   vsde_head_backward       launch_bwd + sde_bwd_kernel   src/variational_sde/kernels/backward.py:627-784
+ *                            (called from _SDEFunction.backward, kernels/autograd.py:191-201)
+ *   vsde_elbo_path_terms     the B*T-sized part of compute_evidence_lower_bound
+ *   vsde_elbo_path_terms_bwd   src/variational_sde/inference/evidence_lower_bound.py:42-50,77-83 and
+ *                              DiffusionPathSample.log_jacobian, inference/types.py:23-24
+ *   vsde_elbo_aux_terms      observation / prior / posterior log-densities,
+ *                            evidence_lower_bound.py:52-61 (core/observations.py:52-74,
+ *                            core/priors.py:46-60, models/sde_parameter_posterior.py:48-59)
+ *
+ * Weight tensors use torch.nn.GRU's native layout exactly as they are handed to
+ * _SDEFunction.apply (kernels/autograd.py:46-56): W_ih_l0[3H][S+C+P] with input order
+ * [state | context | theta] (models/head.py:75), W_hh_l0[3H][H], biases [3H], the stacked
+ * layers >=1 as [L-1][3H][H] / [L-1][3H], out_weight[S+ntril][H], out_bias[S+ntril];
+ * gate order r, z(u), n.  Gradients come back in the same layout and the same order as
+ * launch_bwd's 13-tuple (backward.py:766-784).
+ *
+ * Error convention: every function returns 0 on success, a negative VSDE_E_* code for
+ * argument errors (the Python host maps them to ValueError like the reference's own checks,
+ * models/head.py:33-36) or a positive hipError_t.  vsde_last_error() returns a static,
+ * thread-local, human-readable message for the last failure.
+ *
+ * Threading/streams: functions only enqueue work on `stream` (no device synchronisation, no
+ * allocation); all scratch memory is the caller-provided workspace, sized by the matching
+ * *_workspace_bytes query.  Inputs are never written; outputs are fully overwritten.
+ */
+#ifndef VSDE_HIP_H
+#define VSDE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSDE_ABI_VERSION 1
+
+#define VSDE_E_BADARG (-1)   /* shape/pointer/dtype argument invalid                    */
+#define VSDE_E_LAYERS (-2)   /* num_layers outside [1, 4]  (kernels/constants.py:13)    */
+#define VSDE_E_HIDDEN (-3)   /* hidden_dim not supported by the compiled kernels        */
+#define VSDE_E_WORKSPACE (-4) /* workspace too small                                    */
+#define VSDE_E_STATE (-5)    /* state_dim not supported by the compiled kernels         */
+
+#define VSDE_MAX_LAYERS 4
+#define VSDE_MAX_HIDDEN 64   /* one wavefront per sample path: lane j owns hidden unit j */
+#define VSDE_MAX_STATE 10    /* S + S(S+1)/2 emission rows must fit one wavefront (<=64 lanes +1) */
+
+#define VSDE_CTX_F32 0
+#define VSDE_CTX_BF16 1
+
+int vsde_abi_version(void);
+const char *vsde_last_error(void);
+
+/* Problem dimensions shared by the head entry points (names as in SURVEY.md section 8). */
+typedef struct vsde_head_dims {
+    int B; /* Monte-Carlo sample paths in this launch          */
+    int T; /* Euler-Maruyama steps (= context.shape[1])        */
+    int S; /* state_dim                                        */
+    int P; /* sde_param_dim                                    */
+    int C; /* context_dim (= encoder hidden_dim)               */
+    int H; /* GRU hidden_dim                                   */
+    int L; /* GRU num_layers                                   */
+} vsde_head_dims;
+
+/* The ten weight tensors of the head (device pointers, fp32, contiguous). */
+typedef struct vsde_head_weights {
+    const float *W_ih_l0, *W_hh_l0, *b_ih_l0, *b_hh_l0;
+    const float *W_ih_stack, *W_hh_stack, *b_ih_stack, *b_hh_stack; /* may be NULL when L == 1 */
+    const float *out_weight, *out_bias;
+} vsde_head_weights;
+
+/* Strided view of the encoder context: element (b, t, c) lives at
+ * base + (b*batch_stride + t*step_stride + c) * sizeof(elem).  This lets the caller pass the
+ * reference's non-contiguous context[:, :-1] slice (inference/diffusion_path_sampler.py:61)
+ * and the autocast bf16 context without the .contiguous().float() copies of forward.py:495. */
+typedef struct vsde_context_view {
+    const void *base;
+    int dtype; /* VSDE_CTX_F32 or VSDE_CTX_BF16 */
+    int64_t batch_stride;
+    int64_t step_stride;
+} vsde_context_view;
+
+size_t vsde_head_forward_workspace_bytes(const vsde_head_dims *d);
+
+/* Fused multi-layer-GRU + Gaussian emission + Euler-Maruyama time stepping.
+ *   x0[B][S], theta[B][P], eps[B][T][S]
+ *   paths[B][T+1][S], means[B][T][S], chol[B][T][S][S] (strict upper triangle written as 0)
+ * Training mode (save != 0) additionally fills what the backward needs
+ * (kernels/weights.py:11-23 SavedActivations), packed as
+ *   chol_raw[B][T][ntril]  and  acts[B][T][L][5][H] with slots (h, r, z, n, n_hh). */
+int vsde_head_forward(const vsde_head_dims *d, const float *x0, const vsde_context_view *ctx,
+                      const float *theta, const float *eps, const vsde_head_weights *w,
+                      double time_step, double diag_min, int save,
+                      float *paths, float *means, float *chol, float *chol_raw, float *acts,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* The 13 gradient outputs of launch_bwd, same order (backward.py:766-784). */
+typedef struct vsde_head_grads {
+    float *x0;          /* [B][S]        */
+    float *context;     /* [B][T][C]     */
+    float *theta;       /* [B][P]        */
+    float *W_ih_l0, *W_hh_l0, *b_ih_l0, *b_hh_l0;
+    float *W_ih_stack, *W_hh_stack, *b_ih_stack, *b_hh_stack; /* unused when L == 1 */
+    float *out_weight, *out_bias;
+} vsde_head_grads;
+
+size_t vsde_head_backward_workspace_bytes(const vsde_head_dims *d);
+
+/* Reverse-time BPTT through the fused head.  g_paths[B][T+1][S], g_means[B][T][S],
+ * g_chol[B][T][S][S] are the upstream gradients; paths/chol_raw/acts are the tensors the
+ * forward saved.  Deterministic: weight gradients are tree-reduced, no atomics
+ * (the reference uses global fp32 atomics, backward.py:108-139,575-590). */
+int vsde_head_backward(const vsde_head_dims *d, const float *g_paths, const float *g_means,
+                       const float *g_chol, const vsde_context_view *ctx, const float *theta,
+                       const float *eps, const float *paths, const float *chol_raw,
+                       const float *acts, const vsde_head_weights *w, double time_step,
+                       double diag_min, const vsde_head_grads *grads, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* Per-sample path terms of the ELBO.  z, x: [B][T+1][S] (x = StateSpace.to_state(z));
+ * means/drift: [B][T][S]; chol/diffusion: [B][T][S][S] lower-triangular factors;
+ * positive_mask: S bytes on the HOST (state_space.positive_dims).
+ * Outputs [B]: sde_lp, gen_lp, log_jac. */
+int vsde_elbo_path_terms(int B, int T, int S, const float *z, const float *x, const float *means,
+                         const float *chol, const float *drift, const float *diffusion,
+                         const uint8_t *positive_mask_host, double time_step,
+                         float *sde_lp, float *gen_lp, float *log_jac, void *stream);
+
+/* Adjoint of vsde_elbo_path_terms for upstream per-sample gradients g_sde/g_gen/g_jac [B].
+ * Outputs are fully overwritten: g_z, g_x [B][T+1][S]; g_means, g_drift [B][T][S];
+ * g_chol, g_diffusion [B][T][S][S]. */
+int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x,
+                             const float *means, const float *chol, const float *drift,
+                             const float *diffusion, const uint8_t *positive_mask_host,
+                             double time_step, const float *g_sde, const float *g_gen,
+                             const float *g_jac, float *g_z, float *g_x, float *g_means,
+                             float *g_chol, float *g_drift, float *g_diffusion, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSDE_HIP_H */

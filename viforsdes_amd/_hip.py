@@ -1,0 +1,253 @@
+"""ctypes binding of libvsde_hip.so (see include/vsde_hip.h for the C ABI).
+
+This is the only place the package touches native code.  There is deliberately NO CPU or
+PyTorch fallback: if the library is missing, or tensors are not on a HIP device, the call
+raises.  Tensors are passed as raw device pointers + the current torch stream handle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import torch
+
+from .build import LIB_PATH
+
+VSDE_ABI_VERSION = 1
+MAX_LAYERS = 4      # reference: kernels/constants.py:13
+MAX_HIDDEN = 64
+MAX_STATE = 9
+DIAG_MIN = 1e-2     # reference: inference/constants.py:6
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class _Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "T", "S", "P", "C", "H", "L")]
+
+
+class _Weights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "W_ih_l0", "W_hh_l0", "b_ih_l0", "b_hh_l0", "W_ih_stack", "W_hh_stack",
+        "b_ih_stack", "b_hh_stack", "out_weight", "out_bias")]
+
+
+class _CtxView(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("dtype", ctypes.c_int),
+                ("batch_stride", ctypes.c_int64), ("step_stride", ctypes.c_int64)]
+
+
+class _Grads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "x0", "context", "theta", "W_ih_l0", "W_hh_l0", "b_ih_l0", "b_hh_l0",
+        "W_ih_stack", "W_hh_stack", "b_ih_stack", "b_hh_stack", "out_weight", "out_bias")]
+
+
+EXPORTS = (
+    "vsde_abi_version", "vsde_last_error",
+    "vsde_head_forward_workspace_bytes", "vsde_head_forward",
+    "vsde_head_backward_workspace_bytes", "vsde_head_backward",
+    "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library_path() -> str:
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (fails loudly if it was never built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m viforsdes_amd.build` "
+            "(there is no CPU fallback for the fused head / ELBO kernels)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}")
+    lib.vsde_abi_version.restype = ctypes.c_int
+    if lib.vsde_abi_version() != VSDE_ABI_VERSION:
+        raise HipLibraryError("libvsde_hip.so ABI version mismatch; rebuild it")
+    lib.vsde_last_error.restype = ctypes.c_char_p
+    lib.vsde_head_forward_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsde_head_backward_workspace_bytes.restype = ctypes.c_size_t
+    for f in (lib.vsde_head_forward, lib.vsde_head_backward, lib.vsde_elbo_path_terms, lib.vsde_elbo_path_terms_bwd):
+        f.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _raise(rc: int) -> None:
+    msg = load().vsde_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(msg)          # argument errors, like the reference's ValueError (models/head.py:33-36)
+    raise HipLibraryError(f"HIP error {rc}: {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(None if t is None or t.numel() == 0 else t.data_ptr())
+
+
+def _require_hip(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipLibraryError(
+                "the fused head / ELBO kernels only run on a HIP (cuda) device; got a "
+                f"{t.device} tensor and there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("all tensors must live on the same device")
+    assert dev is not None
+    return dev
+
+
+def _stream(dev: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def context_view(ctx: torch.Tensor):
+    """Describe a [B, T, C] context (fp32 or bf16, last dim contiguous) without copying."""
+    if ctx.dtype not in (torch.float32, torch.bfloat16):
+        ctx = ctx.float()
+    if ctx.stride(2) != 1:
+        ctx = ctx.contiguous()
+    v = _CtxView(ctypes.c_void_p(ctx.data_ptr()), 1 if ctx.dtype == torch.bfloat16 else 0,
+                 ctx.stride(0), ctx.stride(1))
+    return ctx, v
+
+
+def _weights_struct(ws: Sequence[torch.Tensor]):
+    keep = [_f32c(w) for w in ws]
+    return keep, _Weights(*[_ptr(w) for w in keep])
+
+
+def _dims(x0, ctx, theta, ws) -> _Dims:
+    B, S = x0.shape
+    T, C = ctx.shape[1], ctx.shape[2]
+    P = theta.shape[1]
+    H = ws[1].shape[1]
+    L = 1 + (ws[4].shape[0] if ws[4].numel() > 0 else 0)
+    if tuple(ws[0].shape) != (3 * H, S + C + P):
+        raise ValueError(f"W_ih_l0 has shape {tuple(ws[0].shape)}, expected {(3 * H, S + C + P)}")
+    return _Dims(B, T, S, P, C, H, L)
+
+
+def head_forward(x0, ctx, theta, eps, ws, time_step: float, save: bool, diag_min: float = DIAG_MIN):
+    """-> (paths[B,T+1,S], means[B,T,S], chol[B,T,S,S], chol_raw|None, acts|None), all fp32."""
+    lib = load()
+    dev = _require_hip(x0, ctx, theta, eps, *ws)
+    x0 = _f32c(x0); theta = _f32c(theta); eps = _f32c(eps)
+    ctx, cview = context_view(ctx)
+    keep, wstruct = _weights_struct(ws)
+    d = _dims(x0, ctx, theta, keep)
+    B, T, S, H, L = d.B, d.T, d.S, d.H, d.L
+    ntril = S * (S + 1) // 2
+    with torch.cuda.device(dev):
+        paths = torch.empty(B, T + 1, S, device=dev, dtype=torch.float32)
+        means = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+        chol = torch.empty(B, T, S, S, device=dev, dtype=torch.float32)
+        chol_raw = torch.empty(B, T, ntril, device=dev, dtype=torch.float32) if save else None
+        acts = torch.empty(B, T, L, 5, H, device=dev, dtype=torch.float32) if save else None
+        nbytes = lib.vsde_head_forward_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            _raise(-1)
+        wsbuf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rc = lib.vsde_head_forward(
+            ctypes.byref(d), _ptr(x0), ctypes.byref(cview), _ptr(theta), _ptr(eps), ctypes.byref(wstruct),
+            ctypes.c_double(time_step), ctypes.c_double(diag_min), ctypes.c_int(1 if save else 0),
+            _ptr(paths), _ptr(means), _ptr(chol), _ptr(chol_raw), _ptr(acts),
+            _ptr(wsbuf), ctypes.c_size_t(nbytes), _stream(dev))
+    if rc != 0:
+        _raise(rc)
+    return paths, means, chol, chol_raw, acts
+
+
+def head_backward(g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, acts, ws,
+                  time_step: float, diag_min: float = DIAG_MIN):
+    """-> 13 fp32 gradients in launch_bwd order (reference kernels/backward.py:766-784)."""
+    lib = load()
+    dev = _require_hip(g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, acts, *ws)
+    g_paths = _f32c(g_paths); g_means = _f32c(g_means); g_chol = _f32c(g_chol)
+    theta = _f32c(theta); eps = _f32c(eps)
+    ctx, cview = context_view(ctx)
+    keep, wstruct = _weights_struct(ws)
+    B, T1, S = paths.shape
+    d = _dims(paths[:, 0], ctx, theta, keep)
+    T, C, P, H, L = d.T, d.C, d.P, d.H, d.L
+    NO = S + S * (S + 1) // 2
+    with torch.cuda.device(dev):
+        mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        g = [mk(B, S), mk(B, T, C), mk(B, P), mk(3 * H, S + C + P), mk(3 * H, H), mk(3 * H), mk(3 * H),
+             mk(L - 1, 3 * H, H), mk(L - 1, 3 * H, H), mk(L - 1, 3 * H), mk(L - 1, 3 * H), mk(NO, H), mk(NO)]
+        gstruct = _Grads(*[_ptr(t) for t in g])
+        nbytes = lib.vsde_head_backward_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            _raise(-1)
+        wsbuf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        rc = lib.vsde_head_backward(
+            ctypes.byref(d), _ptr(g_paths), _ptr(g_means), _ptr(g_chol), ctypes.byref(cview), _ptr(theta),
+            _ptr(eps), _ptr(paths), _ptr(chol_raw), _ptr(acts), ctypes.byref(wstruct),
+            ctypes.c_double(time_step), ctypes.c_double(diag_min), ctypes.byref(gstruct),
+            _ptr(wsbuf), ctypes.c_size_t(nbytes), _stream(dev))
+    if rc != 0:
+        _raise(rc)
+    return tuple(g)
+
+
+def _mask_bytes(positive_dims, S: int):
+    m = (ctypes.c_uint8 * S)()
+    for dd in positive_dims or []:
+        m[dd] = 1
+    return m
+
+
+def elbo_path_terms(z, x, means, chol, drift, diffusion, positive_dims, time_step: float):
+    lib = load()
+    dev = _require_hip(z, x, means, chol, drift, diffusion)
+    z, x, means, chol, drift, diffusion = (_f32c(t) for t in (z, x, means, chol, drift, diffusion))
+    B, T1, S = z.shape
+    with torch.cuda.device(dev):
+        outs = [torch.empty(B, device=dev, dtype=torch.float32) for _ in range(3)]
+        rc = lib.vsde_elbo_path_terms(
+            ctypes.c_int(B), ctypes.c_int(T1 - 1), ctypes.c_int(S), _ptr(z), _ptr(x), _ptr(means), _ptr(chol),
+            _ptr(drift), _ptr(diffusion), _mask_bytes(positive_dims, S), ctypes.c_double(time_step),
+            *[_ptr(o) for o in outs], _stream(dev))
+    if rc != 0:
+        _raise(rc)
+    return tuple(outs)
+
+
+def elbo_path_terms_bwd(z, x, means, chol, drift, diffusion, positive_dims, time_step: float, g_sde, g_gen, g_jac):
+    lib = load()
+    dev = _require_hip(z, x, means, chol, drift, diffusion, g_sde, g_gen, g_jac)
+    z, x, means, chol, drift, diffusion, g_sde, g_gen, g_jac = (
+        _f32c(t) for t in (z, x, means, chol, drift, diffusion, g_sde, g_gen, g_jac))
+    B, T1, S = z.shape
+    with torch.cuda.device(dev):
+        outs = [torch.empty_like(z), torch.empty_like(x), torch.empty_like(means), torch.empty_like(chol),
+                torch.empty_like(drift), torch.empty_like(diffusion)]
+        rc = lib.vsde_elbo_path_terms_bwd(
+            ctypes.c_int(B), ctypes.c_int(T1 - 1), ctypes.c_int(S), _ptr(z), _ptr(x), _ptr(means), _ptr(chol),
+            _ptr(drift), _ptr(diffusion), _mask_bytes(positive_dims, S), ctypes.c_double(time_step),
+            _ptr(g_sde), _ptr(g_gen), _ptr(g_jac), *[_ptr(o) for o in outs], _stream(dev))
+    if rc != 0:
+        _raise(rc)
+    return tuple(outs)

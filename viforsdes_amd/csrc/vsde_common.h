@@ -1,0 +1,107 @@
+// Shared device/host helpers for libvsde_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vsde_hip.h"
+
+namespace vsde {
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kHP = 64;        // hidden units padded to one wavefront
+constexpr int kChunks = 16;    // kHP / 4 (float4 chunks along the reduction index)
+constexpr int kMatF4 = kChunks * 3 * kHP;  // float4 elements of one packed 64x192 matrix
+
+void set_error(const char *fmt, ...);
+
+#define VSDE_CHECK_ARG(cond, code, ...)          \
+    do {                                         \
+        if (!(cond)) {                           \
+            vsde::set_error(__VA_ARGS__);        \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define VSDE_CHECK_HIP(expr)                                                         \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            vsde::set_error("%s failed: %s", #expr, hipGetErrorString(e_));          \
+            return (int)e_;                                                          \
+        }                                                                            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Row-mapped 2-D operand view used by the GEMM kernels.  Logical row m in [0, M) maps to
+//   b = m / rows_per_batch, t = m % rows_per_batch + shift   (row is all-zero when t < 0)
+//   element(m, k) = base[b*batch_stride + t*row_stride + colmap(k)]
+// with colmap(k) = k < col_split ? k : k + col_skip (lets one view read (dr,du | dcn) out
+// of a [dr,du,dn,dcn] record).  dtype: 0 = f32, 1 = bf16.
+struct RowView {
+    const void *base;
+    int64_t batch_stride;
+    int64_t row_stride;
+    int rows_per_batch;
+    int shift;
+    int col_split;
+    int col_skip;
+    int dtype;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ int64_t rowview_offset(const RowView &v, int m, bool &valid) {
+    int b = m / v.rows_per_batch;
+    int t = m - b * v.rows_per_batch + v.shift;
+    valid = t >= 0;
+    return (int64_t)b * v.batch_stride + (int64_t)t * v.row_stride;
+}
+
+__device__ __forceinline__ float rowview_load(const RowView &v, int64_t off, int k) {
+    int kk = k < v.col_split ? k : k + v.col_skip;
+    if (v.dtype == 0) return ((const float *)v.base)[off + kk];
+    return bf16_to_f32(((const uint16_t *)v.base)[off + kk]);
+}
+
+// fast transcendental forms (v_exp_f32 / v_rcp_f32); abs error ~1e-7 on outputs in [-1, 1]
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront retire in order; this only stops the compiler from
+    // moving LDS reads above the preceding LDS writes of other lanes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the 64 lanes; result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- GEMM launchers (vsde_gemm.hip) ----------------------------------------------------
+// C[m][n] = sum_k A(m,k) * Bt[n][k] (+ bias[n]);  Bt row-major [N][K] with leading dim ldb.
+int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int N, const float *bias,
+                   float *C, int64_t ldc, hipStream_t stream);
+
+// Grouped "X^T Y" reductions over the row index:  out[n][col_off + k] = sum_m X(m,n) * Y(m,k)
+// and, when bias_out != nullptr, bias_out[n] = sum_m X(m,n).
+struct TnProblem {
+    RowView X;
+    RowView Y;
+    int NX, NY;
+    float *out;       // [NX][ldo]
+    int64_t ldo;
+    int col_off;
+    float *bias_out;  // [NX] or nullptr
+};
+constexpr int kMaxTnProblems = 12;
+size_t tn_workspace_bytes(const TnProblem *probs, int nprob, int M);
+int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes,
+                      hipStream_t stream);
+
+}  // namespace vsde

@@ -1,0 +1,732 @@
+// Fused GRU DiffusionTransitionHead: batched Euler-Maruyama path sampler, forward and
+// reverse-time backward, for gfx950 (MI355X).
+//
+// Replaces sde_fwd_kernel / sde_bwd_kernel of the reference
+// (src/variational_sde/kernels/forward.py:91-375, backward.py:156-624).  Design:
+//   * one wavefront (64 lanes) per sample path, lane j owns hidden unit j of every layer;
+//   * the recurrent matrices (W_hh_l0, W_ih_l1, W_hh_l1: 3 x 48 KB fp32) are staged once per
+//     workgroup in LDS in a [k/4][gate][j][k%4] layout so that a lane reads its weights with
+//     conflict-free ds_read_b128 and the hidden state is broadcast with ds_read_b128;
+//   * the context projection ctx_t . W_c (the reference's C-long scalar loop per step,
+//     kernels/helpers.py:42-72) is NOT recurrent: it is hoisted into one fp32-MFMA GEMM over all
+//     B*T path-steps (vsde_gemm.hip) and the time loop only streams 3H coalesced floats/step;
+//   * after h^l_t is known the wave computes, in one pass over h^l_t, both the input
+//     pre-activations of layer l+1 (or the emission rows) and the recurrent pre-activations
+//     c^l_{t+1} = b_hh + W_hh h^l_t of the NEXT step, so each step has L broadcast rounds;
+//   * the backward only carries d_x and d_h^l through time and emits the gate pre-activation
+//     gradients; every weight gradient is a deterministic MFMA reduction afterwards instead of
+//     ~87k global atomics per path-step (backward.py:108-139,575-590).
+// All arithmetic is fp32 (README.md:95 of the reference; kernels/autograd.py:80-83).
+#include "vsde_common.h"
+
+namespace vsde {
+
+// ----------------------------------------------------------------------------- packing
+// Matrix order q: 0 = W_hh_l0, 2l-1 = W_ih_l(l), 2l = W_hh_l(l)  (l >= 1).
+struct PackParams {
+    int S, P, C, H, L, NO;
+    const float *W_ih0, *W_hh0, *W_ih_st, *W_hh_st, *out_W;
+    float4 *packF;  // [2L-1][16][3][64]  forward layout  (k-chunk, gate, lane j)      or nullptr
+    float4 *packO;  // [16][NO]            emission rows   (k-chunk, row)                or nullptr
+    float *Wc;      // [3H][C]             context block of W_ih_l0, contiguous          or nullptr
+    float4 *packB;  // [2L-1][3][16][64]  backward layout (gate, j-chunk, lane i)       or nullptr
+    float *WcT;     // [C][3H]                                                          or nullptr
+};
+
+__device__ __forceinline__ const float *mat_ptr(const PackParams &p, int q) {
+    if (q == 0) return p.W_hh0;
+    int l = (q + 1) >> 1;
+    return ((q & 1) ? p.W_ih_st : p.W_hh_st) + (int64_t)(l - 1) * 3 * p.H * p.H;
+}
+
+__global__ void pack_weights_kernel(PackParams p) {
+    const int H = p.H, I = p.S + p.C + p.P, nmat = 2 * p.L - 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.packF) {
+        for (int64_t e = tid0; e < (int64_t)nmat * kMatF4; e += stride) {
+            int j = e % kHP, g = (e / kHP) % 3, c = (e / (kHP * 3)) % kChunks, q = e / kMatF4;
+            const float *W = mat_ptr(p, q);
+            float v[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                int k = 4 * c + x;
+                v[x] = (j < H && k < H) ? W[(int64_t)(g * H + j) * H + k] : 0.f;
+            }
+            p.packF[e] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (p.packO) {
+        for (int64_t e = tid0; e < (int64_t)kChunks * p.NO; e += stride) {
+            int r = e % p.NO, c = e / p.NO;
+            float v[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { int k = 4 * c + x; v[x] = k < H ? p.out_W[(int64_t)r * H + k] : 0.f; }
+            p.packO[e] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (p.Wc) {
+        for (int64_t e = tid0; e < (int64_t)3 * H * p.C; e += stride) {
+            int c = e % p.C, n = e / p.C;
+            p.Wc[e] = p.W_ih0[(int64_t)n * I + p.S + c];
+        }
+    }
+    if (p.packB) {
+        for (int64_t e = tid0; e < (int64_t)nmat * kMatF4; e += stride) {
+            int i = e % kHP, jc = (e / kHP) % kChunks, g = (e / (kHP * kChunks)) % 3, q = e / kMatF4;
+            const float *W = mat_ptr(p, q);
+            float v[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                int j = 4 * jc + x;
+                v[x] = (j < H && i < H) ? W[(int64_t)(g * H + j) * H + i] : 0.f;
+            }
+            p.packB[e] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (p.WcT) {
+        for (int64_t e = tid0; e < (int64_t)3 * H * p.C; e += stride) {
+            int n = e % (3 * H), c = e / (3 * H);
+            p.WcT[e] = p.W_ih0[(int64_t)n * I + p.S + c];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- forward
+struct FwdParams {
+    int B, T, S, P, C, H, NO, ntril, wpb;
+    const float *x0, *theta, *eps;
+    const float *G;  // [B*T][3H] = ctx . W_c^T + b_ih_l0
+    const float *W_ih0, *b_hh0, *b_ih_st, *b_hh_st, *out_b;
+    const float4 *packF, *packO;
+    float dt, sqdt, diag_min;
+    float *paths, *means, *chol, *chol_raw, *acts;
+};
+
+constexpr int kScratchPerWave = 3 * 64;  // hbuf, obuf, ebuf
+constexpr int kMaxSReg = 8;              // state rows of W_ih_l0 kept in registers
+
+__host__ __device__ inline int fwd_lds_matrices(int L) { int n = 2 * L - 1; return n < 3 ? n : 3; }
+
+// acc[g] += sum_k h[k] * W[k][g][lane] for one packed matrix; hv = 4 broadcast values of chunk c
+__device__ __forceinline__ void fma3(const float4 *__restrict__ W, int c, int lane, const float4 &hv, float (&acc)[3]) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float4 w = W[(c * 3 + g) * kHP + lane];
+        acc[g] = fmaf(hv.x, w.x, acc[g]); acc[g] = fmaf(hv.y, w.y, acc[g]);
+        acc[g] = fmaf(hv.z, w.z, acc[g]); acc[g] = fmaf(hv.w, w.w, acc[g]);
+    }
+}
+
+template <int L, bool SAVE>
+__global__ void __launch_bounds__(512) head_fwd_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    constexpr int NMAT = 2 * L - 1;
+    constexpr int NLDS = NMAT < 3 ? NMAT : 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * p.wpb + wave;
+    const int H = p.H, S = p.S, T = p.T, NO = p.NO;
+
+    float4 *Wl = smem4;                       // NLDS packed matrices
+    float4 *POl = Wl + NLDS * kMatF4;         // emission rows [16][NO]
+    float *scratch = (float *)(POl + kChunks * NO) + wave * kScratchPerWave;
+    float *hbuf = scratch, *obuf = scratch + 64, *ebuf = scratch + 128;
+
+    for (int i = threadIdx.x; i < NLDS * kMatF4; i += blockDim.x) Wl[i] = p.packF[i];
+    for (int i = threadIdx.x; i < kChunks * NO; i += blockDim.x) POl[i] = p.packO[i];
+    __syncthreads();
+    if (b >= p.B) return;
+
+    const int I = S + p.C + p.P, G3 = 3 * H;
+    const bool act = lane < H;
+    const int nchunk = (H + 3) >> 2;
+    // per-lane constants
+    float bhh[L][3], bih[L][3], gth[3], wx[kMaxSReg][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bhh[0][g] = act ? p.b_hh0[g * H + lane] : 0.f;
+        bih[0][g] = 0.f;  // folded into G by the projection GEMM
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            bhh[l][g] = act ? p.b_hh_st[(l - 1) * G3 + g * H + lane] : 0.f;
+            bih[l][g] = act ? p.b_ih_st[(l - 1) * G3 + g * H + lane] : 0.f;
+        }
+        float acc = 0.f;  // hoisted theta projection (reference: forward.py:157-175)
+        if (act)
+            for (int q = 0; q < p.P; ++q) acc = fmaf(p.theta[(int64_t)b * p.P + q], p.W_ih0[(int64_t)(g * H + lane) * I + S + p.C + q], acc);
+        gth[g] = acc;
+#pragma unroll
+        for (int i = 0; i < kMaxSReg; ++i) wx[i][g] = (act && i < S) ? p.W_ih0[(int64_t)(g * H + lane) * I + i] : 0.f;
+    }
+    const float outb = lane < NO ? p.out_b[lane] : 0.f;
+    // lane k >= S owns tril entry q = k - S -> (row, col)
+    int trow = 0, tcol = 0;
+    if (lane >= S && lane < NO) {
+        int q = lane - S, r = 0;
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        trow = r; tcol = q - r * (r + 1) / 2;
+    }
+    const bool is_diag = lane >= S && lane < NO && trow == tcol;
+
+    float h[L], cc[L][3];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        h[l] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) cc[l][g] = bhh[l][g];  // c = b_hh + W_hh . 0
+    }
+    float xreg = lane < S ? p.x0[(int64_t)b * S + lane] : 0.f;  // lane i holds z_t[i]
+    if (lane < S) p.paths[(int64_t)b * (T + 1) * S + lane] = xreg;
+
+    const float *Gb = p.G + (int64_t)b * T * G3;
+    const float *eb = p.eps + (int64_t)b * T * S;
+    float gcur[3], gnext[3], ecur, enext;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        gcur[g] = act ? Gb[g * H + lane] : 0.f;
+        gnext[g] = (act && T > 1) ? Gb[G3 + g * H + lane] : 0.f;
+    }
+    ecur = lane < S ? eb[lane] : 0.f;
+    enext = (lane < S && T > 1) ? eb[S + lane] : 0.f;
+
+    for (int t = 0; t < T; ++t) {
+        float gpre[3] = {0.f, 0.f, 0.f}, epre = 0.f;  // prefetch step t+2
+        if (t + 2 < T) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gpre[g] = act ? Gb[(int64_t)(t + 2) * G3 + g * H + lane] : 0.f;
+            epre = lane < S ? eb[(int64_t)(t + 2) * S + lane] : 0.f;
+        }
+        // ---- layer-0 input pre-activations: a = G[b,t] + theta part + z_t . W_x  (forward.py:195-219)
+        float a[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[g] = gcur[g] + gth[g];
+#pragma unroll
+        for (int i = 0; i < kMaxSReg; ++i) {
+            if (i < S) {
+                float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xreg), i));
+#pragma unroll
+                for (int g = 0; g < 3; ++g) a[g] = fmaf(xi, wx[i][g], a[g]);
+            }
+        }
+        for (int i = kMaxSReg; i < S; ++i) {
+            float xi = __shfl(xreg, i, 64);
+            if (act)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) a[g] = fmaf(xi, p.W_ih0[(int64_t)(g * H + lane) * I + i], a[g]);
+        }
+        float o = outb;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            // ---- GRU cell (forward.py:235-238)
+            float r = fast_sigmoid(a[0] + cc[l][0]);
+            float u = fast_sigmoid(a[1] + cc[l][1]);
+            float n = fast_tanh(a[2] + r * cc[l][2]);
+            float hn = (1.0f - u) * n + u * h[l];
+            if (SAVE && act) {
+                float *A = p.acts + ((((int64_t)b * T + t) * L + l) * 5) * H + lane;
+                A[0] = hn; A[H] = r; A[2 * H] = u; A[3 * H] = n; A[4 * H] = cc[l][2];
+            }
+            h[l] = hn;
+            hbuf[lane] = hn;
+            wave_lds_fence();
+            // ---- one pass over h^l_t: recurrent pre-activations of step t+1 and the inputs of layer l+1
+            float cn[3] = {bhh[l][0], bhh[l][1], bhh[l][2]};
+            if (l < L - 1) {
+                float an[3] = {bih[l + 1][0], bih[l + 1][1], bih[l + 1][2]};
+                const int qh = 2 * l, qi = 2 * l + 1;
+                const float4 *Wh = (qh < NLDS) ? (const float4 *)(Wl + qh * kMatF4) : (p.packF + (int64_t)qh * kMatF4);
+                const float4 *Wi = (qi < NLDS) ? (const float4 *)(Wl + qi * kMatF4) : (p.packF + (int64_t)qi * kMatF4);
+#pragma unroll 4
+                for (int c = 0; c < nchunk; ++c) {
+                    float4 hv = *(const float4 *)&hbuf[4 * c];
+                    if (qh < NLDS) fma3(Wl + qh * kMatF4, c, lane, hv, cn); else fma3(Wh, c, lane, hv, cn);
+                    if (qi < NLDS) fma3(Wl + qi * kMatF4, c, lane, hv, an); else fma3(Wi, c, lane, hv, an);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) a[g] = an[g];
+            } else {
+                const int qh = 2 * l;
+                const float4 *Wh = p.packF + (int64_t)qh * kMatF4;
+                const int orow = lane < NO ? lane : NO - 1;
+#pragma unroll 4
+                for (int c = 0; c < nchunk; ++c) {
+                    float4 hv = *(const float4 *)&hbuf[4 * c];
+                    if (qh < NLDS) fma3(Wl + qh * kMatF4, c, lane, hv, cn); else fma3(Wh, c, lane, hv, cn);
+                    float4 w = POl[c * NO + orow];
+                    o = fmaf(hv.x, w.x, o); o = fmaf(hv.y, w.y, o); o = fmaf(hv.z, w.z, o); o = fmaf(hv.w, w.w, o);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) cc[l][g] = cn[g];
+            wave_lds_fence();  // hbuf is rewritten by the next layer
+        }
+        // ---- emission (forward.py:314-375): lane k < S holds mu_k, lane S+q holds tril entry q
+        float lval = is_diag ? fmaxf(o, p.diag_min) : o;
+        obuf[lane] = lane < S ? o : lval;
+        if (lane < S) ebuf[lane] = ecur;
+        wave_lds_fence();
+        if (lane < S) {
+            float acc = 0.f;
+            const int base = S + lane * (lane + 1) / 2;
+            for (int j = 0; j <= lane; ++j) acc = fmaf(obuf[base + j], ebuf[j], acc);
+            xreg = xreg + o * p.dt + acc * p.sqdt;
+            p.means[((int64_t)b * T + t) * S + lane] = o;
+            p.paths[((int64_t)b * (T + 1) + t + 1) * S + lane] = xreg;
+        }
+        if (SAVE && lane >= S && lane < NO) p.chol_raw[((int64_t)b * T + t) * p.ntril + (lane - S)] = o;
+        for (int e = lane; e < S * S; e += 64) {  // full S x S matrix, strict upper triangle = 0
+            int rr = e / S, cl = e - rr * S;
+            float v = cl <= rr ? obuf[S + rr * (rr + 1) / 2 + cl] : 0.f;
+            p.chol[((int64_t)b * T + t) * S * S + e] = v;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { gcur[g] = gnext[g]; gnext[g] = gpre[g]; }
+        ecur = enext; enext = epre;
+    }
+}
+
+// ---------------------------------------------------------------------------- backward
+struct BwdParams {
+    int B, T, S, P, C, H, NO, ntril, wpb;
+    const float *g_paths, *g_means, *g_chol, *theta, *eps, *chol_raw, *acts;
+    const float *W_ih0, *out_W;
+    const float4 *packB;
+    float dt, sqdt, diag_min;
+    float *D4;   // [B*T][L][4H]  (dr_pre, du_pre, dn_pre, dc_n)
+    float *DO;   // [B*T][NO]     gradient wrt the emission rows
+    float *g_x0, *g_theta;
+};
+
+// acc += sum_j W[g][j][lane] * d[g][j] for one packed (backward layout) matrix and gate g
+__device__ __forceinline__ float bdot(const float4 *__restrict__ W, int g, int jc, int lane, const float4 &dv, float acc) {
+    float4 w = W[(g * kChunks + jc) * kHP + lane];
+    acc = fmaf(dv.x, w.x, acc); acc = fmaf(dv.y, w.y, acc); acc = fmaf(dv.z, w.z, acc); acc = fmaf(dv.w, w.w, acc);
+    return acc;
+}
+
+constexpr int kBwdScratchPerWave = 4 * 64 + 3 * 64;  // dbuf[4][64], dobuf, xbuf, ebuf
+
+template <int L>
+__global__ void __launch_bounds__(512) head_bwd_kernel(BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    constexpr int NMAT = 2 * L - 1;
+    constexpr int NLDS = NMAT < 3 ? NMAT : 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * p.wpb + wave;
+    const int H = p.H, S = p.S, T = p.T, NO = p.NO;
+
+    float4 *Wl = smem4;
+    float *OWl = (float *)(Wl + NLDS * kMatF4);  // out_W native [NO][64] (zero padded columns)
+    float *scratch = OWl + NO * kHP + wave * kBwdScratchPerWave;
+    float *dbuf = scratch, *dobuf = scratch + 256, *xbuf = scratch + 320, *ebuf = scratch + 384;
+
+    for (int i = threadIdx.x; i < NLDS * kMatF4; i += blockDim.x) Wl[i] = p.packB[i];
+    for (int i = threadIdx.x; i < NO * kHP; i += blockDim.x) {
+        int j = i & 63, k = i >> 6;
+        OWl[i] = j < H ? p.out_W[(int64_t)k * H + j] : 0.f;
+    }
+    __syncthreads();
+    if (b >= p.B) return;
+
+    const int I = S + p.C + p.P;
+    const bool act = lane < H;
+    const int nchunk = (H + 3) >> 2;
+    float wx[kMaxSReg][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < kMaxSReg; ++i) wx[i][g] = (act && i < S) ? p.W_ih0[(int64_t)(g * H + lane) * I + i] : 0.f;
+    int trow = 0, tcol = 0;
+    if (lane >= S && lane < NO) {
+        int q = lane - S, r = 0;
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        trow = r; tcol = q - r * (r + 1) / 2;
+    }
+    const bool is_tril = lane >= S && lane < NO;
+    const bool is_diag = is_tril && trow == tcol;
+
+    float dh[L], spi[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) dh[l] = 0.f;
+    float dx = 0.f;  // lane i < S carries d z_t[i]
+
+    const int64_t bt0 = (int64_t)b * T;
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t bt = bt0 + t;
+        // ---- upstream gradients for this step (backward.py:257-349)
+        float gl = 0.f, raw = 0.f;
+        if (lane < S) {
+            dx += p.g_paths[((int64_t)b * (T + 1) + t + 1) * S + lane];
+            xbuf[lane] = dx;
+            ebuf[lane] = p.eps[bt * S + lane];
+        }
+        if (is_tril) {
+            gl = p.g_chol[(bt * S + trow) * S + tcol];
+            raw = p.chol_raw[bt * p.ntril + (lane - S)];
+        }
+        wave_lds_fence();
+        float dO = 0.f;
+        if (lane < S) dO = dx * p.dt + p.g_means[bt * S + lane];
+        else if (is_tril) {
+            float dL = xbuf[trow] * ebuf[tcol] * p.sqdt + gl;
+            if (is_diag && !(raw >= p.diag_min || dL < 0.f)) dL = 0.f;  // bounds.py:20 / backward.py:331-334
+            dO = dL;
+        }
+        dobuf[lane] = dO;
+        if (lane < NO) p.DO[bt * NO + lane] = dO;
+        wave_lds_fence();
+        float dcur = 0.f;  // d h_top[j] = sum_k dO_k out_W[k][j]
+        for (int k = 0; k < NO; ++k) dcur = fmaf(dobuf[k], OWl[k * kHP + lane], dcur);
+
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const float *A = p.acts + ((bt * L + l) * 5) * H + lane;
+            float r = 0.f, u = 0.f, n = 0.f, cn = 0.f, hprev = 0.f;
+            if (act) {
+                r = A[H]; u = A[2 * H]; n = A[3 * H]; cn = A[4 * H];
+                if (t > 0) hprev = A[-(int64_t)L * 5 * H];
+            }
+            // ---- GRU cell adjoint (backward.py:59-67, 452-486)
+            float d = dcur + dh[l];
+            float dn = (1.0f - u) * d, du = (hprev - n) * d;
+            float dn_pre = dn * (1.0f - n * n);
+            float du_pre = du * (u * (1.0f - u));
+            float dcn = dn_pre * r;
+            float dr_pre = (dn_pre * cn) * (r * (1.0f - r));
+            float carry = u * d;
+            if (act) {
+                float *D = p.D4 + (bt * L + l) * 4 * H + lane;
+                D[0] = dr_pre; D[H] = du_pre; D[2 * H] = dn_pre; D[3 * H] = dcn;
+            }
+            dbuf[lane] = dr_pre; dbuf[64 + lane] = du_pre; dbuf[128 + lane] = dn_pre; dbuf[192 + lane] = dcn;
+            wave_lds_fence();
+            const int qh = 2 * l, qi = 2 * l - 1;
+            const float4 *Wh = (qh < NLDS) ? (const float4 *)(Wl + qh * kMatF4) : (p.packB + (int64_t)qh * kMatF4);
+            float acc_h = carry, acc_i = 0.f;
+            if (l > 0) {
+                const float4 *Wi = (qi < NLDS) ? (const float4 *)(Wl + qi * kMatF4) : (p.packB + (int64_t)qi * kMatF4);
+#pragma unroll 4
+                for (int jc = 0; jc < nchunk; ++jc) {
+                    float4 vr = *(const float4 *)&dbuf[4 * jc], vu = *(const float4 *)&dbuf[64 + 4 * jc];
+                    float4 vn = *(const float4 *)&dbuf[128 + 4 * jc], vc = *(const float4 *)&dbuf[192 + 4 * jc];
+                    if (qh < NLDS) {
+                        acc_h = bdot(Wl + qh * kMatF4, 0, jc, lane, vr, acc_h); acc_h = bdot(Wl + qh * kMatF4, 1, jc, lane, vu, acc_h);
+                        acc_h = bdot(Wl + qh * kMatF4, 2, jc, lane, vc, acc_h);
+                    } else {
+                        acc_h = bdot(Wh, 0, jc, lane, vr, acc_h); acc_h = bdot(Wh, 1, jc, lane, vu, acc_h); acc_h = bdot(Wh, 2, jc, lane, vc, acc_h);
+                    }
+                    if (qi < NLDS) {
+                        acc_i = bdot(Wl + qi * kMatF4, 0, jc, lane, vr, acc_i); acc_i = bdot(Wl + qi * kMatF4, 1, jc, lane, vu, acc_i);
+                        acc_i = bdot(Wl + qi * kMatF4, 2, jc, lane, vn, acc_i);
+                    } else {
+                        acc_i = bdot(Wi, 0, jc, lane, vr, acc_i); acc_i = bdot(Wi, 1, jc, lane, vu, acc_i); acc_i = bdot(Wi, 2, jc, lane, vn, acc_i);
+                    }
+                }
+                dcur = acc_i;
+            } else {
+#pragma unroll 4
+                for (int jc = 0; jc < nchunk; ++jc) {
+                    float4 vr = *(const float4 *)&dbuf[4 * jc], vu = *(const float4 *)&dbuf[64 + 4 * jc];
+                    float4 vc = *(const float4 *)&dbuf[192 + 4 * jc];
+                    acc_h = bdot(Wl, 0, jc, lane, vr, acc_h); acc_h = bdot(Wl, 1, jc, lane, vu, acc_h); acc_h = bdot(Wl, 2, jc, lane, vc, acc_h);
+                }
+                // d z_t += W_ih_l0[:, state rows]^T . d_pre  (backward.py:494-509): wave reductions
+                spi[0] += dr_pre; spi[1] += du_pre; spi[2] += dn_pre;
+#pragma unroll
+                for (int i = 0; i < kMaxSReg; ++i) {
+                    if (i < S) {
+                        float v = wx[i][0] * dr_pre + wx[i][1] * du_pre + wx[i][2] * dn_pre;
+                        v = wave_sum(v);
+                        if (lane == i) dx += v;
+                    }
+                }
+                for (int i = kMaxSReg; i < S; ++i) {
+                    float v = 0.f;
+                    if (act) v = p.W_ih0[(int64_t)lane * I + i] * dr_pre + p.W_ih0[(int64_t)(H + lane) * I + i] * du_pre +
+                                 p.W_ih0[(int64_t)(2 * H + lane) * I + i] * dn_pre;
+                    v = wave_sum(v);
+                    if (lane == i) dx += v;
+                }
+            }
+            dh[l] = acc_h;
+            wave_lds_fence();
+        }
+    }
+    if (lane < S) p.g_x0[(int64_t)b * S + lane] = dx + p.g_paths[(int64_t)b * (T + 1) * S + lane];  // backward.py:620-624
+    // d theta_b = W_ih_l0[:, theta rows]^T . sum_t d_pre_0   (backward.py:511-548)
+    for (int q = 0; q < p.P; ++q) {
+        float v = 0.f;
+        if (act) v = p.W_ih0[(int64_t)lane * I + S + p.C + q] * spi[0] + p.W_ih0[(int64_t)(H + lane) * I + S + p.C + q] * spi[1] +
+                     p.W_ih0[(int64_t)(2 * H + lane) * I + S + p.C + q] * spi[2];
+        v = wave_sum(v);
+        if (lane == 0) p.g_theta[(int64_t)b * p.P + q] = v;
+    }
+}
+
+// ------------------------------------------------------------------------ host launchers
+static int check_dims(const vsde_head_dims *d) {
+    VSDE_CHECK_ARG(d != nullptr, VSDE_E_BADARG, "dims is NULL");
+    VSDE_CHECK_ARG(d->B > 0 && d->T > 0 && d->S > 0 && d->P >= 0 && d->C > 0 && d->H > 0, VSDE_E_BADARG,
+                   "bad dims B=%d T=%d S=%d P=%d C=%d H=%d", d->B, d->T, d->S, d->P, d->C, d->H);
+    VSDE_CHECK_ARG(d->L >= 1 && d->L <= VSDE_MAX_LAYERS, VSDE_E_LAYERS, "num_layers must be in [1, %d], got %d",
+                   VSDE_MAX_LAYERS, d->L);
+    VSDE_CHECK_ARG(d->H <= VSDE_MAX_HIDDEN, VSDE_E_HIDDEN, "hidden_dim %d > %d is not supported by the gfx950 kernels", d->H,
+                   VSDE_MAX_HIDDEN);
+    VSDE_CHECK_ARG(d->S <= VSDE_MAX_STATE, VSDE_E_STATE, "state_dim %d > %d is not supported by the gfx950 kernels", d->S,
+                   VSDE_MAX_STATE);
+    return 0;
+}
+
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct FwdLayout { size_t packF, packO, Wc, G, total; };
+static FwdLayout fwd_layout(const vsde_head_dims *d) {
+    const int NO = d->S + d->S * (d->S + 1) / 2;
+    FwdLayout o; size_t off = 0;
+    o.packF = off; off += align256((size_t)(2 * d->L - 1) * kMatF4 * sizeof(float4));
+    o.packO = off; off += align256((size_t)kChunks * NO * sizeof(float4));
+    o.Wc = off; off += align256((size_t)3 * d->H * d->C * sizeof(float));
+    o.G = off; off += align256((size_t)d->B * d->T * 3 * d->H * sizeof(float));
+    o.total = off;
+    return o;
+}
+
+static int pick_wpb(int B, size_t lds_fixed, size_t lds_per_wave) {
+    int wpb = (B + 255) / 256;  // fill all 256 CUs first
+    if (wpb < 1) wpb = 1;
+    if (wpb > 8) wpb = 8;
+    while (wpb > 1 && lds_fixed + (size_t)wpb * lds_per_wave > 160 * 1024) --wpb;
+    return wpb;
+}
+
+static RowView ctx_rowview(const vsde_context_view *c, int T, int C) {
+    RowView v;
+    v.base = c->base; v.batch_stride = c->batch_stride; v.row_stride = c->step_stride; v.rows_per_batch = T;
+    v.shift = 0; v.col_split = C; v.col_skip = 0; v.dtype = c->dtype == VSDE_CTX_BF16 ? 1 : 0;
+    return v;
+}
+
+template <int L>
+static int launch_fwd_L(const FwdParams &p, bool save, int grid, int block, size_t lds, hipStream_t s) {
+    if (save) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_fwd_kernel<L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((head_fwd_kernel<L, true>), dim3(grid), dim3(block), lds, s, p);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_fwd_kernel<L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((head_fwd_kernel<L, false>), dim3(grid), dim3(block), lds, s, p);
+    }
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int L>
+static int launch_bwd_L(const BwdParams &p, int grid, int block, size_t lds, hipStream_t s) {
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((head_bwd_kernel<L>), dim3(grid), dim3(block), lds, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vsde
+
+using namespace vsde;
+
+extern "C" size_t vsde_head_forward_workspace_bytes(const vsde_head_dims *d) {
+    if (check_dims(d) != 0) return 0;
+    return fwd_layout(d).total;
+}
+
+extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const vsde_context_view *ctx,
+                                 const float *theta, const float *eps, const vsde_head_weights *w,
+                                 double time_step, double diag_min, int save, float *paths, float *means,
+                                 float *chol, float *chol_raw, float *acts, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(x0 && ctx && ctx->base && eps && w && paths && means && chol && workspace, VSDE_E_BADARG, "NULL argument");
+    VSDE_CHECK_ARG(d->P == 0 || theta, VSDE_E_BADARG, "theta is NULL");
+    VSDE_CHECK_ARG(!save || (chol_raw && acts), VSDE_E_BADARG, "training mode needs chol_raw and acts buffers");
+    VSDE_CHECK_ARG(d->L == 1 || (w->W_ih_stack && w->W_hh_stack && w->b_ih_stack && w->b_hh_stack), VSDE_E_BADARG,
+                   "stacked layer weights are NULL");
+    VSDE_CHECK_ARG(time_step > 0, VSDE_E_BADARG, "time_step must be positive");
+    const FwdLayout lay = fwd_layout(d);
+    VSDE_CHECK_ARG(workspace_bytes >= lay.total, VSDE_E_WORKSPACE, "forward workspace too small: %zu < %zu", workspace_bytes, lay.total);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const int NO = d->S + d->S * (d->S + 1) / 2;
+
+    PackParams pk = {};
+    pk.S = d->S; pk.P = d->P; pk.C = d->C; pk.H = d->H; pk.L = d->L; pk.NO = NO;
+    pk.W_ih0 = w->W_ih_l0; pk.W_hh0 = w->W_hh_l0; pk.W_ih_st = w->W_ih_stack; pk.W_hh_st = w->W_hh_stack; pk.out_W = w->out_weight;
+    pk.packF = (float4 *)(ws + lay.packF); pk.packO = (float4 *)(ws + lay.packO); pk.Wc = (float *)(ws + lay.Wc);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
+    VSDE_CHECK_HIP(hipGetLastError());
+
+    float *G = (float *)(ws + lay.G);
+    rc = launch_gemm_nt(ctx_rowview(ctx, d->T, d->C), d->B * d->T, d->C, pk.Wc, d->C, 3 * d->H, w->b_ih_l0, G, 3 * d->H, s);
+    if (rc) return rc;
+
+    FwdParams p = {};
+    p.B = d->B; p.T = d->T; p.S = d->S; p.P = d->P; p.C = d->C; p.H = d->H; p.NO = NO; p.ntril = NO - d->S;
+    p.x0 = x0; p.theta = theta; p.eps = eps; p.G = G;
+    p.W_ih0 = w->W_ih_l0; p.b_hh0 = w->b_hh_l0; p.b_ih_st = w->b_ih_stack; p.b_hh_st = w->b_hh_stack; p.out_b = w->out_bias;
+    p.packF = pk.packF; p.packO = pk.packO;
+    p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
+    p.paths = paths; p.means = means; p.chol = chol; p.chol_raw = chol_raw; p.acts = acts;
+    const size_t lds_fixed = (size_t)fwd_lds_matrices(d->L) * kMatF4 * sizeof(float4) + (size_t)kChunks * NO * sizeof(float4);
+    const size_t lds_wave = kScratchPerWave * sizeof(float);
+    p.wpb = pick_wpb(d->B, lds_fixed, lds_wave);
+    const size_t lds = lds_fixed + p.wpb * lds_wave;
+    VSDE_CHECK_ARG(lds <= 160 * 1024, VSDE_E_STATE, "LDS budget exceeded (%zu B)", lds);
+    const int grid = (d->B + p.wpb - 1) / p.wpb, block = 64 * p.wpb;
+    switch (d->L) {
+        case 1: return launch_fwd_L<1>(p, save != 0, grid, block, lds, s);
+        case 2: return launch_fwd_L<2>(p, save != 0, grid, block, lds, s);
+        case 3: return launch_fwd_L<3>(p, save != 0, grid, block, lds, s);
+        default: return launch_fwd_L<4>(p, save != 0, grid, block, lds, s);
+    }
+}
+
+namespace vsde {
+struct BwdLayout { size_t packB, WcT, D4, DO, tn, total; };
+
+static int build_tn(const vsde_head_dims *d, const vsde_context_view *ctx, const float *theta, const float *paths,
+                    const float *acts, const float *D4, const float *DO, const vsde_head_grads *g, TnProblem *pr) {
+    const int H = d->H, L = d->L, S = d->S, C = d->C, P = d->P, T = d->T, I = S + C + P, NO = S + S * (S + 1) / 2;
+    int n = 0;
+    auto d4view = [&](int l, bool hh) {
+        RowView v; v.base = D4 + (int64_t)l * 4 * H; v.batch_stride = (int64_t)T * L * 4 * H; v.row_stride = (int64_t)L * 4 * H;
+        v.rows_per_batch = T; v.shift = 0; v.dtype = 0;
+        if (hh) { v.col_split = 2 * H; v.col_skip = H; } else { v.col_split = 3 * H; v.col_skip = 0; }
+        return v;
+    };
+    auto actview = [&](int l, int shift) {  // hidden state h^l_{t+shift}
+        RowView v; v.base = acts + (int64_t)l * 5 * H; v.batch_stride = (int64_t)T * L * 5 * H; v.row_stride = (int64_t)L * 5 * H;
+        v.rows_per_batch = T; v.shift = shift; v.col_split = H; v.col_skip = 0; v.dtype = 0;
+        return v;
+    };
+    // layer 0, W_ih_l0 = [state | context | theta] column blocks  (backward.py:494-564)
+    {
+        TnProblem &q = pr[n++]; q.X = d4view(0, false); q.NX = 3 * H;
+        q.Y = ctx_rowview(ctx, T, C); q.NY = C; q.out = g->W_ih_l0; q.ldo = I; q.col_off = S; q.bias_out = g->b_ih_l0;
+    }
+    {
+        TnProblem &q = pr[n++]; q.X = d4view(0, false); q.NX = 3 * H;
+        RowView y; y.base = paths; y.batch_stride = (int64_t)(T + 1) * S; y.row_stride = S; y.rows_per_batch = T; y.shift = 0;
+        y.col_split = S; y.col_skip = 0; y.dtype = 0;
+        q.Y = y; q.NY = S; q.out = g->W_ih_l0; q.ldo = I; q.col_off = 0; q.bias_out = nullptr;
+    }
+    if (P > 0) {
+        TnProblem &q = pr[n++]; q.X = d4view(0, false); q.NX = 3 * H;
+        RowView y; y.base = theta; y.batch_stride = P; y.row_stride = 0; y.rows_per_batch = T; y.shift = 0;
+        y.col_split = P; y.col_skip = 0; y.dtype = 0;
+        q.Y = y; q.NY = P; q.out = g->W_ih_l0; q.ldo = I; q.col_off = S + C; q.bias_out = nullptr;
+    }
+    {
+        TnProblem &q = pr[n++]; q.X = d4view(0, true); q.NX = 3 * H;
+        q.Y = actview(0, -1); q.NY = H; q.out = g->W_hh_l0; q.ldo = H; q.col_off = 0; q.bias_out = g->b_hh_l0;
+    }
+    for (int l = 1; l < L; ++l) {
+        {
+            TnProblem &q = pr[n++]; q.X = d4view(l, false); q.NX = 3 * H;
+            q.Y = actview(l - 1, 0); q.NY = H; q.out = g->W_ih_stack + (int64_t)(l - 1) * 3 * H * H; q.ldo = H; q.col_off = 0;
+            q.bias_out = g->b_ih_stack + (int64_t)(l - 1) * 3 * H;
+        }
+        {
+            TnProblem &q = pr[n++]; q.X = d4view(l, true); q.NX = 3 * H;
+            q.Y = actview(l, -1); q.NY = H; q.out = g->W_hh_stack + (int64_t)(l - 1) * 3 * H * H; q.ldo = H; q.col_off = 0;
+            q.bias_out = g->b_hh_stack + (int64_t)(l - 1) * 3 * H;
+        }
+    }
+    {
+        TnProblem &q = pr[n++];
+        RowView x; x.base = DO; x.batch_stride = (int64_t)T * NO; x.row_stride = NO; x.rows_per_batch = T; x.shift = 0;
+        x.col_split = NO; x.col_skip = 0; x.dtype = 0;
+        q.X = x; q.NX = NO; q.Y = actview(L - 1, 0); q.NY = H; q.out = g->out_weight; q.ldo = H; q.col_off = 0;
+        q.bias_out = g->out_bias;
+    }
+    return n;
+}
+
+static BwdLayout bwd_layout(const vsde_head_dims *d) {
+    const int NO = d->S + d->S * (d->S + 1) / 2;
+    BwdLayout o; size_t off = 0;
+    o.packB = off; off += align256((size_t)(2 * d->L - 1) * kMatF4 * sizeof(float4));
+    o.WcT = off; off += align256((size_t)3 * d->H * d->C * sizeof(float));
+    o.D4 = off; off += align256((size_t)d->B * d->T * d->L * 4 * d->H * sizeof(float));
+    o.DO = off; off += align256((size_t)d->B * d->T * NO * sizeof(float));
+    o.tn = off;
+    // the TN plan only depends on shapes; build it with dummy pointers
+    TnProblem pr[kMaxTnProblems];
+    vsde_head_grads g = {}; vsde_context_view cv = {}; float dummy = 0.f;
+    g.b_ih_l0 = g.b_hh_l0 = g.b_ih_stack = g.b_hh_stack = g.out_bias = &dummy;
+    int n = build_tn(d, &cv, nullptr, nullptr, nullptr, nullptr, nullptr, &g, pr);
+    off += align256(tn_workspace_bytes(pr, n, d->B * d->T));
+    o.total = off;
+    return o;
+}
+}  // namespace vsde
+
+extern "C" size_t vsde_head_backward_workspace_bytes(const vsde_head_dims *d) {
+    if (check_dims(d) != 0) return 0;
+    return bwd_layout(d).total;
+}
+
+extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths, const float *g_means,
+                                  const float *g_chol, const vsde_context_view *ctx, const float *theta,
+                                  const float *eps, const float *paths, const float *chol_raw,
+                                  const float *acts, const vsde_head_weights *w, double time_step,
+                                  double diag_min, const vsde_head_grads *g, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(g_paths && g_means && g_chol && ctx && ctx->base && eps && paths && chol_raw && acts && w && g && workspace,
+                   VSDE_E_BADARG, "NULL argument");
+    VSDE_CHECK_ARG(g->x0 && g->context && g->W_ih_l0 && g->W_hh_l0 && g->b_ih_l0 && g->b_hh_l0 && g->out_weight && g->out_bias,
+                   VSDE_E_BADARG, "NULL gradient output");
+    VSDE_CHECK_ARG(d->P == 0 || (theta && g->theta), VSDE_E_BADARG, "theta / grad theta is NULL");
+    VSDE_CHECK_ARG(d->L == 1 || (w->W_ih_stack && w->W_hh_stack && g->W_ih_stack && g->W_hh_stack && g->b_ih_stack && g->b_hh_stack),
+                   VSDE_E_BADARG, "stacked layer tensors are NULL");
+    const BwdLayout lay = bwd_layout(d);
+    VSDE_CHECK_ARG(workspace_bytes >= lay.total, VSDE_E_WORKSPACE, "backward workspace too small: %zu < %zu", workspace_bytes, lay.total);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const int NO = d->S + d->S * (d->S + 1) / 2, M = d->B * d->T;
+
+    PackParams pk = {};
+    pk.S = d->S; pk.P = d->P; pk.C = d->C; pk.H = d->H; pk.L = d->L; pk.NO = NO;
+    pk.W_ih0 = w->W_ih_l0; pk.W_hh0 = w->W_hh_l0; pk.W_ih_st = w->W_ih_stack; pk.W_hh_st = w->W_hh_stack; pk.out_W = w->out_weight;
+    pk.packB = (float4 *)(ws + lay.packB); pk.WcT = (float *)(ws + lay.WcT);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
+    VSDE_CHECK_HIP(hipGetLastError());
+
+    BwdParams p = {};
+    p.B = d->B; p.T = d->T; p.S = d->S; p.P = d->P; p.C = d->C; p.H = d->H; p.NO = NO; p.ntril = NO - d->S;
+    p.g_paths = g_paths; p.g_means = g_means; p.g_chol = g_chol; p.theta = theta; p.eps = eps; p.chol_raw = chol_raw; p.acts = acts;
+    p.W_ih0 = w->W_ih_l0; p.out_W = w->out_weight; p.packB = pk.packB;
+    p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
+    p.D4 = (float *)(ws + lay.D4); p.DO = (float *)(ws + lay.DO); p.g_x0 = g->x0; p.g_theta = g->theta;
+    const size_t lds_fixed = (size_t)fwd_lds_matrices(d->L) * kMatF4 * sizeof(float4) + (size_t)NO * kHP * sizeof(float);
+    const size_t lds_wave = kBwdScratchPerWave * sizeof(float);
+    p.wpb = pick_wpb(d->B, lds_fixed, lds_wave);
+    const size_t lds = lds_fixed + p.wpb * lds_wave;
+    VSDE_CHECK_ARG(lds <= 160 * 1024, VSDE_E_STATE, "LDS budget exceeded (%zu B)", lds);
+    const int grid = (d->B + p.wpb - 1) / p.wpb, block = 64 * p.wpb;
+    switch (d->L) {
+        case 1: rc = launch_bwd_L<1>(p, grid, block, lds, s); break;
+        case 2: rc = launch_bwd_L<2>(p, grid, block, lds, s); break;
+        case 3: rc = launch_bwd_L<3>(p, grid, block, lds, s); break;
+        default: rc = launch_bwd_L<4>(p, grid, block, lds, s); break;
+    }
+    if (rc) return rc;
+
+    // grad_context[m][c] = sum_n d_pre0(m, n) W_ih_l0[n][S + c]   (backward.py:550-564)
+    RowView dv; dv.base = p.D4; dv.batch_stride = (int64_t)d->T * d->L * 4 * d->H; dv.row_stride = (int64_t)d->L * 4 * d->H;
+    dv.rows_per_batch = d->T; dv.shift = 0; dv.col_split = 3 * d->H; dv.col_skip = 0; dv.dtype = 0;
+    rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s);
+    if (rc) return rc;
+
+    TnProblem pr[kMaxTnProblems];
+    int n = build_tn(d, ctx, theta, paths, acts, p.D4, p.DO, g, pr);
+    return launch_tn_grouped(pr, n, M, ws + lay.tn, lay.total - lay.tn, s);
+}
