@@ -1,0 +1,125 @@
+"""Data parallelism over Monte-Carlo sample paths: one process per GPU, RCCL over xGMI.
+
+Every path (and its theta draw) is independent through encoder, head and ELBO; the only coupling
+is the mean over the batch in the loss, i.e. a gradient average.  Parameters are replicated
+(8.3 M fp32 = 33 MB at the example configs), each rank draws its own ``batch_size`` samples with
+seed ``base + rank`` and the gradients are averaged once per optimizer step, before unscale/clip
+so that the clipping norm is global.
+
+All gradients live in ONE flat fp32 buffer (``p.grad`` are views into it), so the exchange is a
+single large all-reduce per step (split into at most ``max_buckets`` launches): with 8 GPUs fully
+connected by point-to-point xGMI links a few large messages beat many small ones, and at 33 MB the
+step is latency-, not bandwidth-, bound.
+
+The reference wraps the model in DDP but never calls the wrapper's forward, so its reducer is
+never armed and gradients are not synchronised; this module implements the
+intended semantics instead of copying that behaviour."""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+
+def env_rank_info() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", 0)))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    return rank, local, world
+
+
+def init_process_group_if_needed(device_type: str) -> bool:
+    """Initialise torch.distributed from the environment. ``nccl`` on ROCm *is* RCCL."""
+    _, _, world = env_rank_info()
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo")
+    return True
+
+
+class FlatGradientAllReduce:
+    """Owns the flat gradient buffer of ``params`` and averages it across ranks."""
+
+    def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._views: list[Tensor] = []
+        off = 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            self._views.append(v)
+            p.grad = v
+        n = max(1, min(max_buckets, total // (1 << 20) or 1))
+        cuts = [round(i * total / n) for i in range(n + 1)]
+        self.buckets = [self.flat[cuts[i]:cuts[i + 1]] for i in range(n)]
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+
+    def zero_grad(self) -> None:
+        """Replaces ``optimizer.zero_grad()``: one memset, and re-attaches the views if needed."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self._views):
+            if p.grad is not v:
+                p.grad = v
+
+    def _gather_strays(self) -> None:
+        # autograd normally accumulates in place into the views; if it replaced a .grad, copy it in
+        for p, v in zip(self.params, self._views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    @torch.no_grad()
+    def all_reduce(self) -> None:
+        self._gather_strays()
+        if self.world_size <= 1:
+            return
+        handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+        for h in handles:
+            h.wait()
+        self.flat.mul_(1.0 / self.world_size)
+
+
+@torch.no_grad()
+def broadcast_module_state(module: nn.Module, src: int = 0) -> None:
+    """Make every rank start from rank ``src``'s parameters and buffers (what DDP's constructor does)."""
+    if not dist.is_initialized() or dist.get_world_size() <= 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    real = [t for t in tensors if not t.is_complex()]
+    by_dtype: dict[torch.dtype, list[Tensor]] = {}
+    for t in real:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, group in by_dtype.items():
+        send_dtype = torch.uint8 if dtype == torch.bool else dtype
+        flat = torch.cat([t.detach().to(send_dtype).reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t).to(dtype))
+            off += t.numel()
+    for t in tensors:
+        if t.is_complex():
+            r = torch.view_as_real(t).contiguous()
+            dist.broadcast(r, src=src)
+            t.copy_(torch.view_as_complex(r))
+
+
+def all_reduce_mean_(values: Tensor) -> Tensor:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+        values.div_(dist.get_world_size())
+    return values

@@ -1,0 +1,47 @@
+"""EMA of the trainable parameters (reference: inference/exponential_moving_average.py:13-47).
+The update is one fused ``torch._foreach_lerp_`` over all parameters instead of a Python loop."""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Iterator
+
+import torch
+from torch import Tensor, nn
+
+from .constants import DEFAULT_EMA_DECAY
+
+
+class ExponentialMovingAverage:
+    def __init__(self, model: nn.Module, decay: float = DEFAULT_EMA_DECAY) -> None:
+        self.model, self.decay = model, decay
+        self.shadow: dict[str, Tensor] = {}
+        self._init_shadow()
+
+    def _init_shadow(self) -> None:
+        self.shadow = {name: p.detach().clone() for name, p in self.model.named_parameters()}
+
+    @torch.no_grad()
+    def update(self) -> None:
+        names, params = zip(*self.model.named_parameters())
+        torch._foreach_lerp_([self.shadow[n] for n in names], [p.detach() for p in params], 1.0 - self.decay)
+
+    @contextmanager
+    def apply(self) -> Iterator[None]:
+        """Temporarily swap the averaged weights into the model."""
+        named = list(self.model.named_parameters())
+        backup = [p.detach().clone() for _, p in named]
+        with torch.no_grad():
+            for name, p in named:
+                p.copy_(self.shadow[name])
+        try:
+            yield
+        finally:
+            with torch.no_grad():
+                for (_, p), saved in zip(named, backup):
+                    p.copy_(saved)
+
+    def state_dict(self) -> dict[str, Tensor]:
+        return {k: v.clone() for k, v in self.shadow.items()}
+
+    def load_state_dict(self, state: dict[str, Tensor]) -> None:
+        self.shadow = {k.replace("encoder.sit._orig_mod.", "encoder.sit."): v.clone() for k, v in state.items()}

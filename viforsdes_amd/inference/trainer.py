@@ -1,0 +1,184 @@
+"""Training loop (reference: inference/trainer.py:49-262).
+
+One optimizer step = theta ~ q(theta) -> encoder -> fused head -> ELBO -> backward ->
+[gradient all-reduce] -> unscale -> clip -> AdamW -> EMA.  Differences from the reference that do
+not change results: the ELBO scalars stay on the device and are copied to the host every
+``update_interval`` steps instead of a ``.item()`` sync per step; under torchrun gradients are
+actually averaged across ranks (see data_parallel.py)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import TYPE_CHECKING, Callable, Optional
+
+import torch
+from torch import Tensor, nn
+
+from ..accelerate import suppress_torch_compile_output
+from ..config import EncoderConfig, HeadConfig, PretrainConfig, TrainingConfig
+from ..console import Console
+from ..core.euler_maruyama import euler_maruyama
+from ..core.observations import ObservationLikelihood, Observations
+from ..core.priors import Prior
+from ..core.sde import SDE
+from .constants import LOSS_EMA_DECAY
+from .data_parallel import all_reduce_mean_
+from .diffusion_path_sampler import sample_diffusion_paths
+from .evidence_lower_bound import compute_evidence_lower_bound
+from .exponential_moving_average import ExponentialMovingAverage
+from .state_space import StateSpace
+from .training_context import TrainingContext
+from .types import EvidenceLowerBoundResult
+from ..models.variational_sde_posterior import VariationalSDEPosterior
+
+if TYPE_CHECKING:
+    from ..accelerate import Accelerator
+
+
+@dataclass
+class TrainingState:
+    step: int
+    evidence_lower_bound_history: list[float]
+    best_evidence_lower_bound: float
+    model: VariationalSDEPosterior
+    exponential_moving_average: ExponentialMovingAverage
+
+
+@dataclass(frozen=True)
+class TrainStepResult:
+    elbo_result: EvidenceLowerBoundResult
+    grad_norm: Tensor  # 0-dim tensor on the training device (call .item() to sync)
+
+
+class VariationalInferenceTrainer:
+    def __init__(self, sde: SDE, observations: Observations, observation_likelihood: ObservationLikelihood,
+                 prior: Prior, time_horizon: float, config: TrainingConfig, encoder_config: EncoderConfig,
+                 head_config: HeadConfig, state_positive_dims: list[int], sde_param_positive_dims: list[int],
+                 device: torch.device | str = "cuda", mixed_precision: bool = True, console: Optional[Console] = None,
+                 param_names: Optional[list[str]] = None, accelerator: "Optional[Accelerator]" = None,
+                 sde_param_init_mean: Optional[Tensor] = None, seed: Optional[int] = None) -> None:
+        self.sde, self.param_names = sde, param_names
+        self.observation_likelihood, self.prior = observation_likelihood, prior
+        self.time_horizon, self.config = time_horizon, config
+        self.state_space = StateSpace(sde.state_dim, state_positive_dims)
+        self.sde_param_positive_dims = sde_param_positive_dims
+        self.console = console if console is not None else Console()
+        self.ctx = TrainingContext.create(
+            observations=observations, state_dim=sde.state_dim, sde_param_dim=sde.sde_param_dim, config=config,
+            encoder_config=encoder_config, head_config=head_config, sde_param_positive_dims=sde_param_positive_dims,
+            device=device, mixed_precision=mixed_precision, accelerator=accelerator,
+            sde_param_init_mean=sde_param_init_mean, seed=seed)
+        self.step = 0
+        self.evidence_lower_bound_history: list[float] = []
+        self.best_evidence_lower_bound = float("-inf")
+
+    @property
+    def device(self) -> torch.device:
+        return self.ctx.device
+
+    # ------------------------------------------------------------------------------ one step
+    def _train_step(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,
+                    path_noise: Optional[Tensor] = None) -> TrainStepResult:
+        ctx, cfg = self.ctx, self.config
+        ctx.grad_sync.zero_grad()
+        sde_parameters = model.sde_parameter_posterior.rsample(cfg.batch_size, eps=theta_eps)
+        with torch.autocast(device_type=ctx.device.type, dtype=cfg.amp_dtype.value, enabled=ctx.scaler.is_enabled()):
+            sample = sample_diffusion_paths(model.encoder, model.head, ctx.observations, sde_parameters, ctx.x0_buffer,
+                                            self.time_horizon, cfg.time_step, self.state_space, noise=path_noise)
+            result = compute_evidence_lower_bound(self.sde, ctx.observations, self.observation_likelihood, self.prior,
+                                                  model.sde_parameter_posterior, sde_parameters, sample, cfg.time_step)
+        ctx.scaler.scale(-result.evidence_lower_bound).backward()
+        ctx.grad_sync.all_reduce()          # mean over ranks of the (still loss-scaled) gradients
+        ctx.scaler.unscale_(ctx.optimizer)
+        grad_norm = nn.utils.clip_grad_norm_(ctx.model.parameters(), cfg.grad_clip_norm)
+        ctx.scaler.step(ctx.optimizer)
+        ctx.scaler.update()
+        return TrainStepResult(elbo_result=result, grad_norm=grad_norm)
+
+    # ----------------------------------------------------------------------------- main loop
+    def train(self, callback: Optional[Callable[[int, float], None]] = None, update_interval: int = 10) -> TrainingState:
+        ctx, n_iter = self.ctx, self.config.n_iterations
+        model = ctx.model
+        model.train()
+        if ctx.is_main:
+            self.console.config_panel(self.config)
+        if callback is not None:
+            update_interval = 1
+        pending: list[Tensor] = []
+        pending_first = 0
+        last: Optional[TrainStepResult] = None
+        loss_ema = 0.0
+
+        def flush(progress) -> None:
+            nonlocal pending, pending_first, loss_ema
+            if not pending:
+                return
+            vals = all_reduce_mean_(torch.stack(pending).float()) if ctx.is_distributed else torch.stack(pending)
+            for offset, elbo in enumerate(vals.tolist()):
+                step = pending_first + offset
+                loss_ema = -elbo if step == 0 else LOSS_EMA_DECAY * loss_ema + (1 - LOSS_EMA_DECAY) * (-elbo)
+                smoothed = loss_ema / (1 - LOSS_EMA_DECAY ** (step + 1))
+                self.evidence_lower_bound_history.append(elbo)
+                self.best_evidence_lower_bound = max(self.best_evidence_lower_bound, elbo)
+                if callback is not None and ctx.is_main:
+                    callback(step, elbo)
+            if ctx.is_main and last is not None:
+                progress.update(step=pending_first + len(pending) - 1, loss=smoothed, elbo=elbo,
+                                best_elbo=self.best_evidence_lower_bound, components=last.elbo_result.components,
+                                grad_norm=float(last.grad_norm), param_means=model.sde_parameter_posterior.expected_value)
+            pending_first += len(pending)
+            pending = []
+
+        with suppress_torch_compile_output(), self.console.training_progress(
+                n_iter, update_interval=update_interval, param_names=self.param_names) as progress:
+            for step in range(n_iter):
+                self.step = step
+                last = self._train_step(model)
+                ctx.ema.update()
+                pending.append(last.elbo_result.evidence_lower_bound.detach())
+                if len(pending) >= update_interval or step + 1 == n_iter:
+                    flush(progress)
+        return TrainingState(step=self.step, evidence_lower_bound_history=self.evidence_lower_bound_history,
+                             best_evidence_lower_bound=self.best_evidence_lower_bound, model=ctx.model,
+                             exponential_moving_average=ctx.ema)
+
+    # --------------------------------------------------------------------------- pre-training
+    def pretrain_sde_parameters(self, config: Optional[PretrainConfig] = None) -> Tensor:
+        """Fit a Gaussian over (log-)theta by matching simulated paths of the MODEL SDE to the
+        observations (reference: trainer.py:208-259). Returns the best mean found."""
+        cfg = config or PretrainConfig()
+        d, dev = self.sde.sde_param_dim, self.device
+        pos = list(self.sde_param_positive_dims)
+        free = [i for i in range(d) if i not in pos]
+        mu = nn.Parameter(torch.zeros(d, device=dev))
+        if free:
+            mu.data[free] = cfg.init_scale * torch.randn(len(free), device=dev)
+        log_sigma = nn.Parameter(torch.zeros(d, device=dev))
+        opt = torch.optim.Adam([mu, log_sigma], lr=cfg.learning_rate)
+        best_mu, best_mse = mu.detach().clone(), float("inf")
+        obs = self.ctx.observations
+        obs_idx = (obs.times / self.config.time_step).round().long()
+        with self.console.pretrain_progress(cfg.n_iterations) as progress:
+            for step in range(cfg.n_iterations):
+                opt.zero_grad()
+                sigma = log_sigma.exp()
+                log_theta = mu + sigma * torch.randn(cfg.batch_size, d, device=dev)
+                theta = log_theta.clone()
+                if pos:
+                    theta[:, pos] = log_theta[:, pos].exp()
+                x0 = obs.values[0].unsqueeze(0).expand(cfg.batch_size, -1)
+                paths = euler_maruyama(self.sde, x0, theta, self.time_horizon, self.config.time_step,
+                                       self.state_space.positive_dims)
+                mse = ((paths[:, obs_idx] - obs.values) ** 2).mean()
+                finite = bool(torch.isfinite(mse))
+                value = mse.item()
+                if finite and value < best_mse:
+                    best_mu, best_mse = mu.detach().clone(), value
+                if finite:
+                    mse.backward()
+                    nn.utils.clip_grad_norm_([mu, log_sigma], 1.0)
+                    opt.step()
+                progress.update(step, value, best_mse, sigma.median().item())
+        return best_mu
+
+    def cleanup(self) -> None:
+        self.ctx.cleanup()

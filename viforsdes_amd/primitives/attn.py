@@ -1,0 +1,54 @@
+"""Multi-head self attention of the SiT encoder (reference: primitives/attn.py:26-117):
+QK RMS-norm (frozen unit weights, fp32), rotary embedding, optional value-residual mixing with the
+first block's values, full (non-causal) SDPA, a sigmoid output gate shared across heads."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from .embeddings import RotarySpec, apply_rope_1d
+from .initializer import init_linear_, zero_linear_
+from .norm import RMS
+
+
+class Attention(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int, *, qk_norm_eps: float = 1e-6, qk_norm: bool = True,
+                 bias: bool = True, gate: bool = True, residual_v: bool = False) -> None:
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.qkv_proj = init_linear_(nn.Linear(embed_dim, 3 * embed_dim, bias=bias))
+        self.out_proj = init_linear_(nn.Linear(embed_dim, embed_dim, bias=bias))
+        self._use_gate = gate
+        if gate:
+            self.gate_proj = zero_linear_(nn.Linear(embed_dim, self.head_dim, bias=True))
+        self._use_residual_v = residual_v
+        if residual_v:
+            self.v_residual_lambda = nn.Parameter(torch.tensor(0.5))
+        make_norm = (lambda: RMS(self.head_dim, eps=qk_norm_eps, requires_grad=False)) if qk_norm else nn.Identity
+        self.q_norm, self.k_norm = make_norm(), make_norm()
+
+    def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,
+                return_value: bool = False):
+        B, N, _ = hidden_states.shape
+        q, k, v = self.qkv_proj(hidden_states).view(B, N, 3, self.num_heads, self.head_dim).unbind(dim=2)
+        q, k = self.q_norm(q), self.k_norm(k)
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)  # [B, h, N, d]
+        if rotary is not None:
+            q, k = apply_rope_1d(q, rotary.rotary_freqs), apply_rope_1d(k, rotary.rotary_freqs)
+        if self._use_residual_v and v0 is not None:
+            if v0.shape != v.shape:
+                raise ValueError(f"v0 shape {tuple(v0.shape)} must match value heads {tuple(v.shape)}")
+            lam = self.v_residual_lambda
+            v = lam * v + (1.0 - lam) * v0
+        out = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
+        if self._use_gate:
+            out = out * torch.sigmoid(self.gate_proj(hidden_states)).unsqueeze(1)
+        out = self.out_proj(out.transpose(1, 2).reshape(B, N, self.embed_dim))
+        if self._use_residual_v or return_value:
+            return out, v
+        return out

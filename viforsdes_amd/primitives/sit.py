@@ -1,0 +1,94 @@
+"""SiT transformer trunk of the observation encoder (reference: primitives/sit.py:18-186).
+
+Per block: conditioning -> (scale, shift, gate) for the attention and MLP branches; each branch is
+``x + gate * f((1 + scale) * LayerNorm(x) + shift)`` with a non-affine LayerNorm.  Blocks >= 1 mix
+their values with block 0's values (value residual).
+
+The conditioning tensor may be ``[B, cond]`` (one vector per batch row, broadcast over tokens) or
+``[B, N, cond]``.  The reference always materialises the per-token form (models/encoder.py:85-86)
+and runs the ``cond -> 6*dim`` linear per token; per-row evaluation is the same arithmetic N times
+cheaper."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+from torch import Tensor, nn
+
+from .attn import Attention
+from .cond import CondBranch, CondModulator
+from .embeddings import RotarySpec
+from .initializer import init_linear_
+from .mlp import SwiGLU
+from .norm import LayerNormConfig
+
+
+@dataclass(frozen=True)
+class SiTConfig:
+    in_dim: int
+    hidden_dim: int
+    out_dim: int
+    cond_dim: int
+    num_heads: int
+    depth: int
+    mlp_hidden_dim: int
+    bias: bool = True
+    attn_gate: bool = True
+    attn_residual_v: bool = True
+    use_qk_norm: bool = True
+    qk_norm_eps: float = 1e-6
+    attn_norm: LayerNormConfig = LayerNormConfig(affine=False)
+    mlp_norm: LayerNormConfig = LayerNormConfig(affine=False)
+
+
+class SiTBlock(nn.Module):
+    def __init__(self, *, dim: int, num_heads: int, mlp_hidden_dim: int, cond_dim: int, bias: bool = True,
+                 attn_gate: bool = True, attn_residual_v: bool = False, use_qk_norm: bool = True,
+                 qk_norm_eps: float = 1e-6, attn_norm: LayerNormConfig = LayerNormConfig(affine=False),
+                 mlp_norm: LayerNormConfig = LayerNormConfig(affine=False)) -> None:
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self._cond_modulator = CondModulator(cond_dim=cond_dim, hidden_dim=dim, branches=2)
+        self.self_attn = Attention(dim, num_heads, bias=bias, gate=attn_gate, qk_norm=use_qk_norm,
+                                   qk_norm_eps=qk_norm_eps, residual_v=attn_residual_v)
+        self.mlp = SwiGLU(dim, mlp_hidden_dim, bias=bias)
+        self.attn_norm = attn_norm.build(dim=dim)
+        self.mlp_norm = mlp_norm.build(dim=dim)
+
+    def cond_params(self, *, cond: Tensor) -> tuple[CondBranch, ...]:
+        return self._cond_modulator(cond=cond)
+
+    def forward(self, hidden_states: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None,
+                v0: Optional[Tensor] = None) -> tuple[Tensor, Tensor]:
+        """Returns ``(hidden_states, value_heads)``; the caller keeps block 0's values as ``v0``."""
+        if cond.ndim == 2:
+            cond = cond.unsqueeze(1)  # broadcast over the token axis
+        attn_mod, mlp_mod = self.cond_params(cond=cond)
+        attn_out, values = self.self_attn(attn_mod.affine(self.attn_norm(hidden_states)), rotary=rotary, v0=v0,
+                                          return_value=True)
+        hidden_states = hidden_states + attn_mod.gate(attn_out)
+        mlp_out = self.mlp(mlp_mod.affine(self.mlp_norm(hidden_states)))
+        return hidden_states + mlp_mod.gate(mlp_out), values
+
+
+class SiT(nn.Module):
+    def __init__(self, config: SiTConfig) -> None:
+        super().__init__()
+        self.config = config
+        self.blocks = nn.ModuleList([
+            SiTBlock(dim=config.hidden_dim, num_heads=config.num_heads, mlp_hidden_dim=config.mlp_hidden_dim,
+                     cond_dim=config.cond_dim, bias=config.bias, attn_gate=config.attn_gate,
+                     attn_residual_v=config.attn_residual_v and idx > 0, use_qk_norm=config.use_qk_norm,
+                     qk_norm_eps=config.qk_norm_eps, attn_norm=config.attn_norm, mlp_norm=config.mlp_norm)
+            for idx in range(config.depth)])
+        self.input_proj = init_linear_(nn.Linear(config.in_dim, config.hidden_dim, bias=config.bias))
+        self.output_proj = init_linear_(nn.Linear(config.hidden_dim, config.out_dim, bias=config.bias))
+
+    def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None) -> Tensor:
+        tokens = self.input_proj(x)
+        v0: Optional[Tensor] = None
+        for block in self.blocks:
+            tokens, values = block(tokens, cond=cond, rotary=rotary, v0=v0)
+            if v0 is None and self.config.attn_residual_v:
+                v0 = values
+        return self.output_proj(tokens)
