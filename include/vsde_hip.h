@@ -13,9 +13,6 @@
  *   vsde_elbo_path_terms     the B*T-sized part of compute_evidence_lower_bound
  *   vsde_elbo_path_terms_bwd   src/variational_sde/inference/evidence_lower_bound.py:42-50,77-83 and
  *                              DiffusionPathSample.log_jacobian, inference/types.py:23-24
- *   vsde_elbo_aux_terms      observation / prior / posterior log-densities,
- *                            evidence_lower_bound.py:52-61 (core/observations.py:52-74,
- *                            core/priors.py:46-60, models/sde_parameter_posterior.py:48-59)
  *
  * Weight tensors use torch.nn.GRU's native layout exactly as they are handed to
  * _SDEFunction.apply (kernels/autograd.py:46-56): W_ih_l0[3H][S+C+P] with input order
@@ -145,6 +142,12 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
                              double time_step, const float *g_sde, const float *g_gen,
                              const float *g_jac, float *g_z, float *g_x, float *g_means,
                              float *g_chol, float *g_drift, float *g_diffusion, void *stream);
+
+/* Measurement aid (no reference counterpart): when enabled, the launchers bracket the serial
+ * time-stepping kernel with hipEvents on the launch stream.  which: 0 = forward (training
+ * variant), 1 = backward.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */
+int vsde_profile_enable(int on);
+int vsde_profile_elapsed_ms(int which, float *ms);
 
 #ifdef __cplusplus
 }

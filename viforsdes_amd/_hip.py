@@ -51,6 +51,7 @@ EXPORTS = (
     "vsde_head_forward_workspace_bytes", "vsde_head_forward",
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
     "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd",
+    "vsde_profile_enable", "vsde_profile_elapsed_ms",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -251,3 +252,16 @@ def elbo_path_terms_bwd(z, x, means, chol, drift, diffusion, positive_dims, time
     if rc != 0:
         _raise(rc)
     return tuple(outs)
+
+
+def profile_enable(on: bool) -> None:
+    load().vsde_profile_enable(ctypes.c_int(1 if on else 0))
+
+
+def profile_elapsed_ms(which: int) -> float:
+    """Duration of the last timed serial kernel (0 = forward/train, 1 = backward), HIP events."""
+    ms = ctypes.c_float(0.0)
+    rc = load().vsde_profile_elapsed_ms(ctypes.c_int(which), ctypes.byref(ms))
+    if rc != 0:
+        _raise(rc)
+    return float(ms.value)

@@ -464,6 +464,21 @@ __global__ void __launch_bounds__(512) head_bwd_kernel(BwdParams p) {
 }
 
 // ------------------------------------------------------------------------ host launchers
+// Optional per-kernel timing with HIP events on the launch stream (bench.py roofline block).
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[2][2];
+static bool g_prof_init = false;
+static bool g_prof_valid[2] = {false, false};
+static void prof_mark(int which, int edge, hipStream_t s) {
+    if (!g_prof_on) return;
+    if (!g_prof_init) {
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) (void)hipEventCreate(&g_prof_ev[i][j]);
+        g_prof_init = true;
+    }
+    (void)hipEventRecord(g_prof_ev[which][edge], s);
+    if (edge == 1) g_prof_valid[which] = true;
+}
+
 static int check_dims(const vsde_head_dims *d) {
     VSDE_CHECK_ARG(d != nullptr, VSDE_E_BADARG, "dims is NULL");
     VSDE_CHECK_ARG(d->B > 0 && d->T > 0 && d->S > 0 && d->P >= 0 && d->C > 0 && d->H > 0, VSDE_E_BADARG,
@@ -510,7 +525,9 @@ template <int L>
 static int launch_fwd_L(const FwdParams &p, bool save, int grid, int block, size_t lds, hipStream_t s) {
     if (save) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_fwd_kernel<L, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_mark(0, 0, s);
         hipLaunchKernelGGL((head_fwd_kernel<L, true>), dim3(grid), dim3(block), lds, s, p);
+        prof_mark(0, 1, s);
     } else {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_fwd_kernel<L, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((head_fwd_kernel<L, false>), dim3(grid), dim3(block), lds, s, p);
@@ -522,7 +539,9 @@ static int launch_fwd_L(const FwdParams &p, bool save, int grid, int block, size
 template <int L>
 static int launch_bwd_L(const BwdParams &p, int grid, int block, size_t lds, hipStream_t s) {
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_mark(1, 0, s);
     hipLaunchKernelGGL((head_bwd_kernel<L>), dim3(grid), dim3(block), lds, s, p);
+    prof_mark(1, 1, s);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -530,6 +549,20 @@ static int launch_bwd_L(const BwdParams &p, int grid, int block, size_t lds, hip
 }  // namespace vsde
 
 using namespace vsde;
+
+extern "C" int vsde_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_valid[0] = g_prof_valid[1] = false;
+    return 0;
+}
+
+extern "C" int vsde_profile_elapsed_ms(int which, float *ms) {
+    VSDE_CHECK_ARG(which >= 0 && which < 2 && ms, VSDE_E_BADARG, "bad profile query");
+    VSDE_CHECK_ARG(g_prof_valid[which], VSDE_E_BADARG, "no timed launch of kernel %d recorded", which);
+    VSDE_CHECK_HIP(hipEventSynchronize(g_prof_ev[which][1]));
+    VSDE_CHECK_HIP(hipEventElapsedTime(ms, g_prof_ev[which][0], g_prof_ev[which][1]));
+    return 0;
+}
 
 extern "C" size_t vsde_head_forward_workspace_bytes(const vsde_head_dims *d) {
     if (check_dims(d) != 0) return 0;
