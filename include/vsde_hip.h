@@ -147,6 +147,8 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
  * time-stepping kernel with hipEvents on the launch stream.  which: 0 = forward (training
  * variant), 1 = backward.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */
 int vsde_profile_enable(int on);
+/* Test hook: route L <= 2 through the LDS-resident one-wave-per-path kernels that serve L = 3, 4. */
+int vsde_debug_force_v1(int on);
 int vsde_profile_elapsed_ms(int which, float *ms);
 
 #ifdef __cplusplus

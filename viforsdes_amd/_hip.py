@@ -51,7 +51,7 @@ EXPORTS = (
     "vsde_head_forward_workspace_bytes", "vsde_head_forward",
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
     "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd",
-    "vsde_profile_enable", "vsde_profile_elapsed_ms",
+    "vsde_profile_enable", "vsde_profile_elapsed_ms", "vsde_debug_force_v1",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -265,3 +265,8 @@ def profile_elapsed_ms(which: int) -> float:
     if rc != 0:
         _raise(rc)
     return float(ms.value)
+
+
+def debug_force_v1(on: bool) -> None:
+    """Test hook: run 1-2 layer heads through the kernels that normally serve 3-4 layers."""
+    load().vsde_debug_force_v1(ctypes.c_int(1 if on else 0))

@@ -65,8 +65,11 @@ __device__ __forceinline__ float rowview_load(const RowView &v, int64_t off, int
 }
 
 // fast transcendental forms (v_exp_f32 / v_rcp_f32); abs error ~1e-7 on outputs in [-1, 1]
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// NOTE: __frcp_rn expands to a 12-instruction correctly-rounded division; the raw v_rcp_f32 (1 ulp) is what we want.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2(2.8853900817779268f * x)); }
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wavefront retire in order; this only stops the compiler from

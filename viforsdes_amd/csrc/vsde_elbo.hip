@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) elbo_path_terms_bwd_kernel(ElboParams p) 
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             gz[i] -= gg * v[i];
-            if ((p.pos_mask >> i) & 1u) gz[i] += gj * __frcp_rn(1.0f + __expf(p.z[o1 + S + i]));  // d logsigmoid = sigmoid(-z)
+            if ((p.pos_mask >> i) & 1u) gz[i] += gj * fast_rcp(1.0f + __expf(p.z[o1 + S + i]));  // d logsigmoid = sigmoid(-z)
         }
     }
     const int64_t o = ((int64_t)b * (p.T + 1) + tau) * S;

@@ -21,6 +21,14 @@
 
 namespace vsde {
 
+#ifdef VSDE_TRACE
+// debug build only: cycle stamps of one wave for one time step (tools/trace_fwd.py)
+__device__ long long g_trace[64];
+#define VSDE_TP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && c == 1 && tt == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_trace[(k)] = clock64(); } } while (0)
+#else
+#define VSDE_TP(k) do { } while (0)
+#endif
+
 // ----------------------------------------------------------------------------- packing
 // Matrix order q: 0 = W_hh_l0, 2l-1 = W_ih_l(l), 2l = W_hh_l(l)  (l >= 1).
 struct PackParams {
@@ -97,6 +105,7 @@ struct FwdParams {
     const float *x0, *theta, *eps;
     const float *G;  // [B*T][3H] = ctx . W_c^T + b_ih_l0
     const float *W_ih0, *b_hh0, *b_ih_st, *b_hh_st, *out_b;
+    const float *W_hh0, *W_ih_st, *W_hh_st, *out_W;  // native tensors (v2 kernels load them straight into VGPRs)
     const float4 *packF, *packO;
     float dt, sqdt, diag_min;
     float *paths, *means, *chol, *chol_raw, *acts;
@@ -104,6 +113,7 @@ struct FwdParams {
 
 constexpr int kScratchPerWave = 3 * 64;  // hbuf, obuf, ebuf
 constexpr int kMaxSReg = 8;              // state rows of W_ih_l0 kept in registers
+constexpr int kMaxSRegV2 = 4;            // same for the register-heavy v2 kernels
 
 __host__ __device__ inline int fwd_lds_matrices(int L) { int n = 2 * L - 1; return n < 3 ? n : 3; }
 
@@ -290,6 +300,7 @@ struct BwdParams {
     int B, T, S, P, C, H, NO, ntril, wpb;
     const float *g_paths, *g_means, *g_chol, *theta, *eps, *chol_raw, *acts;
     const float *W_ih0, *out_W;
+    const float *W_hh0, *W_ih_st, *W_hh_st;  // native tensors for the register-resident v2 kernel
     const float4 *packB;
     float dt, sqdt, diag_min;
     float *D4;   // [B*T][L][4H]  (dr_pre, du_pre, dn_pre, dc_n)
@@ -463,8 +474,571 @@ __global__ void __launch_bounds__(512) head_bwd_kernel(BwdParams p) {
     }
 }
 
+// =========================================================================================
+// v2 kernels (L <= 2): four wavefronts per sample path, recurrent weights resident in VGPRs.
+//
+// Thread (wave w, lane) owns hidden unit j = 16 w + (lane >> 2) together with the three other
+// lanes of its quad; lane kq = lane & 3 of the quad multiplies the k-slice [16 kq, 16 kq + 16) of
+// every dot product and the quad sums with two DPP quad_perm adds.  Each lane therefore keeps
+// 3 x 16 floats per recurrent matrix (W_hh_l0, W_ih_l1, W_hh_l1) + 16 floats of the emission
+// rows = 160 VGPRs of weights and the time loop issues NO weight loads at all; the hidden state
+// crosses waves through a 256-byte LDS buffer and one workgroup barrier per GRU layer.
+// 512 paths -> 2048 waves = 2 per SIMD on all 256 CUs (the v1 kernel put one wave on half of
+// the SIMDs and was bound by the latency of 224 dependent ds_read_b128 per step).
+// =========================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_quad<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_quad<0x4E>(v);  // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float quad_bcast(float v, int q) {
+    float a = dpp_quad<0x00>(v), b = dpp_quad<0x55>(v), c = dpp_quad<0xAA>(v), d = dpp_quad<0xFF>(v);
+    return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
+}
+
+// LDS carve of the v2 forward kernel (floats); CH = time steps staged per chunk.
+constexpr int kWoStride = 68;
+struct FwdV2Lds {
+    int hb, obuf, wx, wo, gbuf, ebuf, s_paths, s_means, s_chol, s_raw, s_acts, total;
+};
+__host__ __device__ inline FwdV2Lds fwd_v2_lds(int H, int S, int L, int CH, bool save) {
+    const int ntril = S * (S + 1) / 2;
+    FwdV2Lds o; int off = 0;
+    auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
+    o.hb = take(L * 64); o.obuf = take(64); o.wx = take(S * 3 * 64);
+    o.wo = take((S + ntril) * kWoStride);  // emission rows, row stride 68 floats: conflict-free ds_read_b128
+    o.gbuf = take(2 * CH * 3 * H); o.ebuf = take(2 * CH * S);
+    o.s_paths = take(CH * S); o.s_means = take(CH * S); o.s_chol = take(CH * S * S);
+    o.s_raw = take(save ? CH * ntril : 0); o.s_acts = take(save ? CH * L * 5 * H : 0);
+    o.total = off;
+    return o;
+}
+
+// All global traffic of the v2 kernels happens at chunk boundaries as wide coalesced bursts
+// (the record layouts [b][t][...] are contiguous over a run of time steps); the per-step loop
+// only touches LDS, so no s_waitcnt vmcnt ever sits on the recurrence's critical path.
+// MODE: 1, 2 = state_dim known at compile time (z_t kept as wave-uniform registers, no LDS on the
+// emission -> Euler update -> next-step-input path); 3 = generic state_dim with NO <= 16; 4 = generic.
+template <int L, bool SAVE, int CH, int MODE>
+__global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
+    constexpr bool SMALL = MODE <= 3;
+    constexpr int SS = MODE <= 2 ? MODE : 0;   // compile-time state_dim (0 = runtime)
+    constexpr int SSN = SS > 0 ? SS : 1;
+    static_assert(L >= 1 && L <= 2, "v2 keeps at most three 64x192 matrices in registers");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, u = lane >> 2, kq = lane & 3;
+    const int j = 16 * wave + u, k0 = 16 * kq;
+    const int b = blockIdx.x;
+    const int H = p.H, S = SS > 0 ? SS : p.S, T = p.T, NO = p.NO;
+    const int I = S + p.C + p.P, G3 = 3 * H;
+    // SMALL (NO <= 16): every wave computes all emission rows (row = quad index u) redundantly, so the
+    // Euler update needs no third workgroup barrier; otherwise row r = j is owned by one quad of the block.
+    const int orow = SMALL ? u : j;
+    const bool unit_ok = j < H, row_ok = orow < NO;
+    const FwdV2Lds lay = fwd_v2_lds(H, S, L, CH, SAVE);
+    float *hb = smem + lay.hb, *obuf = smem + lay.obuf, *wxl = smem + lay.wx, *wol = smem + lay.wo;
+    float *gbuf = smem + lay.gbuf, *ebuf = smem + lay.ebuf;
+    float *s_paths = smem + lay.s_paths, *s_means = smem + lay.s_means, *s_chol = smem + lay.s_chol;
+    float *s_raw = smem + lay.s_raw, *s_acts = smem + lay.s_acts;
+
+    // ---- register-resident weights ---------------------------------------------------------
+    float wh[L][3][16], wi[L][3][16];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = unit_ok && (k0 + i) < H;
+            wh[0][g][i] = ok ? p.W_hh0[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+            wi[0][g][i] = 0.f;
+            if (L > 1) {
+                wh[L - 1][g][i] = ok ? p.W_hh_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+                wi[L - 1][g][i] = ok ? p.W_ih_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+            }
+        }
+    for (int e = tid; e < NO * 64; e += 256) {  // emission rows -> LDS (kept out of the VGPR budget)
+        int kk = e & 63, r = e >> 6;
+        wol[r * kWoStride + kk] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
+    }
+    const float *wop = wol + (row_ok ? orow : 0) * kWoStride + k0;
+    float bhh[L][3], bih[L][3], gth[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bhh[0][g] = unit_ok ? p.b_hh0[g * H + j] : 0.f;
+        bih[0][g] = 0.f;
+        if (L > 1) {
+            bhh[L - 1][g] = unit_ok ? p.b_hh_st[g * H + j] : 0.f;
+            bih[L - 1][g] = unit_ok ? p.b_ih_st[g * H + j] : 0.f;
+        }
+        float acc = 0.f;  // hoisted theta projection (forward.py:157-175)
+        if (unit_ok)
+            for (int q = 0; q < p.P; ++q) acc = fmaf(p.theta[(int64_t)b * p.P + q], p.W_ih0[(int64_t)(g * H + j) * I + S + p.C + q], acc);
+        gth[g] = acc;
+    }
+    for (int e = tid; e < S * 3 * 64; e += 256) {  // state rows of W_ih_l0: wxl[i][g][unit]
+        int un = e & 63, g = (e >> 6) % 3, i = e / 192;
+        wxl[e] = un < H ? p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
+    }
+    float wxr[SSN][3], xu[SSN];  // SS > 0: state rows of W_ih_l0 and z_t as wave-uniform values
+#pragma unroll
+    for (int i = 0; i < SSN; ++i) {
+        xu[i] = (SS > 0) ? p.x0[(int64_t)b * S + i] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wxr[i][g] = (SS > 0 && unit_ok) ? p.W_ih0[(int64_t)(g * H + j) * I + i] : 0.f;
+    }
+    const float outb = row_ok ? p.out_b[orow] : 0.f;
+    int trow = 0, tcol = 0;
+    if (orow >= S && orow < NO) {
+        int q = orow - S, r = 0;
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        trow = r; tcol = q - r * (r + 1) / 2;
+    }
+    const bool is_tril = orow >= S && orow < NO;
+    const bool is_diag = is_tril && trow == tcol;
+
+    float h[L], cc[L][3];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        h[l] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) cc[l][g] = bhh[l][g];
+    }
+    float xreg = lane < S ? p.x0[(int64_t)b * S + lane] : 0.f;  // every wave keeps z_t[i] on its lane i
+    if (wave == 0 && lane < S) p.paths[(int64_t)b * (T + 1) * S + lane] = xreg;
+
+    // ---- chunked staging of the projected context record G[b, t, 3H] and eps ---------------
+    const float *Gb = p.G + (int64_t)b * T * G3;
+    const float *eb = p.eps + (int64_t)b * T * S;
+    constexpr int PF = (CH * 3 * 64 + 255) / 256;  // floats of G per thread and chunk (H <= 64)
+    float pf[PF], pe = 0.f;
+    auto issue_loads = [&](int t0) {
+        const int nG = min(CH, T - t0) * G3, nE = min(CH, T - t0) * S;
+#pragma unroll
+        for (int r = 0; r < PF; ++r) { int e = tid + 256 * r; pf[r] = (t0 < T && e < nG) ? Gb[(int64_t)t0 * G3 + e] : 0.f; }
+        pe = (t0 < T && tid < nE) ? eb[(int64_t)t0 * S + tid] : 0.f;
+    };
+    auto commit_loads = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) { int e = tid + 256 * r; if (e < CH * G3) gbuf[buf * CH * G3 + e] = pf[r]; }
+        if (tid < CH * S) ebuf[buf * CH * S + tid] = pe;
+    };
+    for (int e = tid; e < CH * S * S; e += 256) s_chol[e] = 0.f;
+    issue_loads(0);
+    commit_loads(0);
+    __syncthreads();
+
+    const int nchunks = (T + CH - 1) / CH;
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * CH, nsteps = min(CH, T - t0), cur = c & 1;
+        const float *gch = gbuf + cur * CH * G3, *ech = ebuf + cur * CH * S;
+        float gcur[3];
+        gcur[0] = unit_ok ? gch[j] : 0.f; gcur[1] = unit_ok ? gch[H + j] : 0.f; gcur[2] = unit_ok ? gch[2 * H + j] : 0.f;
+        for (int tt = 0; tt < nsteps; ++tt) {
+            VSDE_TP(0);
+            float a[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a[g] = gcur[g] + gth[g];
+            {   // prefetch the next step's projected record from LDS (off the critical path)
+                const float *gr = gch + min(tt + 1, nsteps - 1) * G3 + j;
+                gcur[0] = unit_ok ? gr[0] : 0.f; gcur[1] = unit_ok ? gr[H] : 0.f; gcur[2] = unit_ok ? gr[2 * H] : 0.f;
+            }
+            if (SS > 0) {
+#pragma unroll
+                for (int i = 0; i < SSN; ++i)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) a[g] = fmaf(xu[i], wxr[i][g], a[g]);
+            } else {
+                for (int i = 0; i < S; ++i) {
+                    const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xreg), i));
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) a[g] = fmaf(xi, wxl[(i * 3 + g) * 64 + j], a[g]);
+                }
+            }
+            VSDE_TP(1);
+            float o = 0.f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                float r = fast_sigmoid(a[0] + cc[l][0]);
+                float uu = fast_sigmoid(a[1] + cc[l][1]);
+                float n = fast_tanh(a[2] + r * cc[l][2]);
+                float hn = (1.0f - uu) * n + uu * h[l];
+                if (kq == 0) hb[l * 64 + j] = hn;
+                if (SAVE && unit_ok) {  // quad lane kq stages slot kq (h, r, z, n); lane 0 also n_hh
+                    float *A = s_acts + ((tt * L + l) * 5) * H + j;
+                    float v = kq == 0 ? hn : (kq == 1 ? r : (kq == 2 ? uu : n));
+                    A[kq * H] = v;
+                    if (kq == 0) A[4 * H] = cc[l][2];
+                }
+                h[l] = hn;
+                VSDE_TP(2 + 4 * l);
+                __syncthreads();
+                VSDE_TP(3 + 4 * l);
+                float4 hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = *(const float4 *)&hb[l * 64 + k0 + 4 * q];
+                const float *hs = (const float *)hv;
+                // v_pk_fma_f32: two fp32 FMAs per issue slot (this loop is VALU-issue bound)
+                // six (four) independent accumulator chains: even/odd k, summed at the end
+                f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+                VSDE_TP(4 + 4 * l);
+                if (l < L - 1) {
+                    constexpr int ln = (L > 1) ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 hh = {hs[i], hs[i]}, hg = {hs[i + 1], hs[i + 1]};
+                        p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
+                        p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wi[ln][0][i]}, p1);
+                        p2 = __builtin_elementwise_fma(hh, (f32x2){wi[ln][1][i], wi[ln][2][i]}, p2);
+                        q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
+                        q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wi[ln][0][i + 1]}, q1);
+                        q2 = __builtin_elementwise_fma(hg, (f32x2){wi[ln][1][i + 1], wi[ln][2][i + 1]}, q2);
+                    }
+                    p0 += q0; p1 += q1; p2 += q2;
+                    a[0] = bih[ln][0] + quad_sum(p1.y); a[1] = bih[ln][1] + quad_sum(p2.x); a[2] = bih[ln][2] + quad_sum(p2.y);
+                } else {
+                    float4 wv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(wop + 4 * q);
+                    const float *wo = (const float *)wv;
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 hh = {hs[i], hs[i]}, hg = {hs[i + 1], hs[i + 1]};
+                        p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
+                        p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wo[i]}, p1);
+                        q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
+                        q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wo[i + 1]}, q1);
+                    }
+                    if (!row_ok) { p1.y = 0.f; q1.y = 0.f; }
+                    p0 += q0; p1 += q1;
+                    o = outb + quad_sum(p1.y);
+                }
+                cc[l][0] = bhh[l][0] + quad_sum(p0.x); cc[l][1] = bhh[l][1] + quad_sum(p0.y); cc[l][2] = bhh[l][2] + quad_sum(p1.x);
+                VSDE_TP(5 + 4 * l);
+            }
+            // ---- emission (forward.py:314-375)
+            VSDE_TP(10);
+            if (SMALL) {
+                // o of row r sits on lanes 4r..4r+3 of EVERY wave: no LDS exchange, no barrier
+                const float oc = is_diag ? fmaxf(o, p.diag_min) : o;
+                if (wave == 0 && kq == 0 && is_tril) {
+                    s_chol[tt * S * S + trow * S + tcol] = oc;  // strict upper triangle stays 0 (zeroed once)
+                    if (SAVE) s_raw[tt * p.ntril + (orow - S)] = o;
+                }
+                if (SS > 0) {
+                    float ev[SSN];
+#pragma unroll
+                    for (int i = 0; i < SSN; ++i) ev[i] = ech[tt * SS + i];
+#pragma unroll
+                    for (int i = 0; i < SSN; ++i) {
+                        const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * i));
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q = 0; q <= i; ++q)
+                            acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * (SS + i * (i + 1) / 2 + q))), ev[q], acc);
+                        xu[i] = xu[i] + mu * p.dt + acc * p.sqdt;
+                        if (tid == 0) { s_means[tt * SS + i] = mu; s_paths[tt * SS + i] = xu[i]; }
+                    }
+                } else
+                for (int i = 0; i < S; ++i) {
+                    const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * i));
+                    float acc = 0.f;
+                    const int base = S + i * (i + 1) / 2;
+                    for (int q = 0; q <= i; ++q)
+                        acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * (base + q))), ech[tt * S + q], acc);
+                    if (lane == i) {
+                        xreg = xreg + mu * p.dt + acc * p.sqdt;
+                        if (wave == 0) { s_means[tt * S + i] = mu; s_paths[tt * S + i] = xreg; }
+                    }
+                }
+                VSDE_TP(11);
+            } else {
+                if (kq == 0 && row_ok) {
+                    obuf[j] = is_diag ? fmaxf(o, p.diag_min) : o;
+                    if (SAVE && j >= S) s_raw[tt * p.ntril + (j - S)] = o;
+                }
+                __syncthreads();
+                VSDE_TP(11);
+                if (lane < S) {
+                    float acc = 0.f;
+                    const int base = S + lane * (lane + 1) / 2;
+                    for (int q = 0; q <= lane; ++q) acc = fmaf(obuf[base + q], ech[tt * S + q], acc);
+                    const float mu = obuf[lane];
+                    xreg = xreg + mu * p.dt + acc * p.sqdt;
+                    if (wave == 0) { s_means[tt * S + lane] = mu; s_paths[tt * S + lane] = xreg; }
+                }
+                if (wave == 1) {
+                    for (int e = lane; e < S * S; e += 64) {
+                        int rr = e / S, cl = e - rr * S;
+                        s_chol[tt * S * S + e] = cl <= rr ? obuf[S + rr * (rr + 1) / 2 + cl] : 0.f;
+                    }
+                }
+            }
+            VSDE_TP(12);
+        }
+        __syncthreads();                 // chunk complete: staging buffers final
+        issue_loads(t0 + CH);            // next chunk's records; their latency hides behind the flush below
+        // ---- flush the staged outputs (contiguous runs in the [b][t][...] layouts)
+        {
+            const int64_t bt = (int64_t)b * T + t0;
+#pragma unroll 1
+            for (int e = tid; e < nsteps * S; e += 256) {
+                p.means[bt * S + e] = s_means[e];
+                p.paths[(bt + b + 1) * S + e] = s_paths[e];
+            }
+#pragma unroll 1
+            for (int e = tid; e < nsteps * S * S; e += 256) p.chol[bt * S * S + e] = s_chol[e];
+            if (SAVE) {
+#pragma unroll 1
+                for (int e = tid; e < nsteps * p.ntril; e += 256) p.chol_raw[bt * p.ntril + e] = s_raw[e];
+                const int nA = nsteps * L * 5 * H;
+                float *dst = p.acts + bt * L * 5 * H;
+                if ((H & 3) == 0) {
+#pragma unroll 1
+                    for (int e = tid; e < nA / 4; e += 256) ((float4 *)dst)[e] = ((const float4 *)s_acts)[e];
+                } else {
+#pragma unroll 1
+                    for (int e = tid; e < nA; e += 256) dst[e] = s_acts[e];
+                }
+            }
+        }
+        commit_loads(cur ^ 1);
+        __syncthreads();                 // staging reusable, gbuf[next] visible
+    }
+}
+
+// ---------------------------------------------------------------------------- backward v2
+// Same decomposition as head_fwd_v2_kernel for the reverse-time sweep (L <= 2, NO <= 16):
+// quad (wave w, u) owns unit i = 16 w + u as an OUTPUT of the transposed products
+//   d h^l_{t-1}[i] += sum_{g,j} W_hh^l[gH+j][i] ph_g[j],   d in^l[i] = sum_{g,j} W_ih^l[gH+j][i] pi_g[j]
+// and lane kq multiplies the j-slice [16 kq, 16 kq + 16) with weights held in VGPRs.  The gate
+// gradients cross waves through the staged D4 record itself (it is both the exchange buffer and
+// the kernel's output), one workgroup barrier per layer.  All global traffic (saved activations,
+// upstream gradients in; D4/DO out) is staged per chunk of CH steps as contiguous bursts.
+struct BwdV2Lds {
+    int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, total;
+};
+__host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH) {
+    const int ntril = S * (S + 1) / 2, NO = S + ntril;
+    BwdV2Lds o; int off = 0;
+    auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
+    o.acts = take((CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
+    o.gp = take(CH * S); o.gm = take(CH * S); o.gl = take(CH * S * S); o.raw = take(CH * ntril); o.eps = take(CH * S);
+    o.owl = take(NO * 64); o.dxp = take(4 * 16);
+    o.total = off;
+    return o;
+}
+
+template <int L, int CH>
+__global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
+    static_assert(L >= 1 && L <= 2, "v2 keeps at most three 64x192 matrices in registers");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, u = lane >> 2, kq = lane & 3;
+    const int i_unit = 16 * wave + u, k0 = 16 * kq;
+    const int b = blockIdx.x;
+    const int H = p.H, S = p.S, T = p.T, NO = p.NO, ntril = p.ntril;
+    const int I = S + p.C + p.P;
+    const bool unit_ok = i_unit < H;
+    const int orow = u;                       // every wave owns all emission rows (NO <= 16)
+    const bool row_ok = orow < NO;
+    const BwdV2Lds lay = bwd_v2_lds(H, S, L, CH);
+    float *s_acts = smem + lay.acts, *s_d4 = smem + lay.d4, *s_dO = smem + lay.dO;
+    float *s_gp = smem + lay.gp, *s_gm = smem + lay.gm, *s_gl = smem + lay.gl, *s_raw = smem + lay.raw, *s_eps = smem + lay.eps;
+    float *owl = smem + lay.owl, *dxp = smem + lay.dxp;
+    const int REC = L * 5 * H, DREC = L * 4 * H;
+
+    // ---- register-resident (transposed-use) weights: w[g][jj] = W[(g H + 16 kq + jj)][i]
+    float whh[L][3][16], wih[3][16];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const bool ok = unit_ok && (k0 + jj) < H;
+            whh[0][g][jj] = ok ? p.W_hh0[(int64_t)(g * H + k0 + jj) * H + i_unit] : 0.f;
+            if (L > 1) {
+                whh[L - 1][g][jj] = ok ? p.W_hh_st[(int64_t)(g * H + k0 + jj) * H + i_unit] : 0.f;
+                wih[g][jj] = ok ? p.W_ih_st[(int64_t)(g * H + k0 + jj) * H + i_unit] : 0.f;
+            } else {
+                wih[g][jj] = 0.f;
+            }
+        }
+    for (int e = tid; e < NO * 64; e += 256) {
+        int kk = e & 63, r = e >> 6;
+        owl[e] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
+    }
+    float wxr[kMaxSRegV2][3];  // state rows of W_ih_l0 for this lane's unit
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < kMaxSRegV2; ++i) wxr[i][g] = (unit_ok && i < S) ? p.W_ih0[(int64_t)(g * H + i_unit) * I + i] : 0.f;
+    int trow = 0, tcol = 0;
+    if (orow >= S && orow < NO) {
+        int q = orow - S, r = 0;
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        trow = r; tcol = q - r * (r + 1) / 2;
+    }
+    const bool is_tril = orow >= S && orow < NO;
+    const bool is_diag = is_tril && trow == tcol;
+
+    float dh[L], spi[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) dh[l] = 0.f;
+    float dxreg = 0.f;  // lane i < S of every wave carries d z_t[i]
+
+    const int64_t bt0 = (int64_t)b * T;
+    const int nchunks = (T + CH - 1) / CH;
+    // staged chunk loader (synchronous; its latency overlaps the previous chunk's flush)
+    auto load_chunk = [&](int t0, int n) {
+        // activation records t0-1 .. t0+n-1 (record -1 of the path is all zero)
+        const int nrec = (n + 1) * REC;
+        const float *src = p.acts + (bt0 + t0 - 1) * REC;
+#pragma unroll 1
+        for (int e = tid; e < nrec; e += 256) s_acts[e] = (t0 == 0 && e < REC) ? 0.f : src[e];
+#pragma unroll 1
+        for (int e = tid; e < n * S; e += 256) {
+            s_gp[e] = p.g_paths[((int64_t)b * (T + 1) + t0 + 1) * S + e];
+            s_gm[e] = p.g_means[(bt0 + t0) * S + e];
+            s_eps[e] = p.eps[(bt0 + t0) * S + e];
+        }
+#pragma unroll 1
+        for (int e = tid; e < n * S * S; e += 256) s_gl[e] = p.g_chol[(bt0 + t0) * S * S + e];
+#pragma unroll 1
+        for (int e = tid; e < n * ntril; e += 256) s_raw[e] = p.chol_raw[(bt0 + t0) * ntril + e];
+    };
+    {
+        const int t0 = (nchunks - 1) * CH;
+        load_chunk(t0, T - t0);
+    }
+    __syncthreads();
+
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int t0 = c * CH, nsteps = min(CH, T - t0);
+        for (int tt = nsteps - 1; tt >= 0; --tt) {
+            // ---- saved activations of this lane's unit (independent of the recurrence: issue first)
+            float sr[L], su[L], sn[L], scn[L], shp[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float *A = s_acts + ((tt + 1) * L + l) * 5 * H + i_unit;
+                sr[l] = unit_ok ? A[H] : 0.f; su[l] = unit_ok ? A[2 * H] : 0.f; sn[l] = unit_ok ? A[3 * H] : 0.f;
+                scn[l] = unit_ok ? A[4 * H] : 0.f; shp[l] = unit_ok ? A[-REC] : 0.f;
+            }
+            // ---- upstream gradients for this step (backward.py:257-349); every wave redundantly
+            if (lane < S) dxreg += s_gp[tt * S + lane];
+            float mydx = 0.f;
+            for (int i = 0; i < S; ++i) {
+                const float dxi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dxreg), i));
+                if ((orow < S ? orow : trow) == i) mydx = dxi;
+            }
+            float dO = 0.f;
+            if (orow < S) dO = mydx * p.dt + s_gm[tt * S + orow];
+            else if (is_tril) {
+                float dL = mydx * s_eps[tt * S + tcol] * p.sqdt + s_gl[(tt * S + trow) * S + tcol];
+                const float raw = s_raw[tt * ntril + (orow - S)];
+                if (is_diag && !(raw >= p.diag_min || dL < 0.f)) dL = 0.f;  // bounds.py:20 / backward.py:331-334
+                dO = dL;
+            }
+            if (wave == 0 && kq == 0 && row_ok) s_dO[tt * NO + orow] = dO;
+            float dcur = 0.f;  // d h_top[i] = sum_r dO_r out_W[r][i]
+            for (int r = 0; r < NO; ++r)
+                dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
+
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                // ---- GRU cell adjoint (backward.py:59-67, 452-486)
+                const float d = dcur + dh[l];
+                const float dn = (1.0f - su[l]) * d, du = (shp[l] - sn[l]) * d;
+                const float dn_pre = dn * (1.0f - sn[l] * sn[l]);
+                const float du_pre = du * (su[l] * (1.0f - su[l]));
+                const float dcn = dn_pre * sr[l];
+                const float dr_pre = (dn_pre * scn[l]) * (sr[l] * (1.0f - sr[l]));
+                const float carry = su[l] * d;
+                float *D = s_d4 + (tt * L + l) * 4 * H;
+                if (unit_ok) D[kq * H + i_unit] = kq == 0 ? dr_pre : (kq == 1 ? du_pre : (kq == 2 ? dn_pre : dcn));
+                if (l == 0) {
+                    spi[0] += dr_pre; spi[1] += du_pre; spi[2] += dn_pre;
+                    // d z_t += W_ih_l0[:, state rows]^T . d_pre (backward.py:494-509): per-wave partial sums
+#pragma unroll
+                    for (int i = 0; i < kMaxSRegV2; ++i) {
+                        if (i < S) {
+                            float v = wxr[i][0] * dr_pre + wxr[i][1] * du_pre + wxr[i][2] * dn_pre;
+                            v = wave_sum(v) * 0.25f;  // the four lanes of a quad hold identical values
+                            if (lane == 0) dxp[wave * 16 + i] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- transposed products over this lane's j-slice
+                const float4 *vr4 = (const float4 *)(D + k0), *vu4 = (const float4 *)(D + H + k0);
+                const float4 *vn4 = (const float4 *)(D + 2 * H + k0), *vc4 = (const float4 *)(D + 3 * H + k0);
+                float4 tr[4], tu[4], tn[4], tc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { tr[q] = vr4[q]; tu[q] = vu4[q]; tc[q] = vc4[q]; if (l > 0) tn[q] = vn4[q]; }
+                const float *vr = (const float *)tr, *vu = (const float *)tu, *vn = (const float *)tn, *vc = (const float *)tc;
+                if (l > 0) {
+                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};  // (acc_h, acc_i) pairs
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        pa = __builtin_elementwise_fma((f32x2){vr[jj], vr[jj]}, (f32x2){whh[l][0][jj], wih[0][jj]}, pa);
+                        pb = __builtin_elementwise_fma((f32x2){vu[jj], vu[jj]}, (f32x2){whh[l][1][jj], wih[1][jj]}, pb);
+                        pc = __builtin_elementwise_fma((f32x2){vc[jj], vn[jj]}, (f32x2){whh[l][2][jj], wih[2][jj]}, pc);
+                    }
+                    pa += pb; pa += pc;
+                    dh[l] = carry + quad_sum(pa.x);
+                    dcur = quad_sum(pa.y);
+                } else {
+                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};  // even/odd j pairs
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj += 2) {
+                        pa = __builtin_elementwise_fma((f32x2){vr[jj], vr[jj + 1]}, (f32x2){whh[0][0][jj], whh[0][0][jj + 1]}, pa);
+                        pb = __builtin_elementwise_fma((f32x2){vu[jj], vu[jj + 1]}, (f32x2){whh[0][1][jj], whh[0][1][jj + 1]}, pb);
+                        pc = __builtin_elementwise_fma((f32x2){vc[jj], vc[jj + 1]}, (f32x2){whh[0][2][jj], whh[0][2][jj + 1]}, pc);
+                    }
+                    pa += pb; pa += pc;
+                    dh[0] = carry + quad_sum(pa.x + pa.y);
+                    if (lane < S) dxreg += dxp[lane] + dxp[16 + lane] + dxp[32 + lane] + dxp[48 + lane];
+                }
+            }
+        }
+        __syncthreads();  // chunk done: D4 / DO staging final, input staging free
+        // ---- flush D4 / DO (contiguous runs), then stage the next (earlier) chunk
+        {
+            const int nD = nsteps * DREC;
+            float *dst = p.D4 + (bt0 + t0) * DREC;
+            if ((H & 3) == 0) {
+#pragma unroll 1
+                for (int e = tid; e < nD / 4; e += 256) ((float4 *)dst)[e] = ((const float4 *)s_d4)[e];
+            } else {
+#pragma unroll 1
+                for (int e = tid; e < nD; e += 256) dst[e] = s_d4[e];
+            }
+#pragma unroll 1
+            for (int e = tid; e < nsteps * NO; e += 256) p.DO[(bt0 + t0) * NO + e] = s_dO[e];
+        }
+        if (c > 0) load_chunk(t0 - CH, CH);
+        __syncthreads();
+    }
+    if (wave == 0 && lane < S) p.g_x0[(int64_t)b * S + lane] = dxreg + p.g_paths[(int64_t)b * (T + 1) * S + lane];  // :620-624
+    // d theta_b = W_ih_l0[:, theta rows]^T . sum_t d_pre_0   (backward.py:511-548)
+    for (int q = 0; q < p.P; ++q) {
+        float v = 0.f;
+        if (unit_ok && kq == 0)
+            v = p.W_ih0[(int64_t)i_unit * I + S + p.C + q] * spi[0] + p.W_ih0[(int64_t)(H + i_unit) * I + S + p.C + q] * spi[1] +
+                p.W_ih0[(int64_t)(2 * H + i_unit) * I + S + p.C + q] * spi[2];
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) dxp[wave] = v;
+        __syncthreads();
+        if (tid == 0) p.g_theta[(int64_t)b * p.P + q] = dxp[0] + dxp[1] + dxp[2] + dxp[3];
+    }
+}
+
 // ------------------------------------------------------------------------ host launchers
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline block).
+static bool g_force_v1 = false;  // test hook: run L<=2 through the LDS-resident v1 kernels
 static bool g_prof_on = false;
 static hipEvent_t g_prof_ev[2][2];
 static bool g_prof_init = false;
@@ -550,6 +1124,18 @@ static int launch_bwd_L(const BwdParams &p, int grid, int block, size_t lds, hip
 
 using namespace vsde;
 
+#ifdef VSDE_TRACE
+extern "C" int vsde_debug_read_trace(long long *host64) {
+    VSDE_CHECK_HIP(hipMemcpyFromSymbol(host64, HIP_SYMBOL(vsde::g_trace), sizeof(long long) * 64));
+    return 0;
+}
+#endif
+
+extern "C" int vsde_debug_force_v1(int on) {
+    g_force_v1 = on != 0;
+    return 0;
+}
+
 extern "C" int vsde_profile_enable(int on) {
     g_prof_on = on != 0;
     g_prof_valid[0] = g_prof_valid[1] = false;
@@ -603,9 +1189,43 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     p.B = d->B; p.T = d->T; p.S = d->S; p.P = d->P; p.C = d->C; p.H = d->H; p.NO = NO; p.ntril = NO - d->S;
     p.x0 = x0; p.theta = theta; p.eps = eps; p.G = G;
     p.W_ih0 = w->W_ih_l0; p.b_hh0 = w->b_hh_l0; p.b_ih_st = w->b_ih_stack; p.b_hh_st = w->b_hh_stack; p.out_b = w->out_bias;
+    p.W_hh0 = w->W_hh_l0; p.W_ih_st = w->W_ih_stack; p.W_hh_st = w->W_hh_stack; p.out_W = w->out_weight;
     p.packF = pk.packF; p.packO = pk.packO;
     p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
     p.paths = paths; p.means = means; p.chol = chol; p.chol_raw = chol_raw; p.acts = acts;
+    if (d->L <= 2 && !g_force_v1) {  // register-resident 4-waves-per-path kernels
+        p.wpb = 1;
+        int ch = 16;  // two workgroups per CU need <= 80 KB of LDS each
+        if ((size_t)fwd_v2_lds(d->H, d->S, d->L, 16, save != 0).total * sizeof(float) > 80 * 1024) ch = 8;
+        const size_t lds2 = (size_t)fwd_v2_lds(d->H, d->S, d->L, ch, save != 0).total * sizeof(float);
+        VSDE_CHECK_ARG(lds2 <= 160 * 1024, VSDE_E_STATE, "LDS budget exceeded (%zu B)", lds2);
+#define VSDE_LAUNCH_FWD_V2_(LL, SV, CC, SM)                                                                         \
+    do {                                                                                                            \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_fwd_v2_kernel<LL, SV, CC, SM>,                        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        prof_mark(0, 0, s);                                                                                         \
+        hipLaunchKernelGGL((head_fwd_v2_kernel<LL, SV, CC, SM>), dim3(d->B), dim3(256), lds2, s, p);                \
+        prof_mark(0, 1, s);                                                                                         \
+    } while (0)
+#define VSDE_LAUNCH_FWD_V2(LL, SV, CC)                                                                              \
+    do {                                                                                                            \
+        if (d->S == 1 && CC == 16) VSDE_LAUNCH_FWD_V2_(LL, SV, 16, 1);                                              \
+        else if (d->S == 2 && CC == 16) VSDE_LAUNCH_FWD_V2_(LL, SV, 16, 2);                                         \
+        else if (NO <= 16) VSDE_LAUNCH_FWD_V2_(LL, SV, CC, 3);                                                      \
+        else VSDE_LAUNCH_FWD_V2_(LL, SV, CC, 4);                                                                    \
+    } while (0)
+        if (d->L == 1) {
+            if (save) { if (ch == 16) VSDE_LAUNCH_FWD_V2(1, true, 16); else VSDE_LAUNCH_FWD_V2(1, true, 8); }
+            else { if (ch == 16) VSDE_LAUNCH_FWD_V2(1, false, 16); else VSDE_LAUNCH_FWD_V2(1, false, 8); }
+        } else {
+            if (save) { if (ch == 16) VSDE_LAUNCH_FWD_V2(2, true, 16); else VSDE_LAUNCH_FWD_V2(2, true, 8); }
+            else { if (ch == 16) VSDE_LAUNCH_FWD_V2(2, false, 16); else VSDE_LAUNCH_FWD_V2(2, false, 8); }
+        }
+#undef VSDE_LAUNCH_FWD_V2
+#undef VSDE_LAUNCH_FWD_V2_
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds_fixed = (size_t)fwd_lds_matrices(d->L) * kMatF4 * sizeof(float4) + (size_t)kChunks * NO * sizeof(float4);
     const size_t lds_wave = kScratchPerWave * sizeof(float);
     p.wpb = pick_wpb(d->B, lds_fixed, lds_wave);
@@ -737,8 +1357,40 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     p.B = d->B; p.T = d->T; p.S = d->S; p.P = d->P; p.C = d->C; p.H = d->H; p.NO = NO; p.ntril = NO - d->S;
     p.g_paths = g_paths; p.g_means = g_means; p.g_chol = g_chol; p.theta = theta; p.eps = eps; p.chol_raw = chol_raw; p.acts = acts;
     p.W_ih0 = w->W_ih_l0; p.out_W = w->out_weight; p.packB = pk.packB;
+    p.W_hh0 = w->W_hh_l0; p.W_ih_st = w->W_ih_stack; p.W_hh_st = w->W_hh_stack;
     p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
     p.D4 = (float *)(ws + lay.D4); p.DO = (float *)(ws + lay.DO); p.g_x0 = g->x0; p.g_theta = g->theta;
+    if (d->L <= 2 && NO <= 16 && !g_force_v1) {
+        int ch = 16;
+        while (ch > 4 && (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float) > 80 * 1024) --ch;
+        const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float);
+        p.wpb = 1;
+#define VSDE_LAUNCH_BWD_V2(LL, CC)                                                                                  \
+    do {                                                                                                            \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_v2_kernel<LL, CC>,                                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        prof_mark(1, 0, s);                                                                                         \
+        hipLaunchKernelGGL((head_bwd_v2_kernel<LL, CC>), dim3(d->B), dim3(256), lds2, s, p);                        \
+        prof_mark(1, 1, s);                                                                                         \
+    } while (0)
+#define VSDE_LAUNCH_BWD_V2_L(LL)                                                                                    \
+    do {                                                                                                            \
+        switch (ch) {                                                                                               \
+            case 16: VSDE_LAUNCH_BWD_V2(LL, 16); break;                                                             \
+            case 15: VSDE_LAUNCH_BWD_V2(LL, 15); break;                                                             \
+            case 14: VSDE_LAUNCH_BWD_V2(LL, 14); break;                                                             \
+            case 13: VSDE_LAUNCH_BWD_V2(LL, 13); break;                                                             \
+            case 12: VSDE_LAUNCH_BWD_V2(LL, 12); break;                                                             \
+            default: ch = 8; VSDE_LAUNCH_BWD_V2(LL, 8); break;                                                      \
+        }                                                                                                           \
+    } while (0)
+        if (ch < 12) ch = 8;
+        if (d->L == 1) VSDE_LAUNCH_BWD_V2_L(1); else VSDE_LAUNCH_BWD_V2_L(2);
+#undef VSDE_LAUNCH_BWD_V2_L
+#undef VSDE_LAUNCH_BWD_V2
+        VSDE_CHECK_HIP(hipGetLastError());
+        rc = 0;
+    } else {
     const size_t lds_fixed = (size_t)fwd_lds_matrices(d->L) * kMatF4 * sizeof(float4) + (size_t)NO * kHP * sizeof(float);
     const size_t lds_wave = kBwdScratchPerWave * sizeof(float);
     p.wpb = pick_wpb(d->B, lds_fixed, lds_wave);
@@ -750,6 +1402,7 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
         case 2: rc = launch_bwd_L<2>(p, grid, block, lds, s); break;
         case 3: rc = launch_bwd_L<3>(p, grid, block, lds, s); break;
         default: rc = launch_bwd_L<4>(p, grid, block, lds, s); break;
+    }
     }
     if (rc) return rc;
 
