@@ -143,6 +143,35 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
                              const float *g_jac, float *g_z, float *g_x, float *g_means,
                              float *g_chol, float *g_drift, float *g_diffusion, void *stream);
 
+/* ---- Fused encoder operators (SiT blocks of the observation encoder) -------------------------
+ * dtype: 0 = f32, 1 = bf16 for every `void *` tensor of the call; cos/sin tables, RMS weights,
+ * lambda, mean/rstd are always f32.  Contiguous tensors; B = batch rows, N = tokens per row.
+ * Replaces the unfused torch chains of primitives/sit.py:99-128 (LayerNorm -> (1+scale)x+shift,
+ * gate*branch residual), primitives/attn.py:80-113 (QK RMS-norm, RoPE, value-residual mix, head
+ * layout, sigmoid output gate) and primitives/mlp.py:21-24 (SwiGLU activation). */
+int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
+                         float *rstd, int64_t B, int N, int C, double eps, void *stream);
+int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
+                         const float *rstd, void *dx, void *dscale, void *dshift, int64_t B, int N, int C, void *stream);
+int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N, int C,
+                            void *stream);
+int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate, int64_t B,
+                            int N, int C, void *stream);
+int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream);
+int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream);
+int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
+                        void *stream);
+int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog, int64_t B,
+                        int N, int heads, int d, void *stream);
+/* qkv[B][N][3C] -> q, k, v [B][heads][N][d]; cosT/sinT [N][d/2]; wq/wk [d]; v0 (optional) [B][heads][N][d] */
+int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
+                          const void *v0, const float *lam, void *q, void *k, void *v, int64_t B, int N, int heads, int d,
+                          double eps, void *stream);
+int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d);
+int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
+                          const void *v0, const float *lam, const void *dq, const void *dk, const void *dv, void *dqkv,
+                          void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, the launchers bracket the serial
  * time-stepping kernel with hipEvents on the launch stream.  which: 0 = forward (training
  * variant), 1 = backward.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */

@@ -1,0 +1,113 @@
+"""GPU parity of the fused encoder operators against the unfused torch chains (which themselves are
+pinned against the reference's encoder by tests/test_host_logic.py::test_encoder_matches_reference...).
+
+fp32: forward 2e-5, gradients 2e-4 (relative to max).  bf16: both sides round at different points,
+tolerance 3e-2 relative to max (bf16 eps = 7.8e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _block(dim=128, heads=4, cond=32, residual_v=True, seed=0):
+    from viforsdes_amd.primitives.sit import SiTBlock
+    torch.manual_seed(seed)
+    blk = SiTBlock(dim=dim, num_heads=heads, mlp_hidden_dim=int(dim * 8 / 3), cond_dim=cond, attn_residual_v=residual_v).to(DEV)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if p.requires_grad and (p.abs().sum() == 0 or "lambda" in n):
+                p.add_(torch.randn_like(p) * 0.2)
+    return blk
+
+
+def _run(blk, x, cond, rot, v0, fused_on, dtype):
+    from viforsdes_amd.primitives import fused
+    fused.ENABLED = fused_on
+    try:
+        xs = x.clone().requires_grad_(True); cs = cond.clone().requires_grad_(True)
+        v0s = v0.clone().requires_grad_(True) if v0 is not None else None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            xin = xs.to(dtype) if dtype == torch.bfloat16 else xs
+            out, vals = blk(xin, cond=cs, rotary=rot, v0=v0s.to(dtype) if v0s is not None and dtype == torch.bfloat16 else v0s)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        go = torch.randn(out.shape, generator=g).to(DEV)
+        gv = torch.randn(vals.shape, generator=g).to(DEV)
+        loss = (out.float() * go).sum() + (vals.float() * gv).sum()
+        params = [p for p in blk.parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, [xs, cs] + ([v0s] if v0s is not None else []) + params)
+        return out.float().detach(), vals.float().detach(), grads
+    finally:
+        fused.ENABLED = True
+
+
+@pytest.mark.parametrize("dtype,ftol,gtol", [(torch.float32, 2e-5, 2e-4), (torch.bfloat16, 3e-2, 6e-2)])
+@pytest.mark.parametrize("residual_v", [False, True])
+def test_fused_block_matches_unfused(dtype, ftol, gtol, residual_v):
+    from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis
+    B, N, C, h = 3, 37, 128, 4
+    blk = _block(C, h, 32, residual_v)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, N, C, generator=g).to(DEV)
+    cond = torch.randn(B, 32, generator=g).to(DEV)
+    v0 = torch.randn(B, h, N, C // h, generator=g).to(DEV) if residual_v else None
+    rot = RotarySpec.from_freqs(precompute_freq_cis(C // h, end=64).to(DEV)[:N])
+    o1, v1, g1 = _run(blk, x, cond, rot, v0, False, dtype)
+    o2, v2, g2 = _run(blk, x, cond, rot, v0, True, dtype)
+    assert rel_err(o2.cpu().numpy(), o1.cpu().numpy()) < ftol
+    assert rel_err(v2.cpu().numpy(), v1.cpu().numpy()) < ftol
+    names = ["x", "cond"] + (["v0"] if residual_v else []) + [n for n, p in blk.named_parameters() if p.requires_grad]
+    for n, a, b_ in zip(names, g2, g1):
+        assert rel_err(a.float().cpu().numpy(), b_.float().cpu().numpy()) < gtol, n
+
+
+def test_fused_ops_individually_fp32():
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(2)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    B, N, C = 4, 19, 256
+    x, sc, sh, gate, y = rn(B, N, C).requires_grad_(), rn(B, C).requires_grad_(), rn(B, C).requires_grad_(), rn(B, C).requires_grad_(), rn(B, N, C).requires_grad_()
+    ref = torch.nn.functional.layer_norm(x, (C,), eps=1e-5) * (1 + sc[:, None]) + sh[:, None]
+    got = fused.ln_modulate(x, sc, sh, 1e-5)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)
+    go = rn(B, N, C)
+    for a, b_ in zip(torch.autograd.grad((got * go).sum(), [x, sc, sh]), torch.autograd.grad((ref * go).sum(), [x, sc, sh])):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < 1e-5
+    ref = x + gate[:, None] * y
+    got = fused.gated_residual(x, y, gate)
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+    for a, b_ in zip(torch.autograd.grad((got * go).sum(), [x, y, gate]), torch.autograd.grad((ref * go).sum(), [x, y, gate])):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < 1e-5
+    u = rn(B, N, 2 * 170).requires_grad_()
+    a_, b2 = u.chunk(2, -1)
+    ref = torch.nn.functional.silu(a_) * b2
+    got = fused.swiglu(u)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    go2 = rn(B, N, 170)
+    assert rel_err(torch.autograd.grad((got * go2).sum(), u)[0].cpu().numpy(), torch.autograd.grad((ref * go2).sum(), u)[0].cpu().numpy()) < 1e-5
+
+
+def test_encoder_fused_vs_unfused_full_module_bf16_autocast():
+    """Whole ObservationContextEncoder at the benchmark width (C=256, 4 heads) under bf16 autocast."""
+    from viforsdes_amd import EncoderConfig
+    from viforsdes_amd.models.encoder import ObservationContextEncoder
+    from viforsdes_amd.primitives import fused
+    torch.manual_seed(0)
+    enc = ObservationContextEncoder(2, 3, EncoderConfig(hidden_dim=256, num_heads=4, depth=2)).to(DEV)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.requires_grad and p.abs().sum() == 0:
+                p.add_(torch.randn_like(p) * 0.05)
+    obs_t, obs_v = torch.tensor([0.0, 1.0, 2.0], device=DEV), torch.randn(3, 2, device=DEV)
+    theta = torch.rand(6, 3, device=DEV) + 0.2
+    outs = []
+    for on in (False, True):
+        fused.ENABLED = on
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs.append(enc(obs_v, obs_t, theta, 2.0, 0.05).float().detach())
+    fused.ENABLED = True
+    assert outs[0].shape == (6, 41, 256)
+    assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 3e-2

@@ -52,6 +52,9 @@ EXPORTS = (
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
     "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd",
     "vsde_profile_enable", "vsde_profile_elapsed_ms", "vsde_debug_force_v1",
+    "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
+    "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
+    "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -82,6 +85,7 @@ def load() -> ctypes.CDLL:
     lib.vsde_head_backward_workspace_bytes.restype = ctypes.c_size_t
     for f in (lib.vsde_head_forward, lib.vsde_head_backward, lib.vsde_elbo_path_terms, lib.vsde_elbo_path_terms_bwd):
         f.restype = ctypes.c_int
+    lib.vsde_qk_norm_rope_bwd_partials.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -270,3 +274,130 @@ def profile_elapsed_ms(which: int) -> float:
 def debug_force_v1(on: bool) -> None:
     """Test hook: run 1-2 layer heads through the kernels that normally serve 3-4 layers."""
     load().vsde_debug_force_v1(ctypes.c_int(1 if on else 0))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused encoder operators (csrc/vsde_encoder.hip)
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise ValueError(f"fused encoder ops support float32/bfloat16, got {t.dtype}")
+
+
+def _call(fn, *args):
+    rc = fn(*args)
+    if rc != 0:
+        _raise(rc)
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def ln_modulate_fwd(x, scale, shift, eps):
+    lib = load(); dev = _require_hip(x, scale, shift)
+    B, N, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B, N, device=dev, dtype=torch.float32); rstd = torch.empty_like(mean)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_ln_modulate_fwd, _dt(x), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(mean), _ptr(rstd), _i64(B),
+              ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps), _stream(dev))
+    return y, mean, rstd
+
+
+def ln_modulate_bwd(x, scale, dy, mean, rstd):
+    lib = load(); dev = _require_hip(x, scale, dy)
+    B, N, C = x.shape
+    dx = torch.empty_like(x); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_ln_modulate_bwd, _dt(x), _ptr(x), _ptr(scale), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dscale),
+              _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
+    return dx, dscale, dshift
+
+
+def gated_residual_fwd(x, y, gate):
+    lib = load(); dev = _require_hip(x, y, gate)
+    B, N, C = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_gated_residual_fwd, _dt(x), _ptr(x), _ptr(y), _ptr(gate), _ptr(out), _i64(B), ctypes.c_int(N),
+              ctypes.c_int(C), _stream(dev))
+    return out
+
+
+def gated_residual_bwd(y, gate, dout):
+    lib = load(); dev = _require_hip(y, gate, dout)
+    B, N, C = y.shape
+    dy = torch.empty_like(y); dgate = torch.empty_like(gate)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_gated_residual_bwd, _dt(y), _ptr(y), _ptr(gate), _ptr(dout), _ptr(dy), _ptr(dgate), _i64(B),
+              ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
+    return dy, dgate
+
+
+def swiglu_fwd(u):
+    lib = load(); dev = _require_hip(u)
+    H2 = u.shape[-1] // 2
+    out = torch.empty(*u.shape[:-1], H2, device=dev, dtype=u.dtype)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_swiglu_fwd, _dt(u), _ptr(u), _ptr(out), _i64(u.numel() // (2 * H2)), ctypes.c_int(H2), _stream(dev))
+    return out
+
+
+def swiglu_bwd(u, dout):
+    lib = load(); dev = _require_hip(u, dout)
+    H2 = u.shape[-1] // 2
+    du = torch.empty_like(u)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_swiglu_bwd, _dt(u), _ptr(u), _ptr(dout), _ptr(du), _i64(u.numel() // (2 * H2)), ctypes.c_int(H2), _stream(dev))
+    return du
+
+
+def gate_merge_fwd(attn, glog):
+    lib = load(); dev = _require_hip(attn, glog)
+    B, h, N, d = attn.shape
+    out = torch.empty(B, N, h * d, device=dev, dtype=attn.dtype)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_gate_merge_fwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(out), _i64(B), ctypes.c_int(N), ctypes.c_int(h),
+              ctypes.c_int(d), _stream(dev))
+    return out
+
+
+def gate_merge_bwd(attn, glog, dout):
+    lib = load(); dev = _require_hip(attn, glog, dout)
+    B, h, N, d = attn.shape
+    dattn = torch.empty_like(attn); dglog = torch.empty_like(glog)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_gate_merge_bwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(dout), _ptr(dattn), _ptr(dglog), _i64(B),
+              ctypes.c_int(N), ctypes.c_int(h), ctypes.c_int(d), _stream(dev))
+    return dattn, dglog
+
+
+def qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0, lam, heads, eps):
+    lib = load(); dev = _require_hip(qkv, cos, sin, wq, wk)
+    B, N, C3 = qkv.shape
+    d = C3 // 3 // heads
+    q = torch.empty(B, heads, N, d, device=dev, dtype=qkv.dtype); k = torch.empty_like(q); v = torch.empty_like(q)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_qk_norm_rope_fwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
+              _ptr(q), _ptr(k), _ptr(v), _i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d), ctypes.c_double(eps),
+              _stream(dev))
+    return q, k, v
+
+
+def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps):
+    lib = load(); dev = _require_hip(qkv, dq, dk, dv)
+    B, N, C3 = qkv.shape
+    d = C3 // 3 // heads
+    dqkv = torch.empty_like(qkv)
+    dv0 = torch.empty_like(dv) if v0 is not None else None
+    nparts = lib.vsde_qk_norm_rope_bwd_partials(_i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d))
+    parts = torch.empty(nparts, device=dev, dtype=torch.float32) if v0 is not None else None
+    with torch.cuda.device(dev):
+        _call(lib.vsde_qk_norm_rope_bwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
+              _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(dv0), _ptr(parts), _i64(B), ctypes.c_int(N), ctypes.c_int(heads),
+              ctypes.c_int(d), ctypes.c_double(eps), _stream(dev))
+    dlam = parts.sum() if parts is not None else None
+    return dqkv, dv0, dlam

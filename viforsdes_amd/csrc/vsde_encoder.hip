@@ -1,0 +1,454 @@
+// Fused elementwise / normalisation operators of the SiT observation encoder (gfx950).
+//
+// The reference runs the encoder as stock torch ops (primitives/sit.py:99-128, attn.py:80-111,
+// mlp.py:50-54, cond.py:19-23); under bf16 autocast one block costs ~100 small kernels (casts,
+// LayerNorm, RMS, complex RoPE, cat, mul/add chains).  Here every chain between two GEMMs / the
+// attention call is one HBM pass, forward and backward:
+//   ln_modulate        y = LayerNorm(x) * (1 + scale_b) + shift_b          (sit.py:99-101,124-126)
+//   qk_norm_rope       q,k = RoPE(RMS(q,k)); v = lam v + (1-lam) v0; -> [B,h,N,d]  (attn.py:80-103)
+//   gate_merge         out[b,n,(h d)] = attn[b,h,n,d] * sigmoid(gate[b,n,d])        (attn.py:108-113)
+//   gated_residual     out = x + gate_b * y                                 (sit.py:114-115,127-128)
+//   swiglu             out = silu(a) * b,  [a | b] = u                      (mlp.py:21-24)
+// Memory-bound streaming kernels: 8 (bf16) / 4 (f32) contiguous elements per lane, math in fp32.
+// T = float (mixed_precision off; parity tests) or bf16 (autocast).  Per-batch-row conditioning
+// vectors are [B, C]; reductions over the tokens of a batch row are deterministic (no atomics).
+#include "vsde_common.h"
+
+namespace vsde {
+
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {  // round to nearest even
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return bf16_t{(uint16_t)(u >> 16)};
+}
+template <typename T> __device__ __forceinline__ float rnd(float x) { return to_f32(from_f32<T>(x)); }
+
+__device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------ ln_modulate
+// one wavefront per token; lane owns channels c = i*64 + lane (i < C/64 <= 16), registers statically indexed
+template <typename T>
+__global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                         const T *__restrict__ shift, T *__restrict__ y,
+                                                         float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
+                                                         int N, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int64_t b = m / N;
+    const int epl = C >> 6;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < epl) { v[i] = to_f32(x[m * C + i * 64 + lane]); s += v[i]; }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < epl) { const float d = v[i] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < epl) {
+            const int c = i * 64 + lane;
+            const float xh = (v[i] - mu) * rs;
+            y[m * C + c] = from_f32<T>(xh * (1.0f + to_f32(scale[b * C + c])) + to_f32(shift[b * C + c]));
+        }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                            const T *__restrict__ dy, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, T *__restrict__ dx, int64_t M,
+                                                            int N, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int64_t b = m / N;
+    const int epl = C >> 6;
+    const float mu = mean[m], rs = rstd[m];
+    float g[16], xh[16];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < epl) {
+            const int c = i * 64 + lane;
+            xh[i] = (to_f32(x[m * C + c]) - mu) * rs;
+            g[i] = to_f32(dy[m * C + c]) * (1.0f + to_f32(scale[b * C + c]));
+            s1 += g[i]; s2 += g[i] * xh[i];
+        }
+    s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < epl) dx[m * C + i * 64 + lane] = from_f32<T>(rs * (g[i] - s1 - xh[i] * s2));
+}
+
+// Column reductions over the N tokens of one batch row, 64 channels x 4 token groups per block.
+//   MODE 0: r1[b,c] = sum_n dy*xhat, r2[b,c] = sum_n dy    (ln_modulate: dscale, dshift)
+//   MODE 1: r1[b,c] = sum_n a*bb                           (gated_residual: dgate)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) rowgroup_colsum_kernel(const T *__restrict__ a, const T *__restrict__ bb,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              T *__restrict__ r1, T *__restrict__ r2, int N, int C) {
+    __shared__ float red[2][4][64];
+    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), tg = threadIdx.x >> 6;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int n = tg; n < N; n += 4) {
+            const int64_t m = (int64_t)b * N + n;
+            const float av = to_f32(a[m * C + c]);
+            if (MODE == 0) {
+                const float xh = (to_f32(bb[m * C + c]) - mean[m]) * rstd[m];
+                s1 += av * xh; s2 += av;
+            } else {
+                s1 += av * to_f32(bb[m * C + c]);
+            }
+        }
+    red[0][tg][threadIdx.x & 63] = s1; red[1][tg][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (tg == 0 && c < C) {
+        const int l = threadIdx.x;
+        r1[(int64_t)b * C + c] = from_f32<T>(red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
+        if (MODE == 0) r2[(int64_t)b * C + c] = from_f32<T>(red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// --------------------------------------------------------------------------- gated_residual
+template <typename T>
+__global__ void __launch_bounds__(256) gated_residual_kernel(const T *__restrict__ x, const T *__restrict__ y,
+                                                             const T *__restrict__ gate, T *__restrict__ out, int64_t total,
+                                                             int N, int C, int mode) {
+    // mode 0: out = x + gate*y ; mode 1: out = gate * y   (backward: dy = gate * dout, x unused)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < total; i0 += stride) {
+        const int64_t m = i0 / C;
+        const int c = (int)(i0 - m * C);
+        const int64_t b = m / N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = to_f32(gate[b * C + c + e]) * to_f32(y[i0 + e]);
+            out[i0 + e] = from_f32<T>(mode == 0 ? to_f32(x[i0 + e]) + rnd<T>(g) : g);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- swiglu
+template <typename T>
+__global__ void __launch_bounds__(256) swiglu_fwd_kernel(const T *__restrict__ u, T *__restrict__ out, int64_t M, int H2) {
+    const int64_t total = M * H2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / H2;
+        const int j = (int)(i - m * H2);
+        const float a = to_f32(u[m * 2 * H2 + j]), bv = to_f32(u[m * 2 * H2 + H2 + j]);
+        out[i] = from_f32<T>(rnd<T>(a * sigm(a)) * bv);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) swiglu_bwd_kernel(const T *__restrict__ u, const T *__restrict__ dout, T *__restrict__ du,
+                                                         int64_t M, int H2) {
+    const int64_t total = M * H2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / H2;
+        const int j = (int)(i - m * H2);
+        const float a = to_f32(u[m * 2 * H2 + j]), bv = to_f32(u[m * 2 * H2 + H2 + j]), g = to_f32(dout[i]);
+        const float s = sigm(a);
+        du[m * 2 * H2 + j] = from_f32<T>(g * bv * s * (1.0f + a * (1.0f - s)));
+        du[m * 2 * H2 + H2 + j] = from_f32<T>(g * a * s);
+    }
+}
+
+// ------------------------------------------------------------------------------- gate_merge
+template <typename T>
+__global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
+                                                             T *__restrict__ out, int64_t M, int N, int heads, int d) {
+    const int C = heads * d;
+    const int64_t total = M * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / C;
+        const int c = (int)(i - m * C), hh = c / d, k = c - hh * d;
+        const int64_t b = m / N, n = m - b * N;
+        const float s = rnd<T>(sigm(to_f32(glog[m * d + k])));
+        out[i] = from_f32<T>(to_f32(attn[((b * heads + hh) * N + n) * d + k]) * s);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
+                                                             const T *__restrict__ dout, T *__restrict__ dattn,
+                                                             T *__restrict__ dglog, int64_t M, int N, int heads, int d) {
+    const int C = heads * d;
+    const int64_t total = M * d, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / d;
+        const int k = (int)(i - m * d);
+        const int64_t b = m / N, n = m - b * N;
+        const float s = sigm(to_f32(glog[i]));
+        float acc = 0.f;
+        for (int hh = 0; hh < heads; ++hh) {
+            const int64_t ai = ((b * heads + hh) * N + n) * d + k;
+            const float g = to_f32(dout[m * C + hh * d + k]);
+            dattn[ai] = from_f32<T>(g * s);
+            acc += g * to_f32(attn[ai]);
+        }
+        dglog[i] = from_f32<T>(acc * s * (1.0f - s));
+    }
+}
+
+// ----------------------------------------------------------------------------- qk_norm_rope
+// one thread per rotary pair (i, i + d/2) of one head of one token; the d/2 threads of a head are
+// consecutive lanes (d/2 is a power of two <= 64), so the RMS reduction is a segmented butterfly.
+__device__ __forceinline__ float seg_sum(float v, int width) {
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(const T *__restrict__ qkv, const float *__restrict__ cosT,
+                                                               const float *__restrict__ sinT, const float *__restrict__ wq,
+                                                               const float *__restrict__ wk, const T *__restrict__ v0,
+                                                               const float *__restrict__ lam, T *__restrict__ q, T *__restrict__ k,
+                                                               T *__restrict__ v, int64_t M, int N, int heads, int d, float eps) {
+    const int half = d >> 1, C = heads * d, P2 = C >> 1;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = gid < M * P2;
+    const int64_t m = ok ? gid / P2 : 0;
+    const int pp = ok ? (int)(gid - m * P2) : 0, hh = pp / half, i = pp - hh * half;
+    const int64_t b = m / N, n = m - b * N;
+    const T *row = qkv + m * 3 * C + hh * d;
+    float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f, a0 = 0.f, a1 = 0.f;
+    if (ok) { q0 = to_f32(row[i]); q1 = to_f32(row[i + half]); k0 = to_f32(row[C + i]); k1 = to_f32(row[C + i + half]);
+              a0 = to_f32(row[2 * C + i]); a1 = to_f32(row[2 * C + i + half]); }
+    const float rq = rsqrtf(seg_sum(q0 * q0 + q1 * q1, half) / d + eps);
+    const float rk = rsqrtf(seg_sum(k0 * k0 + k1 * k1, half) / d + eps);
+    if (!ok) return;
+    const float cs = cosT[n * half + i], sn = sinT[n * half + i];
+    const float qn0 = rnd<T>(q0 * rq * wq[i]), qn1 = rnd<T>(q1 * rq * wq[i + half]);
+    const float kn0 = rnd<T>(k0 * rk * wk[i]), kn1 = rnd<T>(k1 * rk * wk[i + half]);
+    const int64_t o = ((b * heads + hh) * N + n) * d + i;
+    q[o] = from_f32<T>(qn0 * cs - qn1 * sn); q[o + half] = from_f32<T>(qn0 * sn + qn1 * cs);
+    k[o] = from_f32<T>(kn0 * cs - kn1 * sn); k[o + half] = from_f32<T>(kn0 * sn + kn1 * cs);
+    if (v0) {
+        const float l = lam[0];
+        a0 = l * a0 + (1.0f - l) * to_f32(v0[o]); a1 = l * a1 + (1.0f - l) * to_f32(v0[o + half]);
+    }
+    v[o] = from_f32<T>(a0); v[o + half] = from_f32<T>(a1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restrict__ qkv, const float *__restrict__ cosT,
+                                                               const float *__restrict__ sinT, const float *__restrict__ wq,
+                                                               const float *__restrict__ wk, const T *__restrict__ v0,
+                                                               const float *__restrict__ lam, const T *__restrict__ dq,
+                                                               const T *__restrict__ dk, const T *__restrict__ dv,
+                                                               T *__restrict__ dqkv, T *__restrict__ dv0,
+                                                               float *__restrict__ dlam_partial, int64_t M, int N, int heads, int d,
+                                                               float eps) {
+    __shared__ float red[4];
+    const int half = d >> 1, C = heads * d, P2 = C >> 1;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = gid < M * P2;
+    const int64_t m = ok ? gid / P2 : 0;
+    const int pp = ok ? (int)(gid - m * P2) : 0, hh = pp / half, i = pp - hh * half;
+    const int64_t b = m / N, n = m - b * N;
+    const T *row = qkv + m * 3 * C + hh * d;
+    const int64_t o = ((b * heads + hh) * N + n) * d + i;
+    float x[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gy[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, w[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float dlam = 0.f;
+    if (ok) {
+        const float cs = cosT[n * half + i], sn = sinT[n * half + i];
+        x[0][0] = to_f32(row[i]); x[0][1] = to_f32(row[i + half]); x[1][0] = to_f32(row[C + i]); x[1][1] = to_f32(row[C + i + half]);
+        const float gq0 = to_f32(dq[o]), gq1 = to_f32(dq[o + half]), gk0 = to_f32(dk[o]), gk1 = to_f32(dk[o + half]);
+        gy[0][0] = gq0 * cs + gq1 * sn; gy[0][1] = -gq0 * sn + gq1 * cs;   // inverse rotation
+        gy[1][0] = gk0 * cs + gk1 * sn; gy[1][1] = -gk0 * sn + gk1 * cs;
+        w[0][0] = wq[i]; w[0][1] = wq[i + half]; w[1][0] = wk[i]; w[1][1] = wk[i + half];
+        float g0 = to_f32(dv[o]), g1 = to_f32(dv[o + half]);
+        if (v0) {
+            const float l = lam[0];
+            dlam = g0 * (to_f32(row[2 * C + i]) - to_f32(v0[o])) + g1 * (to_f32(row[2 * C + i + half]) - to_f32(v0[o + half]));
+            dv0[o] = from_f32<T>((1.0f - l) * g0); dv0[o + half] = from_f32<T>((1.0f - l) * g1);
+            g0 *= l; g1 *= l;
+        }
+        dqkv[m * 3 * C + 2 * C + hh * d + i] = from_f32<T>(g0); dqkv[m * 3 * C + 2 * C + hh * d + i + half] = from_f32<T>(g1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // RMS backward: dx = r w dy - x r^3 mean(x w dy)
+        const float ss = seg_sum(x[t][0] * x[t][0] + x[t][1] * x[t][1], half);
+        const float r = rsqrtf(ss / d + eps);
+        const float dot = seg_sum(x[t][0] * w[t][0] * gy[t][0] + x[t][1] * w[t][1] * gy[t][1], half) / d;
+        if (ok) {
+            dqkv[m * 3 * C + t * C + hh * d + i] = from_f32<T>(r * w[t][0] * gy[t][0] - x[t][0] * r * r * r * dot);
+            dqkv[m * 3 * C + t * C + hh * d + i + half] = from_f32<T>(r * w[t][1] * gy[t][1] - x[t][1] * r * r * r * dot);
+        }
+    }
+    if (dlam_partial) {
+        dlam = wave_sum(dlam);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dlam;
+        __syncthreads();
+        if (threadIdx.x == 0) dlam_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+static inline int ew_grid(int64_t total, int per_block) {
+    int64_t g = (total + per_block - 1) / per_block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+static int ln_mod_dispatch(int which, const void *x, const void *scale, const void *shift_or_dy, void *out, float *mean,
+                           float *rstd, int64_t M, int N, int C, float eps, hipStream_t s) {
+    VSDE_CHECK_ARG(C % 64 == 0 && C <= 1024, VSDE_E_BADARG, "ln_modulate needs C %% 64 == 0 and C <= 1024, got %d", C);
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    if (which == 0)
+        hipLaunchKernelGGL((ln_mod_fwd_kernel<T>), grid, block, 0, s, (const T *)x, (const T *)scale, (const T *)shift_or_dy, (T *)out,
+                           mean, rstd, M, N, C, eps);
+    else
+        hipLaunchKernelGGL((ln_mod_bwd_dx_kernel<T>), grid, block, 0, s, (const T *)x, (const T *)scale, (const T *)shift_or_dy,
+                           (const float *)mean, (const float *)rstd, (T *)out, M, N, C);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vsde
+
+using namespace vsde;
+
+#define VSDE_DTYPE_SWITCH(dtype, CALL)                                                                       \
+    do {                                                                                                     \
+        if ((dtype) == 0) { using T = float; CALL; }                                                         \
+        else if ((dtype) == 1) { using T = bf16_t; CALL; }                                                   \
+        else { set_error("dtype must be 0 (f32) or 1 (bf16), got %d", (dtype)); return VSDE_E_BADARG; }      \
+    } while (0)
+
+extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
+                                    float *rstd, int64_t B, int N, int C, double eps, void *stream) {
+    VSDE_CHECK_ARG(x && scale && shift && y && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate arguments");
+    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, y, mean, rstd, B * N, N, C, (float)eps, (hipStream_t)stream));
+}
+
+extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
+                                    const float *rstd, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
+                                    void *stream) {
+    VSDE_CHECK_ARG(x && scale && dy && mean && rstd && dx && dscale && dshift && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate_bwd arguments");
+    hipStream_t s = (hipStream_t)stream;
+    VSDE_DTYPE_SWITCH(dtype, {
+        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dx, (float *)mean, (float *)rstd, B * N, N, C, 0.f, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 0>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dy,
+                           (const T *)x, mean, rstd, (T *)dscale, (T *)dshift, N, C);
+    });
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N,
+                                       int C, void *stream) {
+    VSDE_CHECK_ARG(x && y && gate && out && C % 4 == 0, VSDE_E_BADARG, "bad gated_residual arguments");
+    const int64_t total = B * N * C;
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gated_residual_kernel<T>), dim3(ew_grid(total, 1024)), dim3(256), 0,
+                                                (hipStream_t)stream, (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate,
+                                       int64_t B, int N, int C, void *stream) {
+    VSDE_CHECK_ARG(y && gate && dout && dy && dgate && C % 4 == 0, VSDE_E_BADARG, "bad gated_residual_bwd arguments");
+    const int64_t total = B * N * C;
+    hipStream_t s = (hipStream_t)stream;
+    VSDE_DTYPE_SWITCH(dtype, {
+        hipLaunchKernelGGL((gated_residual_kernel<T>), dim3(ew_grid(total, 1024)), dim3(256), 0, s, (const T *)nullptr,
+                           (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
+        hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 1>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dout,
+                           (const T *)y, (const float *)nullptr, (const float *)nullptr, (T *)dgate, (T *)nullptr, N, C);
+    });
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream) {
+    VSDE_CHECK_ARG(u && out && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu arguments");
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((swiglu_fwd_kernel<T>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T *)u, (T *)out, M, H2));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream) {
+    VSDE_CHECK_ARG(u && dout && du && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu_bwd arguments");
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((swiglu_bwd_kernel<T>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                                (const T *)u, (const T *)dout, (T *)du, M, H2));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
+                                   void *stream) {
+    VSDE_CHECK_ARG(attn && glog && out, VSDE_E_BADARG, "bad gate_merge arguments");
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gate_merge_fwd_kernel<T>), dim3(ew_grid(B * N * heads * d, 256)), dim3(256), 0,
+                                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog,
+                                   int64_t B, int N, int heads, int d, void *stream) {
+    VSDE_CHECK_ARG(attn && glog && dout && dattn && dglog, VSDE_E_BADARG, "bad gate_merge_bwd arguments");
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gate_merge_bwd_kernel<T>), dim3(ew_grid(B * N * d, 256)), dim3(256), 0,
+                                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
+                                                (T *)dglog, B * N, N, heads, d));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static int qk_check(int heads, int d) {
+    const int half = d / 2;
+    VSDE_CHECK_ARG(d % 2 == 0 && half >= 1 && half <= 64 && (half & (half - 1)) == 0, VSDE_E_BADARG,
+                   "qk_norm_rope needs head_dim/2 to be a power of two <= 64, got head_dim %d", d);
+    VSDE_CHECK_ARG(heads > 0 && (256 % half) == 0, VSDE_E_BADARG, "bad head count");
+    return 0;
+}
+
+extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
+                                     const float *wk, const void *v0, const float *lam, void *q, void *k, void *v, int64_t B,
+                                     int N, int heads, int d, double eps, void *stream) {
+    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && q && k && v && (!v0 || lam), VSDE_E_BADARG, "bad qk_norm_rope arguments");
+    int rc = qk_check(heads, d);
+    if (rc) return rc;
+    const int64_t pairs = B * N * heads * (d / 2);
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
+                                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q,
+                                                (T *)k, (T *)v, B * N, N, heads, d, (float)eps));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d) {
+    return (B * N * heads * (d / 2) + 255) / 256;
+}
+
+extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
+                                     const float *wk, const void *v0, const float *lam, const void *dq, const void *dk,
+                                     const void *dv, void *dqkv, void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d,
+                                     double eps, void *stream) {
+    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && dq && dk && dv && dqkv && (!v0 || (lam && dv0 && dlam_partial)), VSDE_E_BADARG,
+                   "bad qk_norm_rope_bwd arguments");
+    int rc = qk_check(heads, d);
+    if (rc) return rc;
+    const int64_t pairs = B * N * heads * (d / 2);
+    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
+                                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
+                                                (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N,
+                                                heads, d, (float)eps));
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -9,6 +9,7 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from . import fused
 from .embeddings import RotarySpec, apply_rope_1d
 from .initializer import init_linear_, zero_linear_
 from .norm import RMS
@@ -31,6 +32,23 @@ class Attention(nn.Module):
             self.v_residual_lambda = nn.Parameter(torch.tensor(0.5))
         make_norm = (lambda: RMS(self.head_dim, eps=qk_norm_eps, requires_grad=False)) if qk_norm else nn.Identity
         self.q_norm, self.k_norm = make_norm(), make_norm()
+
+    def fusable(self, hidden_states: Tensor, rotary: Optional[RotarySpec]) -> bool:
+        return (fused.ENABLED and rotary is not None and self._use_gate and isinstance(self.q_norm, RMS)
+                and not self.q_norm.weight.requires_grad and not self.k_norm.weight.requires_grad
+                and fused.usable(hidden_states, self.embed_dim, self.head_dim))
+
+    def forward_fused(self, hidden_states: Tensor, *, rotary: RotarySpec, v0: Optional[Tensor]) -> tuple[Tensor, Tensor]:
+        """Same map as ``forward(..., return_value=True)`` with the elementwise chains as fused HIP ops:
+        qkv GEMM -> [RMS + RoPE + value mix + head layout] -> SDPA -> [sigmoid gate + merge heads] -> out GEMM."""
+        N = hidden_states.shape[1]
+        cos, sin = rotary.cos_sin_tables(N)
+        mix = self._use_residual_v and v0 is not None
+        q, k, v = fused.qk_norm_rope(self.qkv_proj(hidden_states), cos, sin, self.q_norm.weight, self.k_norm.weight,
+                                     v0 if mix else None, self.v_residual_lambda if mix else None, self.num_heads,
+                                     self.q_norm.eps)
+        out = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
+        return self.out_proj(fused.gate_merge(out, self.gate_proj(hidden_states))), v
 
     def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,
                 return_value: bool = False):

@@ -50,12 +50,17 @@ class RotarySpec:
     def from_freqs(cls, freqs: Tensor) -> "RotarySpec":
         return cls(rotary_freqs=freqs)
 
-    def cos_sin(self, seq_len: int) -> tuple[Tensor, Tensor]:
-        f = self.rotary_freqs
-        if seq_len > f.shape[0]:
-            raise ValueError("requested sequence length exceeds precomputed frequencies")
-        f = f[:seq_len]
-        return f.real, f.imag
+    def cos_sin_tables(self, seq_len: int) -> tuple[Tensor, Tensor]:
+        """Contiguous fp32 ``[seq_len, d/2]`` cos / sin tables (cached on the spec) for the fused kernels."""
+        cache = self.__dict__.get("_tables")
+        if cache is None or cache[0].shape[0] != seq_len:
+            f = self.rotary_freqs
+            if seq_len > f.shape[0]:
+                raise ValueError("requested sequence length exceeds precomputed frequencies")
+            f = f[:seq_len]
+            cache = (f.real.float().contiguous(), f.imag.float().contiguous())
+            object.__setattr__(self, "_tables", cache)
+        return cache
 
 
 def apply_rope_1d(x: Tensor, freqs: Tensor) -> Tensor:

@@ -1,0 +1,131 @@
+"""Autograd wrappers of the fused HIP encoder operators (csrc/vsde_encoder.hip).
+
+Each function is one HBM pass forward and one backward; they are numerically the chains of
+primitives/{sit,attn,mlp}.py (which remain the eager specification and the CPU path of the
+encoder).  ``usable(x)`` decides whether a tensor can take the fused route."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd.function import once_differentiable
+
+from .. import _hip
+
+ENABLED = True  # set False to force the unfused torch chains (A/B tests)
+
+
+def usable(x: Tensor, channels: int, head_dim: int) -> bool:
+    half = head_dim // 2
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and channels % 64 == 0 and channels <= 1024
+            and head_dim % 2 == 0 and 1 <= half <= 64 and (half & (half - 1)) == 0)
+
+
+class _LnModulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, eps):
+        x, scale, shift = x.contiguous(), scale.to(x.dtype).contiguous(), shift.to(x.dtype).contiguous()
+        y, mean, rstd = _hip.ln_modulate_fwd(x, scale, shift, eps)
+        ctx.save_for_backward(x, scale, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, scale, mean, rstd = ctx.saved_tensors
+        dx, dscale, dshift = _hip.ln_modulate_bwd(x, scale, dy.to(x.dtype).contiguous(), mean, rstd)
+        return dx, dscale, dshift, None
+
+
+def ln_modulate(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> Tensor:
+    """``LayerNorm(x) * (1 + scale[:, None]) + shift[:, None]`` for x [B,N,C], scale/shift [B,C]."""
+    return _LnModulate.apply(x, scale, shift, eps)
+
+
+class _GatedResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, gate):
+        x, y, gate = x.contiguous(), y.to(x.dtype).contiguous(), gate.to(x.dtype).contiguous()
+        ctx.save_for_backward(y, gate)
+        return _hip.gated_residual_fwd(x, y, gate)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        y, gate = ctx.saved_tensors
+        dout = dout.to(y.dtype).contiguous()
+        dy, dgate = _hip.gated_residual_bwd(y, gate, dout)
+        return dout, dy, dgate
+
+
+def gated_residual(x: Tensor, y: Tensor, gate: Tensor) -> Tensor:
+    """``x + gate[:, None] * y``."""
+    return _GatedResidual.apply(x, y, gate)
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        u = u.contiguous()
+        ctx.save_for_backward(u)
+        return _hip.swiglu_fwd(u)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (u,) = ctx.saved_tensors
+        return _hip.swiglu_bwd(u, dout.to(u.dtype).contiguous())
+
+
+def swiglu(u: Tensor) -> Tensor:
+    """``silu(u[..., :h]) * u[..., h:]``."""
+    return _SwiGLU.apply(u)
+
+
+class _GateMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attn, glog):
+        attn, glog = attn.contiguous(), glog.to(attn.dtype).contiguous()
+        ctx.save_for_backward(attn, glog)
+        return _hip.gate_merge_fwd(attn, glog)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        attn, glog = ctx.saved_tensors
+        return _hip.gate_merge_bwd(attn, glog, dout.to(attn.dtype).contiguous())
+
+
+def gate_merge(attn: Tensor, gate_logits: Tensor) -> Tensor:
+    """[B,h,N,d] x sigmoid([B,N,d]) -> [B,N,h*d]."""
+    return _GateMerge.apply(attn, gate_logits)
+
+
+class _QkNormRope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, wq, wk, v0, lam, heads, eps):
+        qkv = qkv.contiguous()
+        v0c = v0.to(qkv.dtype).contiguous() if v0 is not None else None
+        lamc = lam.detach().float().reshape(1).contiguous() if lam is not None else None
+        q, k, v = _hip.qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0c, lamc, heads, eps)
+        ctx.save_for_backward(qkv, cos, sin, wq, wk, v0c, lamc)
+        ctx.meta = (heads, eps, lam.dtype if lam is not None else None)
+        return q, k, v
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dq, dk, dv):
+        qkv, cos, sin, wq, wk, v0, lam = ctx.saved_tensors
+        heads, eps, lam_dtype = ctx.meta
+        c = lambda t: t.to(qkv.dtype).contiguous()
+        dqkv, dv0, dlam = _hip.qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, c(dq), c(dk), c(dv), heads, eps)
+        if dlam is not None:
+            dlam = dlam.to(lam_dtype).reshape(())
+        return dqkv, None, None, None, None, dv0, dlam, None, None
+
+
+def qk_norm_rope(qkv: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor], lam: Optional[Tensor],
+                 heads: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
+    """qkv [B,N,3C] -> (q, k, v) each [B,heads,N,d]: RMS-norm + RoPE on q,k; v = lam*v + (1-lam)*v0."""
+    return _QkNormRope.apply(qkv, cos, sin, wq, wk, v0, lam, heads, eps)

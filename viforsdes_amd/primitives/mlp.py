@@ -1,9 +1,11 @@
 """SwiGLU feed-forward (reference: primitives/mlp.py:11-54): silu(a) * b with [a | b] = W_in x."""
 from __future__ import annotations
 
+import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from . import fused
 from .initializer import init_linear_
 
 
@@ -15,5 +17,8 @@ class SwiGLU(nn.Module):
         self.output_proj = init_linear_(nn.Linear(hidden_dim, in_dim, bias=bias))
 
     def forward(self, x: Tensor) -> Tensor:
-        a, b = self.input_proj(x).chunk(2, dim=-1)
+        u = self.input_proj(x)
+        if fused.ENABLED and u.is_cuda and u.dtype in (torch.float32, torch.bfloat16):
+            return self.output_proj(fused.swiglu(u))
+        a, b = u.chunk(2, dim=-1)
         return self.output_proj(F.silu(a) * b)

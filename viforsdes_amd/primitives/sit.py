@@ -15,6 +15,7 @@ from typing import Optional
 
 from torch import Tensor, nn
 
+from . import fused
 from .attn import Attention
 from .cond import CondBranch, CondModulator
 from .embeddings import RotarySpec
@@ -61,6 +62,15 @@ class SiTBlock(nn.Module):
     def forward(self, hidden_states: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None,
                 v0: Optional[Tensor] = None) -> tuple[Tensor, Tensor]:
         """Returns ``(hidden_states, value_heads)``; the caller keeps block 0's values as ``v0``."""
+        if cond.ndim == 2 and isinstance(self.attn_norm, nn.LayerNorm) and not self.attn_norm.elementwise_affine \
+                and self.self_attn.fusable(hidden_states, rotary):
+            # fused HIP route: 6 fused passes + 5 GEMMs + 1 attention call per block
+            sa, ha, ga, sm, hm, gm = self._cond_modulator.net(cond).chunk(6, dim=-1)
+            h1 = fused.ln_modulate(hidden_states, sa, ha, self.attn_norm.eps)
+            attn_out, values = self.self_attn.forward_fused(h1, rotary=rotary, v0=v0)
+            hidden_states = fused.gated_residual(hidden_states, attn_out, ga)
+            h2 = fused.ln_modulate(hidden_states, sm, hm, self.mlp_norm.eps)
+            return fused.gated_residual(hidden_states, self.mlp(h2), gm), values
         if cond.ndim == 2:
             cond = cond.unsqueeze(1)  # broadcast over the token axis
         attn_mod, mlp_mod = self.cond_params(cond=cond)
