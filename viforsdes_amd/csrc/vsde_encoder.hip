@@ -32,9 +32,60 @@ template <typename T> __device__ __forceinline__ float rnd(float x) { return to_
 
 __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
+// V contiguous elements of T <-> V floats with one (8/16-byte) memory instruction
+template <typename T, int V> struct Pack;
+template <int V> struct Pack<float, V> {
+    static __device__ __forceinline__ void load(const float *p, float (&o)[V]) {
+        if (V == 4) { float4 t = *(const float4 *)p; o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+        else if (V == 2) { float2 t = *(const float2 *)p; o[0] = t.x; o[1] = t.y; }
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = p[i];
+        }
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&o)[V]) {
+        if (V == 4) *(float4 *)p = make_float4(o[0], o[1], o[2], o[3]);
+        else if (V == 2) *(float2 *)p = make_float2(o[0], o[1]);
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) p[i] = o[i];
+        }
+    }
+};
+template <int V> struct Pack<bf16_t, V> {
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[V]) {
+        if (V == 8) { uint4 t = *(const uint4 *)p; const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); } }
+        else if (V == 4) { uint2 t = *(const uint2 *)p; const uint32_t w[2] = {t.x, t.y};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); } }
+        else if (V == 2) { uint32_t w = *(const uint32_t *)p; o[0] = __uint_as_float(w << 16); o[1] = __uint_as_float(w & 0xffff0000u); }
+        else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = to_f32(p[i]);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[V]) {
+        if (V == 8 || V == 4 || V == 2) {
+            uint32_t w[V / 2 > 0 ? V / 2 : 1];
+#pragma unroll
+            for (int i = 0; i < V / 2; ++i) w[i] = (uint32_t)from_f32<bf16_t>(o[2 * i]).v | ((uint32_t)from_f32<bf16_t>(o[2 * i + 1]).v << 16);
+            if (V == 8) *(uint4 *)p = make_uint4(w[0], w[1], w[2 % (V / 2)], w[3 % (V / 2)]);
+            else if (V == 4) *(uint2 *)p = make_uint2(w[0], w[1 % (V / 2)]);
+            else *(uint32_t *)p = w[0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) p[i] = from_f32<bf16_t>(o[i]);
+        }
+    }
+};
+template <typename T> struct VecOf { static constexpr int v = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int v = 8; };
+
 // ------------------------------------------------------------------------------ ln_modulate
-// one wavefront per token; lane owns channels c = i*64 + lane (i < C/64 <= 16), registers statically indexed
-template <typename T>
+// one wavefront per token; lane owns V contiguous channels of each 64*V-wide slab (<= 4 slabs)
+template <typename T, int V>
 __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ shift, T *__restrict__ y,
                                                          float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
@@ -43,29 +94,38 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int64_t b = m / N;
-    const int epl = C >> 6;
-    float v[16];
+    const int nslab = C / (64 * V);
+    float v[4][V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < epl) { v[i] = to_f32(x[m * C + i * 64 + lane]); s += v[i]; }
+    for (int sl = 0; sl < 4; ++sl)
+        if (sl < nslab) {
+            Pack<T, V>::load(x + m * C + (sl * 64 + lane) * V, v[sl]);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s += v[sl][e];
+        }
     const float mu = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < epl) { const float d = v[i] - mu; q += d * d; }
+    for (int sl = 0; sl < 4; ++sl)
+        if (sl < nslab)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const float d = v[sl][e] - mu; q += d * d; }
     const float rs = rsqrtf(wave_sum(q) / C + eps);
     if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < epl) {
-            const int c = i * 64 + lane;
-            const float xh = (v[i] - mu) * rs;
-            y[m * C + c] = from_f32<T>(xh * (1.0f + to_f32(scale[b * C + c])) + to_f32(shift[b * C + c]));
+    for (int sl = 0; sl < 4; ++sl)
+        if (sl < nslab) {
+            const int c = (sl * 64 + lane) * V;
+            float sc[V], sh[V], o[V];
+            Pack<T, V>::load(scale + b * C + c, sc); Pack<T, V>::load(shift + b * C + c, sh);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = (v[sl][e] - mu) * rs * (1.0f + sc[e]) + sh[e];
+            Pack<T, V>::store(y + m * C + c, o);
         }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                             const T *__restrict__ dy, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, T *__restrict__ dx, int64_t M,
@@ -74,22 +134,31 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict_
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int64_t b = m / N;
-    const int epl = C >> 6;
+    const int nslab = C / (64 * V);
     const float mu = mean[m], rs = rstd[m];
-    float g[16], xh[16];
+    float g[4][V], xh[4][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < epl) {
-            const int c = i * 64 + lane;
-            xh[i] = (to_f32(x[m * C + c]) - mu) * rs;
-            g[i] = to_f32(dy[m * C + c]) * (1.0f + to_f32(scale[b * C + c]));
-            s1 += g[i]; s2 += g[i] * xh[i];
+    for (int sl = 0; sl < 4; ++sl)
+        if (sl < nslab) {
+            const int c = (sl * 64 + lane) * V;
+            float sc[V];
+            Pack<T, V>::load(x + m * C + c, xh[sl]); Pack<T, V>::load(dy + m * C + c, g[sl]); Pack<T, V>::load(scale + b * C + c, sc);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                xh[sl][e] = (xh[sl][e] - mu) * rs; g[sl][e] *= (1.0f + sc[e]);
+                s1 += g[sl][e]; s2 += g[sl][e] * xh[sl][e];
+            }
         }
     s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < epl) dx[m * C + i * 64 + lane] = from_f32<T>(rs * (g[i] - s1 - xh[i] * s2));
+    for (int sl = 0; sl < 4; ++sl)
+        if (sl < nslab) {
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = rs * (g[sl][e] - s1 - xh[sl][e] * s2);
+            Pack<T, V>::store(dx + m * C + (sl * 64 + lane) * V, o);
+        }
 }
 
 // Column reductions over the N tokens of one batch row, 64 channels x 4 token groups per block.
@@ -123,84 +192,103 @@ __global__ void __launch_bounds__(256) rowgroup_colsum_kernel(const T *__restric
 }
 
 // --------------------------------------------------------------------------- gated_residual
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) gated_residual_kernel(const T *__restrict__ x, const T *__restrict__ y,
                                                              const T *__restrict__ gate, T *__restrict__ out, int64_t total,
                                                              int N, int C, int mode) {
     // mode 0: out = x + gate*y ; mode 1: out = gate * y   (backward: dy = gate * dout, x unused)
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < total; i0 += stride) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i0 < total; i0 += stride) {
         const int64_t m = i0 / C;
         const int c = (int)(i0 - m * C);
         const int64_t b = m / N;
+        float gv[V], yv[V], xv[V], o[V];
+        Pack<T, V>::load(gate + b * C + c, gv); Pack<T, V>::load(y + i0, yv);
+        if (mode == 0) Pack<T, V>::load(x + i0, xv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float g = to_f32(gate[b * C + c + e]) * to_f32(y[i0 + e]);
-            out[i0 + e] = from_f32<T>(mode == 0 ? to_f32(x[i0 + e]) + rnd<T>(g) : g);
-        }
+        for (int e = 0; e < V; ++e) { const float g = gv[e] * yv[e]; o[e] = mode == 0 ? xv[e] + rnd<T>(g) : g; }
+        Pack<T, V>::store(out + i0, o);
     }
 }
 
 // ----------------------------------------------------------------------------------- swiglu
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) swiglu_fwd_kernel(const T *__restrict__ u, T *__restrict__ out, int64_t M, int H2) {
-    const int64_t total = M * H2, stride = (int64_t)gridDim.x * blockDim.x;
+    const int hv = H2 / V;
+    const int64_t total = M * hv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t m = i / H2;
-        const int j = (int)(i - m * H2);
-        const float a = to_f32(u[m * 2 * H2 + j]), bv = to_f32(u[m * 2 * H2 + H2 + j]);
-        out[i] = from_f32<T>(rnd<T>(a * sigm(a)) * bv);
+        const int64_t m = i / hv;
+        const int j = (int)(i - m * hv) * V;
+        float a[V], bv[V], o[V];
+        Pack<T, V>::load(u + m * 2 * H2 + j, a); Pack<T, V>::load(u + m * 2 * H2 + H2 + j, bv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = rnd<T>(a[e] * sigm(a[e])) * bv[e];
+        Pack<T, V>::store(out + m * H2 + j, o);
     }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) swiglu_bwd_kernel(const T *__restrict__ u, const T *__restrict__ dout, T *__restrict__ du,
                                                          int64_t M, int H2) {
-    const int64_t total = M * H2, stride = (int64_t)gridDim.x * blockDim.x;
+    const int hv = H2 / V;
+    const int64_t total = M * hv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t m = i / H2;
-        const int j = (int)(i - m * H2);
-        const float a = to_f32(u[m * 2 * H2 + j]), bv = to_f32(u[m * 2 * H2 + H2 + j]), g = to_f32(dout[i]);
-        const float s = sigm(a);
-        du[m * 2 * H2 + j] = from_f32<T>(g * bv * s * (1.0f + a * (1.0f - s)));
-        du[m * 2 * H2 + H2 + j] = from_f32<T>(g * a * s);
+        const int64_t m = i / hv;
+        const int j = (int)(i - m * hv) * V;
+        float a[V], bv[V], g[V], da[V], db[V];
+        Pack<T, V>::load(u + m * 2 * H2 + j, a); Pack<T, V>::load(u + m * 2 * H2 + H2 + j, bv); Pack<T, V>::load(dout + m * H2 + j, g);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float sg = sigm(a[e]);
+            da[e] = g[e] * bv[e] * sg * (1.0f + a[e] * (1.0f - sg)); db[e] = g[e] * a[e] * sg;
+        }
+        Pack<T, V>::store(du + m * 2 * H2 + j, da); Pack<T, V>::store(du + m * 2 * H2 + H2 + j, db);
     }
 }
 
 // ------------------------------------------------------------------------------- gate_merge
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
                                                              T *__restrict__ out, int64_t M, int N, int heads, int d) {
-    const int C = heads * d;
-    const int64_t total = M * C, stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = heads * d, cv = C / V;
+    const int64_t total = M * cv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t m = i / C;
-        const int c = (int)(i - m * C), hh = c / d, k = c - hh * d;
+        const int64_t m = i / cv;
+        const int c = (int)(i - m * cv) * V, hh = c / d, k = c - hh * d;
         const int64_t b = m / N, n = m - b * N;
-        const float s = rnd<T>(sigm(to_f32(glog[m * d + k])));
-        out[i] = from_f32<T>(to_f32(attn[((b * heads + hh) * N + n) * d + k]) * s);
+        float gl[V], av[V], o[V];
+        Pack<T, V>::load(glog + m * d + k, gl); Pack<T, V>::load(attn + ((b * heads + hh) * N + n) * d + k, av);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = av[e] * rnd<T>(sigm(gl[e]));
+        Pack<T, V>::store(out + m * C + c, o);
     }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
                                                              const T *__restrict__ dout, T *__restrict__ dattn,
                                                              T *__restrict__ dglog, int64_t M, int N, int heads, int d) {
-    const int C = heads * d;
-    const int64_t total = M * d, stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = heads * d, dv = d / V;
+    const int64_t total = M * dv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t m = i / d;
-        const int k = (int)(i - m * d);
+        const int64_t m = i / dv;
+        const int k = (int)(i - m * dv) * V;
         const int64_t b = m / N, n = m - b * N;
-        const float s = sigm(to_f32(glog[i]));
-        float acc = 0.f;
+        float gl[V], sg[V], acc[V];
+        Pack<T, V>::load(glog + m * d + k, gl);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sg[e] = sigm(gl[e]); acc[e] = 0.f; }
         for (int hh = 0; hh < heads; ++hh) {
             const int64_t ai = ((b * heads + hh) * N + n) * d + k;
-            const float g = to_f32(dout[m * C + hh * d + k]);
-            dattn[ai] = from_f32<T>(g * s);
-            acc += g * to_f32(attn[ai]);
+            float g[V], av[V], o[V];
+            Pack<T, V>::load(dout + m * C + hh * d + k, g); Pack<T, V>::load(attn + ai, av);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { o[e] = g[e] * sg[e]; acc[e] += g[e] * av[e]; }
+            Pack<T, V>::store(dattn + ai, o);
         }
-        dglog[i] = from_f32<T>(acc * s * (1.0f - s));
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] *= sg[e] * (1.0f - sg[e]);
+        Pack<T, V>::store(dglog + m * d + k, acc);
     }
 }
 
@@ -308,12 +396,22 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
                            float *rstd, int64_t M, int N, int C, float eps, hipStream_t s) {
     VSDE_CHECK_ARG(C % 64 == 0 && C <= 1024, VSDE_E_BADARG, "ln_modulate needs C %% 64 == 0 and C <= 1024, got %d", C);
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
-    if (which == 0)
-        hipLaunchKernelGGL((ln_mod_fwd_kernel<T>), grid, block, 0, s, (const T *)x, (const T *)scale, (const T *)shift_or_dy, (T *)out,
-                           mean, rstd, M, N, C, eps);
-    else
-        hipLaunchKernelGGL((ln_mod_bwd_dx_kernel<T>), grid, block, 0, s, (const T *)x, (const T *)scale, (const T *)shift_or_dy,
-                           (const float *)mean, (const float *)rstd, (T *)out, M, N, C);
+    constexpr int VF = VecOf<T>::v;  // 8 bf16 / 4 f32 = 16 bytes per lane
+#define LNM(V)                                                                                                                \
+    do {                                                                                                                      \
+        if (which == 0) hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,      \
+                                           (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                       \
+        else hipLaunchKernelGGL((ln_mod_bwd_dx_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,              \
+                                (const T *)shift_or_dy, (const float *)mean, (const float *)rstd, (T *)out, M, N, C);         \
+    } while (0)
+    if (C % (64 * VF) == 0 && C / (64 * VF) <= 4) LNM(VF);
+    else if (C % (64 * (VF / 2)) == 0 && C / (64 * (VF / 2)) <= 4) LNM(VF / 2);
+    else if (C % (64 * (VF / 4)) == 0 && C / (64 * (VF / 4)) <= 4) LNM(VF / 4);
+    else {
+        VSDE_CHECK_ARG(C / 64 <= 4, VSDE_E_BADARG, "ln_modulate: unsupported channel count %d", C);
+        LNM(1);
+    }
+#undef LNM
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -354,8 +452,13 @@ extern "C" int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, 
                                        int C, void *stream) {
     VSDE_CHECK_ARG(x && y && gate && out && C % 4 == 0, VSDE_E_BADARG, "bad gated_residual arguments");
     const int64_t total = B * N * C;
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gated_residual_kernel<T>), dim3(ew_grid(total, 1024)), dim3(256), 0,
-                                                (hipStream_t)stream, (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0));
+    VSDE_DTYPE_SWITCH(dtype, {
+        constexpr int VF = VecOf<T>::v;
+        if (C % VF == 0) hipLaunchKernelGGL((gated_residual_kernel<T, VF>), dim3(ew_grid(total, 256 * VF)), dim3(256), 0, (hipStream_t)stream,
+                                            (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0);
+        else hipLaunchKernelGGL((gated_residual_kernel<T, 4>), dim3(ew_grid(total, 1024)), dim3(256), 0, (hipStream_t)stream,
+                                (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -366,8 +469,11 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
     const int64_t total = B * N * C;
     hipStream_t s = (hipStream_t)stream;
     VSDE_DTYPE_SWITCH(dtype, {
-        hipLaunchKernelGGL((gated_residual_kernel<T>), dim3(ew_grid(total, 1024)), dim3(256), 0, s, (const T *)nullptr,
-                           (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
+        constexpr int VF = VecOf<T>::v;
+        if (C % VF == 0) hipLaunchKernelGGL((gated_residual_kernel<T, VF>), dim3(ew_grid(total, 256 * VF)), dim3(256), 0, s,
+                                            (const T *)nullptr, (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
+        else hipLaunchKernelGGL((gated_residual_kernel<T, 4>), dim3(ew_grid(total, 1024)), dim3(256), 0, s, (const T *)nullptr,
+                                (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
         hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 1>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dout,
                            (const T *)y, (const float *)nullptr, (const float *)nullptr, (T *)dgate, (T *)nullptr, N, C);
     });
@@ -377,16 +483,24 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
 
 extern "C" int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream) {
     VSDE_CHECK_ARG(u && out && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu arguments");
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((swiglu_fwd_kernel<T>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
-                                                (const T *)u, (T *)out, M, H2));
+    VSDE_DTYPE_SWITCH(dtype, {
+        if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_fwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                            (const T *)u, (T *)out, M, H2);
+        else hipLaunchKernelGGL((swiglu_fwd_kernel<T, 1>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                (const T *)u, (T *)out, M, H2);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream) {
     VSDE_CHECK_ARG(u && dout && du && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu_bwd arguments");
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((swiglu_bwd_kernel<T>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
-                                                (const T *)u, (const T *)dout, (T *)du, M, H2));
+    VSDE_DTYPE_SWITCH(dtype, {
+        if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                            (const T *)u, (const T *)dout, (T *)du, M, H2);
+        else hipLaunchKernelGGL((swiglu_bwd_kernel<T, 1>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                (const T *)u, (const T *)dout, (T *)du, M, H2);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -394,8 +508,13 @@ extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void 
 extern "C" int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
                                    void *stream) {
     VSDE_CHECK_ARG(attn && glog && out, VSDE_E_BADARG, "bad gate_merge arguments");
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gate_merge_fwd_kernel<T>), dim3(ew_grid(B * N * heads * d, 256)), dim3(256), 0,
-                                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d));
+    VSDE_DTYPE_SWITCH(dtype, {
+        constexpr int VF = VecOf<T>::v;
+        if (d % VF == 0) hipLaunchKernelGGL((gate_merge_fwd_kernel<T, VF>), dim3(ew_grid(B * N * heads * d / VF, 256)), dim3(256), 0,
+                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d);
+        else hipLaunchKernelGGL((gate_merge_fwd_kernel<T, 1>), dim3(ew_grid(B * N * heads * d, 256)), dim3(256), 0,
+                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -403,9 +522,15 @@ extern "C" int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog
 extern "C" int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog,
                                    int64_t B, int N, int heads, int d, void *stream) {
     VSDE_CHECK_ARG(attn && glog && dout && dattn && dglog, VSDE_E_BADARG, "bad gate_merge_bwd arguments");
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((gate_merge_bwd_kernel<T>), dim3(ew_grid(B * N * d, 256)), dim3(256), 0,
-                                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
-                                                (T *)dglog, B * N, N, heads, d));
+    VSDE_DTYPE_SWITCH(dtype, {
+        constexpr int VF = VecOf<T>::v;
+        if (d % VF == 0) hipLaunchKernelGGL((gate_merge_bwd_kernel<T, VF>), dim3(ew_grid(B * N * d / VF, 256)), dim3(256), 0,
+                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
+                                            (T *)dglog, B * N, N, heads, d);
+        else hipLaunchKernelGGL((gate_merge_bwd_kernel<T, 1>), dim3(ew_grid(B * N * d, 256)), dim3(256), 0,
+                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
+                                (T *)dglog, B * N, N, heads, d);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
