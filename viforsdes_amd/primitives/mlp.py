@@ -16,9 +16,20 @@ class SwiGLU(nn.Module):
         self.input_proj = init_linear_(nn.Linear(in_dim, 2 * hidden_dim, bias=bias))
         self.output_proj = init_linear_(nn.Linear(hidden_dim, in_dim, bias=bias))
 
+    def _padded_weights(self, width: int):
+        """Zero-pad the hidden width (682 at the example configs) to a multiple of 128 so that the GEMMs
+        see 16-byte aligned rows / full MFMA tiles; padded units contribute silu(0)*0 = 0 exactly."""
+        h, pad = self.hidden_dim, width - self.hidden_dim
+        w1 = F.pad(self.input_proj.weight.view(2, h, self.in_dim), (0, 0, 0, pad)).reshape(2 * width, self.in_dim)
+        b1 = None if self.input_proj.bias is None else F.pad(self.input_proj.bias.view(2, h), (0, pad)).reshape(2 * width)
+        return w1, b1, F.pad(self.output_proj.weight, (0, pad))
+
     def forward(self, x: Tensor) -> Tensor:
-        u = self.input_proj(x)
-        if fused.ENABLED and u.is_cuda and u.dtype in (torch.float32, torch.bfloat16):
-            return self.output_proj(fused.swiglu(u))
-        a, b = u.chunk(2, dim=-1)
+        if fused.ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            width = -(-self.hidden_dim // 128) * 128
+            if width != self.hidden_dim:
+                w1, b1, w2 = self._padded_weights(width)
+                return F.linear(fused.swiglu(F.linear(x, w1, b1)), w2, self.output_proj.bias)
+            return self.output_proj(fused.swiglu(self.input_proj(x)))
+        a, b = self.input_proj(x).chunk(2, dim=-1)
         return self.output_proj(F.silu(a) * b)
