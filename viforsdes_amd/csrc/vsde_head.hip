@@ -546,6 +546,8 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
     float *gbuf = smem + lay.gbuf, *ebuf = smem + lay.ebuf;
     float *s_paths = smem + lay.s_paths, *s_means = smem + lay.s_means, *s_chol = smem + lay.s_chol;
     float *s_raw = smem + lay.s_raw, *s_acts = smem + lay.s_acts;
+    for (int e = tid; e < lay.total; e += 256) smem[e] = 0.f;  // finite data everywhere (see head_bwd_v2_kernel)
+    __syncthreads();
 
     // ---- register-resident weights ---------------------------------------------------------
     float wh[L][3][16], wi[L][3][16];
@@ -850,6 +852,10 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     float *s_gp = smem + lay.gp, *s_gm = smem + lay.gm, *s_gl = smem + lay.gl, *s_raw = smem + lay.raw, *s_eps = smem + lay.eps;
     float *owl = smem + lay.owl, *dxp = smem + lay.dxp;
     const int REC = L * 5 * H, DREC = L * 4 * H;
+    // For H < 64 a lane's 16-wide j-slice can reach past the H valid entries of a staged record; its
+    // weights are zero there, so the data only has to be finite: start from an all-zero LDS image.
+    for (int e = tid; e < lay.total; e += 256) smem[e] = 0.f;
+    __syncthreads();
 
     // ---- register-resident (transposed-use) weights: w[g][jj] = W[(g H + 16 kq + jj)][i]
     float whh[L][3][16], wih[3][16];
