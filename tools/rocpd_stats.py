@@ -22,3 +22,29 @@ def main(path):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+
+
+def categories(path):
+    """Coarse time split of a trace: our HIP kernels / hipBLASLt GEMMs / attention / other torch kernels."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    cat = {}
+    for n, d in cur.execute(f"select {name_col}, end-start from kernels"):
+        if "vsde::" in n:
+            k = "vsde " + ("head/gemm/elbo" if any(x in n for x in ("head_", "tn_", "gemm_nt", "elbo", "pack_")) else "encoder fused")
+        elif n.startswith("Cijk_"):
+            k = "hipBLASLt GEMM"
+        elif n in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess"):
+            k = "flash attention (aotriton)"
+        else:
+            k = "other torch kernels"
+        cat[k] = cat.get(k, 0) + d
+    tot = sum(cat.values())
+    for k, v in sorted(cat.items(), key=lambda kv: -kv[1]):
+        print(f"{k:<32} {v/1e6:>10.3f} ms {100*v/tot:>6.2f}%")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--categories":
+    categories(sys.argv[1])

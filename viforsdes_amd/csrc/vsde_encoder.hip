@@ -300,39 +300,65 @@ __device__ __forceinline__ float seg_sum(float v, int width) {
     return v;
 }
 
-template <typename T>
+// PV consecutive rotary pairs per thread (PV = 4: 8-byte bf16 / 16-byte f32 accesses); the head's
+// half/PV threads are consecutive lanes, so the RMS reduction is a segmented butterfly of that width.
+template <typename T, int PV>
 __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(const T *__restrict__ qkv, const float *__restrict__ cosT,
                                                                const float *__restrict__ sinT, const float *__restrict__ wq,
                                                                const float *__restrict__ wk, const T *__restrict__ v0,
                                                                const float *__restrict__ lam, T *__restrict__ q, T *__restrict__ k,
                                                                T *__restrict__ v, int64_t M, int N, int heads, int d, float eps) {
-    const int half = d >> 1, C = heads * d, P2 = C >> 1;
+    const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;  // threads per head / per token
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = gid < M * P2;
-    const int64_t m = ok ? gid / P2 : 0;
-    const int pp = ok ? (int)(gid - m * P2) : 0, hh = pp / half, i = pp - hh * half;
+    const bool ok = gid < M * TPT;
+    const int64_t m = ok ? gid / TPT : 0;
+    const int pp = ok ? (int)(gid - m * TPT) : 0, hh = pp / tph, i = (pp - hh * tph) * PV;
     const int64_t b = m / N, n = m - b * N;
     const T *row = qkv + m * 3 * C + hh * d;
-    float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f, a0 = 0.f, a1 = 0.f;
-    if (ok) { q0 = to_f32(row[i]); q1 = to_f32(row[i + half]); k0 = to_f32(row[C + i]); k1 = to_f32(row[C + i + half]);
-              a0 = to_f32(row[2 * C + i]); a1 = to_f32(row[2 * C + i + half]); }
-    const float rq = rsqrtf(seg_sum(q0 * q0 + q1 * q1, half) / d + eps);
-    const float rk = rsqrtf(seg_sum(k0 * k0 + k1 * k1, half) / d + eps);
+    float x[6][PV];  // q lo, q hi, k lo, k hi, v lo, v hi
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < PV; ++e) x[t][e] = 0.f;
+    if (ok) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { Pack<T, PV>::load(row + t * C + i, x[2 * t]); Pack<T, PV>::load(row + t * C + i + half, x[2 * t + 1]); }
+    }
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int e = 0; e < PV; ++e) { sq += x[0][e] * x[0][e] + x[1][e] * x[1][e]; sk += x[2][e] * x[2][e] + x[3][e] * x[3][e]; }
+    const float rq = rsqrtf(seg_sum(sq, tph) / d + eps);
+    const float rk = rsqrtf(seg_sum(sk, tph) / d + eps);
     if (!ok) return;
-    const float cs = cosT[n * half + i], sn = sinT[n * half + i];
-    const float qn0 = rnd<T>(q0 * rq * wq[i]), qn1 = rnd<T>(q1 * rq * wq[i + half]);
-    const float kn0 = rnd<T>(k0 * rk * wk[i]), kn1 = rnd<T>(k1 * rk * wk[i + half]);
+    float cs[PV], sn[PV], wql[PV], wqh[PV], wkl[PV], wkh[PV];
+    Pack<float, PV>::load(cosT + n * half + i, cs); Pack<float, PV>::load(sinT + n * half + i, sn);
+    Pack<float, PV>::load(wq + i, wql); Pack<float, PV>::load(wq + i + half, wqh);
+    Pack<float, PV>::load(wk + i, wkl); Pack<float, PV>::load(wk + i + half, wkh);
     const int64_t o = ((b * heads + hh) * N + n) * d + i;
-    q[o] = from_f32<T>(qn0 * cs - qn1 * sn); q[o + half] = from_f32<T>(qn0 * sn + qn1 * cs);
-    k[o] = from_f32<T>(kn0 * cs - kn1 * sn); k[o + half] = from_f32<T>(kn0 * sn + kn1 * cs);
+    float o0[PV], o1[PV];
+#pragma unroll
+    for (int e = 0; e < PV; ++e) {
+        const float a0 = rnd<T>(x[0][e] * rq * wql[e]), a1 = rnd<T>(x[1][e] * rq * wqh[e]);
+        o0[e] = a0 * cs[e] - a1 * sn[e]; o1[e] = a0 * sn[e] + a1 * cs[e];
+    }
+    Pack<T, PV>::store(q + o, o0); Pack<T, PV>::store(q + o + half, o1);
+#pragma unroll
+    for (int e = 0; e < PV; ++e) {
+        const float a0 = rnd<T>(x[2][e] * rk * wkl[e]), a1 = rnd<T>(x[3][e] * rk * wkh[e]);
+        o0[e] = a0 * cs[e] - a1 * sn[e]; o1[e] = a0 * sn[e] + a1 * cs[e];
+    }
+    Pack<T, PV>::store(k + o, o0); Pack<T, PV>::store(k + o + half, o1);
     if (v0) {
         const float l = lam[0];
-        a0 = l * a0 + (1.0f - l) * to_f32(v0[o]); a1 = l * a1 + (1.0f - l) * to_f32(v0[o + half]);
+        float p0[PV], p1[PV];
+        Pack<T, PV>::load(v0 + o, p0); Pack<T, PV>::load(v0 + o + half, p1);
+#pragma unroll
+        for (int e = 0; e < PV; ++e) { x[4][e] = l * x[4][e] + (1.0f - l) * p0[e]; x[5][e] = l * x[5][e] + (1.0f - l) * p1[e]; }
     }
-    v[o] = from_f32<T>(a0); v[o + half] = from_f32<T>(a1);
+    Pack<T, PV>::store(v + o, x[4]); Pack<T, PV>::store(v + o + half, x[5]);
 }
 
-template <typename T>
+template <typename T, int PV>
 __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restrict__ qkv, const float *__restrict__ cosT,
                                                                const float *__restrict__ sinT, const float *__restrict__ wq,
                                                                const float *__restrict__ wk, const T *__restrict__ v0,
@@ -342,40 +368,65 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
                                                                float *__restrict__ dlam_partial, int64_t M, int N, int heads, int d,
                                                                float eps) {
     __shared__ float red[4];
-    const int half = d >> 1, C = heads * d, P2 = C >> 1;
+    const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = gid < M * P2;
-    const int64_t m = ok ? gid / P2 : 0;
-    const int pp = ok ? (int)(gid - m * P2) : 0, hh = pp / half, i = pp - hh * half;
+    const bool ok = gid < M * TPT;
+    const int64_t m = ok ? gid / TPT : 0;
+    const int pp = ok ? (int)(gid - m * TPT) : 0, hh = pp / tph, i = (pp - hh * tph) * PV;
     const int64_t b = m / N, n = m - b * N;
     const T *row = qkv + m * 3 * C + hh * d;
+    T *drow = dqkv + m * 3 * C + hh * d;
     const int64_t o = ((b * heads + hh) * N + n) * d + i;
-    float x[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gy[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, w[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float x[4][PV], gy[4][PV], w[4][PV];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < PV; ++e) { x[t][e] = 0.f; gy[t][e] = 0.f; w[t][e] = 0.f; }
     float dlam = 0.f;
     if (ok) {
-        const float cs = cosT[n * half + i], sn = sinT[n * half + i];
-        x[0][0] = to_f32(row[i]); x[0][1] = to_f32(row[i + half]); x[1][0] = to_f32(row[C + i]); x[1][1] = to_f32(row[C + i + half]);
-        const float gq0 = to_f32(dq[o]), gq1 = to_f32(dq[o + half]), gk0 = to_f32(dk[o]), gk1 = to_f32(dk[o + half]);
-        gy[0][0] = gq0 * cs + gq1 * sn; gy[0][1] = -gq0 * sn + gq1 * cs;   // inverse rotation
-        gy[1][0] = gk0 * cs + gk1 * sn; gy[1][1] = -gk0 * sn + gk1 * cs;
-        w[0][0] = wq[i]; w[0][1] = wq[i + half]; w[1][0] = wk[i]; w[1][1] = wk[i + half];
-        float g0 = to_f32(dv[o]), g1 = to_f32(dv[o + half]);
+        float cs[PV], sn[PV], g0[PV], g1[PV];
+        Pack<float, PV>::load(cosT + n * half + i, cs); Pack<float, PV>::load(sinT + n * half + i, sn);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            Pack<T, PV>::load(row + t * C + i, x[2 * t]); Pack<T, PV>::load(row + t * C + i + half, x[2 * t + 1]);
+            Pack<T, PV>::load((t == 0 ? dq : dk) + o, g0); Pack<T, PV>::load((t == 0 ? dq : dk) + o + half, g1);
+            Pack<float, PV>::load((t == 0 ? wq : wk) + i, w[2 * t]); Pack<float, PV>::load((t == 0 ? wq : wk) + i + half, w[2 * t + 1]);
+#pragma unroll
+            for (int e = 0; e < PV; ++e) { gy[2 * t][e] = g0[e] * cs[e] + g1[e] * sn[e]; gy[2 * t + 1][e] = -g0[e] * sn[e] + g1[e] * cs[e]; }  // inverse rotation
+        }
+        Pack<T, PV>::load(dv + o, g0); Pack<T, PV>::load(dv + o + half, g1);
         if (v0) {
             const float l = lam[0];
-            dlam = g0 * (to_f32(row[2 * C + i]) - to_f32(v0[o])) + g1 * (to_f32(row[2 * C + i + half]) - to_f32(v0[o + half]));
-            dv0[o] = from_f32<T>((1.0f - l) * g0); dv0[o + half] = from_f32<T>((1.0f - l) * g1);
-            g0 *= l; g1 *= l;
+            float a0[PV], a1[PV], p0[PV], p1[PV], z0[PV], z1[PV];
+            Pack<T, PV>::load(row + 2 * C + i, a0); Pack<T, PV>::load(row + 2 * C + i + half, a1);
+            Pack<T, PV>::load(v0 + o, p0); Pack<T, PV>::load(v0 + o + half, p1);
+#pragma unroll
+            for (int e = 0; e < PV; ++e) {
+                dlam += g0[e] * (a0[e] - p0[e]) + g1[e] * (a1[e] - p1[e]);
+                z0[e] = (1.0f - l) * g0[e]; z1[e] = (1.0f - l) * g1[e]; g0[e] *= l; g1[e] *= l;
+            }
+            Pack<T, PV>::store(dv0 + o, z0); Pack<T, PV>::store(dv0 + o + half, z1);
         }
-        dqkv[m * 3 * C + 2 * C + hh * d + i] = from_f32<T>(g0); dqkv[m * 3 * C + 2 * C + hh * d + i + half] = from_f32<T>(g1);
+        Pack<T, PV>::store(drow + 2 * C + i, g0); Pack<T, PV>::store(drow + 2 * C + i + half, g1);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {  // RMS backward: dx = r w dy - x r^3 mean(x w dy)
-        const float ss = seg_sum(x[t][0] * x[t][0] + x[t][1] * x[t][1], half);
-        const float r = rsqrtf(ss / d + eps);
-        const float dot = seg_sum(x[t][0] * w[t][0] * gy[t][0] + x[t][1] * w[t][1] * gy[t][1], half) / d;
+        float ss = 0.f, dt = 0.f;
+#pragma unroll
+        for (int e = 0; e < PV; ++e) {
+            ss += x[2 * t][e] * x[2 * t][e] + x[2 * t + 1][e] * x[2 * t + 1][e];
+            dt += x[2 * t][e] * w[2 * t][e] * gy[2 * t][e] + x[2 * t + 1][e] * w[2 * t + 1][e] * gy[2 * t + 1][e];
+        }
+        const float r = rsqrtf(seg_sum(ss, tph) / d + eps);
+        const float dot = seg_sum(dt, tph) / d;
         if (ok) {
-            dqkv[m * 3 * C + t * C + hh * d + i] = from_f32<T>(r * w[t][0] * gy[t][0] - x[t][0] * r * r * r * dot);
-            dqkv[m * 3 * C + t * C + hh * d + i + half] = from_f32<T>(r * w[t][1] * gy[t][1] - x[t][1] * r * r * r * dot);
+            float o0[PV], o1[PV];
+#pragma unroll
+            for (int e = 0; e < PV; ++e) {
+                o0[e] = r * w[2 * t][e] * gy[2 * t][e] - x[2 * t][e] * r * r * r * dot;
+                o1[e] = r * w[2 * t + 1][e] * gy[2 * t + 1][e] - x[2 * t + 1][e] * r * r * r * dot;
+            }
+            Pack<T, PV>::store(drow + t * C + i, o0); Pack<T, PV>::store(drow + t * C + i + half, o1);
         }
     }
     if (dlam_partial) {
@@ -535,6 +586,8 @@ extern "C" int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog
     return 0;
 }
 
+static int qk_pv(int d) { return ((d / 2) % 4 == 0) ? 4 : 1; }  // rotary pairs per thread
+
 static int qk_check(int heads, int d) {
     const int half = d / 2;
     VSDE_CHECK_ARG(d % 2 == 0 && half >= 1 && half <= 64 && (half & (half - 1)) == 0, VSDE_E_BADARG,
@@ -549,16 +602,22 @@ extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *co
     VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && q && k && v && (!v0 || lam), VSDE_E_BADARG, "bad qk_norm_rope arguments");
     int rc = qk_check(heads, d);
     if (rc) return rc;
-    const int64_t pairs = B * N * heads * (d / 2);
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
-                                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q,
-                                                (T *)k, (T *)v, B * N, N, heads, d, (float)eps));
+    const int pv = qk_pv(d);
+    const int64_t threads = B * N * heads * (d / 2 / pv);
+    VSDE_DTYPE_SWITCH(dtype, {
+        if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k,
+                                        (T *)v, B * N, N, heads, d, (float)eps);
+        else hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k, (T *)v,
+                                B * N, N, heads, d, (float)eps);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d) {
-    return (B * N * heads * (d / 2) + 255) / 256;
+    return (B * N * heads * (d / 2 / qk_pv(d)) + 255) / 256;
 }
 
 extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
@@ -569,11 +628,18 @@ extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *co
                    "bad qk_norm_rope_bwd arguments");
     int rc = qk_check(heads, d);
     if (rc) return rc;
-    const int64_t pairs = B * N * heads * (d / 2);
-    VSDE_DTYPE_SWITCH(dtype, hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
-                                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
-                                                (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N,
-                                                heads, d, (float)eps));
+    const int pv = qk_pv(d);
+    const int64_t threads = B * N * heads * (d / 2 / pv);
+    VSDE_DTYPE_SWITCH(dtype, {
+        if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
+                                        (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
+                                        (float)eps);
+        else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                                (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
+                                (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
+                                (float)eps);
+    });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
