@@ -148,7 +148,7 @@ int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int
 }
 
 // -------------------------------------------------------------------------- grouped TN
-constexpr int TN_BM = 32, TN_T = 64, TN_LD = 72;  // LD 72: conflict-free ds_read_b32 fragments
+constexpr int TN_BM = 64, TN_T = 64, TN_LD = 72;  // LD 72: conflict-free ds_read_b32 fragments
 
 struct TnKernelArgs {
     TnProblem prob[kMaxTnProblems];
@@ -157,10 +157,11 @@ struct TnKernelArgs {
     int M;
     int rows_per_split;  // multiple of TN_BM
     int nsplit;
-    float *partial;      // [ntiles][nsplit][64*64]
+    float *partial;      // [ntiles][nsplit][64*64 + 64]  (tile + column sums of X for the bias gradient)
 };
+constexpr int TN_PART = TN_T * TN_T + TN_T;
 
-__device__ __forceinline__ float4 load_row4(const RowView &V, int64_t off, bool valid, int c, int NC, int vec, bool ones) {
+__device__ __forceinline__ float4 load_row4(const RowView &V, int64_t off, bool valid, int c, int NC, int vec) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!valid) return r;
     if (vec && c + 3 < NC) {
@@ -170,15 +171,15 @@ __device__ __forceinline__ float4 load_row4(const RowView &V, int64_t off, bool 
         r.z = __uint_as_float(raw.y << 16); r.w = __uint_as_float(raw.y & 0xffff0000u);
         return r;
     }
-    float t[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        int cc = c + e;
-        t[e] = cc < NC ? rowview_load(V, off, cc) : ((ones && cc == NC) ? 1.0f : 0.f);
-    }
-    return make_float4(t[0], t[1], t[2], t[3]);
+    if (c + 0 < NC) r.x = rowview_load(V, off, c + 0);
+    if (c + 1 < NC) r.y = rowview_load(V, off, c + 1);
+    if (c + 2 < NC) r.z = rowview_load(V, off, c + 2);
+    if (c + 3 < NC) r.w = rowview_load(V, off, c + 3);
+    return r;
 }
 
+// out tile (n_blk.., k_blk..) += X^T Y over this block's row range; rows are staged 64 at a time through
+// LDS with the NEXT 64 rows prefetched into registers while the MFMAs of the current ones run.
 __global__ void __launch_bounds__(256) tn_grouped_kernel(TnKernelArgs a) {
     __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_LD];
     __shared__ __attribute__((aligned(16))) float Ys[TN_BM * TN_LD];
@@ -186,99 +187,122 @@ __global__ void __launch_bounds__(256) tn_grouped_kernel(TnKernelArgs a) {
     const int tile = blockIdx.y, split = blockIdx.x;
     int pi = 0;
     while (pi + 1 < a.nprob && tile >= a.tile_begin[pi + 1]) ++pi;
-    const TnProblem &P = a.prob[pi];
-    const bool ones = P.bias_out != nullptr;
-    const int tiles_k = (P.NY + (ones ? 1 : 0) + TN_T - 1) / TN_T;
+    // copy the descriptor with static indices (a runtime-indexed kernarg array would live in scratch)
+    TnProblem P = a.prob[0];
+#pragma unroll
+    for (int i = 1; i < kMaxTnProblems; ++i)
+        if (pi == i) P = a.prob[i];
+    const int tiles_k = (P.NY + TN_T - 1) / TN_T;
     const int lt = tile - a.tile_begin[pi];
     const int n_blk = (lt / tiles_k) * TN_T, k_blk = (lt % tiles_k) * TN_T;
+    const bool want_bias = P.bias_out != nullptr && k_blk == 0;
     const int x_vec = (P.X.col_split >= P.NX && ((uintptr_t)P.X.base % 16 == 0) && P.X.batch_stride % 4 == 0 &&
                        P.X.row_stride % 4 == 0) ? 1 : 0;
     const int y_vec = (P.Y.col_split >= P.NY && ((uintptr_t)P.Y.base % 16 == 0) && P.Y.batch_stride % 4 == 0 &&
                        P.Y.row_stride % 4 == 0) ? 1 : 0;
 
-    const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 16 rows x 64 cols per pass
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;  // staging: 16 rows x 64 cols per pass, 4 passes
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
 
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
-        float4 xv[2], yv[2];
+    float4 xv[4], yv[4];
+    auto fetch = [&](int m0) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            int m = m0 + srow + 16 * ps;
-            bool in = m < m_end, vx = false, vy = false;
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = m0 + srow + 16 * ps;
+            const bool in = m < m_end;
+            bool vx = false, vy = false;
             int64_t ox = 0, oy = 0;
             if (in) { ox = rowview_offset(P.X, m, vx); oy = rowview_offset(P.Y, m, vy); }
-            xv[ps] = load_row4(P.X, ox, in && vx, n_blk + sc4, P.NX, x_vec, false);
-            // the appended ones column must be 1 on every in-range row, also when Y's row is "shifted out"
-            yv[ps] = load_row4(P.Y, oy, in && vy, k_blk + sc4, P.NY, y_vec, ones);
-            if (ones && in && !vy) {
-                int c = P.NY - (k_blk + sc4);
-                if (c >= 0 && c < 4) ((float *)&yv[ps])[c] = 1.0f;
-            }
+            xv[ps] = load_row4(P.X, ox, in && vx, n_blk + sc4, P.NX, x_vec);
+            yv[ps] = load_row4(P.Y, oy, in && vy, k_blk + sc4, P.NY, y_vec);
         }
-        __syncthreads();
+    };
+    if (m_begin < m_end) fetch(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_BM) {
+        __syncthreads();  // previous rows fully consumed
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        for (int ps = 0; ps < 4; ++ps) {
             *(float4 *)&Xs[(srow + 16 * ps) * TN_LD + sc4] = xv[ps];
             *(float4 *)&Ys[(srow + 16 * ps) * TN_LD + sc4] = yv[ps];
         }
         __syncthreads();
+        if (m0 + TN_BM < m_end) fetch(m0 + TN_BM);  // in flight during the MFMAs below
 #pragma unroll
         for (int c = 0; c < TN_BM / 8; ++c) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                int row = 8 * c + 2 * fq + s;
-                float xa = Xs[row * TN_LD + 16 * wave + fr];
+                const int row = 8 * c + 2 * fq + s;
+                const float xa = Xs[row * TN_LD + 16 * wave + fr];
+                bsum += xa;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    float yb = Ys[row * TN_LD + 16 * kt + fr];
+                    const float yb = Ys[row * TN_LD + 16 * kt + fr];
                     acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, yb, acc[kt], 0, 0, 0);
                 }
             }
         }
     }
-    float *dst = a.partial + ((int64_t)tile * a.nsplit + split) * (TN_T * TN_T);
+    float *dst = a.partial + ((int64_t)tile * a.nsplit + split) * TN_PART;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[(16 * wave + 4 * fq + r) * TN_T + 16 * kt + fr] = acc[kt][r];
+    if (want_bias) {  // column sums of X: lanes fr, fr+16, fr+32, fr+48 hold disjoint rows of column 16*wave+fr
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (fq == 0) dst[TN_T * TN_T + 16 * wave + fr] = bsum;
+    }
 }
 
+// 16 blocks per tile: block (tile, part) reduces 256 outputs (+ the bias row in part 0) over the splits
 __global__ void __launch_bounds__(256) tn_reduce_kernel(TnKernelArgs a) {
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x, part = blockIdx.y;
     int pi = 0;
     while (pi + 1 < a.nprob && tile >= a.tile_begin[pi + 1]) ++pi;
-    const TnProblem &P = a.prob[pi];
-    const bool ones = P.bias_out != nullptr;
-    const int tiles_k = (P.NY + (ones ? 1 : 0) + TN_T - 1) / TN_T;
+    TnProblem P = a.prob[0];
+#pragma unroll
+    for (int i = 1; i < kMaxTnProblems; ++i)
+        if (pi == i) P = a.prob[i];
+    const int tiles_k = (P.NY + TN_T - 1) / TN_T;
     const int lt = tile - a.tile_begin[pi];
     const int n_blk = (lt / tiles_k) * TN_T, k_blk = (lt % tiles_k) * TN_T;
-    const float *src = a.partial + (int64_t)tile * a.nsplit * (TN_T * TN_T);
-    for (int e = threadIdx.x; e < TN_T * TN_T; e += blockDim.x) {
-        int n = n_blk + e / TN_T, k = k_blk + e % TN_T;
-        if (n >= P.NX || k > P.NY || (k == P.NY && !ones)) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < a.nsplit; ++sp) s += src[(int64_t)sp * (TN_T * TN_T) + e];  // fixed order
-        if (k < P.NY) P.out[(int64_t)n * P.ldo + P.col_off + k] = s;
-        else P.bias_out[n] = s;
+    const float *src = a.partial + (int64_t)tile * a.nsplit * TN_PART;
+    {
+        const int e = part * 256 + threadIdx.x;
+        const int n = n_blk + e / TN_T, k = k_blk + e % TN_T;
+        if (n < P.NX && k < P.NY) {
+            float s = 0.f;
+            for (int sp = 0; sp < a.nsplit; ++sp) s += src[(int64_t)sp * TN_PART + e];  // fixed order
+            P.out[(int64_t)n * P.ldo + P.col_off + k] = s;
+        }
+    }
+    if (part == 0 && P.bias_out != nullptr && k_blk == 0 && threadIdx.x < TN_T) {
+        const int n = n_blk + threadIdx.x;
+        if (n < P.NX) {
+            float s = 0.f;
+            for (int sp = 0; sp < a.nsplit; ++sp) s += src[(int64_t)sp * TN_PART + TN_T * TN_T + threadIdx.x];
+            P.bias_out[n] = s;
+        }
     }
 }
 
 static int tn_plan(const TnProblem *probs, int nprob, int M, TnKernelArgs &a) {
     a.nprob = nprob; a.M = M;
     int tiles = 0;
-    for (int i = 0; i < nprob; ++i) {
-        a.prob[i] = probs[i];
-        a.tile_begin[i] = tiles;
-        int tn = (probs[i].NX + TN_T - 1) / TN_T;
-        int tk = (probs[i].NY + (probs[i].bias_out ? 1 : 0) + TN_T - 1) / TN_T;
-        tiles += tn * tk;
+    for (int i = 0; i < kMaxTnProblems; ++i) {
+        a.prob[i] = probs[i < nprob ? i : 0];
+        if (i < nprob) {
+            a.tile_begin[i] = tiles;
+            tiles += ((probs[i].NX + TN_T - 1) / TN_T) * ((probs[i].NY + TN_T - 1) / TN_T);
+        }
     }
-    a.tile_begin[nprob] = tiles;
+    for (int i = nprob; i <= kMaxTnProblems; ++i) a.tile_begin[i] = tiles;
     int chunks = (M + TN_BM - 1) / TN_BM;
     int want = tiles > 0 ? (2048 + tiles - 1) / tiles : 1;
     int nsplit = want < 1 ? 1 : want;
@@ -293,7 +317,7 @@ static int tn_plan(const TnProblem *probs, int nprob, int M, TnKernelArgs &a) {
 size_t tn_workspace_bytes(const TnProblem *probs, int nprob, int M) {
     TnKernelArgs a;
     int tiles = tn_plan(probs, nprob, M, a);
-    return (size_t)tiles * a.nsplit * TN_T * TN_T * sizeof(float);
+    return (size_t)tiles * a.nsplit * TN_PART * sizeof(float);
 }
 
 int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes,
@@ -302,12 +326,12 @@ int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace,
     VSDE_CHECK_ARG(nprob <= kMaxTnProblems, VSDE_E_BADARG, "too many grouped TN problems (%d)", nprob);
     TnKernelArgs a;
     int tiles = tn_plan(probs, nprob, M, a);
-    size_t need = (size_t)tiles * a.nsplit * TN_T * TN_T * sizeof(float);
+    size_t need = (size_t)tiles * a.nsplit * TN_PART * sizeof(float);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "TN workspace too small: %zu < %zu", workspace_bytes, need);
     a.partial = (float *)workspace;
     hipLaunchKernelGGL(tn_grouped_kernel, dim3(a.nsplit, tiles), dim3(256), 0, stream, a);
     VSDE_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(tiles, TN_T * TN_T / 256), dim3(256), 0, stream, a);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
