@@ -61,6 +61,26 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
     return tr
 
 
+def pmc_traffic_bytes(workload, batch):
+    """HBM bytes per launch of the serial forward kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_head_lv.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512).  The
+    kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
+    counter is used; null for other workloads."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_head_lv.txt")
+    if workload != "lv" or batch != 512 or not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        if "head_fwd_v2_kernel" in line:
+            parts = line.split()
+            ctr = [p for p in parts if p in ("FETCH_SIZE", "WRITE_SIZE")]
+            if ctr:
+                vals[ctr[0]] = float(line.split("mean=")[1])
+    if len(vals) != 2:
+        return None
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def sync(device):
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -206,8 +226,9 @@ def main():
                    "global_batch": global_batch, "parallelism": f"dp{world}"},
         "elbo_iters_per_sec": iters_per_sec,
         "sampled_paths_per_sec": global_batch * args.steps / s_elapsed,
-        "roofline": {"kernel": f"head_fwd_kernel<{L},true>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"kernel": f"vsde::head_fwd_v2_kernel<{L}, true, ...> (serial GRU time-stepping forward, training variant)",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(args.workload, args.batch),
                      "avg_ms": fwd_ms_avg, "algorithmic_bytes": fwd_bytes, "bytes_per_path_step": fwd_bytes_step,
                      "bwd_kernel_avg_ms": bwd_ms_avg,
                      "bwd_achieved_GBs": bwd_bytes_step * args.batch * T / (bwd_ms_avg * 1e-3) / 1e9},
