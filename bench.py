@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="sample paths per GPU")
     ap.add_argument("--workload", default="lv", choices=["lv", "ou", "synthetic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hip-graph", action="store_true", help="step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -180,6 +181,13 @@ def main():
         tr._train_step(model)
         ctx.ema.update()
 
+    # single-process runs replay the whole step (same kernels, same work) from a HIP graph
+    graph_mode = False
+    if not distributed and not args.no_hip_graph:
+        replay = tr.capture_step_graph(warmup=3)
+        if replay is not None:
+            train_step, graph_mode = replay, True
+
     elapsed = timed(train_step, args.steps, args.warmup, device, distributed)
     iters_per_sec = args.steps / elapsed
     global_batch = args.batch * world
@@ -223,7 +231,7 @@ def main():
         "vs_baseline": None, "dtype": "f32 (GRU/ELBO kernels) + bf16-autocast encoder", "data": "synthetic",
         "config": {"workload": f"{args.workload}: state_dim={S}, T={T} Euler steps (dt={dt}), batch={args.batch}/GPU, "
                                f"encoder {enc['enc_hidden']}x{enc['enc_depth']}x4 heads, GRU {H}x{L}",
-                   "global_batch": global_batch, "parallelism": f"dp{world}"},
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "hip_graph": graph_mode},
         "elbo_iters_per_sec": iters_per_sec,
         "sampled_paths_per_sec": global_batch * args.steps / s_elapsed,
         "roofline": {"kernel": f"vsde::head_fwd_v2_kernel<{L}, true, ...> (serial GRU time-stepping forward, training variant)",

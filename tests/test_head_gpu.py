@@ -146,3 +146,50 @@ def test_full_size_properties_lv():
     for a, b_ in zip(g1, g2):
         assert torch.allclose(2 * a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
     assert all(torch.isfinite(t_).all() for t_ in g1)
+
+
+@pytest.mark.parametrize("name", ["tiny_l2", "ou_dims", "lv_dims", "clamp"])
+def test_lds_resident_v1_kernels_also_match(name):
+    """L <= 2 normally runs the register-resident v2 kernels; the one-wave-per-path v1 kernels (which serve
+    L = 3, 4 and state dims with more than 16 emission rows) must give the same numbers."""
+    from viforsdes_amd import _hip
+    d = load_head_case(name)
+    tag = "o1f64" if "o1f64_paths" in d else "o1f32"
+    _hip.debug_force_v1(True)
+    try:
+        (paths, means, chol, chol_raw, acts), grads, _ = _run_case(d)
+    finally:
+        _hip.debug_force_v1(False)
+    for k, v in (("paths", paths), ("means", means), ("chol", chol)):
+        assert rel_err(v.cpu().numpy(), d[f"{tag}_{k}"]) < FWD_TOL, k
+    for gname, g in zip(G_NAMES, grads):
+        ref = d[f"{tag}_grad_{gname}"]
+        if ref.size:
+            assert rel_err(g.cpu().numpy(), ref) < BWD_TOL, gname
+
+
+def test_full_size_ou_matches_oracle():
+    """OU size (B=128, T=100, S=1, C=256, H=64, L=2): the whole batch against the CPU oracle."""
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, T, S, C, P, H, L = 128, 100, 1, 256, 3, 64, 2
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    ws = [rn(3 * H, S + C + P, sc=0.08), rn(3 * H, H, sc=0.12), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1),
+          rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1),
+          rn(S + 1, H, sc=0.1), torch.tensor([0.0, 0.5])]
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C), rn(B, P).abs(), rn(B, T, S)
+    gp, gm, gl = rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+    d_ = lambda t: t.to(dev)
+    out = _hip.head_forward(d_(x0), d_(ctx)[:, :-1], d_(theta), d_(eps), [d_(w) for w in ws], 0.05, True)
+    grads = _hip.head_backward(d_(gp), d_(gm), d_(gl), d_(ctx)[:, :-1], d_(theta), d_(eps), out[0], out[3], out[4],
+                               [d_(w) for w in ws], 0.05)
+    w = vo.HeadWeights(*[t.numpy() for t in ws])
+    f = vo.head_forward(x0.numpy(), ctx.numpy()[:, :-1], theta.numpy(), eps.numpy(), w, 0.05, True, np.float64)
+    gref = vo.head_backward(gp.numpy(), gm.numpy(), gl.numpy(), ctx.numpy()[:, :-1], theta.numpy(), eps.numpy(), f, w, 0.05,
+                            np.float64)
+    assert rel_err(out[0].cpu().numpy(), f.paths) < FWD_TOL and rel_err(out[2].cpu().numpy(), f.chol) < FWD_TOL
+    for a, b_, n in zip(grads, gref, G_NAMES):
+        if b_.size:
+            assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, n

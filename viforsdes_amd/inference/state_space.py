@@ -17,10 +17,16 @@ class StateSpace:
         if len(set(pos)) != len(pos):
             raise ValueError(f"positive_dims must be unique, got {pos}")
         self.dim, self.positive_dims = dim, pos
+        self._masks: dict = {}
 
     def _mask(self, like: Tensor) -> Tensor:
-        m = torch.zeros(self.dim, dtype=torch.bool, device=like.device)
-        m[self.positive_dims] = True
+        """Boolean [dim] mask of the positive dims on ``like``'s device (cached: building it copies from the
+        host, which must not happen inside a captured HIP graph)."""
+        m = self._masks.get(like.device)
+        if m is None:
+            host = torch.zeros(self.dim, dtype=torch.bool)
+            host[self.positive_dims] = True
+            m = self._masks[like.device] = host.to(like.device)
         return m
 
     def to_state(self, z: Tensor) -> Tensor:

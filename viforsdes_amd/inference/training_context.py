@@ -79,10 +79,11 @@ class TrainingContext:
         net_params = [p for p in model.parameters() if id(p) not in theta_ids]
         # Same AdamW hyper-parameters as the reference (training_context.py:97-102).  On the GPU the fused
         # implementation is used: GradScaler hands it `found_inf` on the device, so the optimizer step needs
-        # no host synchronisation (the unfused path does a .item() per step, which drains the launch queue).
+        # no host synchronisation (the unfused path does a .item() per step, which drains the launch queue);
+        # capturable=True keeps the step counters on the device so the whole step can be captured in a HIP graph.
         optimizer = torch.optim.AdamW([{"params": net_params, "lr": config.learning_rate},
                                        {"params": theta_params, "lr": config.sde_param_lr}],
-                                      fused=dev.type == "cuda")
+                                      fused=dev.type == "cuda", capturable=dev.type == "cuda")
         scaler = GradScaler("cuda", enabled=bool(mixed_precision and dev.type == "cuda" and torch.cuda.is_available()))
         dev_obs = observations.to(dev)
         x0 = dev_obs.values[0].unsqueeze(0).expand(config.batch_size, -1).contiguous()
