@@ -49,8 +49,8 @@ extern "C" {
 #define VSDE_E_STATE (-5)    /* state_dim not supported by the compiled kernels         */
 
 #define VSDE_MAX_LAYERS 4
-#define VSDE_MAX_HIDDEN 64   /* one wavefront per sample path: lane j owns hidden unit j */
-#define VSDE_MAX_STATE 10    /* S + S(S+1)/2 emission rows must fit one wavefront (<=64 lanes +1) */
+#define VSDE_MAX_HIDDEN 1024 /* tuned kernels: hidden_dim <= 64; generic kernels: one thread per unit up to 1024 */
+#define VSDE_MAX_STATE 32    /* tuned kernels: S + S(S+1)/2 <= 64 emission rows (S <= 9); generic kernels beyond */
 
 #define VSDE_CTX_F32 0
 #define VSDE_CTX_BF16 1

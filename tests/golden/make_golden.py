@@ -378,6 +378,10 @@ if __name__ == "__main__":
         make_head_case("clamp", 4, 9, 3, 8, 2, 24, 2, seed=15, with_o2=False, clamp_stress=True)
         make_head_case("ou_dims", 3, 10, 1, 64, 3, 64, 2, seed=16, with_o2=False)
         make_head_case("lv_dims", 2, 12, 2, 256, 3, 64, 2, seed=17, with_o2=False, with_f64=False)
+    if "head_wide" in which:
+        make_head_case("h80_l2", 2, 6, 2, 8, 2, 80, 2, seed=18, with_o2=False)
+        make_head_case("h130_l1_s10", 2, 4, 10, 6, 2, 130, 1, seed=19, with_o2=False)
+        make_head_case("h96_l3", 2, 5, 3, 8, 3, 96, 3, seed=20, with_o2=False)
     ou, lv = example_sdes()
     if "elbo" in which:
         make_elbo_case("ou", ou, [0.0, 1.0, 2.0, 3.0, 4.0, 5.0], [[2.0], [1.5], [0.8], [1.2], [0.9], [1.1]],

@@ -16,8 +16,8 @@ from .build import LIB_PATH
 
 VSDE_ABI_VERSION = 1
 MAX_LAYERS = 4      # reference: kernels/constants.py:13
-MAX_HIDDEN = 64
-MAX_STATE = 9
+MAX_HIDDEN = 1024
+MAX_STATE = 32
 DIAG_MIN = 1e-2     # reference: inference/constants.py:6
 
 

@@ -160,8 +160,15 @@ static int dispatch_elbo(int S, const ElboParams &p, bool bwd, hipStream_t s) {
         case 7: return launch_elbo<7>(p, bwd, s);
         case 8: return launch_elbo<8>(p, bwd, s);
         case 9: return launch_elbo<9>(p, bwd, s);
+        case 10: return launch_elbo<10>(p, bwd, s);
+        case 11: return launch_elbo<11>(p, bwd, s);
+        case 12: return launch_elbo<12>(p, bwd, s);
+        case 13: return launch_elbo<13>(p, bwd, s);
+        case 14: return launch_elbo<14>(p, bwd, s);
+        case 15: return launch_elbo<15>(p, bwd, s);
+        case 16: return launch_elbo<16>(p, bwd, s);
         default:
-            set_error("state_dim %d not supported by the ELBO kernels (1..9)", S);
+            set_error("state_dim %d not supported by the ELBO kernels (1..16)", S);
             return VSDE_E_STATE;
     }
 }

@@ -1042,6 +1042,197 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     }
 }
 
+// =========================================================================================
+// Generic ("wide") kernels: any hidden_dim <= 1024, any state_dim <= 32, L <= 4.  One workgroup
+// per sample path, thread j = hidden unit j, weights streamed from global memory (L2-resident),
+// hidden state and gate gradients exchanged through LDS.  Correctness-first path so that every
+// HeadConfig the reference accepts (models/head.py:33-36 only bounds num_layers) runs; the tuned
+// kernels above cover hidden_dim <= 64.
+// =========================================================================================
+template <bool SAVE>
+__global__ void head_fwd_wide_kernel(FwdParams p, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+    const int H = p.H, S = p.S, T = p.T, NO = p.NO, I = S + p.C + p.P, G3 = 3 * H;
+    float *hst = smem;              // [L][H] hidden state of every layer
+    float *hnew = hst + L * H;      // [H]    output of the layer just evaluated
+    float *xbuf = hnew + H;         // [S]
+    float *obuf = xbuf + S;         // [NO]
+    for (int e = tid; e < L * H; e += nthr) hst[e] = 0.f;
+    if (tid < S) { xbuf[tid] = p.x0[(int64_t)b * S + tid]; p.paths[(int64_t)b * (T + 1) * S + tid] = xbuf[tid]; }
+    const int j = tid;
+    const bool act = j < H;
+    float gth[3] = {0.f, 0.f, 0.f};
+    if (act)
+        for (int g = 0; g < 3; ++g)
+            for (int q = 0; q < p.P; ++q) gth[g] = fmaf(p.theta[(int64_t)b * p.P + q], p.W_ih0[(int64_t)(g * H + j) * I + S + p.C + q], gth[g]);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int64_t bt = (int64_t)b * T + t;
+        for (int l = 0; l < L; ++l) {
+            float a[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
+            if (act) {
+                const float *Wh = l == 0 ? p.W_hh0 : p.W_hh_st + (int64_t)(l - 1) * G3 * H;
+                const float *bh = l == 0 ? p.b_hh0 : p.b_hh_st + (int64_t)(l - 1) * G3;
+                for (int g = 0; g < 3; ++g) {
+                    const float *wr = Wh + (int64_t)(g * H + j) * H;
+                    float acc = bh[g * H + j];
+                    for (int k = 0; k < H; ++k) acc = fmaf(hst[l * H + k], wr[k], acc);
+                    c[g] = acc;
+                    if (l == 0) {
+                        float ai = p.G[bt * G3 + g * H + j] + gth[g];
+                        for (int i = 0; i < S; ++i) ai = fmaf(xbuf[i], p.W_ih0[(int64_t)(g * H + j) * I + i], ai);
+                        a[g] = ai;
+                    } else {
+                        const float *wi = p.W_ih_st + (int64_t)(l - 1) * G3 * H + (int64_t)(g * H + j) * H;
+                        float ai = p.b_ih_st[(int64_t)(l - 1) * G3 + g * H + j];
+                        for (int k = 0; k < H; ++k) ai = fmaf(hnew[k], wi[k], ai);
+                        a[g] = ai;
+                    }
+                }
+            }
+            __syncthreads();  // every thread finished reading hnew / hst[l]
+            if (act) {
+                const float r = fast_sigmoid(a[0] + c[0]), u = fast_sigmoid(a[1] + c[1]);
+                const float n = fast_tanh(a[2] + r * c[2]);
+                const float hn = (1.0f - u) * n + u * hst[l * H + j];
+                if (SAVE) {
+                    float *A = p.acts + ((bt * L + l) * 5) * H + j;
+                    A[0] = hn; A[H] = r; A[2 * H] = u; A[3 * H] = n; A[4 * H] = c[2];
+                }
+                hst[l * H + j] = hn; hnew[j] = hn;
+            }
+            __syncthreads();
+        }
+        for (int r = tid; r < NO; r += nthr) {  // emission rows (forward.py:314-362)
+            float acc = p.out_b[r];
+            for (int k = 0; k < H; ++k) acc = fmaf(hnew[k], p.out_W[(int64_t)r * H + k], acc);
+            if (SAVE && r >= S) p.chol_raw[bt * p.ntril + (r - S)] = acc;
+            if (r >= S) {
+                int q = r - S, rr = 0;
+                while ((rr + 1) * (rr + 2) / 2 <= q) ++rr;
+                if (q - rr * (rr + 1) / 2 == rr) acc = fmaxf(acc, p.diag_min);
+            }
+            obuf[r] = acc;
+        }
+        __syncthreads();
+        float xn = 0.f;
+        if (tid < S) {
+            float acc = 0.f;
+            const int base = S + tid * (tid + 1) / 2;
+            for (int q = 0; q <= tid; ++q) acc = fmaf(obuf[base + q], p.eps[bt * S + q], acc);
+            xn = xbuf[tid] + obuf[tid] * p.dt + acc * p.sqdt;
+            p.means[bt * S + tid] = obuf[tid];
+            p.paths[((int64_t)b * (T + 1) + t + 1) * S + tid] = xn;
+        }
+        for (int e = tid; e < S * S; e += nthr) {
+            int rr = e / S, cl = e - rr * S;
+            p.chol[bt * S * S + e] = cl <= rr ? obuf[S + rr * (rr + 1) / 2 + cl] : 0.f;
+        }
+        __syncthreads();
+        if (tid < S) xbuf[tid] = xn;
+        __syncthreads();
+    }
+}
+
+__global__ void head_bwd_wide_kernel(BwdParams p, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+    const int H = p.H, S = p.S, T = p.T, NO = p.NO, I = S + p.C + p.P, G3 = 3 * H;
+    float *dbuf = smem;             // [4][H] gate gradients of the layer being processed
+    float *dobuf = dbuf + 4 * H;    // [NO]
+    float *xbuf = dobuf + NO;       // [S]   d z_t
+    float *red = xbuf + S;          // [S][H] per-unit contributions to d z_t
+    const int j = tid;
+    const bool act = j < H;
+    float dh[VSDE_MAX_LAYERS] = {0.f, 0.f, 0.f, 0.f}, spi[3] = {0.f, 0.f, 0.f};
+    if (tid < S) xbuf[tid] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t bt = (int64_t)b * T + t;
+        if (tid < S) xbuf[tid] += p.g_paths[((int64_t)b * (T + 1) + t + 1) * S + tid];
+        __syncthreads();
+        for (int r = tid; r < NO; r += nthr) {
+            float dO;
+            if (r < S) dO = xbuf[r] * p.dt + p.g_means[bt * S + r];
+            else {
+                int q = r - S, rr = 0;
+                while ((rr + 1) * (rr + 2) / 2 <= q) ++rr;
+                const int cl = q - rr * (rr + 1) / 2;
+                dO = xbuf[rr] * p.eps[bt * S + cl] * p.sqdt + p.g_chol[(bt * S + rr) * S + cl];
+                if (rr == cl && !(p.chol_raw[bt * p.ntril + q] >= p.diag_min || dO < 0.f)) dO = 0.f;
+            }
+            dobuf[r] = dO;
+            p.DO[bt * NO + r] = dO;
+        }
+        __syncthreads();
+        float dcur = 0.f;
+        if (act)
+            for (int r = 0; r < NO; ++r) dcur = fmaf(dobuf[r], p.out_W[(int64_t)r * H + j], dcur);
+        for (int l = L - 1; l >= 0; --l) {
+            float carry = 0.f, pi0 = 0.f, pi1 = 0.f, pi2 = 0.f;
+            if (act) {
+                const float *A = p.acts + ((bt * L + l) * 5) * H + j;
+                const float r = A[H], u = A[2 * H], n = A[3 * H], cn = A[4 * H];
+                const float hprev = t > 0 ? A[-(int64_t)L * 5 * H] : 0.f;
+                const float d = dcur + dh[l];
+                const float dn = (1.0f - u) * d, du = (hprev - n) * d;
+                const float dn_pre = dn * (1.0f - n * n), du_pre = du * (u * (1.0f - u));
+                const float dcn = dn_pre * r, dr_pre = (dn_pre * cn) * (r * (1.0f - r));
+                carry = u * d;
+                float *D = p.D4 + (bt * L + l) * 4 * H + j;
+                D[0] = dr_pre; D[H] = du_pre; D[2 * H] = dn_pre; D[3 * H] = dcn;
+                dbuf[j] = dr_pre; dbuf[H + j] = du_pre; dbuf[2 * H + j] = dn_pre; dbuf[3 * H + j] = dcn;
+                pi0 = dr_pre; pi1 = du_pre; pi2 = dn_pre;
+            }
+            __syncthreads();
+            if (act) {
+                const float *Wh = l == 0 ? p.W_hh0 : p.W_hh_st + (int64_t)(l - 1) * G3 * H;
+                float acc_h = carry, acc_i = 0.f;
+                for (int k = 0; k < H; ++k) {
+                    acc_h = fmaf(Wh[(int64_t)k * H + j], dbuf[k], acc_h);
+                    acc_h = fmaf(Wh[(int64_t)(H + k) * H + j], dbuf[H + k], acc_h);
+                    acc_h = fmaf(Wh[(int64_t)(2 * H + k) * H + j], dbuf[3 * H + k], acc_h);
+                }
+                if (l > 0) {
+                    const float *Wi = p.W_ih_st + (int64_t)(l - 1) * G3 * H;
+                    for (int k = 0; k < H; ++k) {
+                        acc_i = fmaf(Wi[(int64_t)k * H + j], dbuf[k], acc_i);
+                        acc_i = fmaf(Wi[(int64_t)(H + k) * H + j], dbuf[H + k], acc_i);
+                        acc_i = fmaf(Wi[(int64_t)(2 * H + k) * H + j], dbuf[2 * H + k], acc_i);
+                    }
+                    dcur = acc_i;
+                } else {
+                    spi[0] += pi0; spi[1] += pi1; spi[2] += pi2;
+                    for (int i = 0; i < S; ++i)
+                        red[i * H + j] = p.W_ih0[(int64_t)j * I + i] * pi0 + p.W_ih0[(int64_t)(H + j) * I + i] * pi1 +
+                                         p.W_ih0[(int64_t)(2 * H + j) * I + i] * pi2;
+                }
+                dh[l] = acc_h;
+            }
+            __syncthreads();
+            if (l == 0 && tid < S) {  // fixed-order sum over the units
+                float acc = 0.f;
+                for (int k = 0; k < H; ++k) acc += red[tid * H + k];
+                xbuf[tid] += acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < S) p.g_x0[(int64_t)b * S + tid] = xbuf[tid] + p.g_paths[(int64_t)b * (T + 1) * S + tid];
+    for (int q = 0; q < p.P; ++q) {  // d theta (backward.py:511-548)
+        __syncthreads();
+        if (act) red[j] = p.W_ih0[(int64_t)j * I + S + p.C + q] * spi[0] + p.W_ih0[(int64_t)(H + j) * I + S + p.C + q] * spi[1] +
+                          p.W_ih0[(int64_t)(2 * H + j) * I + S + p.C + q] * spi[2];
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int k = 0; k < H; ++k) acc += red[k];
+            p.g_theta[(int64_t)b * p.P + q] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------ host launchers
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline block).
 static bool g_force_v1 = false;  // test hook: run L<=2 through the LDS-resident v1 kernels
@@ -1069,6 +1260,8 @@ static int check_dims(const vsde_head_dims *d) {
                    VSDE_MAX_HIDDEN);
     VSDE_CHECK_ARG(d->S <= VSDE_MAX_STATE, VSDE_E_STATE, "state_dim %d > %d is not supported by the gfx950 kernels", d->S,
                    VSDE_MAX_STATE);
+    VSDE_CHECK_ARG((size_t)(d->L * d->H + 2 * d->H + 4 * d->H + (d->S + 2) * (d->S + d->H + 4)) * sizeof(float) <= 150 * 1024,
+                   VSDE_E_HIDDEN, "hidden_dim %d x state_dim %d exceeds the LDS budget of the generic kernels", d->H, d->S);
     return 0;
 }
 
@@ -1183,7 +1376,9 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     PackParams pk = {};
     pk.S = d->S; pk.P = d->P; pk.C = d->C; pk.H = d->H; pk.L = d->L; pk.NO = NO;
     pk.W_ih0 = w->W_ih_l0; pk.W_hh0 = w->W_hh_l0; pk.W_ih_st = w->W_ih_stack; pk.W_hh_st = w->W_hh_stack; pk.out_W = w->out_weight;
-    pk.packF = (float4 *)(ws + lay.packF); pk.packO = (float4 *)(ws + lay.packO); pk.Wc = (float *)(ws + lay.Wc);
+    const bool wide = d->H > kHP || NO > kWave;
+    if (!wide) { pk.packF = (float4 *)(ws + lay.packF); pk.packO = (float4 *)(ws + lay.packO); }
+    pk.Wc = (float *)(ws + lay.Wc);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
     VSDE_CHECK_HIP(hipGetLastError());
 
@@ -1199,6 +1394,14 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     p.packF = pk.packF; p.packO = pk.packO;
     p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
     p.paths = paths; p.means = means; p.chol = chol; p.chol_raw = chol_raw; p.acts = acts;
+    if (d->H > kHP || NO > kWave) {  // generic kernels: any hidden_dim / state_dim
+        const int block = ((d->H > NO ? d->H : NO) + 63) / 64 * 64 > 1024 ? 1024 : ((d->H > NO ? d->H : NO) + 63) / 64 * 64;
+        const size_t ldsw = (size_t)(d->L * d->H + d->H + d->S + NO + 8) * sizeof(float);
+        if (save) hipLaunchKernelGGL((head_fwd_wide_kernel<true>), dim3(d->B), dim3(block), ldsw, s, p, d->L);
+        else hipLaunchKernelGGL((head_fwd_wide_kernel<false>), dim3(d->B), dim3(block), ldsw, s, p, d->L);
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (d->L <= 2 && !g_force_v1) {  // register-resident 4-waves-per-path kernels
         p.wpb = 1;
         int ch = 16;  // two workgroups per CU need <= 80 KB of LDS each
@@ -1355,7 +1558,8 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     PackParams pk = {};
     pk.S = d->S; pk.P = d->P; pk.C = d->C; pk.H = d->H; pk.L = d->L; pk.NO = NO;
     pk.W_ih0 = w->W_ih_l0; pk.W_hh0 = w->W_hh_l0; pk.W_ih_st = w->W_ih_stack; pk.W_hh_st = w->W_hh_stack; pk.out_W = w->out_weight;
-    pk.packB = (float4 *)(ws + lay.packB); pk.WcT = (float *)(ws + lay.WcT);
+    if (!(d->H > kHP || NO > kWave)) pk.packB = (float4 *)(ws + lay.packB);
+    pk.WcT = (float *)(ws + lay.WcT);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
     VSDE_CHECK_HIP(hipGetLastError());
 
@@ -1366,7 +1570,13 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     p.W_hh0 = w->W_hh_l0; p.W_ih_st = w->W_ih_stack; p.W_hh_st = w->W_hh_stack;
     p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
     p.D4 = (float *)(ws + lay.D4); p.DO = (float *)(ws + lay.DO); p.g_x0 = g->x0; p.g_theta = g->theta;
-    if (d->L <= 2 && NO <= 16 && !g_force_v1) {
+    if (d->H > kHP || NO > kWave) {  // generic kernels
+        const int block = ((d->H > NO ? d->H : NO) + 63) / 64 * 64 > 1024 ? 1024 : ((d->H > NO ? d->H : NO) + 63) / 64 * 64;
+        const size_t ldsw = (size_t)(4 * d->H + NO + d->S + d->S * d->H + 8) * sizeof(float);
+        hipLaunchKernelGGL(head_bwd_wide_kernel, dim3(d->B), dim3(block), ldsw, s, p, d->L);
+        VSDE_CHECK_HIP(hipGetLastError());
+        rc = 0;
+    } else if (d->L <= 2 && NO <= 16 && !g_force_v1) {
         int ch = 16;
         while (ch > 4 && (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float) > 80 * 1024) --ch;
         const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float);
