@@ -172,6 +172,14 @@ int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const f
                           const void *v0, const float *lam, const void *dq, const void *dk, const void *dv, void *dqkv,
                           void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, void *stream);
 
+/* Weight and bias gradient of y = x W^T + b for bf16 activations:  dW[N][K] = dy^T x,  db[N] = colsum(dy)
+ * (db may be NULL).  dy [M][N], x [M][K] bf16 contiguous, N % 8 == K % 8 == 0; results fp32, deterministic.
+ * Replaces torch's hipBLASLt "wgrad" GEMM + bf16 column-sum kernel of every encoder nn.Linear
+ * (reference: primitives/attn.py:46-47,54, primitives/mlp.py:41-44 via torch autograd). */
+size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
+int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, the launchers bracket the serial
  * time-stepping kernel with hipEvents on the launch stream.  which: 0 = forward (training
  * variant), 1 = backward.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */

@@ -111,3 +111,38 @@ def test_encoder_fused_vs_unfused_full_module_bf16_autocast():
     fused.ENABLED = True
     assert outs[0].shape == (6, 41, 256)
     assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 3e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(8192 + 37, 768, 256), (5000, 64, 256), (4100, 256, 768), (20000, 1536, 256), (4096, 8, 16)])
+def test_linear_wgrad_kernel(M, N, K):
+    """dW = dy^T x, db = colsum(dy): bf16 inputs, fp32 accumulation; reference in float64 on the same bf16 values."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(M)
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    dW, db = _hip.linear_wgrad(dy, x, True)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    assert rel_err(dW.cpu().numpy(), ref_w.cpu().numpy()) < 2e-5
+    assert rel_err(db.cpu().numpy(), ref_b.cpu().numpy()) < 2e-5
+    dW2, none = _hip.linear_wgrad(dy, x, False)
+    assert none is None and torch.equal(dW, dW2)  # deterministic
+
+
+def test_fused_linear_autograd_matches_f_linear():
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(6, 700, 256, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    w = (torch.randn(768, 256, generator=g) * 0.05).to(DEV).requires_grad_()
+    b = (torch.randn(768, generator=g) * 0.05).to(DEV).requires_grad_()
+    go = torch.randn(6, 700, 768, generator=g).to(DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = fused.linear(x, w, b)
+        y2 = torch.nn.functional.linear(x, w, b)
+    assert y1.dtype == torch.bfloat16 and torch.equal(y1, y2)
+    g1 = torch.autograd.grad((y1.float() * go).sum(), [x, w, b])
+    g2 = torch.autograd.grad((y2.float() * go).sum(), [x, w, b])
+    assert rel_err(g1[0].float().cpu().numpy(), g2[0].float().cpu().numpy()) < 1e-2
+    assert rel_err(g1[1].cpu().numpy(), g2[1].cpu().numpy()) < 1e-2   # torch's own wgrad is rounded to bf16
+    assert rel_err(g1[2].cpu().numpy(), g2[2].cpu().numpy()) < 1e-2
+    assert g1[1].dtype == torch.float32

@@ -55,6 +55,7 @@ EXPORTS = (
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
+    "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -86,6 +87,7 @@ def load() -> ctypes.CDLL:
     for f in (lib.vsde_head_forward, lib.vsde_head_backward, lib.vsde_elbo_path_terms, lib.vsde_elbo_path_terms_bwd):
         f.restype = ctypes.c_int
     lib.vsde_qk_norm_rope_bwd_partials.restype = ctypes.c_int64
+    lib.vsde_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     _lib = lib
     return lib
 
@@ -401,3 +403,18 @@ def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps):
               ctypes.c_int(d), ctypes.c_double(eps), _stream(dev))
     dlam = parts.sum() if parts is not None else None
     return dqkv, dv0, dlam
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
+    """dW[N,K] = dy^T x and db[N] = colsum(dy) in fp32 for bf16 dy [M,N], x [M,K]."""
+    lib = load(); dev = _require_hip(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.empty(N, K, device=dev, dtype=torch.float32)
+    db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
+    nbytes = lib.vsde_linear_wgrad_workspace_bytes(_i64(M), ctypes.c_int(N), ctypes.c_int(K))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_wgrad_bf16, _ptr(dy), _ptr(x), _i64(M), ctypes.c_int(N), ctypes.c_int(K), _ptr(dW), _ptr(db),
+              _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
+    return dW, db

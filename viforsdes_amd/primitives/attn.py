@@ -44,11 +44,14 @@ class Attention(nn.Module):
         N = hidden_states.shape[1]
         cos, sin = rotary.cos_sin_tables(N)
         mix = self._use_residual_v and v0 is not None
-        q, k, v = fused.qk_norm_rope(self.qkv_proj(hidden_states), cos, sin, self.q_norm.weight, self.k_norm.weight,
+        lin = fused.linear
+        qkv = lin(hidden_states, self.qkv_proj.weight, self.qkv_proj.bias)
+        q, k, v = fused.qk_norm_rope(qkv, cos, sin, self.q_norm.weight, self.k_norm.weight,
                                      v0 if mix else None, self.v_residual_lambda if mix else None, self.num_heads,
                                      self.q_norm.eps)
         out = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
-        return self.out_proj(fused.gate_merge(out, self.gate_proj(hidden_states))), v
+        merged = fused.gate_merge(out, lin(hidden_states, self.gate_proj.weight, self.gate_proj.bias))
+        return lin(merged, self.out_proj.weight, self.out_proj.bias), v
 
     def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,
                 return_value: bool = False):

@@ -129,3 +129,37 @@ def qk_norm_rope(qkv: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, 
                  heads: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
     """qkv [B,N,3C] -> (q, k, v) each [B,heads,N,d]: RMS-norm + RoPE on q,k; v = lam*v + (1-lam)*v0."""
     return _QkNormRope.apply(qkv, cos, sin, wq, wk, v0, lam, heads, eps)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b for bf16 activations: forward and the input gradient stay on hipBLASLt, the weight/bias
+    gradient (a reduction over ~2e5 rows that hipBLASLt runs at a few % of the HBM roofline) is one fused HIP
+    kernel pair (csrc/vsde_wgrad.hip) with fp32, deterministic results."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb = weight.to(torch.bfloat16)
+        y = torch.nn.functional.linear(x, wb, None if bias is None else bias.to(torch.bfloat16))
+        ctx.save_for_backward(x, wb)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        wdtype, bdtype = ctx.meta
+        dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dx = (dy2 @ wb).reshape(x.shape)
+        dW, db = _hip.linear_wgrad(dy2, x2, bdtype is not None)
+        return dx, dW.to(wdtype), None if db is None else db.to(bdtype)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """Drop-in for ``F.linear`` inside the encoder: uses the HIP weight-gradient kernel for large bf16 inputs."""
+    rows = x.numel() // x.shape[-1]
+    if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and rows >= 4096 and weight.shape[0] % 8 == 0
+            and weight.shape[1] % 8 == 0 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+        return _Linear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -29,7 +29,8 @@ class SwiGLU(nn.Module):
             width = -(-self.hidden_dim // 128) * 128
             if width != self.hidden_dim:
                 w1, b1, w2 = self._padded_weights(width)
-                return F.linear(fused.swiglu(F.linear(x, w1, b1)), w2, self.output_proj.bias)
-            return self.output_proj(fused.swiglu(self.input_proj(x)))
+                return fused.linear(fused.swiglu(fused.linear(x, w1, b1)), w2, self.output_proj.bias)
+            return fused.linear(fused.swiglu(fused.linear(x, self.input_proj.weight, self.input_proj.bias)),
+                                self.output_proj.weight, self.output_proj.bias)
         a, b = self.input_proj(x).chunk(2, dim=-1)
         return self.output_proj(F.silu(a) * b)

@@ -101,4 +101,4 @@ class SiT(nn.Module):
             tokens, values = block(tokens, cond=cond, rotary=rotary, v0=v0)
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
-        return self.output_proj(tokens)
+        return fused.linear(tokens, self.output_proj.weight, self.output_proj.bias)
