@@ -161,13 +161,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradParams p) {
     const int e = part * 256 + threadIdx.x;
     const int n = n_blk + e / T, k = k_blk + e % T;
     if (n < p.N && k < p.K) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed association: deterministic
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // fixed association: deterministic
         int sp = 0;
-        for (; sp + 3 < p.nsplit; sp += 4) {
-            s0 += src[(int64_t)sp * PART + e]; s1 += src[(int64_t)(sp + 1) * PART + e];
-            s2 += src[(int64_t)(sp + 2) * PART + e]; s3 += src[(int64_t)(sp + 3) * PART + e];
+        for (; sp + 7 < p.nsplit; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(sp + q) * PART + e];  // 8 loads in flight
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += v[q];
         }
-        for (; sp < p.nsplit; ++sp) s0 += src[(int64_t)sp * PART + e];
+        for (; sp < p.nsplit; ++sp) acc[0] += src[(int64_t)sp * PART + e];
+        const float s0 = acc[0] + acc[1], s1 = acc[2] + acc[3], s2 = acc[4] + acc[5], s3 = acc[6] + acc[7];
         p.dW[(int64_t)n * p.K + k] = (s0 + s1) + (s2 + s3);
     }
     if (part == 0 && p.db != nullptr && k_blk == 0 && threadIdx.x < T && n_blk + threadIdx.x < p.N) {
