@@ -9,10 +9,29 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from contextlib import nullcontext
+
 from . import fused
 from .embeddings import RotarySpec, apply_rope_1d
 from .initializer import init_linear_, zero_linear_
 from .norm import RMS
+
+
+def _sdpa_backend_context(t: Tensor):
+    """On gfx950 / ROCm 7 the memory-efficient SDPA kernels are ~25 % faster (forward + backward, seq 401,
+    head_dim 64, bf16) than the default flash path; prefer them, keep the others as fallbacks."""
+    if not t.is_cuda:
+        return nullcontext()
+    try:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        return sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True)
+    except Exception:  # older torch: no priority API
+        return nullcontext()
+
+
+def _sdpa(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    with _sdpa_backend_context(q):
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
 
 
 class Attention(nn.Module):
@@ -49,7 +68,7 @@ class Attention(nn.Module):
         q, k, v = fused.qk_norm_rope(qkv, cos, sin, self.q_norm.weight, self.k_norm.weight,
                                      v0 if mix else None, self.v_residual_lambda if mix else None, self.num_heads,
                                      self.q_norm.eps)
-        out = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
+        out = _sdpa(q, k, v)
         merged = fused.gate_merge(out, lin(hidden_states, self.gate_proj.weight, self.gate_proj.bias))
         return lin(merged, self.out_proj.weight, self.out_proj.bias), v
 
@@ -66,7 +85,7 @@ class Attention(nn.Module):
                 raise ValueError(f"v0 shape {tuple(v0.shape)} must match value heads {tuple(v.shape)}")
             lam = self.v_residual_lambda
             v = lam * v + (1.0 - lam) * v0
-        out = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0)
+        out = _sdpa(q, k, v)
         if self._use_gate:
             out = out * torch.sigmoid(self.gate_proj(hidden_states)).unsqueeze(1)
         out = self.out_proj(out.transpose(1, 2).reshape(B, N, self.embed_dim))
