@@ -159,18 +159,22 @@ int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const vo
                             int N, int C, void *stream);
 int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream);
 int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream);
+/* token_major selects the memory layout of the per-head tensors (attn, dattn, q, k, v, v0, dq, dk, dv, dv0):
+ * 0 = [B][heads][N][d] (the reference's layout after attn.py:96), 1 = [B][N][heads][d] (what the memory-efficient
+ * SDPA kernels read and write natively, so no transposing copies are needed around the attention call). */
 int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
-                        void *stream);
+                        int token_major, void *stream);
 int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog, int64_t B,
-                        int N, int heads, int d, void *stream);
-/* qkv[B][N][3C] -> q, k, v [B][heads][N][d]; cosT/sinT [N][d/2]; wq/wk [d]; v0 (optional) [B][heads][N][d] */
+                        int N, int heads, int d, int token_major, void *stream);
+/* qkv[B][N][3C] -> q, k, v; cosT/sinT [N][d/2]; wq/wk [d]; v0 optional, same layout as v */
 int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
                           const void *v0, const float *lam, void *q, void *k, void *v, int64_t B, int N, int heads, int d,
-                          double eps, void *stream);
+                          double eps, int token_major, void *stream);
 int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d);
 int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
                           const void *v0, const float *lam, const void *dq, const void *dk, const void *dv, void *dqkv,
-                          void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, void *stream);
+                          void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, int token_major,
+                          void *stream);
 
 /* Weight and bias gradient of y = x W^T + b for bf16 activations:  dW[N][K] = dy^T x,  db[N] = colsum(dy)
  * (db may be NULL).  dy [M][N], x [M][K] bf16 contiguous, N % 8 == K % 8 == 0; results fp32, deterministic.

@@ -146,3 +146,34 @@ def test_fused_linear_autograd_matches_f_linear():
     assert rel_err(g1[1].cpu().numpy(), g2[1].cpu().numpy()) < 1e-2   # torch's own wgrad is rounded to bf16
     assert rel_err(g1[2].cpu().numpy(), g2[2].cpu().numpy()) < 1e-2
     assert g1[1].dtype == torch.float32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_layouts_agree(dtype):
+    """qk_norm_rope / gate_merge give the same values in the [B,h,N,d] and the token-major [B,N,h,d] layout."""
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV, dtype)
+    B, N, h, d = 3, 21, 4, 64
+    ang = torch.arange(N, device=DEV, dtype=torch.float32)[:, None] * torch.linspace(0.1, 1.0, d // 2, device=DEV)
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    wq, wk = (1 + 0.1 * rn(d)).float(), (1 + 0.1 * rn(d)).float()
+    qkv0, v00, glog0 = rn(B, N, 3 * h * d), rn(B, h, N, d), rn(B, N, d)
+    outs = {}
+    for tm in (False, True):
+        qkv, v0, glog = (t.clone().requires_grad_() for t in (qkv0, v00, glog0))
+        lam = torch.tensor(0.7, device=DEV, requires_grad=True)
+        v0_in = v0.transpose(1, 2).contiguous() if tm else v0
+        q, k, v = fused.qk_norm_rope(qkv, cos, sin, wq, wk, v0_in, lam, h, 1e-6, token_major=tm)
+        a = q * 0.5 + k * 0.25 + v  # stand-in for attention, same layout as its inputs
+        merged = fused.gate_merge(a, glog, token_major=tm)
+        go = torch.linspace(-1, 1, merged.numel(), device=DEV).reshape(merged.shape)
+        grads = torch.autograd.grad((merged.float() * go).sum(), [qkv, v0, glog, lam])
+        std = (lambda t: t.transpose(1, 2)) if tm else (lambda t: t)
+        outs[tm] = [std(q), std(k), std(v), merged, *grads[:3]]
+        lam_grad = grads[3]
+        outs[tm].append(lam_grad)
+    for a, b_ in zip(outs[False][:-1], outs[True][:-1]):
+        assert torch.equal(a.contiguous(), b_.contiguous())
+    # d(lambda) is a block-partial sum whose grouping follows the layout
+    assert abs(float(outs[False][-1]) - float(outs[True][-1])) <= 1e-3 * (1 + abs(float(outs[False][-1])))

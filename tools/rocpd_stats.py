@@ -36,8 +36,8 @@ def categories(path):
             k = "vsde " + ("head/gemm/elbo" if any(x in n for x in ("head_", "tn_", "gemm_nt", "elbo", "pack_")) else "encoder fused")
         elif n.startswith("Cijk_"):
             k = "hipBLASLt GEMM"
-        elif n in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess"):
-            k = "flash attention (aotriton)"
+        elif n in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess", "bwd_postprocess") or "fmha_" in n:
+            k = "attention (aotriton / aiter)"
         else:
             k = "other torch kernels"
         cat[k] = cat.get(k, 0) + d

@@ -357,39 +357,49 @@ def swiglu_bwd(u, dout):
     return du
 
 
-def gate_merge_fwd(attn, glog):
+def _head_dims(t, token_major):
+    """(B, heads, N, d) of a per-head tensor stored [B,heads,N,d] (token_major False) or [B,N,heads,d] (True)."""
+    if token_major:
+        B, N, h, d = t.shape
+    else:
+        B, h, N, d = t.shape
+    return B, h, N, d
+
+
+def gate_merge_fwd(attn, glog, token_major=False):
     lib = load(); dev = _require_hip(attn, glog)
-    B, h, N, d = attn.shape
+    B, h, N, d = _head_dims(attn, token_major)
     out = torch.empty(B, N, h * d, device=dev, dtype=attn.dtype)
     with torch.cuda.device(dev):
         _call(lib.vsde_gate_merge_fwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(out), _i64(B), ctypes.c_int(N), ctypes.c_int(h),
-              ctypes.c_int(d), _stream(dev))
+              ctypes.c_int(d), ctypes.c_int(int(token_major)), _stream(dev))
     return out
 
 
-def gate_merge_bwd(attn, glog, dout):
+def gate_merge_bwd(attn, glog, dout, token_major=False):
     lib = load(); dev = _require_hip(attn, glog, dout)
-    B, h, N, d = attn.shape
+    B, h, N, d = _head_dims(attn, token_major)
     dattn = torch.empty_like(attn); dglog = torch.empty_like(glog)
     with torch.cuda.device(dev):
         _call(lib.vsde_gate_merge_bwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(dout), _ptr(dattn), _ptr(dglog), _i64(B),
-              ctypes.c_int(N), ctypes.c_int(h), ctypes.c_int(d), _stream(dev))
+              ctypes.c_int(N), ctypes.c_int(h), ctypes.c_int(d), ctypes.c_int(int(token_major)), _stream(dev))
     return dattn, dglog
 
 
-def qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0, lam, heads, eps):
+def qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major=False):
     lib = load(); dev = _require_hip(qkv, cos, sin, wq, wk)
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
-    q = torch.empty(B, heads, N, d, device=dev, dtype=qkv.dtype); k = torch.empty_like(q); v = torch.empty_like(q)
+    shape = (B, N, heads, d) if token_major else (B, heads, N, d)
+    q = torch.empty(shape, device=dev, dtype=qkv.dtype); k = torch.empty_like(q); v = torch.empty_like(q)
     with torch.cuda.device(dev):
         _call(lib.vsde_qk_norm_rope_fwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               _ptr(q), _ptr(k), _ptr(v), _i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d), ctypes.c_double(eps),
-              _stream(dev))
+              ctypes.c_int(int(token_major)), _stream(dev))
     return q, k, v
 
 
-def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps):
+def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, token_major=False):
     lib = load(); dev = _require_hip(qkv, dq, dk, dv)
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
@@ -400,7 +410,7 @@ def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps):
     with torch.cuda.device(dev):
         _call(lib.vsde_qk_norm_rope_bwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(dv0), _ptr(parts), _i64(B), ctypes.c_int(N), ctypes.c_int(heads),
-              ctypes.c_int(d), ctypes.c_double(eps), _stream(dev))
+              ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _stream(dev))
     dlam = parts.sum() if parts is not None else None
     return dqkv, dv0, dlam
 

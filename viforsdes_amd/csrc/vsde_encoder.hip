@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) swiglu_bwd_kernel(const T *__restrict__ u
 // ------------------------------------------------------------------------------- gate_merge
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
-                                                             T *__restrict__ out, int64_t M, int N, int heads, int d) {
+                                                             T *__restrict__ out, int64_t M, int N, int heads, int d, int token_major) {
     const int C = heads * d, cv = C / V;
     const int64_t total = M * cv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict
         const int c = (int)(i - m * cv) * V, hh = c / d, k = c - hh * d;
         const int64_t b = m / N, n = m - b * N;
         float gl[V], av[V], o[V];
-        Pack<T, V>::load(glog + m * d + k, gl); Pack<T, V>::load(attn + ((b * heads + hh) * N + n) * d + k, av);
+        Pack<T, V>::load(glog + m * d + k, gl);
+        Pack<T, V>::load(attn + (token_major ? m * C + c : ((b * heads + hh) * N + n) * d + k), av);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = av[e] * rnd<T>(sigm(gl[e]));
         Pack<T, V>::store(out + m * C + c, o);
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
                                                              const T *__restrict__ dout, T *__restrict__ dattn,
-                                                             T *__restrict__ dglog, int64_t M, int N, int heads, int d) {
+                                                             T *__restrict__ dglog, int64_t M, int N, int heads, int d, int token_major) {
     const int C = heads * d, dv = d / V;
     const int64_t total = M * dv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict
 #pragma unroll
         for (int e = 0; e < V; ++e) { sg[e] = sigm(gl[e]); acc[e] = 0.f; }
         for (int hh = 0; hh < heads; ++hh) {
-            const int64_t ai = ((b * heads + hh) * N + n) * d + k;
+            const int64_t ai = token_major ? m * C + hh * d + k : ((b * heads + hh) * N + n) * d + k;
             float g[V], av[V], o[V];
             Pack<T, V>::load(dout + m * C + hh * d + k, g); Pack<T, V>::load(attn + ai, av);
 #pragma unroll
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(const T *__restri
                                                                const float *__restrict__ sinT, const float *__restrict__ wq,
                                                                const float *__restrict__ wk, const T *__restrict__ v0,
                                                                const float *__restrict__ lam, T *__restrict__ q, T *__restrict__ k,
-                                                               T *__restrict__ v, int64_t M, int N, int heads, int d, float eps) {
+                                                               T *__restrict__ v, int64_t M, int N, int heads, int d, float eps, int token_major) {
     const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;  // threads per head / per token
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = gid < M * TPT;
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(const T *__restri
     Pack<float, PV>::load(cosT + n * half + i, cs); Pack<float, PV>::load(sinT + n * half + i, sn);
     Pack<float, PV>::load(wq + i, wql); Pack<float, PV>::load(wq + i + half, wqh);
     Pack<float, PV>::load(wk + i, wkl); Pack<float, PV>::load(wk + i + half, wkh);
-    const int64_t o = ((b * heads + hh) * N + n) * d + i;
+    const int64_t o = token_major ? (m * heads + hh) * d + i : ((b * heads + hh) * N + n) * d + i;
     float o0[PV], o1[PV];
 #pragma unroll
     for (int e = 0; e < PV; ++e) {
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
                                                                const T *__restrict__ dk, const T *__restrict__ dv,
                                                                T *__restrict__ dqkv, T *__restrict__ dv0,
                                                                float *__restrict__ dlam_partial, int64_t M, int N, int heads, int d,
-                                                               float eps) {
+                                                               float eps, int token_major) {
     __shared__ float red[4];
     const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
     const int64_t b = m / N, n = m - b * N;
     const T *row = qkv + m * 3 * C + hh * d;
     T *drow = dqkv + m * 3 * C + hh * d;
-    const int64_t o = ((b * heads + hh) * N + n) * d + i;
+    const int64_t o = token_major ? (m * heads + hh) * d + i : ((b * heads + hh) * N + n) * d + i;
     float x[4][PV], gy[4][PV], w[4][PV];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -557,30 +558,30 @@ extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void 
 }
 
 extern "C" int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
-                                   void *stream) {
+                                   int token_major, void *stream) {
     VSDE_CHECK_ARG(attn && glog && out, VSDE_E_BADARG, "bad gate_merge arguments");
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
         if (d % VF == 0) hipLaunchKernelGGL((gate_merge_fwd_kernel<T, VF>), dim3(ew_grid(B * N * heads * d / VF, 256)), dim3(256), 0,
-                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d);
+                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major);
         else hipLaunchKernelGGL((gate_merge_fwd_kernel<T, 1>), dim3(ew_grid(B * N * heads * d, 256)), dim3(256), 0,
-                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d);
+                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog,
-                                   int64_t B, int N, int heads, int d, void *stream) {
+                                   int64_t B, int N, int heads, int d, int token_major, void *stream) {
     VSDE_CHECK_ARG(attn && glog && dout && dattn && dglog, VSDE_E_BADARG, "bad gate_merge_bwd arguments");
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
         if (d % VF == 0) hipLaunchKernelGGL((gate_merge_bwd_kernel<T, VF>), dim3(ew_grid(B * N * d / VF, 256)), dim3(256), 0,
                                             (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
-                                            (T *)dglog, B * N, N, heads, d);
+                                            (T *)dglog, B * N, N, heads, d, token_major);
         else hipLaunchKernelGGL((gate_merge_bwd_kernel<T, 1>), dim3(ew_grid(B * N * d, 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
-                                (T *)dglog, B * N, N, heads, d);
+                                (T *)dglog, B * N, N, heads, d, token_major);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -598,7 +599,7 @@ static int qk_check(int heads, int d) {
 
 extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
                                      const float *wk, const void *v0, const float *lam, void *q, void *k, void *v, int64_t B,
-                                     int N, int heads, int d, double eps, void *stream) {
+                                     int N, int heads, int d, double eps, int token_major, void *stream) {
     VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && q && k && v && (!v0 || lam), VSDE_E_BADARG, "bad qk_norm_rope arguments");
     int rc = qk_check(heads, d);
     if (rc) return rc;
@@ -607,10 +608,10 @@ extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *co
     VSDE_DTYPE_SWITCH(dtype, {
         if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k,
-                                        (T *)v, B * N, N, heads, d, (float)eps);
+                                        (T *)v, B * N, N, heads, d, (float)eps, token_major);
         else hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k, (T *)v,
-                                B * N, N, heads, d, (float)eps);
+                                B * N, N, heads, d, (float)eps, token_major);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -623,7 +624,7 @@ extern "C" int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, i
 extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
                                      const float *wk, const void *v0, const float *lam, const void *dq, const void *dk,
                                      const void *dv, void *dqkv, void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d,
-                                     double eps, void *stream) {
+                                     double eps, int token_major, void *stream) {
     VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && dq && dk && dv && dqkv && (!v0 || (lam && dv0 && dlam_partial)), VSDE_E_BADARG,
                    "bad qk_norm_rope_bwd arguments");
     int rc = qk_check(heads, d);
@@ -634,11 +635,11 @@ extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *co
         if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                         (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                        (float)eps);
+                                        (float)eps, token_major);
         else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                 (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                (float)eps);
+                                (float)eps, token_major);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;

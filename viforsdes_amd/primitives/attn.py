@@ -59,17 +59,22 @@ class Attention(nn.Module):
 
     def forward_fused(self, hidden_states: Tensor, *, rotary: RotarySpec, v0: Optional[Tensor]) -> tuple[Tensor, Tensor]:
         """Same map as ``forward(..., return_value=True)`` with the elementwise chains as fused HIP ops:
-        qkv GEMM -> [RMS + RoPE + value mix + head layout] -> SDPA -> [sigmoid gate + merge heads] -> out GEMM."""
+        qkv GEMM -> [RMS + RoPE + value mix + head layout] -> SDPA -> [sigmoid gate + merge heads] -> out GEMM.
+
+        The per-head tensors live in memory as [B,N,h,d] (the layout the memory-efficient SDPA kernels read and
+        write), handed around as [B,h,N,d] *views*, so neither direction needs a transposing copy."""
         N = hidden_states.shape[1]
         cos, sin = rotary.cos_sin_tables(N)
         mix = self._use_residual_v and v0 is not None
         lin = fused.linear
         qkv = lin(hidden_states, self.qkv_proj.weight, self.qkv_proj.bias)
         q, k, v = fused.qk_norm_rope(qkv, cos, sin, self.q_norm.weight, self.k_norm.weight,
-                                     v0 if mix else None, self.v_residual_lambda if mix else None, self.num_heads,
-                                     self.q_norm.eps)
+                                     v0.transpose(1, 2) if mix else None, self.v_residual_lambda if mix else None,
+                                     self.num_heads, self.q_norm.eps, token_major=True)
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)  # [B,h,N,d] views
         out = _sdpa(q, k, v)
-        merged = fused.gate_merge(out, lin(hidden_states, self.gate_proj.weight, self.gate_proj.bias))
+        merged = fused.gate_merge(out.transpose(1, 2), lin(hidden_states, self.gate_proj.weight, self.gate_proj.bias),
+                                  token_major=True)
         return lin(merged, self.out_proj.weight, self.out_proj.bias), v
 
     def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,

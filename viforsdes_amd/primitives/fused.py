@@ -85,50 +85,53 @@ def swiglu(u: Tensor) -> Tensor:
 
 class _GateMerge(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, attn, glog):
+    def forward(ctx, attn, glog, token_major):
         attn, glog = attn.contiguous(), glog.to(attn.dtype).contiguous()
         ctx.save_for_backward(attn, glog)
-        return _hip.gate_merge_fwd(attn, glog)
+        ctx.token_major = token_major
+        return _hip.gate_merge_fwd(attn, glog, token_major)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         attn, glog = ctx.saved_tensors
-        return _hip.gate_merge_bwd(attn, glog, dout.to(attn.dtype).contiguous())
+        dattn, dglog = _hip.gate_merge_bwd(attn, glog, dout.to(attn.dtype).contiguous(), ctx.token_major)
+        return dattn, dglog, None
 
 
-def gate_merge(attn: Tensor, gate_logits: Tensor) -> Tensor:
-    """[B,h,N,d] x sigmoid([B,N,d]) -> [B,N,h*d]."""
-    return _GateMerge.apply(attn, gate_logits)
+def gate_merge(attn: Tensor, gate_logits: Tensor, token_major: bool = False) -> Tensor:
+    """[B,h,N,d] (or [B,N,h,d] when ``token_major``) x sigmoid([B,N,d]) -> [B,N,h*d]."""
+    return _GateMerge.apply(attn, gate_logits, token_major)
 
 
 class _QkNormRope(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cos, sin, wq, wk, v0, lam, heads, eps):
+    def forward(ctx, qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major):
         qkv = qkv.contiguous()
         v0c = v0.to(qkv.dtype).contiguous() if v0 is not None else None
         lamc = lam.detach().float().reshape(1).contiguous() if lam is not None else None
-        q, k, v = _hip.qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0c, lamc, heads, eps)
+        q, k, v = _hip.qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0c, lamc, heads, eps, token_major)
         ctx.save_for_backward(qkv, cos, sin, wq, wk, v0c, lamc)
-        ctx.meta = (heads, eps, lam.dtype if lam is not None else None)
+        ctx.meta = (heads, eps, lam.dtype if lam is not None else None, token_major)
         return q, k, v
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dq, dk, dv):
         qkv, cos, sin, wq, wk, v0, lam = ctx.saved_tensors
-        heads, eps, lam_dtype = ctx.meta
+        heads, eps, lam_dtype, token_major = ctx.meta
         c = lambda t: t.to(qkv.dtype).contiguous()
-        dqkv, dv0, dlam = _hip.qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, c(dq), c(dk), c(dv), heads, eps)
+        dqkv, dv0, dlam = _hip.qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, c(dq), c(dk), c(dv), heads, eps, token_major)
         if dlam is not None:
             dlam = dlam.to(lam_dtype).reshape(())
-        return dqkv, None, None, None, None, dv0, dlam, None, None
+        return dqkv, None, None, None, None, dv0, dlam, None, None, None
 
 
 def qk_norm_rope(qkv: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor], lam: Optional[Tensor],
-                 heads: int, eps: float) -> tuple[Tensor, Tensor, Tensor]:
-    """qkv [B,N,3C] -> (q, k, v) each [B,heads,N,d]: RMS-norm + RoPE on q,k; v = lam*v + (1-lam)*v0."""
-    return _QkNormRope.apply(qkv, cos, sin, wq, wk, v0, lam, heads, eps)
+                 heads: int, eps: float, token_major: bool = False) -> tuple[Tensor, Tensor, Tensor]:
+    """qkv [B,N,3C] -> (q, k, v) each [B,heads,N,d] ([B,N,heads,d] when ``token_major``; v0 in the same layout):
+    RMS-norm + RoPE on q,k; v = lam*v + (1-lam)*v0."""
+    return _QkNormRope.apply(qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major)
 
 
 class _Linear(torch.autograd.Function):
