@@ -152,7 +152,8 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
 int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
                          float *rstd, int64_t B, int N, int C, double eps, void *stream);
 int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
-                         const float *rstd, void *dx, void *dscale, void *dshift, int64_t B, int N, int C, void *stream);
+                         const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
+                         void *stream); /* dres (optional, [B][N][C]) is added to dx: the gradient reaching x through the residual */
 int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N, int C,
                             void *stream);
 int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate, int64_t B,
@@ -163,18 +164,20 @@ int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_
  * 0 = [B][heads][N][d] (the reference's layout after attn.py:96), 1 = [B][N][heads][d] (what the memory-efficient
  * SDPA kernels read and write natively, so no transposing copies are needed around the attention call). */
 int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
-                        int token_major, void *stream);
+                        int token_major, int64_t glog_stride, void *stream);
 int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog, int64_t B,
-                        int N, int heads, int d, int token_major, void *stream);
-/* qkv[B][N][3C] -> q, k, v; cosT/sinT [N][d/2]; wq/wk [d]; v0 optional, same layout as v */
+                        int N, int heads, int d, int token_major, int64_t glog_stride, void *stream);
+/* qkv[B][N][3C] -> q, k, v; cosT/sinT [N][d/2]; wq/wk [d]; v0 optional, same layout as v.
+ * row_stride (>= 3C elements) / glog_stride (>= d) are the row pitches of qkv+dqkv / glog+dglog, so both can be column
+ * ranges of the output of ONE merged [qkv | gate] projection (and of its gradient buffer). */
 int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
                           const void *v0, const float *lam, void *q, void *k, void *v, int64_t B, int N, int heads, int d,
-                          double eps, int token_major, void *stream);
+                          double eps, int token_major, int64_t row_stride, void *stream);
 int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d);
 int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
                           const void *v0, const float *lam, const void *dq, const void *dk, const void *dv, void *dqkv,
                           void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, int token_major,
-                          void *stream);
+                          int64_t row_stride, void *stream);
 
 /* Weight and bias gradient of y = x W^T + b for bf16 activations:  dW[N][K] = dy^T x,  db[N] = colsum(dy)
  * (db may be NULL).  dy [M][N], x [M][K] bf16 contiguous, N % 8 == K % 8 == 0; results fp32, deterministic.

@@ -309,13 +309,14 @@ def ln_modulate_fwd(x, scale, shift, eps):
     return y, mean, rstd
 
 
-def ln_modulate_bwd(x, scale, dy, mean, rstd):
+def ln_modulate_bwd(x, scale, dy, mean, rstd, dres=None):
+    """dres (optional, same shape as x) is added to dx inside the kernel."""
     lib = load(); dev = _require_hip(x, scale, dy)
     B, N, C = x.shape
     dx = torch.empty_like(x); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
     with torch.cuda.device(dev):
-        _call(lib.vsde_ln_modulate_bwd, _dt(x), _ptr(x), _ptr(scale), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dscale),
-              _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
+        _call(lib.vsde_ln_modulate_bwd, _dt(x), _ptr(x), _ptr(scale), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+              _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
     return dx, dscale, dshift
 
 
@@ -366,23 +367,39 @@ def _head_dims(t, token_major):
     return B, h, N, d
 
 
+def _row_pitch(t, width):
+    """Row pitch (elements) of a [B,N,width] tensor that is either contiguous or a column range of a contiguous
+    [B,N,W] buffer (the merged [qkv | gate] projection)."""
+    B, N, w = t.shape
+    pitch = t.stride(1)
+    if w != width or t.stride(2) != 1 or pitch < width or t.stride(0) != N * pitch:
+        raise ValueError(f"expected a [B,N,{width}] row-pitched tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    return pitch
+
+
 def gate_merge_fwd(attn, glog, token_major=False):
     lib = load(); dev = _require_hip(attn, glog)
     B, h, N, d = _head_dims(attn, token_major)
     out = torch.empty(B, N, h * d, device=dev, dtype=attn.dtype)
     with torch.cuda.device(dev):
         _call(lib.vsde_gate_merge_fwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(out), _i64(B), ctypes.c_int(N), ctypes.c_int(h),
-              ctypes.c_int(d), ctypes.c_int(int(token_major)), _stream(dev))
+              ctypes.c_int(d), ctypes.c_int(int(token_major)), _i64(_row_pitch(glog, d)), _stream(dev))
     return out
 
 
-def gate_merge_bwd(attn, glog, dout, token_major=False):
+def gate_merge_bwd(attn, glog, dout, token_major=False, dglog=None):
+    """dglog: optional preallocated destination with the same row pitch as glog (a column range of a shared buffer)."""
     lib = load(); dev = _require_hip(attn, glog, dout)
     B, h, N, d = _head_dims(attn, token_major)
-    dattn = torch.empty_like(attn); dglog = torch.empty_like(glog)
+    dattn = torch.empty_like(attn)
+    if dglog is None:
+        dglog = torch.empty_like(glog) if glog.is_contiguous() else torch.empty_strided(glog.shape, glog.stride(), device=dev, dtype=glog.dtype)
+    pitch = _row_pitch(glog, d)
+    if _row_pitch(dglog, d) != pitch:
+        raise ValueError("dglog must have the row pitch of glog")
     with torch.cuda.device(dev):
         _call(lib.vsde_gate_merge_bwd, _dt(attn), _ptr(attn), _ptr(glog), _ptr(dout), _ptr(dattn), _ptr(dglog), _i64(B),
-              ctypes.c_int(N), ctypes.c_int(h), ctypes.c_int(d), ctypes.c_int(int(token_major)), _stream(dev))
+              ctypes.c_int(N), ctypes.c_int(h), ctypes.c_int(d), ctypes.c_int(int(token_major)), _i64(pitch), _stream(dev))
     return dattn, dglog
 
 
@@ -390,27 +407,33 @@ def qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major=Fal
     lib = load(); dev = _require_hip(qkv, cos, sin, wq, wk)
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
+    pitch = _row_pitch(qkv, C3)
     shape = (B, N, heads, d) if token_major else (B, heads, N, d)
     q = torch.empty(shape, device=dev, dtype=qkv.dtype); k = torch.empty_like(q); v = torch.empty_like(q)
     with torch.cuda.device(dev):
         _call(lib.vsde_qk_norm_rope_fwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               _ptr(q), _ptr(k), _ptr(v), _i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d), ctypes.c_double(eps),
-              ctypes.c_int(int(token_major)), _stream(dev))
+              ctypes.c_int(int(token_major)), _i64(pitch), _stream(dev))
     return q, k, v
 
 
-def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, token_major=False):
+def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, token_major=False, dqkv=None):
+    """dqkv: optional preallocated destination with the same row pitch as qkv (a column range of a shared buffer)."""
     lib = load(); dev = _require_hip(qkv, dq, dk, dv)
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
-    dqkv = torch.empty_like(qkv)
+    pitch = _row_pitch(qkv, C3)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv) if qkv.is_contiguous() else torch.empty_strided(qkv.shape, qkv.stride(), device=dev, dtype=qkv.dtype)
+    if _row_pitch(dqkv, C3) != pitch:
+        raise ValueError("dqkv must have the row pitch of qkv")
     dv0 = torch.empty_like(dv) if v0 is not None else None
     nparts = lib.vsde_qk_norm_rope_bwd_partials(_i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d))
     parts = torch.empty(nparts, device=dev, dtype=torch.float32) if v0 is not None else None
     with torch.cuda.device(dev):
         _call(lib.vsde_qk_norm_rope_bwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(dv0), _ptr(parts), _i64(B), ctypes.c_int(N), ctypes.c_int(heads),
-              ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _stream(dev))
+              ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _i64(pitch), _stream(dev))
     dlam = parts.sum() if parts is not None else None
     return dqkv, dv0, dlam
 

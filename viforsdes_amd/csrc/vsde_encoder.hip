@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
 template <typename T, int V>
 __global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                             const T *__restrict__ dy, const float *__restrict__ mean,
-                                                            const float *__restrict__ rstd, T *__restrict__ dx, int64_t M,
-                                                            int N, int C) {
+                                                            const float *__restrict__ rstd, const T *__restrict__ dres,
+                                                            T *__restrict__ dx, int64_t M, int N, int C) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -157,6 +157,12 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict_
             float o[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) o[e] = rs * (g[sl][e] - s1 - xh[sl][e] * s2);
+            if (dres) {  // x also feeds the residual branch: fold that gradient in here instead of a separate add
+                float r[V];
+                Pack<T, V>::load(dres + m * C + (sl * 64 + lane) * V, r);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] += r[e];
+            }
             Pack<T, V>::store(dx + m * C + (sl * 64 + lane) * V, o);
         }
 }
@@ -249,7 +255,8 @@ __global__ void __launch_bounds__(256) swiglu_bwd_kernel(const T *__restrict__ u
 // ------------------------------------------------------------------------------- gate_merge
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
-                                                             T *__restrict__ out, int64_t M, int N, int heads, int d, int token_major) {
+                                                             T *__restrict__ out, int64_t M, int N, int heads, int d, int token_major,
+                                                             int64_t gstride) {
     const int C = heads * d, cv = C / V;
     const int64_t total = M * cv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict
         const int c = (int)(i - m * cv) * V, hh = c / d, k = c - hh * d;
         const int64_t b = m / N, n = m - b * N;
         float gl[V], av[V], o[V];
-        Pack<T, V>::load(glog + m * d + k, gl);
+        Pack<T, V>::load(glog + m * gstride + k, gl);
         Pack<T, V>::load(attn + (token_major ? m * C + c : ((b * heads + hh) * N + n) * d + k), av);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = av[e] * rnd<T>(sigm(gl[e]));
@@ -268,7 +275,8 @@ __global__ void __launch_bounds__(256) gate_merge_fwd_kernel(const T *__restrict
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict__ attn, const T *__restrict__ glog,
                                                              const T *__restrict__ dout, T *__restrict__ dattn,
-                                                             T *__restrict__ dglog, int64_t M, int N, int heads, int d, int token_major) {
+                                                             T *__restrict__ dglog, int64_t M, int N, int heads, int d, int token_major,
+                                                             int64_t gstride) {
     const int C = heads * d, dv = d / V;
     const int64_t total = M * dv, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict
         const int k = (int)(i - m * dv) * V;
         const int64_t b = m / N, n = m - b * N;
         float gl[V], sg[V], acc[V];
-        Pack<T, V>::load(glog + m * d + k, gl);
+        Pack<T, V>::load(glog + m * gstride + k, gl);
 #pragma unroll
         for (int e = 0; e < V; ++e) { sg[e] = sigm(gl[e]); acc[e] = 0.f; }
         for (int hh = 0; hh < heads; ++hh) {
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] *= sg[e] * (1.0f - sg[e]);
-        Pack<T, V>::store(dglog + m * d + k, acc);
+        Pack<T, V>::store(dglog + m * gstride + k, acc);
     }
 }
 
@@ -308,14 +316,15 @@ __global__ void __launch_bounds__(256) qk_norm_rope_fwd_kernel(const T *__restri
                                                                const float *__restrict__ sinT, const float *__restrict__ wq,
                                                                const float *__restrict__ wk, const T *__restrict__ v0,
                                                                const float *__restrict__ lam, T *__restrict__ q, T *__restrict__ k,
-                                                               T *__restrict__ v, int64_t M, int N, int heads, int d, float eps, int token_major) {
+                                                               T *__restrict__ v, int64_t M, int N, int heads, int d, float eps, int token_major,
+                                                               int64_t rstride) {
     const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;  // threads per head / per token
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = gid < M * TPT;
     const int64_t m = ok ? gid / TPT : 0;
     const int pp = ok ? (int)(gid - m * TPT) : 0, hh = pp / tph, i = (pp - hh * tph) * PV;
     const int64_t b = m / N, n = m - b * N;
-    const T *row = qkv + m * 3 * C + hh * d;
+    const T *row = qkv + m * rstride + hh * d;
     float x[6][PV];  // q lo, q hi, k lo, k hi, v lo, v hi
 #pragma unroll
     for (int t = 0; t < 6; ++t)
@@ -367,7 +376,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
                                                                const T *__restrict__ dk, const T *__restrict__ dv,
                                                                T *__restrict__ dqkv, T *__restrict__ dv0,
                                                                float *__restrict__ dlam_partial, int64_t M, int N, int heads, int d,
-                                                               float eps, int token_major) {
+                                                               float eps, int token_major, int64_t rstride) {
     __shared__ float red[4];
     const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,8 +384,8 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
     const int64_t m = ok ? gid / TPT : 0;
     const int pp = ok ? (int)(gid - m * TPT) : 0, hh = pp / tph, i = (pp - hh * tph) * PV;
     const int64_t b = m / N, n = m - b * N;
-    const T *row = qkv + m * 3 * C + hh * d;
-    T *drow = dqkv + m * 3 * C + hh * d;
+    const T *row = qkv + m * rstride + hh * d;
+    T *drow = dqkv + m * rstride + hh * d;
     const int64_t o = token_major ? (m * heads + hh) * d + i : ((b * heads + hh) * N + n) * d + i;
     float x[4][PV], gy[4][PV], w[4][PV];
 #pragma unroll
@@ -444,8 +453,8 @@ static inline int ew_grid(int64_t total, int per_block) {
 }
 
 template <typename T>
-static int ln_mod_dispatch(int which, const void *x, const void *scale, const void *shift_or_dy, void *out, float *mean,
-                           float *rstd, int64_t M, int N, int C, float eps, hipStream_t s) {
+static int ln_mod_dispatch(int which, const void *x, const void *scale, const void *shift_or_dy, const void *dres, void *out,
+                           float *mean, float *rstd, int64_t M, int N, int C, float eps, hipStream_t s) {
     VSDE_CHECK_ARG(C % 64 == 0 && C <= 1024, VSDE_E_BADARG, "ln_modulate needs C %% 64 == 0 and C <= 1024, got %d", C);
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
     constexpr int VF = VecOf<T>::v;  // 8 bf16 / 4 f32 = 16 bytes per lane
@@ -454,7 +463,8 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
         if (which == 0) hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,      \
                                            (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                       \
         else hipLaunchKernelGGL((ln_mod_bwd_dx_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,              \
-                                (const T *)shift_or_dy, (const float *)mean, (const float *)rstd, (T *)out, M, N, C);         \
+                                (const T *)shift_or_dy, (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out,  \
+                                M, N, C);                                                                                     \
     } while (0)
     if (C % (64 * VF) == 0 && C / (64 * VF) <= 4) LNM(VF);
     else if (C % (64 * (VF / 2)) == 0 && C / (64 * (VF / 2)) <= 4) LNM(VF / 2);
@@ -482,16 +492,16 @@ using namespace vsde;
 extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
                                     float *rstd, int64_t B, int N, int C, double eps, void *stream) {
     VSDE_CHECK_ARG(x && scale && shift && y && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate arguments");
-    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, y, mean, rstd, B * N, N, C, (float)eps, (hipStream_t)stream));
+    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, y, mean, rstd, B * N, N, C, (float)eps, (hipStream_t)stream));
 }
 
 extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
-                                    const float *rstd, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
-                                    void *stream) {
+                                    const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B,
+                                    int N, int C, void *stream) {
     VSDE_CHECK_ARG(x && scale && dy && mean && rstd && dx && dscale && dshift && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate_bwd arguments");
     hipStream_t s = (hipStream_t)stream;
     VSDE_DTYPE_SWITCH(dtype, {
-        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dx, (float *)mean, (float *)rstd, B * N, N, C, 0.f, s);
+        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dres, dx, (float *)mean, (float *)rstd, B * N, N, C, 0.f, s);
         if (rc) return rc;
         hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 0>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dy,
                            (const T *)x, mean, rstd, (T *)dscale, (T *)dshift, N, C);
@@ -558,30 +568,31 @@ extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void 
 }
 
 extern "C" int vsde_gate_merge_fwd(int dtype, const void *attn, const void *glog, void *out, int64_t B, int N, int heads, int d,
-                                   int token_major, void *stream) {
-    VSDE_CHECK_ARG(attn && glog && out, VSDE_E_BADARG, "bad gate_merge arguments");
+                                   int token_major, int64_t glog_stride, void *stream) {
+    VSDE_CHECK_ARG(attn && glog && out && glog_stride >= d, VSDE_E_BADARG, "bad gate_merge arguments");
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
         if (d % VF == 0) hipLaunchKernelGGL((gate_merge_fwd_kernel<T, VF>), dim3(ew_grid(B * N * heads * d / VF, 256)), dim3(256), 0,
-                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major);
+                                            (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major, glog_stride);
         else hipLaunchKernelGGL((gate_merge_fwd_kernel<T, 1>), dim3(ew_grid(B * N * heads * d, 256)), dim3(256), 0,
-                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major);
+                                (hipStream_t)stream, (const T *)attn, (const T *)glog, (T *)out, B * N, N, heads, d, token_major, glog_stride);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int vsde_gate_merge_bwd(int dtype, const void *attn, const void *glog, const void *dout, void *dattn, void *dglog,
-                                   int64_t B, int N, int heads, int d, int token_major, void *stream) {
-    VSDE_CHECK_ARG(attn && glog && dout && dattn && dglog, VSDE_E_BADARG, "bad gate_merge_bwd arguments");
+                                   int64_t B, int N, int heads, int d, int token_major, int64_t glog_stride,
+                                   void *stream) {
+    VSDE_CHECK_ARG(attn && glog && dout && dattn && dglog && glog_stride >= d, VSDE_E_BADARG, "bad gate_merge_bwd arguments");
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
         if (d % VF == 0) hipLaunchKernelGGL((gate_merge_bwd_kernel<T, VF>), dim3(ew_grid(B * N * d / VF, 256)), dim3(256), 0,
                                             (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
-                                            (T *)dglog, B * N, N, heads, d, token_major);
+                                            (T *)dglog, B * N, N, heads, d, token_major, glog_stride);
         else hipLaunchKernelGGL((gate_merge_bwd_kernel<T, 1>), dim3(ew_grid(B * N * d, 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)attn, (const T *)glog, (const T *)dout, (T *)dattn,
-                                (T *)dglog, B * N, N, heads, d, token_major);
+                                (T *)dglog, B * N, N, heads, d, token_major, glog_stride);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -599,8 +610,10 @@ static int qk_check(int heads, int d) {
 
 extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
                                      const float *wk, const void *v0, const float *lam, void *q, void *k, void *v, int64_t B,
-                                     int N, int heads, int d, double eps, int token_major, void *stream) {
-    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && q && k && v && (!v0 || lam), VSDE_E_BADARG, "bad qk_norm_rope arguments");
+                                     int N, int heads, int d, double eps, int token_major, int64_t row_stride,
+                                     void *stream) {
+    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && q && k && v && (!v0 || lam) && row_stride >= 3 * (int64_t)heads * d,
+                   VSDE_E_BADARG, "bad qk_norm_rope arguments");
     int rc = qk_check(heads, d);
     if (rc) return rc;
     const int pv = qk_pv(d);
@@ -608,10 +621,10 @@ extern "C" int vsde_qk_norm_rope_fwd(int dtype, const void *qkv, const float *co
     VSDE_DTYPE_SWITCH(dtype, {
         if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k,
-                                        (T *)v, B * N, N, heads, d, (float)eps, token_major);
+                                        (T *)v, B * N, N, heads, d, (float)eps, token_major, row_stride);
         else hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (T *)q, (T *)k, (T *)v,
-                                B * N, N, heads, d, (float)eps, token_major);
+                                B * N, N, heads, d, (float)eps, token_major, row_stride);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -624,8 +637,9 @@ extern "C" int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, i
 extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
                                      const float *wk, const void *v0, const float *lam, const void *dq, const void *dk,
                                      const void *dv, void *dqkv, void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d,
-                                     double eps, int token_major, void *stream) {
-    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && dq && dk && dv && dqkv && (!v0 || (lam && dv0 && dlam_partial)), VSDE_E_BADARG,
+                                     double eps, int token_major, int64_t row_stride, void *stream) {
+    VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && dq && dk && dv && dqkv && (!v0 || (lam && dv0 && dlam_partial)) &&
+                       row_stride >= 3 * (int64_t)heads * d, VSDE_E_BADARG,
                    "bad qk_norm_rope_bwd arguments");
     int rc = qk_check(heads, d);
     if (rc) return rc;
@@ -635,11 +649,11 @@ extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *co
         if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                         (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                        (float)eps, token_major);
+                                        (float)eps, token_major, row_stride);
         else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                 (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                (float)eps, token_major);
+                                (float)eps, token_major, row_stride);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;

@@ -67,14 +67,19 @@ class Attention(nn.Module):
         cos, sin = rotary.cos_sin_tables(N)
         mix = self._use_residual_v and v0 is not None
         lin = fused.linear
-        qkv = lin(hidden_states, self.qkv_proj.weight, self.qkv_proj.bias)
-        q, k, v = fused.qk_norm_rope(qkv, cos, sin, self.q_norm.weight, self.k_norm.weight,
-                                     v0.transpose(1, 2) if mix else None, self.v_residual_lambda if mix else None,
-                                     self.num_heads, self.q_norm.eps, token_major=True)
+        # one projection for [q | k | v | gate logits]: one GEMM forward, one input-gradient GEMM and one
+        # weight-gradient reduction backward, and the two consumers fill one gradient buffer between them
+        W = torch.cat([self.qkv_proj.weight, self.gate_proj.weight], dim=0)
+        b = torch.cat([self.qkv_proj.bias, self.gate_proj.bias], dim=0) if self.qkv_proj.bias is not None else None
+        y = lin(hidden_states, W, b)
+        link = fused.GradLink()
+        q, k, v = fused.attention_projection_split(y, cos, sin, self.q_norm.weight, self.k_norm.weight,
+                                                   v0.transpose(1, 2) if mix else None,
+                                                   self.v_residual_lambda if mix else None, self.num_heads,
+                                                   self.q_norm.eps, True, link)
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)  # [B,h,N,d] views
         out = _sdpa(q, k, v)
-        merged = fused.gate_merge(out.transpose(1, 2), lin(hidden_states, self.gate_proj.weight, self.gate_proj.bias),
-                                  token_major=True)
+        merged = fused.gate_merge_joint(out.transpose(1, 2), y, self.num_heads, True, link)
         return lin(merged, self.out_proj.weight, self.out_proj.bias), v
 
     def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,

@@ -22,32 +22,54 @@ def usable(x: Tensor, channels: int, head_dim: int) -> bool:
             and head_dim % 2 == 0 and 1 <= half <= 64 and (half & (half - 1)) == 0)
 
 
+class GradLink:
+    """One-shot mailbox between two autograd Functions that consume the SAME tensor in one forward pass.
+
+    Autograd would add their two gradient contributions with a separate full-size kernel.  Instead the Function whose
+    backward is guaranteed to run first (it sits downstream of the other one in the graph) parks its contribution here
+    and reports ``None``; the upstream Function's backward kernel folds it into the gradient it writes anyway.  Create
+    one link per tensor per forward call and hand it to exactly that pair (see ``SiTBlock._forward_fused``)."""
+    __slots__ = ("value",)
+
+    def __init__(self) -> None:
+        self.value: Optional[Tensor] = None
+
+    def take(self) -> Optional[Tensor]:
+        v, self.value = self.value, None
+        return v
+
+
 class _LnModulate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale, shift, eps):
+    def forward(ctx, x, scale, shift, eps, link):
         x, scale, shift = x.contiguous(), scale.to(x.dtype).contiguous(), shift.to(x.dtype).contiguous()
         y, mean, rstd = _hip.ln_modulate_fwd(x, scale, shift, eps)
         ctx.save_for_backward(x, scale, mean, rstd)
+        ctx.link = link
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         x, scale, mean, rstd = ctx.saved_tensors
-        dx, dscale, dshift = _hip.ln_modulate_bwd(x, scale, dy.to(x.dtype).contiguous(), mean, rstd)
-        return dx, dscale, dshift, None
+        dres = ctx.link.take() if ctx.link is not None else None  # gradient reaching x through the residual branch
+        dx, dscale, dshift = _hip.ln_modulate_bwd(x, scale, dy.to(x.dtype).contiguous(), mean, rstd, dres)
+        return dx, dscale, dshift, None, None
 
 
-def ln_modulate(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> Tensor:
-    """``LayerNorm(x) * (1 + scale[:, None]) + shift[:, None]`` for x [B,N,C], scale/shift [B,C]."""
-    return _LnModulate.apply(x, scale, shift, eps)
+def ln_modulate(x: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5, link: Optional[GradLink] = None) -> Tensor:
+    """``LayerNorm(x) * (1 + scale[:, None]) + shift[:, None]`` for x [B,N,C], scale/shift [B,C].
+
+    ``link``: shared with the ``gated_residual`` that consumes the same ``x`` downstream of this op's output."""
+    return _LnModulate.apply(x, scale, shift, eps, link)
 
 
 class _GatedResidual(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, gate):
+    def forward(ctx, x, y, gate, link):
         x, y, gate = x.contiguous(), y.to(x.dtype).contiguous(), gate.to(x.dtype).contiguous()
         ctx.save_for_backward(y, gate)
+        ctx.link = link
         return _hip.gated_residual_fwd(x, y, gate)
 
     @staticmethod
@@ -56,12 +78,15 @@ class _GatedResidual(torch.autograd.Function):
         y, gate = ctx.saved_tensors
         dout = dout.to(y.dtype).contiguous()
         dy, dgate = _hip.gated_residual_bwd(y, gate, dout)
-        return dout, dy, dgate
+        if ctx.link is not None and ctx.needs_input_grad[0]:
+            ctx.link.value = dout  # picked up by the ln_modulate backward of the same x
+            return None, dy, dgate, None
+        return dout, dy, dgate, None
 
 
-def gated_residual(x: Tensor, y: Tensor, gate: Tensor) -> Tensor:
-    """``x + gate[:, None] * y``."""
-    return _GatedResidual.apply(x, y, gate)
+def gated_residual(x: Tensor, y: Tensor, gate: Tensor, link: Optional[GradLink] = None) -> Tensor:
+    """``x + gate[:, None] * y``.  ``link``: see ``ln_modulate`` (y must depend on that ln_modulate's output)."""
+    return _GatedResidual.apply(x, y, gate, link)
 
 
 class _SwiGLU(torch.autograd.Function):
@@ -102,6 +127,71 @@ class _GateMerge(torch.autograd.Function):
 def gate_merge(attn: Tensor, gate_logits: Tensor, token_major: bool = False) -> Tensor:
     """[B,h,N,d] (or [B,N,h,d] when ``token_major``) x sigmoid([B,N,d]) -> [B,N,h*d]."""
     return _GateMerge.apply(attn, gate_logits, token_major)
+
+
+class _GateMergeJoint(torch.autograd.Function):
+    """gate_merge reading its logits from columns [off, off+d) of the merged [qkv | gate] projection ``y``.  Its
+    backward allocates the gradient buffer of ``y``, fills the gate columns and parks it in ``link`` for
+    ``_QkNormRopeJoint.backward`` (always later: q, k, v feed the attention whose output this op consumes)."""
+
+    @staticmethod
+    def forward(ctx, attn, y, off, token_major, link):
+        attn = attn.contiguous()
+        ctx.save_for_backward(attn, y)
+        ctx.meta = (off, token_major, link)
+        d = attn.shape[-1]
+        return _hip.gate_merge_fwd(attn, y[..., off:off + d], token_major)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        attn, y = ctx.saved_tensors
+        off, token_major, link = ctx.meta
+        d = attn.shape[-1]
+        dy = torch.empty_like(y) if off + d == y.shape[-1] else torch.zeros_like(y)
+        dattn, _ = _hip.gate_merge_bwd(attn, y[..., off:off + d], dout.to(attn.dtype).contiguous(), token_major,
+                                       dglog=dy[..., off:off + d])
+        link.value = dy
+        return dattn, None, None, None, None
+
+
+class _QkNormRopeJoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, cos, sin, wq, wk, v0, lam, heads, eps, token_major, width, link):
+        v0c = v0.to(y.dtype).contiguous() if v0 is not None else None
+        lamc = lam.detach().float().reshape(1).contiguous() if lam is not None else None
+        q, k, v = _hip.qk_norm_rope_fwd(y[..., :width], cos, sin, wq, wk, v0c, lamc, heads, eps, token_major)
+        ctx.save_for_backward(y, cos, sin, wq, wk, v0c, lamc)
+        ctx.meta = (heads, eps, lam.dtype if lam is not None else None, token_major, width, link)
+        return q, k, v
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dq, dk, dv):
+        y, cos, sin, wq, wk, v0, lam = ctx.saved_tensors
+        heads, eps, lam_dtype, token_major, width, link = ctx.meta
+        dy = link.take()
+        if dy is None:  # the gate branch did not take part in this backward pass
+            dy = torch.zeros_like(y)
+        c = lambda t: t.to(y.dtype).contiguous()
+        _, dv0, dlam = _hip.qk_norm_rope_bwd(y[..., :width], cos, sin, wq, wk, v0, lam, c(dq), c(dk), c(dv), heads, eps,
+                                             token_major, dqkv=dy[..., :width])
+        if dlam is not None:
+            dlam = dlam.to(lam_dtype).reshape(())
+        return dy, None, None, None, None, dv0, dlam, None, None, None, None, None
+
+
+def attention_projection_split(y: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor],
+                               lam: Optional[Tensor], heads: int, eps: float, token_major: bool, link: GradLink):
+    """(q, k, v) from the first 3C columns of the merged [qkv | gate] projection ``y`` [B,N,3C+d]."""
+    d = y.shape[-1] // (3 * heads + 1)
+    return _QkNormRopeJoint.apply(y.contiguous(), cos, sin, wq, wk, v0, lam, heads, eps, token_major, 3 * heads * d, link)
+
+
+def gate_merge_joint(attn: Tensor, y: Tensor, heads: int, token_major: bool, link: GradLink) -> Tensor:
+    """gate_merge with the gate logits taken from the last d columns of ``y`` (see attention_projection_split)."""
+    d = y.shape[-1] // (3 * heads + 1)
+    return _GateMergeJoint.apply(attn, y.contiguous(), 3 * heads * d, token_major, link)
 
 
 class _QkNormRope(torch.autograd.Function):

@@ -66,11 +66,13 @@ class SiTBlock(nn.Module):
                 and self.self_attn.fusable(hidden_states, rotary):
             # fused HIP route: 6 fused passes + 5 GEMMs + 1 attention call per block
             sa, ha, ga, sm, hm, gm = self._cond_modulator.net(cond).chunk(6, dim=-1)
-            h1 = fused.ln_modulate(hidden_states, sa, ha, self.attn_norm.eps)
+            # each stream tensor feeds a norm and the residual that follows it: one GradLink per such pair
+            link1, link2 = fused.GradLink(), fused.GradLink()
+            h1 = fused.ln_modulate(hidden_states, sa, ha, self.attn_norm.eps, link1)
             attn_out, values = self.self_attn.forward_fused(h1, rotary=rotary, v0=v0)
-            hidden_states = fused.gated_residual(hidden_states, attn_out, ga)
-            h2 = fused.ln_modulate(hidden_states, sm, hm, self.mlp_norm.eps)
-            return fused.gated_residual(hidden_states, self.mlp(h2), gm), values
+            hidden_states = fused.gated_residual(hidden_states, attn_out, ga, link1)
+            h2 = fused.ln_modulate(hidden_states, sm, hm, self.mlp_norm.eps, link2)
+            return fused.gated_residual(hidden_states, self.mlp(h2), gm, link2), values
         if cond.ndim == 2:
             cond = cond.unsqueeze(1)  # broadcast over the token axis
         attn_mod, mlp_mod = self.cond_params(cond=cond)
