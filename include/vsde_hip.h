@@ -151,13 +151,17 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
  * layout, sigmoid output gate) and primitives/mlp.py:21-24 (SwiGLU activation). */
 int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
                          float *rstd, int64_t B, int N, int C, double eps, void *stream);
+/* The two backward passes below also produce per-(batch row, channel) sums over the tokens (dscale/dshift, dgate);
+ * they need vsde_colsum_workspace_bytes(B, C) bytes of device scratch for the fp32 partials. */
+size_t vsde_colsum_workspace_bytes(int64_t B, int C);
+/* dres (optional, [B][N][C]) is added to dx: the gradient reaching x through the residual branch */
 int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
                          const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
-                         void *stream); /* dres (optional, [B][N][C]) is added to dx: the gradient reaching x through the residual */
+                         void *workspace, size_t workspace_bytes, void *stream);
 int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N, int C,
                             void *stream);
 int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate, int64_t B,
-                            int N, int C, void *stream);
+                            int N, int C, void *workspace, size_t workspace_bytes, void *stream);
 int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream);
 int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream);
 /* token_major selects the memory layout of the per-head tensors (attn, dattn, q, k, v, v0, dq, dk, dv, dv0):

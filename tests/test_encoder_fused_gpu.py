@@ -177,3 +177,31 @@ def test_head_layouts_agree(dtype):
         assert torch.equal(a.contiguous(), b_.contiguous())
     # d(lambda) is a block-partial sum whose grouping follows the layout
     assert abs(float(outs[False][-1]) - float(outs[True][-1])) <= 1e-3 * (1 + abs(float(outs[False][-1])))
+
+
+@pytest.mark.parametrize("C", [64, 128, 192, 256, 512, 1024])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_ln_modulate_and_gated_residual_channel_counts(C, dtype, tol):
+    """Every vector-width / lanes-per-token dispatch of the norm and residual kernels, incl. the fused column sums and the
+    residual-gradient hand-off (GradLink), against the torch chain evaluated in fp32."""
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(C)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV, dtype)
+    B, N = 3, 37
+    leaves = [rn(B, N, C), rn(B, C) * 0.3, rn(B, C) * 0.3, rn(B, C), rn(B, N, C)]
+    go = rn(B, N, C).float()
+
+    def run(use_fused):
+        x, sc, sh, gate, w = (t.clone().float().requires_grad_() if not use_fused else t.clone().requires_grad_() for t in leaves)
+        if use_fused:
+            link = fused.GradLink()
+            h = fused.ln_modulate(x, sc, sh, 1e-5, link)
+            out = fused.gated_residual(x, h * w, gate, link)
+        else:
+            h = torch.nn.functional.layer_norm(x, (C,), eps=1e-5) * (1 + sc[:, None]) + sh[:, None]
+            out = x + gate[:, None] * (h * w)
+        grads = torch.autograd.grad((out.float() * go).sum(), [x, sc, sh, gate, w])
+        return [out.detach().float()] + [t.float() for t in grads]
+
+    for name, a, b_ in zip(["out", "dx", "dscale", "dshift", "dgate", "dw"], run(True), run(False)):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < tol, name

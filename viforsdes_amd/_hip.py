@@ -55,7 +55,7 @@ EXPORTS = (
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
-    "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
+    "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -88,6 +88,7 @@ def load() -> ctypes.CDLL:
         f.restype = ctypes.c_int
     lib.vsde_qk_norm_rope_bwd_partials.restype = ctypes.c_int64
     lib.vsde_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsde_colsum_workspace_bytes.restype = ctypes.c_size_t
     _lib = lib
     return lib
 
@@ -309,14 +310,21 @@ def ln_modulate_fwd(x, scale, shift, eps):
     return y, mean, rstd
 
 
+def _colsum_workspace(lib, B, C, dev):
+    nbytes = lib.vsde_colsum_workspace_bytes(_i64(B), ctypes.c_int(C))
+    return torch.empty(max(int(nbytes), 1), device=dev, dtype=torch.uint8)
+
+
 def ln_modulate_bwd(x, scale, dy, mean, rstd, dres=None):
     """dres (optional, same shape as x) is added to dx inside the kernel."""
     lib = load(); dev = _require_hip(x, scale, dy)
     B, N, C = x.shape
     dx = torch.empty_like(x); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
+    ws = _colsum_workspace(lib, B, C, dev)
     with torch.cuda.device(dev):
         _call(lib.vsde_ln_modulate_bwd, _dt(x), _ptr(x), _ptr(scale), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-              _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
+              _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()),
+              _stream(dev))
     return dx, dscale, dshift
 
 
@@ -334,9 +342,10 @@ def gated_residual_bwd(y, gate, dout):
     lib = load(); dev = _require_hip(y, gate, dout)
     B, N, C = y.shape
     dy = torch.empty_like(y); dgate = torch.empty_like(gate)
+    ws = _colsum_workspace(lib, B, C, dev)
     with torch.cuda.device(dev):
         _call(lib.vsde_gated_residual_bwd, _dt(y), _ptr(y), _ptr(gate), _ptr(dout), _ptr(dy), _ptr(dgate), _i64(B),
-              ctypes.c_int(N), ctypes.c_int(C), _stream(dev))
+              ctypes.c_int(N), ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
     return dy, dgate
 
 

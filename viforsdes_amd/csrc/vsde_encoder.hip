@@ -84,39 +84,46 @@ template <typename T> struct VecOf { static constexpr int v = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int v = 8; };
 
 // ------------------------------------------------------------------------------ ln_modulate
-// one wavefront per token; lane owns V contiguous channels of each 64*V-wide slab (<= 4 slabs)
-template <typename T, int V>
+// sum over aligned groups of `width` (power of two) consecutive lanes
+__device__ __forceinline__ float seg_sum(float v, int width) {
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LPR lanes (64 or 32) per token, 256/LPR tokens per block; a lane owns V contiguous channels of each
+// LPR*V-wide slab (<= 4 slabs).  C = 256 in bf16 runs as 32 lanes x 16 bytes: two tokens per wavefront.
+template <typename T, int V, int LPR>
 __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ shift, T *__restrict__ y,
                                                          float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
                                                          int N, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & (LPR - 1);
+    const int64_t m = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (m >= M) return;
     const int64_t b = m / N;
-    const int nslab = C / (64 * V);
+    const int nslab = C / (LPR * V);
     float v[4][V];
     float s = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl)
         if (sl < nslab) {
-            Pack<T, V>::load(x + m * C + (sl * 64 + lane) * V, v[sl]);
+            Pack<T, V>::load(x + m * C + (sl * LPR + lane) * V, v[sl]);
 #pragma unroll
             for (int e = 0; e < V; ++e) s += v[sl][e];
         }
-    const float mu = wave_sum(s) / C;
+    const float mu = seg_sum(s, LPR) / C;
     float q = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl)
         if (sl < nslab)
 #pragma unroll
             for (int e = 0; e < V; ++e) { const float d = v[sl][e] - mu; q += d * d; }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    const float rs = rsqrtf(seg_sum(q, LPR) / C + eps);
     if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl)
         if (sl < nslab) {
-            const int c = (sl * 64 + lane) * V;
+            const int c = (sl * LPR + lane) * V;
             float sc[V], sh[V], o[V];
             Pack<T, V>::load(scale + b * C + c, sc); Pack<T, V>::load(shift + b * C + c, sh);
 #pragma unroll
@@ -125,75 +132,151 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
         }
 }
 
-template <typename T, int V>
-__global__ void __launch_bounds__(256) ln_mod_bwd_dx_kernel(const T *__restrict__ x, const T *__restrict__ scale,
-                                                            const T *__restrict__ dy, const float *__restrict__ mean,
-                                                            const float *__restrict__ rstd, const T *__restrict__ dres,
-                                                            T *__restrict__ dx, int64_t M, int N, int C) {
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const int64_t b = m / N;
-    const int nslab = C / (64 * V);
-    const float mu = mean[m], rs = rstd[m];
-    float g[4][V], xh[4][V];
-    float s1 = 0.f, s2 = 0.f;
+// Backward passes that also need a per-(batch row, channel) sum over the N tokens.  Grid (nchunk, B): a block
+// walks one chunk of the tokens of one batch row, 256/LPR tokens at a time, writes the token gradients and keeps
+// the channel sums in registers; the token slots are combined through LDS and each block stores one fp32 partial
+// row part[k][b][chunk][C].  colsum_finish_kernel adds the nchunk partials in a fixed order (deterministic).
+constexpr int kColsumChunks = 8;
+
+template <int NACC>
+__device__ __forceinline__ void colsum_block_reduce(float *red, const float (&acc)[NACC], int slot, int slots, int lane_off,
+                                                    int width, float *__restrict__ part, int C) {
+    // red: [slots][width] floats; acc holds NACC consecutive channels starting at lane_off
+    __syncthreads();
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+    for (int e = 0; e < NACC; ++e) red[slot * width + lane_off + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < width && c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int sidx = 0; sidx < slots; ++sidx) t += red[sidx * width + c];
+        part[c] = t;
+    }
+}
+
+// ln_modulate backward: dx (+ dres) per token, and partial sums of dy*xhat (part0) and dy (part1)
+template <typename T, int V, int LPR>
+__global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                         const T *__restrict__ dy, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, const T *__restrict__ dres,
+                                                         T *__restrict__ dx, float *__restrict__ part, int N, int C) {
+    extern __shared__ float red[];
+    constexpr int SLOTS = 256 / LPR;
+    const int lane = threadIdx.x & (LPR - 1), slot = threadIdx.x / LPR;
+    const int b = blockIdx.y, nchunk = gridDim.x, B = gridDim.y;
+    const int CL = (N + nchunk - 1) / nchunk;
+    const int n0 = blockIdx.x * CL, n1 = min(N, n0 + CL);
+    const int nslab = C / (LPR * V);
+    float sc1[4][V], a1[4][V], a2[4][V];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
         if (sl < nslab) {
-            const int c = (sl * 64 + lane) * V;
-            float sc[V];
-            Pack<T, V>::load(x + m * C + c, xh[sl]); Pack<T, V>::load(dy + m * C + c, g[sl]); Pack<T, V>::load(scale + b * C + c, sc);
+            Pack<T, V>::load(scale + (int64_t)b * C + (sl * LPR + lane) * V, sc1[sl]);
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                xh[sl][e] = (xh[sl][e] - mu) * rs; g[sl][e] *= (1.0f + sc[e]);
-                s1 += g[sl][e]; s2 += g[sl][e] * xh[sl][e];
-            }
+            for (int e = 0; e < V; ++e) sc1[sl][e] += 1.0f;
         }
-    s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { a1[sl][e] = 0.f; a2[sl][e] = 0.f; }
+    }
+    for (int n = n0 + slot; n < n1; n += SLOTS) {
+        const int64_t m = (int64_t)b * N + n;
+        const float mu = mean[m], rs = rstd[m];
+        float g[4][V], xh[4][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (sl < nslab) {
+                const int c = (sl * LPR + lane) * V;
+                Pack<T, V>::load(x + m * C + c, xh[sl]); Pack<T, V>::load(dy + m * C + c, g[sl]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[sl][e] = (xh[sl][e] - mu) * rs;
+                    a1[sl][e] += g[sl][e] * xh[sl][e]; a2[sl][e] += g[sl][e];
+                    g[sl][e] *= sc1[sl][e];
+                    s1 += g[sl][e]; s2 += g[sl][e] * xh[sl][e];
+                }
+            }
+        s1 = seg_sum(s1, LPR) / C; s2 = seg_sum(s2, LPR) / C;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+            if (sl < nslab) {
+                const int c = (sl * LPR + lane) * V;
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = rs * (g[sl][e] - s1 - xh[sl][e] * s2);
+                if (dres) {  // x also feeds the residual branch: fold that gradient in here instead of a separate add
+                    float r[V];
+                    Pack<T, V>::load(dres + m * C + c, r);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o[e] += r[e];
+                }
+                Pack<T, V>::store(dx + m * C + c, o);
+            }
+    }
+    float *p0 = part + (((int64_t)0 * B + b) * nchunk + blockIdx.x) * C;
+    float *p1 = part + (((int64_t)1 * B + b) * nchunk + blockIdx.x) * C;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl)
         if (sl < nslab) {
-            float o[V];
-#pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = rs * (g[sl][e] - s1 - xh[sl][e] * s2);
-            if (dres) {  // x also feeds the residual branch: fold that gradient in here instead of a separate add
-                float r[V];
-                Pack<T, V>::load(dres + m * C + (sl * 64 + lane) * V, r);
-#pragma unroll
-                for (int e = 0; e < V; ++e) o[e] += r[e];
-            }
-            Pack<T, V>::store(dx + m * C + (sl * 64 + lane) * V, o);
+            const int off = sl * LPR * V;
+            colsum_block_reduce<V>(red, a1[sl], slot, SLOTS, lane * V, LPR * V, p0 + off, C - off);
+            colsum_block_reduce<V>(red, a2[sl], slot, SLOTS, lane * V, LPR * V, p1 + off, C - off);
         }
 }
 
-// Column reductions over the N tokens of one batch row, 64 channels x 4 token groups per block.
-//   MODE 0: r1[b,c] = sum_n dy*xhat, r2[b,c] = sum_n dy    (ln_modulate: dscale, dshift)
-//   MODE 1: r1[b,c] = sum_n a*bb                           (gated_residual: dgate)
-template <typename T, int MODE>
-__global__ void __launch_bounds__(256) rowgroup_colsum_kernel(const T *__restrict__ a, const T *__restrict__ bb,
-                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                              T *__restrict__ r1, T *__restrict__ r2, int N, int C) {
-    __shared__ float red[2][4][64];
-    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), tg = threadIdx.x >> 6;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-        for (int n = tg; n < N; n += 4) {
-            const int64_t m = (int64_t)b * N + n;
-            const float av = to_f32(a[m * C + c]);
-            if (MODE == 0) {
-                const float xh = (to_f32(bb[m * C + c]) - mean[m]) * rstd[m];
-                s1 += av * xh; s2 += av;
-            } else {
-                s1 += av * to_f32(bb[m * C + c]);
-            }
+// gated_residual backward: dy = gate * dout per token, and partial sums of dout * y (part0)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) gated_residual_bwd_kernel(const T *__restrict__ y, const T *__restrict__ gate,
+                                                                 const T *__restrict__ dout, T *__restrict__ dy,
+                                                                 float *__restrict__ part, int N, int C) {
+    extern __shared__ float red[];
+    const int lpt = C / V;                 // lanes per token
+    const int slots = 256 / lpt;           // tokens in flight per block (threads beyond slots*lpt idle)
+    const int slot = threadIdx.x / lpt, lane = threadIdx.x - slot * lpt;
+    const int b = blockIdx.y, nchunk = gridDim.x;
+    const int CL = (N + nchunk - 1) / nchunk;
+    const int n0 = blockIdx.x * CL, n1 = min(N, n0 + CL);
+    const bool live = slot < slots;
+    float gv[V], acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { gv[e] = 0.f; acc[e] = 0.f; }
+    if (live) Pack<T, V>::load(gate + (int64_t)b * C + lane * V, gv);
+    if (live)
+        for (int n = n0 + slot; n < n1; n += slots) {
+            const int64_t o = ((int64_t)b * N + n) * C + lane * V;
+            float g[V], yv[V], r[V];
+            Pack<T, V>::load(dout + o, g); Pack<T, V>::load(y + o, yv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { r[e] = gv[e] * g[e]; acc[e] += g[e] * yv[e]; }
+            Pack<T, V>::store(dy + o, r);
         }
-    red[0][tg][threadIdx.x & 63] = s1; red[1][tg][threadIdx.x & 63] = s2;
+    float *p0 = part + ((int64_t)b * nchunk + blockIdx.x) * C;
     __syncthreads();
-    if (tg == 0 && c < C) {
-        const int l = threadIdx.x;
-        r1[(int64_t)b * C + c] = from_f32<T>(red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
-        if (MODE == 0) r2[(int64_t)b * C + c] = from_f32<T>(red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[slot * C + lane * V + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int sidx = 0; sidx < slots; ++sidx) t += red[sidx * C + c];
+        p0[c] = t;
+    }
+}
+
+// r_k[b][c] = sum_chunk part[k][b][chunk][c]  (k < nout), converted to T
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restrict__ part, T *__restrict__ r0, T *__restrict__ r1,
+                                                            int64_t BC, int C, int nchunk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    const int nout = r1 ? 2 : 1;
+    for (int k = 0; k < nout; ++k) {
+        const float *p = part + ((int64_t)k * (BC / C) + b) * nchunk * C + c;
+        float t = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) t += p[(int64_t)ch * C];
+        (k == 0 ? r0 : r1)[i] = from_f32<T>(t);
     }
 }
 
@@ -304,11 +387,6 @@ __global__ void __launch_bounds__(256) gate_merge_bwd_kernel(const T *__restrict
 // ----------------------------------------------------------------------------- qk_norm_rope
 // one thread per rotary pair (i, i + d/2) of one head of one token; the d/2 threads of a head are
 // consecutive lanes (d/2 is a power of two <= 64), so the RMS reduction is a segmented butterfly.
-__device__ __forceinline__ float seg_sum(float v, int width) {
-    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // PV consecutive rotary pairs per thread (PV = 4: 8-byte bf16 / 16-byte f32 accesses); the head's
 // half/PV threads are consecutive lanes, so the RMS reduction is a segmented butterfly of that width.
 template <typename T, int PV>
@@ -454,24 +532,30 @@ static inline int ew_grid(int64_t total, int per_block) {
 
 template <typename T>
 static int ln_mod_dispatch(int which, const void *x, const void *scale, const void *shift_or_dy, const void *dres, void *out,
-                           float *mean, float *rstd, int64_t M, int N, int C, float eps, hipStream_t s) {
+                           float *mean, float *rstd, float *part, int64_t B, int N, int C, float eps, hipStream_t s) {
     VSDE_CHECK_ARG(C % 64 == 0 && C <= 1024, VSDE_E_BADARG, "ln_modulate needs C %% 64 == 0 and C <= 1024, got %d", C);
-    dim3 grid((unsigned)((M + 3) / 4)), block(256);
     constexpr int VF = VecOf<T>::v;  // 8 bf16 / 4 f32 = 16 bytes per lane
-#define LNM(V)                                                                                                                \
+    const int64_t M = B * N;
+    dim3 block(256);
+#define LNM(V, LPR)                                                                                                           \
     do {                                                                                                                      \
-        if (which == 0) hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,      \
-                                           (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                       \
-        else hipLaunchKernelGGL((ln_mod_bwd_dx_kernel<T, V>), grid, block, 0, s, (const T *)x, (const T *)scale,              \
-                                (const T *)shift_or_dy, (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out,  \
-                                M, N, C);                                                                                     \
+        if (which == 0) {                                                                                                     \
+            dim3 grid((unsigned)((M + 256 / LPR - 1) / (256 / LPR)));                                                         \
+            hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR>), grid, block, 0, s, (const T *)x, (const T *)scale,             \
+                               (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                                   \
+        } else {                                                                                                              \
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<T, V, LPR>), dim3(kColsumChunks, (unsigned)B), block, 256 * V * sizeof(float), \
+                               s, (const T *)x, (const T *)scale, (const T *)shift_or_dy, (const float *)mean,                \
+                               (const float *)rstd, (const T *)dres, (T *)out, part, N, C);                                   \
+        }                                                                                                                     \
     } while (0)
-    if (C % (64 * VF) == 0 && C / (64 * VF) <= 4) LNM(VF);
-    else if (C % (64 * (VF / 2)) == 0 && C / (64 * (VF / 2)) <= 4) LNM(VF / 2);
-    else if (C % (64 * (VF / 4)) == 0 && C / (64 * (VF / 4)) <= 4) LNM(VF / 4);
+    if (C % (64 * VF) == 0 && C / (64 * VF) <= 4) LNM(VF, 64);
+    else if (C % (32 * VF) == 0 && C / (32 * VF) <= 4) LNM(VF, 32);
+    else if (C % (64 * (VF / 2)) == 0 && C / (64 * (VF / 2)) <= 4) LNM(VF / 2, 64);
+    else if (C % (64 * (VF / 4)) == 0 && C / (64 * (VF / 4)) <= 4) LNM(VF / 4, 64);
     else {
         VSDE_CHECK_ARG(C / 64 <= 4, VSDE_E_BADARG, "ln_modulate: unsupported channel count %d", C);
-        LNM(1);
+        LNM(1, 64);
     }
 #undef LNM
     VSDE_CHECK_HIP(hipGetLastError());
@@ -492,19 +576,27 @@ using namespace vsde;
 extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
                                     float *rstd, int64_t B, int N, int C, double eps, void *stream) {
     VSDE_CHECK_ARG(x && scale && shift && y && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate arguments");
-    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, y, mean, rstd, B * N, N, C, (float)eps, (hipStream_t)stream));
+    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, y, mean, rstd, nullptr, B, N, C, (float)eps, (hipStream_t)stream));
+}
+
+extern "C" size_t vsde_colsum_workspace_bytes(int64_t B, int C) {
+    return (size_t)2 * (size_t)B * kColsumChunks * (size_t)C * sizeof(float);
 }
 
 extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
                                     const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B,
-                                    int N, int C, void *stream) {
+                                    int N, int C, void *workspace, size_t workspace_bytes, void *stream) {
     VSDE_CHECK_ARG(x && scale && dy && mean && rstd && dx && dscale && dshift && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate_bwd arguments");
+    VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C), VSDE_E_WORKSPACE,
+                   "ln_modulate_bwd workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
     VSDE_DTYPE_SWITCH(dtype, {
-        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dres, dx, (float *)mean, (float *)rstd, B * N, N, C, 0.f, s);
+        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dres, dx, (float *)mean, (float *)rstd, part, B, N, C, 0.f, s);
         if (rc) return rc;
-        hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 0>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dy,
-                           (const T *)x, mean, rstd, (T *)dscale, (T *)dshift, N, C);
+        const int64_t BC = B * C;
+        hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
+                           (T *)dscale, (T *)dshift, BC, C, kColsumChunks);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -526,18 +618,24 @@ extern "C" int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, 
 }
 
 extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate,
-                                       int64_t B, int N, int C, void *stream) {
-    VSDE_CHECK_ARG(y && gate && dout && dy && dgate && C % 4 == 0, VSDE_E_BADARG, "bad gated_residual_bwd arguments");
-    const int64_t total = B * N * C;
+                                       int64_t B, int N, int C, void *workspace, size_t workspace_bytes, void *stream) {
+    VSDE_CHECK_ARG(y && gate && dout && dy && dgate && C % 4 == 0 && C <= 2048, VSDE_E_BADARG, "bad gated_residual_bwd arguments");
+    VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C) / 2, VSDE_E_WORKSPACE,
+                   "gated_residual_bwd workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    const int64_t BC = B * C;
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
-        if (C % VF == 0) hipLaunchKernelGGL((gated_residual_kernel<T, VF>), dim3(ew_grid(total, 256 * VF)), dim3(256), 0, s,
-                                            (const T *)nullptr, (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
-        else hipLaunchKernelGGL((gated_residual_kernel<T, 4>), dim3(ew_grid(total, 1024)), dim3(256), 0, s, (const T *)nullptr,
-                                (const T *)dout, (const T *)gate, (T *)dy, total, N, C, 1);
-        hipLaunchKernelGGL((rowgroup_colsum_kernel<T, 1>), dim3((unsigned)B, (C + 63) / 64), dim3(256), 0, s, (const T *)dout,
-                           (const T *)y, (const float *)nullptr, (const float *)nullptr, (T *)dgate, (T *)nullptr, N, C);
+        dim3 grid(kColsumChunks, (unsigned)B);
+        if (C % VF == 0 && C / VF <= 256)
+            hipLaunchKernelGGL((gated_residual_bwd_kernel<T, VF>), grid, dim3(256), 256 * VF * sizeof(float), s, (const T *)y,
+                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
+        else
+            hipLaunchKernelGGL((gated_residual_bwd_kernel<T, 4>), grid, dim3(256), 256 * 4 * sizeof(float), s, (const T *)y,
+                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
+        hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
+                           (T *)dgate, (T *)nullptr, BC, C, kColsumChunks);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -546,8 +644,11 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
 extern "C" int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream) {
     VSDE_CHECK_ARG(u && out && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu arguments");
     VSDE_DTYPE_SWITCH(dtype, {
-        if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_fwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
-                                            (const T *)u, (T *)out, M, H2);
+        constexpr int VF = VecOf<T>::v;  // 16-byte accesses when the (padded) hidden width allows
+        if (H2 % VF == 0) hipLaunchKernelGGL((swiglu_fwd_kernel<T, VF>), dim3(ew_grid(M * H2 / VF, 256)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T *)u, (T *)out, M, H2);
+        else if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_fwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                                 (const T *)u, (T *)out, M, H2);
         else hipLaunchKernelGGL((swiglu_fwd_kernel<T, 1>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
                                 (const T *)u, (T *)out, M, H2);
     });
@@ -558,8 +659,11 @@ extern "C" int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, i
 extern "C" int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream) {
     VSDE_CHECK_ARG(u && dout && du && M > 0 && H2 > 0, VSDE_E_BADARG, "bad swiglu_bwd arguments");
     VSDE_DTYPE_SWITCH(dtype, {
-        if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
-                                            (const T *)u, (const T *)dout, (T *)du, M, H2);
+        constexpr int VF = VecOf<T>::v;
+        if (H2 % VF == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<T, VF>), dim3(ew_grid(M * H2 / VF, 256)), dim3(256), 0, (hipStream_t)stream,
+                                             (const T *)u, (const T *)dout, (T *)du, M, H2);
+        else if (H2 % 2 == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<T, 2>), dim3(ew_grid(M * H2 / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                                                 (const T *)u, (const T *)dout, (T *)du, M, H2);
         else hipLaunchKernelGGL((swiglu_bwd_kernel<T, 1>), dim3(ew_grid(M * H2, 256)), dim3(256), 0, (hipStream_t)stream,
                                 (const T *)u, (const T *)dout, (T *)du, M, H2);
     });
