@@ -28,6 +28,7 @@ struct WgradParams {
     int N, K;
     int tile;            // output tile edge: 128 (256 threads) or 256 (512 threads)
     int tiles_k;         // ceil(K / tile)
+    int tiles;           // output tiles in total
     int nsplit;
     int64_t rows_per_split;  // multiple of WG_BM
     float *partial;      // [tiles][nsplit][tile*tile + tile]
@@ -59,7 +60,12 @@ __global__ void __launch_bounds__(2 * T) wgrad_bf16_kernel(WgradParams p) {
     uint16_t *Bt = wsm + T * WG_LD;     // X^T  tile: [k][m]
     float *bred = (float *)(wsm + 2 * T * WG_LD);  // [8][T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x, tile = blockIdx.y;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so id = 8*local + xcd.  The workgroups
+    // of one split (same rows of dY / X, different output tiles) are given consecutive `local` on ONE xcd: the operand
+    // rows they share are then served by that XCD's L2 instead of being fetched once per tile.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = local % p.tiles, split = (local / p.tiles) * 8 + xcd;
+    if (split >= p.nsplit) return;
     const int n_blk = (tile / p.tiles_k) * T, k_blk = (tile % p.tiles_k) * T;
     const bool want_bias = p.db != nullptr && k_blk == 0;
     // staging role: first T threads load dY, the other T load X; each an 8(m) x 8(col) block
@@ -152,32 +158,69 @@ __global__ void __launch_bounds__(2 * T) wgrad_bf16_kernel(WgradParams p) {
     }
 }
 
-// grid (tiles, T*T/256): block (tile, part) reduces 256 outputs (+ the bias row in part 0) over the splits
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradParams p) {
+// Sum of the nsplit partial tiles, in a fixed association (deterministic).  grid (T*T/4/VPB + 1, tiles), 256 threads:
+// a block owns VPB = 256/G float4 vectors of one tile; thread (v, g) adds the splits g, g+G, ... (8 loads in flight),
+// the G group sums are combined through LDS in order.  The extra block (last blockIdx.x) sums the tile's bias row.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradParams p, int G) {
+    __shared__ float4 red[256];
     const int T = p.tile, PART = T * T + T;
-    const int tile = blockIdx.x, part = blockIdx.y;
+    const int tile = blockIdx.y;
     const int n_blk = (tile / p.tiles_k) * T, k_blk = (tile % p.tiles_k) * T;
     const float *src = p.partial + (int64_t)tile * p.nsplit * PART;
-    const int e = part * 256 + threadIdx.x;
-    const int n = n_blk + e / T, k = k_blk + e % T;
-    if (n < p.N && k < p.K) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // fixed association: deterministic
-        int sp = 0;
-        for (; sp + 7 < p.nsplit; sp += 8) {
+    if (blockIdx.x == gridDim.x - 1) {  // bias row: column c, split group g
+        if (p.db == nullptr || k_blk != 0) return;
+        const int GB = 256 / T, c = threadIdx.x % T, g = threadIdx.x / T;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = g;
+        for (; sp + 7 * GB < p.nsplit; sp += 8 * GB) {
             float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(sp + q) * PART + e];  // 8 loads in flight
+            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(sp + q * GB) * PART + T * T + c];
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] += v[q];
         }
-        for (; sp < p.nsplit; ++sp) acc[0] += src[(int64_t)sp * PART + e];
-        const float s0 = acc[0] + acc[1], s1 = acc[2] + acc[3], s2 = acc[4] + acc[5], s3 = acc[6] + acc[7];
-        p.dW[(int64_t)n * p.K + k] = (s0 + s1) + (s2 + s3);
+        for (; sp < p.nsplit; sp += GB) acc[0] += src[(int64_t)sp * PART + T * T + c];
+        float *r = (float *)red;
+        r[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+        if (g == 0 && n_blk + c < p.N) {
+            float t = r[c];
+            for (int gg = 1; gg < GB; ++gg) t += r[gg * T + c];
+            p.db[n_blk + c] = t;
+        }
+        return;
     }
-    if (part == 0 && p.db != nullptr && k_blk == 0 && threadIdx.x < T && n_blk + threadIdx.x < p.N) {
-        float s = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) s += src[(int64_t)sp * PART + T * T + threadIdx.x];
-        p.db[n_blk + threadIdx.x] = s;
+    const int VPB = 256 / G, vl = threadIdx.x % VPB, g = threadIdx.x / VPB;
+    const int e = (blockIdx.x * VPB + vl) * 4;  // first of 4 consecutive elements (same row of the tile)
+    float4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = g;
+    for (; sp + 7 * G < p.nsplit; sp += 8 * G) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *(const float4 *)(src + (int64_t)(sp + q * G) * PART + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc[q].x += v[q].x; acc[q].y += v[q].y; acc[q].z += v[q].z; acc[q].w += v[q].w; }
+    }
+    for (; sp < p.nsplit; sp += G) {
+        const float4 v = *(const float4 *)(src + (int64_t)sp * PART + e);
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+    float4 t;
+    t.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+    t.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+    t.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+    t.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (g == 0) {
+        for (int gg = 1; gg < G; ++gg) {
+            const float4 u = red[gg * VPB + vl];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const int n = n_blk + e / T, k = k_blk + e % T;
+        if (n < p.N && k < p.K) *(float4 *)(p.dW + (int64_t)n * p.K + k) = t;  // K % 8 == 0: all four or none
     }
 }
 
@@ -187,13 +230,16 @@ static void wgrad_plan(int64_t M, int N, int K, WgradParams &p, int &tiles) {
     p.tiles_k = (K + p.tile - 1) / p.tile;
     tiles = ((N + p.tile - 1) / p.tile) * p.tiles_k;
     const int64_t chunks = (M + WG_BM - 1) / WG_BM;
-    int64_t nsplit = ((p.tile == 256 ? 512 : 1024) + tiles - 1) / tiles;  // ~2 (4) workgroups per CU
+    // one round of workgroups: the 256 tile runs one workgroup per CU (register-limited: 8 waves x ~200 VGPRs), the 128
+    // tile two (measured optimum on MI355X: 256 / 512 workgroups); a multiple of 8 so that every XCD gets whole splits
+    int64_t nsplit = ((p.tile == 256 ? 256 : 512) / tiles) & ~7;
     if (nsplit < 8) nsplit = 8;
     if (nsplit > 256) nsplit = 256;
     if (nsplit > chunks) nsplit = chunks;
     const int64_t cps = (chunks + nsplit - 1) / nsplit;
     p.rows_per_split = cps * WG_BM;
     p.nsplit = (int)((chunks + cps - 1) / cps);
+    p.tiles = tiles;
 }
 
 static size_t wgrad_lds_bytes(int T) { return (size_t)2 * T * WG_LD * sizeof(uint16_t) + (size_t)8 * T * sizeof(float); }
@@ -221,14 +267,18 @@ extern "C" int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, 
     p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = wgrad_lds_bytes(p.tile);
+    const dim3 grid((unsigned)(((p.nsplit + 7) / 8) * 8 * tiles));
     if (p.tile == 256) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_bf16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((wgrad_bf16_kernel<256>), dim3(p.nsplit, tiles), dim3(512), lds, s, p);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<256>), grid, dim3(512), lds, s, p);
     } else {
-        hipLaunchKernelGGL((wgrad_bf16_kernel<128>), dim3(p.nsplit, tiles), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<128>), grid, dim3(256), lds, s, p);
     }
     VSDE_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tiles, p.tile * p.tile / 256), dim3(256), 0, s, p);
+    const int64_t vecs = (int64_t)tiles * p.tile * p.tile / 4;
+    int G = 1;
+    while (G < 16 && vecs * G < 524288 && 2 * G <= p.nsplit) G *= 2;  // enough threads to cover the load latency
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.tile * p.tile / 4 / (256 / G) + 1, tiles), dim3(256), 0, s, p, G);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
