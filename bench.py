@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--workload", default="lv", choices=["lv", "ou", "synthetic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hip-graph", action="store_true", help="step eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--hip-graph", action="store_true", help="always replay the captured HIP graph (default: whichever of "
+                    "eager / replay is faster in a 3-step probe before the warm-up; same kernels and work either way)")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -181,12 +183,29 @@ def main():
         tr._train_step(model)
         ctx.ema.update()
 
-    # single-process runs replay the whole step (same kernels, same work) from a HIP graph
+    # single-process runs may replay the whole step (same kernels, same work) from a HIP graph: a win when the step is
+    # launch-bound (OU), a small loss when it is GPU-bound (graph nodes dispatch with a larger gap than a busy eager queue)
     graph_mode = False
     if not distributed and not args.no_hip_graph:
+        def probe(fn, n=3):
+            fn(); sync(device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync(device)
+            return (time.perf_counter() - t0) / n
+        for _ in range(3):
+            train_step()
+        t_eager = probe(train_step)
         replay = tr.capture_step_graph(warmup=3)
-        if replay is not None:
+        if replay is not None and (args.hip_graph or probe(replay) < t_eager):
             train_step, graph_mode = replay, True
+        elif replay is not None:  # drop the graph and its private memory pool
+            del replay
+            tr._graph = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
 
     elapsed = timed(train_step, args.steps, args.warmup, device, distributed)
     iters_per_sec = args.steps / elapsed

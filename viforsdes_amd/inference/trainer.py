@@ -100,7 +100,8 @@ class VariationalInferenceTrainer:
         """Capture one full optimizer step (+ EMA update) into a HIP graph and return a ``replay()`` callable.
 
         The OU-size step is launch-bound (~900 small kernels): replaying a graph removes the per-kernel host
-        cost (28.7 -> 10.9 ms/step measured); at LV size the GPU is already busy and the gain is ~1 %.
+        cost (28.7 -> 9.6 ms/step measured); at LV size the GPU is busy either way and the eager queue is ~3 %
+        faster than graph replay (44.8 vs 46.1 ms), so callers should prefer eager stepping there.
         ``warmup`` eager steps run first (optimizer state, allocator pools, lazily built caches); they are real
         training steps (their results are appended to ``warm_results`` when given).  Returns ``None`` when
         capture is not applicable (CPU, multi-process) or fails, in which case the caller keeps stepping
