@@ -92,7 +92,7 @@ __device__ __forceinline__ float seg_sum(float v, int width) {
 
 // LPR lanes (64 or 32) per token, 256/LPR tokens per block; a lane owns V contiguous channels of each
 // LPR*V-wide slab (<= 4 slabs).  C = 256 in bf16 runs as 32 lanes x 16 bytes: two tokens per wavefront.
-template <typename T, int V, int LPR>
+template <typename T, int V, int LPR, int NSLAB>
 __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ shift, T *__restrict__ y,
                                                          float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
@@ -101,11 +101,11 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
     const int64_t m = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (m >= M) return;
     const int64_t b = m / N;
-    const int nslab = C / (LPR * V);
-    float v[4][V];
+    constexpr int nslab = NSLAB;  // C == NSLAB * LPR * V
+    float v[NSLAB][V];
     float s = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+    for (int sl = 0; sl < NSLAB; ++sl)
         if (sl < nslab) {
             Pack<T, V>::load(x + m * C + (sl * LPR + lane) * V, v[sl]);
 #pragma unroll
@@ -114,14 +114,14 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
     const float mu = seg_sum(s, LPR) / C;
     float q = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+    for (int sl = 0; sl < NSLAB; ++sl)
         if (sl < nslab)
 #pragma unroll
             for (int e = 0; e < V; ++e) { const float d = v[sl][e] - mu; q += d * d; }
     const float rs = rsqrtf(seg_sum(q, LPR) / C + eps);
     if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+    for (int sl = 0; sl < NSLAB; ++sl)
         if (sl < nslab) {
             const int c = (sl * LPR + lane) * V;
             float sc[V], sh[V], o[V];
@@ -136,7 +136,16 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
 // walks one chunk of the tokens of one batch row, 256/LPR tokens at a time, writes the token gradients and keeps
 // the channel sums in registers; the token slots are combined through LDS and each block stores one fp32 partial
 // row part[k][b][chunk][C].  colsum_finish_kernel adds the nchunk partials in a fixed order (deterministic).
-constexpr int kColsumChunks = 8;
+constexpr int kColsumChunksMax = 64;
+// token chunks per batch row: ~2048 workgroups in total (per-workgroup prologue/epilogue is the overhead that grows
+// with the chunk count: 4 chunks beat 8 by 5 % and 32 by 2x at B = 512), at least 8 tokens per chunk
+static int colsum_chunks(int64_t B, int N) {
+    int64_t c = (2048 + B - 1) / B;
+    if (c < 4) c = 4;
+    if (c > kColsumChunksMax) c = kColsumChunksMax;
+    if (c > N / 8) c = N / 8 > 0 ? N / 8 : 1;
+    return (int)c;
+}
 
 template <int NACC>
 __device__ __forceinline__ void colsum_block_reduce(float *red, const float (&acc)[NACC], int slot, int slots, int lane_off,
@@ -154,7 +163,7 @@ __device__ __forceinline__ void colsum_block_reduce(float *red, const float (&ac
 }
 
 // ln_modulate backward: dx (+ dres) per token, and partial sums of dy*xhat (part0) and dy (part1)
-template <typename T, int V, int LPR>
+template <typename T, int V, int LPR, int NSLAB>
 __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ dy, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd, const T *__restrict__ dres,
@@ -165,10 +174,10 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
     const int b = blockIdx.y, nchunk = gridDim.x, B = gridDim.y;
     const int CL = (N + nchunk - 1) / nchunk;
     const int n0 = blockIdx.x * CL, n1 = min(N, n0 + CL);
-    const int nslab = C / (LPR * V);
-    float sc1[4][V], a1[4][V], a2[4][V];
+    constexpr int nslab = NSLAB;  // C == NSLAB * LPR * V
+    float sc1[NSLAB][V], a1[NSLAB][V], a2[NSLAB][V];
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    for (int sl = 0; sl < NSLAB; ++sl) {
         if (sl < nslab) {
             Pack<T, V>::load(scale + (int64_t)b * C + (sl * LPR + lane) * V, sc1[sl]);
 #pragma unroll
@@ -180,10 +189,10 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
     for (int n = n0 + slot; n < n1; n += SLOTS) {
         const int64_t m = (int64_t)b * N + n;
         const float mu = mean[m], rs = rstd[m];
-        float g[4][V], xh[4][V];
+        float g[NSLAB][V], xh[NSLAB][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl)
+        for (int sl = 0; sl < NSLAB; ++sl)
             if (sl < nslab) {
                 const int c = (sl * LPR + lane) * V;
                 Pack<T, V>::load(x + m * C + c, xh[sl]); Pack<T, V>::load(dy + m * C + c, g[sl]);
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
             }
         s1 = seg_sum(s1, LPR) / C; s2 = seg_sum(s2, LPR) / C;
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl)
+        for (int sl = 0; sl < NSLAB; ++sl)
             if (sl < nslab) {
                 const int c = (sl * LPR + lane) * V;
                 float o[V];
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
     float *p0 = part + (((int64_t)0 * B + b) * nchunk + blockIdx.x) * C;
     float *p1 = part + (((int64_t)1 * B + b) * nchunk + blockIdx.x) * C;
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+    for (int sl = 0; sl < NSLAB; ++sl)
         if (sl < nslab) {
             const int off = sl * LPR * V;
             colsum_block_reduce<V>(red, a1[sl], slot, SLOTS, lane * V, LPR * V, p0 + off, C - off);
@@ -537,16 +546,25 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
     constexpr int VF = VecOf<T>::v;  // 8 bf16 / 4 f32 = 16 bytes per lane
     const int64_t M = B * N;
     dim3 block(256);
-#define LNM(V, LPR)                                                                                                           \
+#define LNM_N(V, LPR, NS)                                                                                                     \
     do {                                                                                                                      \
         if (which == 0) {                                                                                                     \
             dim3 grid((unsigned)((M + 256 / LPR - 1) / (256 / LPR)));                                                         \
-            hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR>), grid, block, 0, s, (const T *)x, (const T *)scale,             \
+            hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR, NS>), grid, block, 0, s, (const T *)x, (const T *)scale,         \
                                (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                                   \
         } else {                                                                                                              \
-            hipLaunchKernelGGL((ln_mod_bwd_kernel<T, V, LPR>), dim3(kColsumChunks, (unsigned)B), block, 256 * V * sizeof(float), \
-                               s, (const T *)x, (const T *)scale, (const T *)shift_or_dy, (const float *)mean,                \
-                               (const float *)rstd, (const T *)dres, (T *)out, part, N, C);                                   \
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<T, V, LPR, NS>), dim3(colsum_chunks(B, N), (unsigned)B), block,                   \
+                               256 * V * sizeof(float), s, (const T *)x, (const T *)scale, (const T *)shift_or_dy,            \
+                               (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out, part, N, C);              \
+        }                                                                                                                     \
+    } while (0)
+#define LNM(V, LPR)                                                                                                           \
+    do {                                                                                                                      \
+        switch (C / ((LPR) * (V))) {                                                                                          \
+            case 1: LNM_N(V, LPR, 1); break;                                                                                  \
+            case 2: LNM_N(V, LPR, 2); break;                                                                                  \
+            case 3: LNM_N(V, LPR, 3); break;                                                                                  \
+            default: LNM_N(V, LPR, 4); break;                                                                                 \
         }                                                                                                                     \
     } while (0)
     if (C % (64 * VF) == 0 && C / (64 * VF) <= 4) LNM(VF, 64);
@@ -557,6 +575,7 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
         VSDE_CHECK_ARG(C / 64 <= 4, VSDE_E_BADARG, "ln_modulate: unsupported channel count %d", C);
         LNM(1, 64);
     }
+#undef LNM_N
 #undef LNM
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -580,7 +599,7 @@ extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale,
 }
 
 extern "C" size_t vsde_colsum_workspace_bytes(int64_t B, int C) {
-    return (size_t)2 * (size_t)B * kColsumChunks * (size_t)C * sizeof(float);
+    return (size_t)2 * (size_t)B * kColsumChunksMax * (size_t)C * sizeof(float);
 }
 
 extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
@@ -596,7 +615,7 @@ extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale,
         if (rc) return rc;
         const int64_t BC = B * C;
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dscale, (T *)dshift, BC, C, kColsumChunks);
+                           (T *)dscale, (T *)dshift, BC, C, colsum_chunks(B, N));
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -627,7 +646,7 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
     const int64_t BC = B * C;
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
-        dim3 grid(kColsumChunks, (unsigned)B);
+        dim3 grid(colsum_chunks(B, N), (unsigned)B);
         if (C % VF == 0 && C / VF <= 256)
             hipLaunchKernelGGL((gated_residual_bwd_kernel<T, VF>), grid, dim3(256), 256 * VF * sizeof(float), s, (const T *)y,
                                (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
@@ -635,7 +654,7 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
             hipLaunchKernelGGL((gated_residual_bwd_kernel<T, 4>), grid, dim3(256), 256 * 4 * sizeof(float), s, (const T *)y,
                                (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dgate, (T *)nullptr, BC, C, kColsumChunks);
+                           (T *)dgate, (T *)nullptr, BC, C, colsum_chunks(B, N));
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
