@@ -183,6 +183,14 @@ int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const f
                           void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, int token_major,
                           int64_t row_stride, void *stream);
 
+/* Attention core for the encoder's shape class (bf16, head_dim 64, N <= vsde_attention_max_tokens() so that K and V of
+ * one (batch, head) stay in LDS):  o = softmax(scale * q k^T) v  with q, k, v, o token-major [B][N][H][64];
+ * lse [B][H][N] = natural-log sum-exp of the scaled scores (what a flash-attention backward consumes).
+ * Replaces F.scaled_dot_product_attention at primitives/attn.py:104-106 for these shapes. */
+int vsde_attention_max_tokens(void);
+int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
+                            int head_dim, double scale, void *stream);
+
 /* Weight and bias gradient of y = x W^T + b for bf16 activations:  dW[N][K] = dy^T x,  db[N] = colsum(dy)
  * (db may be NULL).  dy [M][N], x [M][K] bf16 contiguous, N % 8 == K % 8 == 0; results fp32, deterministic.
  * Replaces torch's hipBLASLt "wgrad" GEMM + bf16 column-sum kernel of every encoder nn.Linear

@@ -205,3 +205,42 @@ def test_ln_modulate_and_gated_residual_channel_counts(C, dtype, tol):
 
     for name, a, b_ in zip(["out", "dx", "dscale", "dshift", "dgate", "dw"], run(True), run(False)):
         assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < tol, name
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 1, 2), (2, 31, 4), (3, 32, 1), (2, 101, 4), (2, 401, 4), (1, 576, 2)])
+def test_attention_kernel_vs_fp32_softmax(B, N, H):
+    """vsde_attention_fwd_bf16 (token-major, K/V resident in LDS) vs an fp32 softmax(q k^T) v of the same bf16 inputs; the
+    backward (library kernel fed with our output and log-sum-exp) vs autograd through the fp32 chain."""
+    from viforsdes_amd import _hip
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16).requires_grad_() for _ in range(3))
+    go = torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16)
+    assert fused.attention_usable(q)
+    o = fused.attention(q, k, v, 0.125)
+    dq, dk, dv = torch.autograd.grad((o.float() * go.float()).sum(), [q, k, v])
+    qf, kf, vf = (t.detach().float().transpose(1, 2).requires_grad_() for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2)
+    rq, rk, rv = torch.autograd.grad((ref * go.float()).sum(), [qf, kf, vf])
+    assert rel_err(o.detach().float().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-2
+    _, lse = _hip.attention_fwd(q.detach(), k.detach(), v.detach(), 0.125)
+    assert torch.allclose(lse, torch.logsumexp(s.detach(), -1), atol=1e-4, rtol=1e-5)
+    for a, r in ((dq, rq), (dk, rk), (dv, rv)):  # absolute floor: at N = 1 dq and dk are exactly 0
+        a, r = a.float().cpu().numpy(), r.transpose(1, 2).cpu().numpy()
+        assert np.abs(a - r).max() <= 2e-2 * np.abs(r).max() + 1e-2
+
+
+def test_attention_kernel_large_scores_take_the_exact_path():
+    """|q||k| scale far above the Cauchy-Schwarz-shift limit: the kernel must fall back to true row maxima (no NaN/underflow)."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(2, 77, 2, 64, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
+    q, k = q * 6, k * 6
+    o, lse = _hip.attention_fwd(q, k, v, 0.125)
+    qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert rel_err(o.float().cpu().numpy(), ref.cpu().numpy()) < 1e-2
+    assert torch.allclose(lse, torch.logsumexp(s, -1), atol=1e-3, rtol=1e-5)

@@ -56,6 +56,7 @@ EXPORTS = (
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
+    "vsde_attention_max_tokens", "vsde_attention_fwd_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -445,6 +446,24 @@ def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, tok
               ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _i64(pitch), _stream(dev))
     dlam = parts.sum() if parts is not None else None
     return dqkv, dv0, dlam
+
+
+def attention_max_tokens() -> int:
+    return int(load().vsde_attention_max_tokens())
+
+
+def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
+    """softmax(scale q k^T) v for token-major bf16 heads [B,N,H,64]; returns (o [B,N,H,64], lse [B,H,N] fp32)."""
+    lib = load(); dev = _require_hip(q, k, v)
+    B, N, H, d = q.shape
+    if q.dtype != torch.bfloat16 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise ValueError("attention_fwd needs contiguous bf16 [B,N,H,64] tensors")
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_attention_fwd_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _i64(B), ctypes.c_int(N),
+              ctypes.c_int(H), ctypes.c_int(d), ctypes.c_double(scale), _stream(dev))
+    return o, lse
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):

@@ -1,0 +1,250 @@
+// Self-attention core of the SiT observation encoder on bf16 MFMA (gfx950), for the encoder's shape class:
+// short sequences (N <= 576 tokens: the observation grid + 1), head_dim 64, many (batch, head) pairs.
+//
+//   O[b,n,h,:] = softmax_j(scale * <q[b,n,h,:], k[b,j,h,:]>) v[b,j,h,:]        (reference: primitives/attn.py:104-106,
+//                                                                               F.scaled_dot_product_attention)
+//
+// The library flash kernels tile for long sequences and reach ~10 % of the MFMA peak here.  At these lengths the whole
+// K and V of one (batch, head) fit in LDS (N = 401: 114 KB), so one workgroup owns one (b, h):
+//   * K is staged row-major [key][d] (the B^T... A operand of S^T = K Q^T wants d contiguous per lane: no transpose),
+//     V is staged transposed [d][key] through an in-register 8x8 bf16 transpose (O^T = V^T P^T wants keys contiguous);
+//   * the products are computed "swapped" (S^T = K Q^T, O^T = V^T P^T) so a lane owns ONE query column: the softmax
+//     statistics are in-register reductions plus a single exchange between lane l and l+32, and P^T leaves the first
+//     MFMA already in the B-operand layout of the second (no LDS round trip for the probabilities);
+//   * softmax without a running-maximum rescale chain: the shift is the Cauchy-Schwarz bound |q_i| max_j |k_j| >= max_j
+//     <q_i, k_j> (softmax is shift-invariant, so this is exact), available before the first product; only if that
+//     bound is so loose that every term could underflow (scale |q||k| > 27, never the case behind the encoder's
+//     QK-RMS-norm) a first pass computes the true row maxima.
+// Token-major layout [B][N][H][64] for q, k, v, o (what qk_norm_rope writes and gate_merge reads).
+#include "vsde_common.h"
+
+namespace vsde {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+
+constexpr int AT_D = 64;     // head dim
+constexpr int AT_KLD = 72;   // LDS row stride of K in bf16 (144 B: conflict-free ds_read_b128 fragments)
+constexpr int AT_MAXN = 576; // 576*272 + 512 B of LDS <= 160 KB
+
+struct AttnParams {
+    const uint16_t *q, *k, *v;  // [B][N][H][64] bf16
+    uint16_t *o;                // [B][N][H][64] bf16
+    float *lse;                 // [B][H][N] natural-log sum-exp of the scaled scores
+    int N, H;
+    int npad;                   // N rounded up to 32
+    int vld;                    // LDS row stride of V^T in bf16: npad + 4 (stride/2 dwords = 2*odd mod 64: conflict-free b64)
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32v2 f = {a, b};
+    bf16v2 r = __builtin_convertvector(f, bf16v2);  // v_cvt_pk_bf16_f32
+    return *(uint32_t *)&r;
+}
+
+__global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
+    uint16_t *Ks = asmem;                      // [npad][AT_KLD]
+    uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
+    const int N = p.N, npad = p.npad, vld = p.vld;
+    const int64_t ts = (int64_t)p.H * AT_D;    // token stride in elements
+    const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
+    const uint16_t *qb = p.q + base, *kb = p.k + base, *vb = p.v + base;
+    // ---- stage K [key][d] and V^T [d][key]: every global load of the workgroup is issued before the first use -----
+    constexpr int KIT = AT_MAXN * 8 / 512, VIT = (AT_MAXN + 511) / 512;
+    uint4 kreg[KIT], vreg[VIT][8];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        kreg[it] = (i < npad * 8 && n < N) ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {  // (npad/8 key blocks) x (8 d-chunks); lanes c = 0..7 read one full 128-byte row
+        const int i = tid + it * 512, kblk = i >> 3, c = i & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = kblk * 8 + j;
+            vreg[it][j] = (i < npad && n < N) ? *(const uint4 *)(vb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    float kss_max = 0.f;  // max_j |k_j|^2 (8 adjacent lanes hold one key row)
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        if (i < npad * 8) *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
+        const uint32_t w[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+        }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        kss_max = fmaxf(kss_max, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kss_max = fmaxf(kss_max, __shfl_xor(kss_max, off, 64));
+    __shared__ float kred[8];
+    if (lane == 0) kred[wave] = kss_max;
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+        const int i = tid + it * 512, kblk = i >> 3, c = i & 7;
+        uint4 ct[8];
+        transpose8x8(vreg[it], ct);
+        if (i < npad) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // row d = c*8+j holds keys kblk*8 .. +7; rows are only 8-byte aligned (vld = 4 mod 8)
+                uint2 *dst = (uint2 *)(Vt + (c * 8 + j) * vld + kblk * 8);
+                dst[0] = make_uint2(ct[j].x, ct[j].y);
+                dst[1] = make_uint2(ct[j].z, ct[j].w);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 8; ++w) kss_max = fmaxf(kss_max, kred[w]);
+    const float kmax = sqrtf(kss_max);
+
+    const int fr = lane & 31, h2 = lane >> 5;
+    const int nkt = npad >> 5, nqb = npad >> 5;
+    const bool ragged = (N & 31) != 0;
+    for (int qblk = wave; qblk < nqb; qblk += 8) {
+        const int query = qblk * 32 + fr;
+        const bool qok = query < N;
+        bf16x8 qf[4];  // B operand of S^T = K Q^T: column = query, k = d
+        float qss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (qok) t = *(const uint4 *)(qb + query * ts + ks * 16 + h2 * 8);
+            qf[ks] = *(bf16x8 *)&t;
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                qss = fmaf(lo, lo, fmaf(hi, hi, qss));
+            }
+        }
+        qss += __shfl_xor(qss, 32, 64);
+        // shift of the softmax: |q| max|k| >= every score of this query (x 1.0001 against rounding of the norms)
+        float mx = sqrtf(qss) * kmax * 1.0001f;
+        const bool exact = !__all(mx * p.scale_log2e <= 40.0f);  // wave-uniform
+        // ---- pass 1 (rare): true maximum score of every query ----------------------------------------------
+        if (exact) mx = -INFINITY;
+        for (int kt = 0; exact && kt < nkt; ++kt) {
+            f32x16 s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint16_t *krow = Ks + (kt * 32 + fr) * AT_KLD + h2 * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(krow + ks * 16), qf[ks], s, 0, 0, 0);
+            if (ragged && kt == nkt - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) s[r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        }
+        if (exact) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other half-wave holds the other 16 keys of every tile
+        // ---- pass 2: P^T = exp2(c (S^T - max)), O^T += V^T P^T -------------------------------------------
+        const float c2 = p.scale_log2e, mc = mx * c2;
+        float lsum = 0.f, lsum2 = 0.f;
+        f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0;
+        // Software pipeline, two key tiles per trip (ping-pong score registers, no copies).  One step, for tile kt:
+        //   1. issue the LDS reads of K tile kt+1 and of the V^T columns of tile kt,
+        //   2. exponentiate score tile kt on the VALU while those reads are in flight,
+        //   3. score tile kt+1 and the PV product of tile kt on the matrix pipe.
+        auto step = [&](f32x16 &scur, f32x16 &snxt, int kt) {
+            const int ktn = min(kt + 1, nkt - 1);  // the last step recomputes its own tile (result unused)
+            const uint16_t *krow = Ks + (ktn * 32 + fr) * AT_KLD + h2 * 8;
+            bf16x8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8 *)(krow + ks * 16);
+            uint2 vf[8];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const uint16_t *vrow = Vt + (dt * 32 + fr) * vld + kt * 32 + 4 * h2;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) vf[dt * 4 + x] = *(const uint2 *)(vrow + 8 * x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ragged && kt == nkt - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) scur[r] = -INFINITY;
+            }
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                pr[r] = fast_exp2(fmaf(scur[r], c2, -mc)); lsum += pr[r];
+                pr[r + 1] = fast_exp2(fmaf(scur[r + 1], c2, -mc)); lsum2 += pr[r + 1];
+            }
+            // registers 0..7 are keys {4h2..4h2+3, 8+4h2..11+4h2} of the tile, 8..15 the same + 16: used as the two
+            // k-steps of the second product, with V^T read at exactly those key columns
+            uint4 pw0 = make_uint4(pack_bf16(pr[0], pr[1]), pack_bf16(pr[2], pr[3]), pack_bf16(pr[4], pr[5]), pack_bf16(pr[6], pr[7]));
+            uint4 pw1 = make_uint4(pack_bf16(pr[8], pr[9]), pack_bf16(pr[10], pr[11]), pack_bf16(pr[12], pr[13]), pack_bf16(pr[14], pr[15]));
+            const bf16x8 pb0 = *(bf16x8 *)&pw0, pb1 = *(bf16x8 *)&pw1;
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], t, 0, 0, 0);
+            snxt = t;
+            uint4 aw;
+            aw = make_uint4(vf[0].x, vf[0].y, vf[1].x, vf[1].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o0, 0, 0, 0);
+            aw = make_uint4(vf[4].x, vf[4].y, vf[5].x, vf[5].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o1, 0, 0, 0);
+            aw = make_uint4(vf[2].x, vf[2].y, vf[3].x, vf[3].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o0, 0, 0, 0);
+            aw = make_uint4(vf[6].x, vf[6].y, vf[7].x, vf[7].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o1, 0, 0, 0);
+        };
+        f32x16 sa = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = sa;
+        {
+            const uint16_t *krow = Ks + fr * AT_KLD + h2 * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(krow + ks * 16), qf[ks], sa, 0, 0, 0);
+        }
+        for (int kt = 0; kt < nkt; kt += 2) {
+            step(sa, sb, kt);
+            if (kt + 1 < nkt) step(sb, sa, kt + 1);
+        }
+        lsum += lsum2;
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (qok) {
+            const float inv = 1.0f / lsum;
+            uint16_t *orow = p.o + base + query * ts;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = rows d = 8g + 4h2 + 0..3 (o0) and 32 + ... (o1)
+                const int d0 = 8 * g + 4 * h2;
+                *(uint2 *)(orow + d0) = make_uint2(pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+                *(uint2 *)(orow + 32 + d0) = make_uint2(pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+            }
+            if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = mx * p.scale + __logf(lsum);
+        }
+    }
+}
+
+}  // namespace vsde
+
+using namespace vsde;
+
+extern "C" int vsde_attention_max_tokens(void) { return AT_MAXN; }
+
+extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
+                                       int head_dim, double scale, void *stream) {
+    VSDE_CHECK_ARG(q && k && v && o && lse && B > 0 && N > 0 && H > 0, VSDE_E_BADARG, "bad attention arguments");
+    VSDE_CHECK_ARG(head_dim == AT_D, VSDE_E_BADARG, "attention kernel is built for head_dim 64, got %d", head_dim);
+    VSDE_CHECK_ARG(N <= AT_MAXN, VSDE_E_BADARG, "attention kernel keeps K and V of one head in LDS: N <= %d, got %d", AT_MAXN, N);
+    VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
+    AttnParams p;
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (uint16_t *)o; p.lse = lse;
+    p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
+    p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(512), lds, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}

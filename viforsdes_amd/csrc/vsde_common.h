@@ -86,6 +86,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 8 rows x 8 bf16 (row i in r[i], 4 dwords) -> 8 columns x 8 bf16 (column j in c[j]: rows 0..7)
+__device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&c)[8]) {
+    const uint32_t *rr = (const uint32_t *)r;
+    uint32_t *cc = (uint32_t *)c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t a = rr[(2 * p) * 4 + (j >> 1)], b = rr[(2 * p + 1) * 4 + (j >> 1)];
+            cc[j * 4 + p] = (j & 1) ? __builtin_amdgcn_perm(b, a, 0x07060302u) : __builtin_amdgcn_perm(b, a, 0x05040100u);
+        }
+}
+
 // ---- GEMM launchers (vsde_gemm.hip) ----------------------------------------------------
 // C[m][n] = sum_k A(m,k) * Bt[n][k] (+ bias[n]);  Bt row-major [N][K] with leading dim ldb.
 int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int N, const float *bias,

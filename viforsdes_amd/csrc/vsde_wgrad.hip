@@ -36,19 +36,6 @@ struct WgradParams {
     float *db;           // [N] or nullptr
 };
 
-// 8 rows x 8 bf16 (row i in r[i], 4 dwords) -> 8 columns x 8 bf16 (column j in c[j]: rows 0..7)
-__device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&c)[8]) {
-    const uint32_t *rr = (const uint32_t *)r;
-    uint32_t *cc = (uint32_t *)c;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t a = rr[(2 * p) * 4 + (j >> 1)], b = rr[(2 * p + 1) * 4 + (j >> 1)];
-            cc[j * 4 + p] = (j & 1) ? __builtin_amdgcn_perm(b, a, 0x07060302u) : __builtin_amdgcn_perm(b, a, 0x05040100u);
-        }
-}
-
 // T x T output tile per workgroup of 2T threads: T=128 -> 4 waves of 64x64, T=256 -> 8 waves of 64(n) x 128(k).
 // The larger tile halves the operand re-reads (dY is re-read K/T times, X N/T times).
 template <int T>

@@ -77,10 +77,12 @@ class Attention(nn.Module):
                                                    v0.transpose(1, 2) if mix else None,
                                                    self.v_residual_lambda if mix else None, self.num_heads,
                                                    self.q_norm.eps, True, link)
-        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)  # [B,h,N,d] views
-        out = _sdpa(q, k, v)
-        merged = fused.gate_merge_joint(out.transpose(1, 2), y, self.num_heads, True, link)
-        return lin(merged, self.out_proj.weight, self.out_proj.bias), v
+        if fused.attention_usable(q):
+            out_tm = fused.attention(q, k, v, self.head_dim ** -0.5)  # token-major in, token-major out
+        else:
+            out_tm = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+        merged = fused.gate_merge_joint(out_tm, y, self.num_heads, True, link)
+        return lin(merged, self.out_proj.weight, self.out_proj.bias), v.transpose(1, 2)  # values as a [B,h,N,d] view
 
     def forward(self, hidden_states: Tensor, *, rotary: Optional[RotarySpec] = None, v0: Optional[Tensor] = None,
                 return_value: bool = False):

@@ -224,6 +224,50 @@ def qk_norm_rope(qkv: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, 
     return _QkNormRope.apply(qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major)
 
 
+class _Attention(torch.autograd.Function):
+    """softmax(scale q k^T) v on token-major heads [B,N,H,64]: forward = csrc/vsde_attn.hip (K and V of one head resident in
+    LDS), backward = the library's memory-efficient attention backward fed with our output and log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o, lse = _hip.attention_fwd(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        N = q.shape[1]
+        zero = _philox_zero()
+        dq, dk, dv, _ = torch.ops.aten._efficient_attention_backward(
+            do.to(q.dtype).contiguous(), q, k, v, None, o, None, None, N, N, lse, 0.0, zero, zero, 0, False, scale=ctx.scale)
+        return dq, dk, dv, None
+
+
+_PHILOX_ZERO = None
+
+
+def _philox_zero() -> Tensor:
+    global _PHILOX_ZERO
+    if _PHILOX_ZERO is None:
+        _PHILOX_ZERO = torch.zeros((), dtype=torch.int64)  # dropout is 0: seed / offset are never read
+    return _PHILOX_ZERO
+
+
+def attention_usable(q: Tensor) -> bool:
+    """q token-major [B,N,H,d]: bf16, head_dim 64, sequence short enough for the LDS-resident kernel."""
+    return (ENABLED and q.is_cuda and q.dtype == torch.bfloat16 and q.ndim == 4 and q.shape[-1] == 64
+            and q.shape[1] <= _hip.attention_max_tokens())
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
+    """Token-major [B,N,H,64] self-attention core (no mask, no dropout); see ``attention_usable``."""
+    return _Attention.apply(q, k, v, scale)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b for bf16 activations: forward and the input gradient stay on hipBLASLt, the weight/bias
     gradient (a reduction over ~2e5 rows that hipBLASLt runs at a few % of the HBM roofline) is one fused HIP
