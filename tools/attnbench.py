@@ -29,6 +29,17 @@ def run(B, N, H, reps=20):
     from torch.nn.attention import SDPBackend, sdpa_kernel
     with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION]):
         t_ref = t(lambda: F.scaled_dot_product_attention(qt, kt, vt))
+    go = torch.randn_like(q)
+    dq, dk, dv = _hip.attention_bwd(go, q, k, v, o, lse, 0.125)
+    qr, kr, vr = (t.float().transpose(1, 2).requires_grad_() for t in (q, k, v))
+    sr = (qr @ kr.transpose(-1, -2)) * 0.125
+    rr = (torch.softmax(sr, -1) @ vr).transpose(1, 2)
+    gq, gk, gv = torch.autograd.grad((rr * go.float()).sum(), [qr, kr, vr])
+    berr = [((a.float() - g.transpose(1, 2)).abs().max() / g.abs().max()).item() for a, g in ((dq, gq), (dk, gk), (dv, gv))]
+    t_bwd = t(lambda: _hip.attention_bwd(go, q, k, v, o, lse, 0.125))
+    zero = torch.zeros((), dtype=torch.int64)
+    t_bref = t(lambda: torch.ops.aten._efficient_attention_backward(go, q, k, v, None, o, None, None, N, N, lse, 0.0, zero, zero, 0, False, scale=0.125))
+    print(f"   bwd rel err dq {berr[0]:.2e} dk {berr[1]:.2e} dv {berr[2]:.2e} | own {t_bwd:7.1f} us  library {t_bref:7.1f} us")
     fl = 4.0 * B * H * N * N * 64
     print(f"B={B} N={N} H={H}: rel err {err:.2e} lse err {lerr:.2e} | own {t_own:7.1f} us ({fl/t_own/1e6:6.1f} TF/s)  sdpa {t_ref:7.1f} us ({fl/t_ref/1e6:6.1f} TF/s)")
 

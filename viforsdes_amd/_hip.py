@@ -56,7 +56,7 @@ EXPORTS = (
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
-    "vsde_attention_max_tokens", "vsde_attention_fwd_bf16",
+    "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -464,6 +464,22 @@ def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: floa
         _call(lib.vsde_attention_fwd_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _i64(B), ctypes.c_int(N),
               ctypes.c_int(H), ctypes.c_int(d), ctypes.c_double(scale), _stream(dev))
     return o, lse
+
+
+def attention_bwd(dout, q, k, v, o, lse, scale: float):
+    """(dq, dk, dv) token-major bf16 for ``attention_fwd``'s inputs/outputs."""
+    lib = load(); dev = _require_hip(dout, q, k, v, o, lse)
+    B, N, H, d = q.shape
+    for t in (dout, q, k, v, o):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.shape != q.shape:
+            raise ValueError("attention_bwd needs contiguous bf16 [B,N,H,64] tensors of one shape")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    delta = torch.empty(B, H, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_attention_bwd_bf16, _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(dq), _ptr(dk),
+              _ptr(dv), _ptr(delta), _i64(B), ctypes.c_int(N), ctypes.c_int(H), ctypes.c_int(d), ctypes.c_double(scale),
+              _stream(dev))
+    return dq, dk, dv
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):

@@ -226,6 +226,232 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     }
 }
 
+// ===================================================================================== backward
+// Two kernels, each the mirror image of the other; both recompute the probabilities from q, k and the saved log-sum-exp.
+//   dq kernel   : a wavefront owns 32 queries (q, dO fragments and the dQ^T accumulators in registers); the key tiles
+//                 (K, V and K^T, 32 keys each) stream through a double-buffered LDS stage shared by the workgroup's 4
+//                 waves.  Products in the lane = query orientation: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
+//                 Also emits D_i = <dO_i, O_i>.
+//   dk/dv kernel: a wavefront owns 32 keys (k, v fragments, dK^T / dV^T accumulators); the query tiles (Q, dO, Q^T, dO^T,
+//                 lse, D) stream through LDS.  Lane = key orientation: S = Q K^T, dP = dO V^T, dV^T += dO^T P,
+//                 dK^T += Q^T dS.
+// In both, the tile that comes out of the first MFMA pair already has the B-operand layout of the accumulating product
+// (with its 32 contraction indices in the order 4h+{0..3}, 8+4h+{0..3}, ...), so P and dS never leave registers; the
+// transposed operands (K^T, Q^T, dO^T) are never materialised: ds_read_b64_tr_b16 reads them out of the row-major tiles.
+// No atomics: every output element is owned by exactly one lane (deterministic).
+
+struct AttnBwdParams {
+    const uint16_t *q, *k, *v, *o, *dout;  // [B][N][H][64] bf16
+    const float *lse;                      // [B][H][N]
+    float *delta;                          // [B][H][N]  D_i = <dO_i, O_i>   (written by the dq kernel, read by dk/dv)
+    uint16_t *dq, *dk, *dv;                // [B][N][H][64] bf16
+    int N, H, ntile;                       // ntile = ceil(N / 32)
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ f32x16 tile_product(const uint16_t *arow, const bf16x8 (&bfrag)[4]) {
+    f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(arow + ks * 16), bfrag[ks], t, 0, 0, 0);
+    return t;
+}
+
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 (probed on gfx950, tools/probes/tr_b16_probe.hip): within a 16-lane group, lane m supplies the address
+// of 4 contiguous bf16 = row m/4, columns 4(m%4).. of a [4][16] block, and lane i receives column i (rows 0..3).
+__device__ __forceinline__ uint2 lds_read_tr(const uint16_t *ptr) {
+    bf16x4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s *)ptr);
+    return *(uint2 *)&r;
+}
+
+// acc[dt] += X^T B for a row-major LDS tile X [32 tokens][64] (stride AT_KLD): the A operand (row = channel d = dt*32 + fr,
+// contraction over the tokens 4h2 + {0..3, 8..11 | 16..19, 24..27}, the order in which B's registers hold them) is read
+// with the hardware transpose -- no transposed copy of the tile exists anywhere.
+__device__ __forceinline__ void accumulate_transposed(const uint16_t *tile, int lane, const bf16x8 &b0, const bf16x8 &b1,
+                                                      f32x16 &acc0, f32x16 &acc1) {
+    const int h2 = lane >> 5, m = lane & 15;
+    const uint16_t *src = tile + (4 * h2 + (m >> 2)) * AT_KLD + ((lane >> 4) & 1) * 16 + (m & 3) * 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const uint2 a0 = lds_read_tr(src + dt * 32), a1 = lds_read_tr(src + dt * 32 + 8 * AT_KLD);
+        const uint2 a2 = lds_read_tr(src + dt * 32 + 16 * AT_KLD), a3 = lds_read_tr(src + dt * 32 + 24 * AT_KLD);
+        uint4 w0 = make_uint4(a0.x, a0.y, a1.x, a1.y), w1 = make_uint4(a2.x, a2.y, a3.x, a3.y);
+        if (dt == 0) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w0, b0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w1, b1, acc0, 0, 0, 0);
+        } else {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w0, b0, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w1, b1, acc1, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void pack_tile(const float (&x)[16], bf16x8 &b0, bf16x8 &b1) {
+    uint4 w0 = make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
+    uint4 w1 = make_uint4(pack_bf16(x[8], x[9]), pack_bf16(x[10], x[11]), pack_bf16(x[12], x[13]), pack_bf16(x[14], x[15]));
+    b0 = *(bf16x8 *)&w0; b1 = *(bf16x8 *)&w1;
+}
+
+// row-major [row][64] global rows (token stride ts) -> registers of the B operand "column = row index, k = d"
+__device__ __forceinline__ void load_bfrag(const uint16_t *base, int64_t ts, int row, bool ok, int h2, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (ok) t = *(const uint4 *)(base + row * ts + ks * 16 + h2 * 8);
+        f[ks] = *(bf16x8 *)&t;
+    }
+}
+
+// accumulator tile (rows d, column = owned token) -> token-major bf16 row, scaled
+__device__ __forceinline__ void store_transposed(uint16_t *row, int h2, const f32x16 &a0, const f32x16 &a1, float mul) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * h2;
+        *(uint2 *)(row + d0) = make_uint2(pack_bf16(a0[4 * g] * mul, a0[4 * g + 1] * mul), pack_bf16(a0[4 * g + 2] * mul, a0[4 * g + 3] * mul));
+        *(uint2 *)(row + 32 + d0) = make_uint2(pack_bf16(a1[4 * g] * mul, a1[4 * g + 1] * mul), pack_bf16(a1[4 * g + 2] * mul, a1[4 * g + 3] * mul));
+    }
+}
+
+// ---- staging of one 32-row tile: two row-major operands (stride AT_KLD) and, for query tiles, lse / delta ------------
+struct TileRegs {
+    uint4 rowchunk[2];   // this thread's 16-byte chunk of the two operands
+    float scal;          // threads 64..127: lse * log2(e) / delta of one row (dk/dv kernel)
+};
+
+template <bool KV_TILE>
+__device__ __forceinline__ void tile_issue(const AttnBwdParams &p, const uint16_t *a, const uint16_t *b2, const float *lse,
+                                           const float *delta, int64_t ts, int t0, int tid, TileRegs &r) {
+    const int n = t0 + (tid >> 3), c = tid & 7;
+    const bool ok = n < p.N;
+    r.rowchunk[0] = ok ? *(const uint4 *)(a + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+    r.rowchunk[1] = ok ? *(const uint4 *)(b2 + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+    if (!KV_TILE && tid >= 64 && tid < 128) {
+        const int m = t0 + (tid & 31);
+        // padded queries: lse = +inf makes their probabilities exactly 0
+        r.scal = (tid < 96) ? (m < p.N ? lse[m] * 1.4426950408889634f : INFINITY) : (m < p.N ? delta[m] : 0.f);
+    }
+}
+
+template <bool KV_TILE>
+__device__ __forceinline__ void tile_commit(uint16_t *rowA, uint16_t *rowB, float *sc, int tid, const TileRegs &r) {
+    const int n = tid >> 3, c = tid & 7;
+    *(uint4 *)(rowA + n * AT_KLD + c * 8) = r.rowchunk[0];
+    *(uint4 *)(rowB + n * AT_KLD + c * 8) = r.rowchunk[1];
+    if (!KV_TILE && tid >= 64 && tid < 128) sc[tid - 64] = r.scal;  // [0..31] lse*log2e, [32..63] delta
+}
+
+constexpr int AT_ROWT = 32 * AT_KLD;  // elements of a row-major tile
+
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * 2 * AT_ROWT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.y / p.H, hh = blockIdx.y - b * p.H, N = p.N;
+    const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
+    const uint16_t *kb_ = p.k + base, *vb_ = p.v + base;
+    const int qblk = blockIdx.x * 4 + wave, query = qblk * 32 + fr;
+    const bool qok = qblk < p.ntile && query < N;
+    const int64_t srow = ((int64_t)b * p.H + hh) * N;
+
+    bf16x8 qf[4], dof[4];
+    load_bfrag(p.q + base, ts, query, qok, h2, qf);
+    load_bfrag(p.dout + base, ts, query, qok, h2, dof);
+    float dsum = 0.f;  // D_i = <dO_i, O_i>: this lane holds half of the 64 channels of its query
+    {
+        bf16x8 of[4];
+        load_bfrag(p.o + base, ts, query, qok, h2, of);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)dof[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)of[ks][e]) << 16), dsum);
+        dsum += __shfl_xor(dsum, 32, 64);
+    }
+    const float lse2 = qok ? p.lse[srow + query] * 1.4426950408889634f : INFINITY;
+    if (qok && h2 == 0) p.delta[srow + query] = dsum;
+
+    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+    TileRegs tr;
+    tile_issue<true>(p, kb_, vb_, nullptr, nullptr, ts, 0, tid, tr);
+    tile_commit<true>(sm, sm + AT_ROWT, nullptr, tid, tr);
+    __syncthreads();
+    const float c2 = p.scale_log2e;
+    for (int kt = 0; kt < p.ntile; ++kt) {
+        const uint16_t *buf = sm + (kt & 1) * (2 * AT_ROWT);
+        uint16_t *nxt = sm + ((kt + 1) & 1) * (2 * AT_ROWT);
+        if (kt + 1 < p.ntile) tile_issue<true>(p, kb_, vb_, nullptr, nullptr, ts, (kt + 1) * 32, tid, tr);
+        const f32x16 st = tile_product(buf + fr * AT_KLD + h2 * 8, qf);              // S^T  [key][query]
+        const f32x16 dpt = tile_product(buf + AT_ROWT + fr * AT_KLD + h2 * 8, dof);  // dP^T [key][query]
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const float pr = fast_exp2(fmaf(st[r], c2, -lse2));
+            ds[r] = key < N ? pr * (dpt[r] - dsum) : 0.f;
+        }
+        bf16x8 b0, b1;
+        pack_tile(ds, b0, b1);
+        accumulate_transposed(buf, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
+        if (kt + 1 < p.ntile) tile_commit<true>(nxt, nxt + AT_ROWT, nullptr, tid, tr);
+        __syncthreads();
+    }
+    if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdParams p) {
+    constexpr int STAGE = 2 * AT_ROWT + 128;  // Q tile, dO tile, 64 floats (lse*log2e, delta)
+    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.y / p.H, hh = blockIdx.y - b * p.H, N = p.N;
+    const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
+    const uint16_t *qb_ = p.q + base, *dob_ = p.dout + base;
+    const int kblk = blockIdx.x * 4 + wave, key = kblk * 32 + fr;
+    const bool kok = kblk < p.ntile && key < N;
+    const int64_t srow = ((int64_t)b * p.H + hh) * N;
+    const float *lse = p.lse + srow, *delta = p.delta + srow;
+
+    bf16x8 kf[4], vf[4];
+    load_bfrag(p.k + base, ts, key, kok, h2, kf);
+    load_bfrag(p.v + base, ts, key, kok, h2, vf);
+    f32x16 dk0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+    TileRegs tr;
+    tile_issue<false>(p, qb_, dob_, lse, delta, ts, 0, tid, tr);
+    tile_commit<false>(sm, sm + AT_ROWT, (float *)(sm + 2 * AT_ROWT), tid, tr);
+    __syncthreads();
+    const float c2 = p.scale_log2e;
+    for (int qt = 0; qt < p.ntile; ++qt) {
+        const uint16_t *buf = sm + (qt & 1) * STAGE;
+        uint16_t *nxt = sm + ((qt + 1) & 1) * STAGE;
+        if (qt + 1 < p.ntile) tile_issue<false>(p, qb_, dob_, lse, delta, ts, (qt + 1) * 32, tid, tr);
+        const f32x16 sc = tile_product(buf + fr * AT_KLD + h2 * 8, kf);              // S  [query][key]
+        const f32x16 dp = tile_product(buf + AT_ROWT + fr * AT_KLD + h2 * 8, vf);    // dP [query][key]
+        const float *scal = (const float *)(buf + 2 * AT_ROWT);
+        float pr[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
+            const float4 l4 = *(const float4 *)(scal + 8 * g + 4 * h2), d4 = *(const float4 *)(scal + 32 + 8 * g + 4 * h2);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                pr[r] = fast_exp2(fmaf(sc[r], c2, -lv[e]));
+                ds[r] = pr[r] * (dp[r] - dv[e]);
+            }
+        }
+        bf16x8 p0, p1, s0, s1;
+        pack_tile(pr, p0, p1);
+        pack_tile(ds, s0, s1);
+        accumulate_transposed(buf + AT_ROWT, lane, p0, p1, dv0, dv1);  // dV^T += dO^T P
+        accumulate_transposed(buf, lane, s0, s1, dk0, dk1);           // dK^T += Q^T dS
+        if (qt + 1 < p.ntile)
+            tile_commit<false>(nxt, nxt + AT_ROWT, (float *)(nxt + 2 * AT_ROWT), tid, tr);
+        __syncthreads();
+    }
+    if (kok) {
+        store_transposed(p.dk + base + key * ts, h2, dk0, dk1, p.scale);
+        store_transposed(p.dv + base + key * ts, h2, dv0, dv1, 1.0f);
+    }
+}
+
 }  // namespace vsde
 
 using namespace vsde;
@@ -245,6 +471,27 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(512), lds, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse,
+                                       void *dq, void *dk, void *dv, float *delta, int64_t B, int N, int H, int head_dim,
+                                       double scale, void *stream) {
+    VSDE_CHECK_ARG(dout && q && k && v && o && lse && dq && dk && dv && delta && B > 0 && N > 0 && H > 0, VSDE_E_BADARG,
+                   "bad attention_bwd arguments");
+    VSDE_CHECK_ARG(head_dim == AT_D, VSDE_E_BADARG, "attention kernels are built for head_dim 64, got %d", head_dim);
+    VSDE_CHECK_ARG(B * H < 65536, VSDE_E_BADARG, "too many (batch, head) pairs for one launch: %lld", (long long)(B * H));
+    AttnBwdParams p;
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o;
+    p.dout = (const uint16_t *)dout; p.lse = lse; p.delta = delta;
+    p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
+    p.N = N; p.H = H; p.ntile = (N + 31) / 32;
+    p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    const dim3 grid((unsigned)((p.ntile + 3) / 4), (unsigned)(B * H));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, p);   // also writes delta, which the second kernel reads
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }

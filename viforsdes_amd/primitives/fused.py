@@ -225,8 +225,8 @@ def qk_norm_rope(qkv: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, 
 
 
 class _Attention(torch.autograd.Function):
-    """softmax(scale q k^T) v on token-major heads [B,N,H,64]: forward = csrc/vsde_attn.hip (K and V of one head resident in
-    LDS), backward = the library's memory-efficient attention backward fed with our output and log-sum-exp."""
+    """softmax(scale q k^T) v on token-major heads [B,N,H,64] (csrc/vsde_attn.hip): forward with K and V of one head resident
+    in LDS; backward as two deterministic kernels (dq | dk, dv) that recompute the probabilities from the saved log-sum-exp."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
@@ -240,21 +240,8 @@ class _Attention(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        N = q.shape[1]
-        zero = _philox_zero()
-        dq, dk, dv, _ = torch.ops.aten._efficient_attention_backward(
-            do.to(q.dtype).contiguous(), q, k, v, None, o, None, None, N, N, lse, 0.0, zero, zero, 0, False, scale=ctx.scale)
+        dq, dk, dv = _hip.attention_bwd(do.to(q.dtype).contiguous(), q, k, v, o, lse, ctx.scale)
         return dq, dk, dv, None
-
-
-_PHILOX_ZERO = None
-
-
-def _philox_zero() -> Tensor:
-    global _PHILOX_ZERO
-    if _PHILOX_ZERO is None:
-        _PHILOX_ZERO = torch.zeros((), dtype=torch.int64)  # dropout is 0: seed / offset are never read
-    return _PHILOX_ZERO
 
 
 def attention_usable(q: Tensor) -> bool:
