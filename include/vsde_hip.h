@@ -190,7 +190,7 @@ int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const f
 int vsde_attention_max_tokens(void);
 int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
                             int head_dim, double scale, void *stream);
-/* Backward of the above (any N; B*H < 65536): dq, dk, dv token-major bf16 from dout, q, k, v, o and the forward's lse;
+/* Backward of the above (same limits): dq, dk, dv token-major bf16 from dout, q, k, v, o and the forward's lse;
  * delta [B][H][N] fp32 is scratch (row sums <dout, o>).  Deterministic (no atomics). */
 int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse,
                             void *dq, void *dk, void *dv, float *delta, int64_t B, int N, int H, int head_dim, double scale,

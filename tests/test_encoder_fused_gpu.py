@@ -207,7 +207,7 @@ def test_ln_modulate_and_gated_residual_channel_counts(C, dtype, tol):
         assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < tol, name
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 1, 2), (2, 31, 4), (3, 32, 1), (2, 101, 4), (2, 401, 4), (1, 576, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 1, 2), (2, 31, 4), (3, 32, 1), (2, 101, 4), (2, 401, 4), (1, 544, 2)])
 def test_attention_kernel_vs_fp32_softmax(B, N, H):
     """vsde_attention_fwd_bf16 (token-major, K/V resident in LDS) vs an fp32 softmax(q k^T) v of the same bf16 inputs; the
     backward (library kernel fed with our output and log-sum-exp) vs autograd through the fp32 chain."""

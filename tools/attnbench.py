@@ -47,4 +47,4 @@ run(2, 37, 4, reps=3)
 run(3, 101, 4, reps=3)
 run(512, 401, 4)
 run(128, 101, 4)
-run(64, 576, 4)
+run(64, 544, 4)

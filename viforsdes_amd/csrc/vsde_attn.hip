@@ -28,7 +28,7 @@ typedef float f32v2 __attribute__((ext_vector_type(2)));
 
 constexpr int AT_D = 64;     // head dim
 constexpr int AT_KLD = 72;   // LDS row stride of K in bf16 (144 B: conflict-free ds_read_b128 fragments)
-constexpr int AT_MAXN = 576; // 576*272 + 512 B of LDS <= 160 KB
+constexpr int AT_MAXN = 544; // forward: 544*272 + 512 B of LDS; backward: 2*544*144 + 8*544 B  (<= 160 KB)
 
 struct AttnParams {
     const uint16_t *q, *k, *v;  // [B][N][H][64] bf16
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
     const uint16_t *qb = p.q + base, *kb = p.k + base, *vb = p.v + base;
     // ---- stage K [key][d] and V^T [d][key]: every global load of the workgroup is issued before the first use -----
-    constexpr int KIT = AT_MAXN * 8 / 512, VIT = (AT_MAXN + 511) / 512;
+    constexpr int KIT = (AT_MAXN * 8 + 511) / 512, VIT = (AT_MAXN + 511) / 512;
     uint4 kreg[KIT], vreg[VIT][8];
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
@@ -228,13 +228,11 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
 
 // ===================================================================================== backward
 // Two kernels, each the mirror image of the other; both recompute the probabilities from q, k and the saved log-sum-exp.
-//   dq kernel   : a wavefront owns 32 queries (q, dO fragments and the dQ^T accumulators in registers); the key tiles
-//                 (K, V and K^T, 32 keys each) stream through a double-buffered LDS stage shared by the workgroup's 4
-//                 waves.  Products in the lane = query orientation: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
-//                 Also emits D_i = <dO_i, O_i>.
-//   dk/dv kernel: a wavefront owns 32 keys (k, v fragments, dK^T / dV^T accumulators); the query tiles (Q, dO, Q^T, dO^T,
-//                 lse, D) stream through LDS.  Lane = key orientation: S = Q K^T, dP = dO V^T, dV^T += dO^T P,
-//                 dK^T += Q^T dS.
+//   dq kernel   : K and V of the head resident in LDS (row-major); a wavefront owns 32 queries (q, dO fragments and the
+//                 dQ^T accumulators in registers).  Lane = query orientation: S^T = K Q^T, dP^T = V dO^T,
+//                 dQ^T += K^T dS^T.  Also emits D_i = <dO_i, O_i>.
+//   dk/dv kernel: Q, dO, lse, D resident in LDS; a wavefront owns 32 keys (k, v fragments, dK^T / dV^T accumulators).
+//                 Lane = key orientation: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
 // In both, the tile that comes out of the first MFMA pair already has the B-operand layout of the accumulating product
 // (with its 32 contraction indices in the order 4h+{0..3}, 8+4h+{0..3}, ...), so P and dS never leave registers; the
 // transposed operands (K^T, Q^T, dO^T) are never materialised: ds_read_b64_tr_b16 reads them out of the row-major tiles.
@@ -312,143 +310,153 @@ __device__ __forceinline__ void store_transposed(uint16_t *row, int h2, const f3
     }
 }
 
-// ---- staging of one 32-row tile: two row-major operands (stride AT_KLD) and, for query tiles, lse / delta ------------
-struct TileRegs {
-    uint4 rowchunk[2];   // this thread's 16-byte chunk of the two operands
-    float scal;          // threads 64..127: lse * log2(e) / delta of one row (dk/dv kernel)
-};
+// ---- staging of whole row-major operands [npad][64] -> LDS [npad][AT_KLD]; all global loads issued before first use ---
+constexpr int AT_SIT = (AT_MAXN * 8 + 511) / 512;  // 16-byte chunks per thread and operand
 
-template <bool KV_TILE>
-__device__ __forceinline__ void tile_issue(const AttnBwdParams &p, const uint16_t *a, const uint16_t *b2, const float *lse,
-                                           const float *delta, int64_t ts, int t0, int tid, TileRegs &r) {
-    const int n = t0 + (tid >> 3), c = tid & 7;
-    const bool ok = n < p.N;
-    r.rowchunk[0] = ok ? *(const uint4 *)(a + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
-    r.rowchunk[1] = ok ? *(const uint4 *)(b2 + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
-    if (!KV_TILE && tid >= 64 && tid < 128) {
-        const int m = t0 + (tid & 31);
-        // padded queries: lse = +inf makes their probabilities exactly 0
-        r.scal = (tid < 96) ? (m < p.N ? lse[m] * 1.4426950408889634f : INFINITY) : (m < p.N ? delta[m] : 0.f);
+__device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2, int64_t ts, int N, int npad, int tid,
+                                          uint16_t *sa, uint16_t *sb) {
+    uint4 ra[AT_SIT], rb[AT_SIT];
+#pragma unroll
+    for (int it = 0; it < AT_SIT; ++it) {
+        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        const bool ok = i < npad * 8 && n < N;
+        ra[it] = ok ? *(const uint4 *)(a + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+        rb[it] = ok ? *(const uint4 *)(b2 + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < AT_SIT; ++it) {
+        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        if (i < npad * 8) {
+            *(uint4 *)(sa + n * AT_KLD + c * 8) = ra[it];
+            *(uint4 *)(sb + n * AT_KLD + c * 8) = rb[it];
+        }
     }
 }
 
-template <bool KV_TILE>
-__device__ __forceinline__ void tile_commit(uint16_t *rowA, uint16_t *rowB, float *sc, int tid, const TileRegs &r) {
-    const int n = tid >> 3, c = tid & 7;
-    *(uint4 *)(rowA + n * AT_KLD + c * 8) = r.rowchunk[0];
-    *(uint4 *)(rowB + n * AT_KLD + c * 8) = r.rowchunk[1];
-    if (!KV_TILE && tid >= 64 && tid < 128) sc[tid - 64] = r.scal;  // [0..31] lse*log2e, [32..63] delta
-}
+// dq: one workgroup per (batch, head); K and V resident in LDS, a wavefront owns 32 queries at a time.
+// The per-wave fragments (B operands with "lane = owned token") are row-strided global loads (one 16-byte piece of a
+// different 128-byte row per lane): slow to issue and long-latency.  They are therefore requested one round ahead -- the
+// first round's before the operand staging, the next round's before the tile loop -- and only waited for at use.
 
-constexpr int AT_ROWT = 32 * AT_KLD;  // elements of a row-major tile
-
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdParams p) {
-    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * 2 * AT_ROWT];
+// dq: one workgroup per (batch, head); K and V resident in LDS, a wavefront owns 32 queries at a time.
+__global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
-    const int b = blockIdx.y / p.H, hh = blockIdx.y - b * p.H, N = p.N;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
+    uint16_t *Ks = asmem, *Vs = asmem + npad * AT_KLD;
     const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
-    const uint16_t *kb_ = p.k + base, *vb_ = p.v + base;
-    const int qblk = blockIdx.x * 4 + wave, query = qblk * 32 + fr;
-    const bool qok = qblk < p.ntile && query < N;
     const int64_t srow = ((int64_t)b * p.H + hh) * N;
-
-    bf16x8 qf[4], dof[4];
-    load_bfrag(p.q + base, ts, query, qok, h2, qf);
-    load_bfrag(p.dout + base, ts, query, qok, h2, dof);
-    float dsum = 0.f;  // D_i = <dO_i, O_i>: this lane holds half of the 64 channels of its query
-    {
-        bf16x8 of[4];
-        load_bfrag(p.o + base, ts, query, qok, h2, of);
+    bf16x8 qn[4], don[4], on[4];  // fragments of the NEXT round
+    float lsen;
+    auto request = [&](int qblk) {
+        const int query = qblk * 32 + fr;
+        const bool ok = qblk < p.ntile && query < N;
+        load_bfrag(p.q + base, ts, query, ok, h2, qn);
+        load_bfrag(p.dout + base, ts, query, ok, h2, don);
+        load_bfrag(p.o + base, ts, query, ok, h2, on);
+        lsen = ok ? p.lse[srow + query] : INFINITY;  // padded queries: P = 0
+    };
+    request(wave);
+    stage_two(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
+    __syncthreads();
+    const float c2 = p.scale_log2e;
+    for (int qblk = wave; qblk < p.ntile; qblk += 8) {
+        const int query = qblk * 32 + fr;
+        const bool qok = query < N;
+        bf16x8 qf[4], dof[4];
+        float dsum = 0.f;  // D_i = <dO_i, O_i>: this lane holds half of the 64 channels of its query
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = qn[ks]; dof[ks] = don[ks];
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)dof[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)of[ks][e]) << 16), dsum);
-        dsum += __shfl_xor(dsum, 32, 64);
-    }
-    const float lse2 = qok ? p.lse[srow + query] * 1.4426950408889634f : INFINITY;
-    if (qok && h2 == 0) p.delta[srow + query] = dsum;
-
-    f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-    TileRegs tr;
-    tile_issue<true>(p, kb_, vb_, nullptr, nullptr, ts, 0, tid, tr);
-    tile_commit<true>(sm, sm + AT_ROWT, nullptr, tid, tr);
-    __syncthreads();
-    const float c2 = p.scale_log2e;
-    for (int kt = 0; kt < p.ntile; ++kt) {
-        const uint16_t *buf = sm + (kt & 1) * (2 * AT_ROWT);
-        uint16_t *nxt = sm + ((kt + 1) & 1) * (2 * AT_ROWT);
-        if (kt + 1 < p.ntile) tile_issue<true>(p, kb_, vb_, nullptr, nullptr, ts, (kt + 1) * 32, tid, tr);
-        const f32x16 st = tile_product(buf + fr * AT_KLD + h2 * 8, qf);              // S^T  [key][query]
-        const f32x16 dpt = tile_product(buf + AT_ROWT + fr * AT_KLD + h2 * 8, dof);  // dP^T [key][query]
-        float ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const float pr = fast_exp2(fmaf(st[r], c2, -lse2));
-            ds[r] = key < N ? pr * (dpt[r] - dsum) : 0.f;
+                dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)don[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)on[ks][e]) << 16), dsum);
         }
-        bf16x8 b0, b1;
-        pack_tile(ds, b0, b1);
-        accumulate_transposed(buf, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
-        if (kt + 1 < p.ntile) tile_commit<true>(nxt, nxt + AT_ROWT, nullptr, tid, tr);
-        __syncthreads();
+        dsum += __shfl_xor(dsum, 32, 64);
+        const float lse2 = lsen * 1.4426950408889634f;
+        if (qok && h2 == 0) p.delta[srow + query] = dsum;
+        request(qblk + 8);
+        f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll 1
+        for (int kt = 0; kt < p.ntile; ++kt) {
+            const uint16_t *kt_ = Ks + kt * 32 * AT_KLD, *vt_ = Vs + kt * 32 * AT_KLD;
+            const f32x16 stl = tile_product(kt_ + fr * AT_KLD + h2 * 8, qf);    // S^T  [key][query]
+            const f32x16 dpt = tile_product(vt_ + fr * AT_KLD + h2 * 8, dof);   // dP^T [key][query]
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                const float pr = fast_exp2(fmaf(stl[r], c2, -lse2));
+                ds[r] = key < N ? pr * (dpt[r] - dsum) : 0.f;
+            }
+            bf16x8 b0, b1;
+            pack_tile(ds, b0, b1);
+            accumulate_transposed(kt_, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
+        }
+        if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
     }
-    if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdParams p) {
-    constexpr int STAGE = 2 * AT_ROWT + 128;  // Q tile, dO tile, 64 floats (lse*log2e, delta)
-    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * STAGE];
+// dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
+__global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
-    const int b = blockIdx.y / p.H, hh = blockIdx.y - b * p.H, N = p.N;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
+    uint16_t *Qs = asmem, *Os = asmem + npad * AT_KLD;
+    float *lse2s = (float *)(asmem + 2 * npad * AT_KLD), *dels = lse2s + npad;
     const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
-    const uint16_t *qb_ = p.q + base, *dob_ = p.dout + base;
-    const int kblk = blockIdx.x * 4 + wave, key = kblk * 32 + fr;
-    const bool kok = kblk < p.ntile && key < N;
     const int64_t srow = ((int64_t)b * p.H + hh) * N;
-    const float *lse = p.lse + srow, *delta = p.delta + srow;
-
-    bf16x8 kf[4], vf[4];
-    load_bfrag(p.k + base, ts, key, kok, h2, kf);
-    load_bfrag(p.v + base, ts, key, kok, h2, vf);
-    f32x16 dk0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
-    TileRegs tr;
-    tile_issue<false>(p, qb_, dob_, lse, delta, ts, 0, tid, tr);
-    tile_commit<false>(sm, sm + AT_ROWT, (float *)(sm + 2 * AT_ROWT), tid, tr);
+    bf16x8 kn[4], vn[4];  // fragments of the NEXT round
+    auto request = [&](int kblk) {
+        const int key = kblk * 32 + fr;
+        const bool ok = kblk < p.ntile && key < N;
+        load_bfrag(p.k + base, ts, key, ok, h2, kn);
+        load_bfrag(p.v + base, ts, key, ok, h2, vn);
+    };
+    request(wave);
+    stage_two(p.q + base, p.dout + base, ts, N, npad, tid, Qs, Os);
+    for (int i = tid; i < npad; i += 512) {  // padded queries: lse = +inf -> P = 0
+        lse2s[i] = i < N ? p.lse[srow + i] * 1.4426950408889634f : INFINITY;
+        dels[i] = i < N ? p.delta[srow + i] : 0.f;
+    }
     __syncthreads();
     const float c2 = p.scale_log2e;
-    for (int qt = 0; qt < p.ntile; ++qt) {
-        const uint16_t *buf = sm + (qt & 1) * STAGE;
-        uint16_t *nxt = sm + ((qt + 1) & 1) * STAGE;
-        if (qt + 1 < p.ntile) tile_issue<false>(p, qb_, dob_, lse, delta, ts, (qt + 1) * 32, tid, tr);
-        const f32x16 sc = tile_product(buf + fr * AT_KLD + h2 * 8, kf);              // S  [query][key]
-        const f32x16 dp = tile_product(buf + AT_ROWT + fr * AT_KLD + h2 * 8, vf);    // dP [query][key]
-        const float *scal = (const float *)(buf + 2 * AT_ROWT);
-        float pr[16], ds[16];
+    for (int kblk = wave; kblk < p.ntile; kblk += 8) {
+        const int key = kblk * 32 + fr;
+        const bool kok = key < N;
+        bf16x8 kf[4], vf[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
-            const float4 l4 = *(const float4 *)(scal + 8 * g + 4 * h2), d4 = *(const float4 *)(scal + 32 + 8 * g + 4 * h2);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+        request(kblk + 8);
+        f32x16 dk0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+#pragma unroll 1
+        for (int qt = 0; qt < p.ntile; ++qt) {
+            const uint16_t *qt_ = Qs + qt * 32 * AT_KLD, *dot_ = Os + qt * 32 * AT_KLD;
+            const f32x16 sc = tile_product(qt_ + fr * AT_KLD + h2 * 8, kf);     // S  [query][key]
+            const f32x16 dp = tile_product(dot_ + fr * AT_KLD + h2 * 8, vf);    // dP [query][key]
+            float pr[16], ds[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                pr[r] = fast_exp2(fmaf(sc[r], c2, -lv[e]));
-                ds[r] = pr[r] * (dp[r] - dv[e]);
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
+                const float4 l4 = *(const float4 *)(lse2s + qt * 32 + 8 * g + 4 * h2);
+                const float4 d4 = *(const float4 *)(dels + qt * 32 + 8 * g + 4 * h2);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    pr[r] = fast_exp2(fmaf(sc[r], c2, -lv[e]));
+                    ds[r] = pr[r] * (dp[r] - dv[e]);
+                }
             }
+            bf16x8 p0, p1, s0, s1;
+            pack_tile(pr, p0, p1);
+            pack_tile(ds, s0, s1);
+            accumulate_transposed(dot_, lane, p0, p1, dv0, dv1);  // dV^T += dO^T P
+            accumulate_transposed(qt_, lane, s0, s1, dk0, dk1);   // dK^T += Q^T dS
         }
-        bf16x8 p0, p1, s0, s1;
-        pack_tile(pr, p0, p1);
-        pack_tile(ds, s0, s1);
-        accumulate_transposed(buf + AT_ROWT, lane, p0, p1, dv0, dv1);  // dV^T += dO^T P
-        accumulate_transposed(buf, lane, s0, s1, dk0, dk1);           // dK^T += Q^T dS
-        if (qt + 1 < p.ntile)
-            tile_commit<false>(nxt, nxt + AT_ROWT, (float *)(nxt + 2 * AT_ROWT), tid, tr);
-        __syncthreads();
-    }
-    if (kok) {
-        store_transposed(p.dk + base + key * ts, h2, dk0, dk1, p.scale);
-        store_transposed(p.dv + base + key * ts, h2, dv0, dv1, 1.0f);
+        if (kok) {
+            store_transposed(p.dk + base + key * ts, h2, dk0, dk1, p.scale);
+            store_transposed(p.dv + base + key * ts, h2, dv0, dv1, 1.0f);
+        }
     }
 }
 
@@ -481,17 +489,20 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
     VSDE_CHECK_ARG(dout && q && k && v && o && lse && dq && dk && dv && delta && B > 0 && N > 0 && H > 0, VSDE_E_BADARG,
                    "bad attention_bwd arguments");
     VSDE_CHECK_ARG(head_dim == AT_D, VSDE_E_BADARG, "attention kernels are built for head_dim 64, got %d", head_dim);
-    VSDE_CHECK_ARG(B * H < 65536, VSDE_E_BADARG, "too many (batch, head) pairs for one launch: %lld", (long long)(B * H));
+    VSDE_CHECK_ARG(N <= AT_MAXN, VSDE_E_BADARG, "attention kernels keep a whole head in LDS: N <= %d, got %d", AT_MAXN, N);
+    VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
     AttnBwdParams p;
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o;
     p.dout = (const uint16_t *)dout; p.lse = lse; p.delta = delta;
     p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32;
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    const dim3 grid((unsigned)((p.ntile + 3) / 4), (unsigned)(B * H));
+    const size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, p);   // also writes delta, which the second kernel reads
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);   // also writes delta, read by the next kernel
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(512), lds_dkv, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
