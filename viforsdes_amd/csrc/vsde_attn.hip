@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
     stage_two(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
     __syncthreads();
     const float c2 = p.scale_log2e;
+    const bool ragged = (N & 31) != 0;
     for (int qblk = wave; qblk < p.ntile; qblk += 8) {
         const int query = qblk * 32 + fr;
         const bool qok = query < N;
@@ -384,10 +385,11 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
             const f32x16 dpt = tile_product(vt_ + fr * AT_KLD + h2 * 8, dof);   // dP^T [key][query]
             float ds[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                const float pr = fast_exp2(fmaf(stl[r], c2, -lse2));
-                ds[r] = key < N ? pr * (dpt[r] - dsum) : 0.f;
+            for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
+            if (ragged && kt == p.ntile - 1) {  // keys beyond N (zero rows of K: their P is not 0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;
             }
             bf16x8 b0, b1;
             pack_tile(ds, b0, b1);
