@@ -32,8 +32,10 @@ def categories(path):
     name_col = "name" if "name" in cols else "kernel_name"
     cat = {}
     for n, d in cur.execute(f"select {name_col}, end-start from kernels"):
-        if "vsde::" in n:
-            k = "vsde " + ("head/gemm/elbo" if any(x in n for x in ("head_", "tn_", "gemm_nt", "elbo", "pack_")) else "encoder fused")
+        if "vsde::attn_" in n:
+            k = "vsde attention"
+        elif "vsde::" in n:
+            k = "vsde " + ("head/gemm/elbo" if any(x in n for x in ("head_", "::tn_", "gemm_nt", "elbo", "pack_")) else "encoder fused")
         elif n.startswith("Cijk_"):
             k = "hipBLASLt GEMM"
         elif n in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess", "bwd_postprocess") or "fmha_" in n:
