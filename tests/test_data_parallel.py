@@ -64,7 +64,7 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(both, eps_theta)
     assert not torch.equal(both[0], both[1]), "ranks must draw different samples"
     tr._train_step(model, theta_eps=eps_theta, path_noise=noise)
-    applied = ctx.grad_sync.flat.clone()  # unscaled (no GradScaler on CPU), clipped in place
+    applied = ctx.grad_sync.flat_gradients()  # unscaled (no GradScaler on CPU), clipped in place
     torch.save({"eps": eps_theta, "noise": noise, "applied": applied}, os.path.join(out_dir, f"r{rank}.pt"))
     for _ in range(2):
         tr._train_step(model)
@@ -101,7 +101,7 @@ def test_two_rank_gradient_average(tmp_path):
             res = compute_evidence_lower_bound(tr.sde, ctx.observations, tr.observation_likelihood, tr.prior,
                                                model.sde_parameter_posterior, theta, sample, tr.config.time_step)
             (-res.evidence_lower_bound).backward()
-            grads.append(ctx.grad_sync.flat.clone())
+            grads.append(ctx.grad_sync.flat_gradients())
         mean = (grads[0] + grads[1]) / 2
         norm = mean.norm()
         clipped = mean * min(1.0, float(1.0 / (norm + 1e-6)))

@@ -45,52 +45,65 @@ def init_process_group_if_needed(device_type: str) -> bool:
 
 
 class FlatGradientAllReduce:
-    """Owns the flat gradient buffer of ``params`` and averages it across ranks."""
+    """Averages the gradients of ``params`` across ranks through ONE flat fp32 buffer.
+
+    Single process: nothing is copied or reduced -- ``zero_grad`` just drops the ``.grad`` tensors, so autograd writes
+    each gradient once instead of accumulating into a pre-zeroed buffer (one fewer kernel per parameter and step).
+    Multi process: after backward the gradients are packed into the flat buffer with one multi-tensor copy, the buffer
+    is all-reduced in at most ``max_buckets`` pieces and ``.grad`` is re-pointed at its views (what unscale / clip / the
+    optimizer then read)."""
 
     def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2) -> None:
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.max_buckets = max_buckets
+        self.flat: Optional[Tensor] = None
+        self._views: list[Tensor] = []
+        self.buckets: list[Tensor] = []
+        if self.world_size > 1:
+            self._allocate()
+
+    def _allocate(self) -> None:
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self._views: list[Tensor] = []
+        self._views = []
         off = 0
         for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
+            self._views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-            self._views.append(v)
-            p.grad = v
-        n = max(1, min(max_buckets, total // (1 << 20) or 1))
+        n = max(1, min(self.max_buckets, total // (1 << 20) or 1))
         cuts = [round(i * total / n) for i in range(n + 1)]
         self.buckets = [self.flat[cuts[i]:cuts[i + 1]] for i in range(n)]
-        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+
+    def flat_gradients(self) -> Tensor:
+        """Copy of all gradients as one fp32 vector in parameter order (zeros where a gradient is absent)."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().float().reshape(-1)
+                          for p in self.params])
 
     def zero_grad(self) -> None:
-        """Replaces ``optimizer.zero_grad()``: one memset, and re-attaches the views if needed."""
-        self.flat.zero_()
-        for p, v in zip(self.params, self._views):
-            if p.grad is not v:
-                p.grad = v
-
-    def _gather_strays(self) -> None:
-        # autograd normally accumulates in place into the views; if it replaced a .grad, copy it in
-        for p, v in zip(self.params, self._views):
-            if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-            p.grad = v
+        """Replaces ``optimizer.zero_grad(set_to_none=True)``."""
+        for p in self.params:
+            p.grad = None
 
     @torch.no_grad()
     def all_reduce(self) -> None:
-        self._gather_strays()
         if self.world_size <= 1:
             return
+        have = [(v, p.grad) for p, v in zip(self.params, self._views) if p.grad is not None]
+        missing = [v for p, v in zip(self.params, self._views) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v in missing:
+            v.zero_()
         handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
         for h in handles:
             h.wait()
         self.flat.mul_(1.0 / self.world_size)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
 
 
 @torch.no_grad()
