@@ -21,6 +21,7 @@ from ..core.observations import ObservationLikelihood, Observations
 from ..core.priors import Prior
 from ..core.sde import SDE
 from .constants import LOSS_EMA_DECAY
+from ..primitives import fused
 from .data_parallel import all_reduce_mean_
 from .diffusion_path_sampler import sample_diffusion_paths
 from .evidence_lower_bound import compute_evidence_lower_bound
@@ -92,6 +93,8 @@ class VariationalInferenceTrainer:
         grad_norm = nn.utils.clip_grad_norm_(ctx.model.parameters(), cfg.grad_clip_norm)
         ctx.scaler.step(ctx.optimizer)
         ctx.scaler.update()
+        if ctx.device.type == "cuda":
+            fused.PackedWeight.refresh_all()  # bf16 GEMM operands of the encoder follow the updated parameters
         return TrainStepResult(elbo_result=result, grad_norm=grad_norm)
 
     # ------------------------------------------------------------------------------ HIP graph

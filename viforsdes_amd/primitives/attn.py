@@ -69,9 +69,19 @@ class Attention(nn.Module):
         lin = fused.linear
         # one projection for [q | k | v | gate logits]: one GEMM forward, one input-gradient GEMM and one
         # weight-gradient reduction backward, and the two consumers fill one gradient buffer between them
-        W = torch.cat([self.qkv_proj.weight, self.gate_proj.weight], dim=0)
-        b = torch.cat([self.qkv_proj.bias, self.gate_proj.bias], dim=0) if self.qkv_proj.bias is not None else None
-        y = lin(hidden_states, W, b)
+        n_out = self.qkv_proj.weight.shape[0] + self.gate_proj.weight.shape[0]
+        if fused.packed_linear_usable(hidden_states, n_out, self.embed_dim):
+            pack = getattr(self, "_proj_pack", None)
+            if pack is None or pack.weight.device != hidden_states.device:
+                has_b = self.qkv_proj.bias is not None
+                pack = fused.row_pack([self.qkv_proj.weight, self.gate_proj.weight],
+                                      [self.qkv_proj.bias, self.gate_proj.bias] if has_b else None)
+                object.__setattr__(self, "_proj_pack", pack)
+            y = fused.packed_linear(hidden_states, pack)
+        else:
+            W = torch.cat([self.qkv_proj.weight, self.gate_proj.weight], dim=0)
+            b = torch.cat([self.qkv_proj.bias, self.gate_proj.bias], dim=0) if self.qkv_proj.bias is not None else None
+            y = lin(hidden_states, W, b)
         link = fused.GradLink()
         q, k, v = fused.attention_projection_split(y, cos, sin, self.q_norm.weight, self.k_norm.weight,
                                                    v0.transpose(1, 2) if mix else None,

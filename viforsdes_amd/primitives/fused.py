@@ -5,6 +5,7 @@ primitives/{sit,attn,mlp}.py (which remain the eager specification and the CPU p
 encoder).  ``usable(x)`` decides whether a tensor can take the fused route."""
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -255,6 +256,113 @@ def attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
     return _Attention.apply(q, k, v, scale)
 
 
+class PackedWeight:
+    """bf16 GEMM operand (weight [rows, cols] and optional bias [rows]) assembled from fp32 parameter row blocks, kept across
+    optimizer steps.
+
+    The encoder's Linears need their weights in bf16 (autocast), some of them concatenated ([qkv | gate]) or zero-padded
+    (SwiGLU width 682 -> 768).  With torch ops that is a cat/pad plus a cast per operand per step and their autograd nodes.
+    A pack owns the assembled bf16 tensors, re-fills them only when a source parameter changed (``Tensor._version``), and
+    hands the fp32 gradient of the packed operand back to the parameters as views.  ``refresh_all()`` (called by the trainer
+    right after the optimizer step) re-fills every live pack with one multi-tensor copy.
+
+    ``weight_pieces`` / ``bias_pieces``: lists of ``(param, src_row, n, dst_row)``: rows ``src_row:src_row+n`` of the 2-D
+    (1-D) parameter land in rows ``dst_row:dst_row+n`` of the packed weight (bias), columns ``:param.shape[1]``; everything
+    not covered stays zero."""
+
+    _live = weakref.WeakSet()
+
+    def __init__(self, rows: int, cols: int, weight_pieces, bias_pieces, device) -> None:
+        self.weight = torch.zeros(rows, cols, device=device, dtype=torch.bfloat16)
+        self.bias = torch.zeros(rows, device=device, dtype=torch.bfloat16) if bias_pieces else None
+        self.weight_pieces, self.bias_pieces = list(weight_pieces), list(bias_pieces or [])
+        self.params: list[Tensor] = []
+        for p, *_ in self.weight_pieces + self.bias_pieces:
+            if not any(p is q for q in self.params):
+                self.params.append(p)
+        self._versions: Optional[list[int]] = None
+        PackedWeight._live.add(self)
+
+    def _copy_lists(self):
+        dst, src = [], []
+        for p, s0, n, d0 in self.weight_pieces:
+            dst.append(self.weight[d0:d0 + n, :p.shape[1]]); src.append(p.detach()[s0:s0 + n])
+        for p, s0, n, d0 in self.bias_pieces:
+            dst.append(self.bias[d0:d0 + n]); src.append(p.detach()[s0:s0 + n])
+        return dst, src
+
+    def stale(self) -> bool:
+        return self._versions != [p._version for p in self.params]
+
+    def mark_fresh(self) -> None:
+        self._versions = [p._version for p in self.params]
+
+    @torch.no_grad()
+    def operands(self):
+        if self.stale():
+            for d, s_ in zip(*self._copy_lists()):
+                d.copy_(s_)
+            self.mark_fresh()
+        return self.weight, self.bias
+
+    def split_grads(self, dW: Tensor, db: Optional[Tensor]) -> list[Optional[Tensor]]:
+        """fp32 gradient of the packed operand -> one gradient per entry of ``self.params`` (a view when the parameter is
+        one whole row block, otherwise its row blocks concatenated)."""
+        out: list[Optional[Tensor]] = []
+        for q in self.params:
+            blocks = [dW[d0:d0 + n, :p.shape[1]] for p, s0, n, d0 in sorted(self.weight_pieces, key=lambda t: t[1]) if p is q]
+            if not blocks and db is not None:
+                blocks = [db[d0:d0 + n] for p, s0, n, d0 in sorted(self.bias_pieces, key=lambda t: t[1]) if p is q]
+            out.append(None if not blocks else blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0))
+        return out
+
+    @staticmethod
+    @torch.no_grad()
+    def refresh_all() -> None:
+        dst, src, packs = [], [], []
+        for pk in list(PackedWeight._live):
+            if pk.stale():
+                d, s_ = pk._copy_lists()
+                dst += d; src += s_; packs.append(pk)
+        if dst:
+            torch._foreach_copy_(dst, src)
+            for pk in packs:
+                pk.mark_fresh()
+
+
+class _PackedLinear(torch.autograd.Function):
+    """y = x W^T + b with a ``PackedWeight``: hipBLASLt forward / input gradient, HIP weight-gradient kernel, gradients
+    returned per parameter piece."""
+
+    @staticmethod
+    def forward(ctx, x, pack, *params):
+        wb, bb = pack.operands()
+        y = torch.nn.functional.linear(x, wb, bb)
+        ctx.save_for_backward(x, wb)
+        ctx.pack = pack
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        pack = ctx.pack
+        dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dx = (dy2 @ wb).reshape(x.shape)
+        dW, db = _hip.linear_wgrad(dy2, x2, pack.bias is not None)
+        return (dx, None, *pack.split_grads(dW, db))
+
+
+def packed_linear_usable(x: Tensor, rows: int, cols: int) -> bool:
+    n = x.numel() // x.shape[-1]
+    return ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and n >= 4096 and rows % 8 == 0 and cols % 8 == 0
+
+
+def packed_linear(x: Tensor, pack: PackedWeight) -> Tensor:
+    return _PackedLinear.apply(x, pack, *pack.params)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b for bf16 activations: forward and the input gradient stay on hipBLASLt, the weight/bias
     gradient (a reduction over ~2e5 rows that hipBLASLt runs at a few % of the HBM roofline) is one fused HIP
@@ -280,10 +388,52 @@ class _Linear(torch.autograd.Function):
         return dx, dW.to(wdtype), None if db is None else db.to(bdtype)
 
 
+_PLAIN_PACKS: dict[int, tuple] = {}  # id(weight) -> (weakref to the weight, pack); tensors cannot be dict keys (== is elementwise)
+
+
+def plain_pack(weight: Tensor, bias: Optional[Tensor]) -> PackedWeight:
+    """The (cached) pack of an ordinary Linear: one weight, one optional bias."""
+    ent = _PLAIN_PACKS.get(id(weight))
+    pk = ent[1] if ent is not None and ent[0]() is weight else None
+    if pk is None or pk.weight.device != weight.device or (pk.bias is None) != (bias is None):
+        n = weight.shape[0]
+        pk = PackedWeight(n, weight.shape[1], [(weight, 0, n, 0)], None if bias is None else [(bias, 0, n, 0)], weight.device)
+        key = id(weight)
+        _PLAIN_PACKS[key] = (weakref.ref(weight, lambda _r, k=key: _PLAIN_PACKS.pop(k, None)), pk)
+    return pk
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
-    """Drop-in for ``F.linear`` inside the encoder: uses the HIP weight-gradient kernel for large bf16 inputs."""
+    """Drop-in for ``F.linear`` inside the encoder: large bf16 inputs go through the packed bf16 operand cache and the HIP
+    weight-gradient kernel."""
+    if (isinstance(weight, torch.nn.Parameter) and (bias is None or isinstance(bias, torch.nn.Parameter))
+            and packed_linear_usable(x, weight.shape[0], weight.shape[1])):
+        return packed_linear(x, plain_pack(weight, bias))
     rows = x.numel() // x.shape[-1]
     if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and rows >= 4096 and weight.shape[0] % 8 == 0
             and weight.shape[1] % 8 == 0 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
         return _Linear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Optional[int] = None) -> PackedWeight:
+    """Pack of several Linears that share their input, stacked along the output rows ([qkv | gate])."""
+    rows = sum(w.shape[0] for w in weights)
+    wp, bp, r = [], [], 0
+    for i, w in enumerate(weights):
+        wp.append((w, 0, w.shape[0], r))
+        if biases is not None:
+            bp.append((biases[i], 0, w.shape[0], r))
+        r += w.shape[0]
+    return PackedWeight(pad_to or rows, weights[0].shape[1], wp, bp or None, weights[0].device)
+
+
+def swiglu_packs(w_in: Tensor, b_in: Optional[Tensor], w_out: Tensor, b_out: Optional[Tensor], width: int):
+    """Packs of a SwiGLU MLP whose hidden size h is zero-padded to ``width``: input projection [2h, K] -> [2*width, K] (the
+    two halves start at rows 0 and ``width``), output projection [K, h] -> [K, width] (extra columns zero)."""
+    h = w_out.shape[1]
+    pin = PackedWeight(2 * width, w_in.shape[1], [(w_in, 0, h, 0), (w_in, h, h, width)],
+                       None if b_in is None else [(b_in, 0, h, 0), (b_in, h, h, width)], w_in.device)
+    n = w_out.shape[0]
+    pout = PackedWeight(n, width, [(w_out, 0, n, 0)], None if b_out is None else [(b_out, 0, n, 0)], w_out.device)
+    return pin, pout

@@ -27,6 +27,14 @@ class SwiGLU(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         if fused.ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
             width = -(-self.hidden_dim // 128) * 128
+            if fused.packed_linear_usable(x, 2 * width, self.in_dim):
+                # bf16 operands of both projections (padded to `width`) live in a cache refreshed once per optimizer step
+                packs = getattr(self, "_packs", None)
+                if packs is None or packs[0].weight.device != x.device or packs[0].weight.shape[0] != 2 * width:
+                    packs = fused.swiglu_packs(self.input_proj.weight, self.input_proj.bias, self.output_proj.weight,
+                                               self.output_proj.bias, width)
+                    object.__setattr__(self, "_packs", packs)
+                return fused.packed_linear(fused.swiglu(fused.packed_linear(x, packs[0])), packs[1])
             if width != self.hidden_dim:
                 w1, b1, w2 = self._padded_weights(width)
                 return fused.linear(fused.swiglu(fused.linear(x, w1, b1)), w2, self.output_proj.bias)
