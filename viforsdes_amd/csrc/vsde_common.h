@@ -99,6 +99,23 @@ __device__ __forceinline__ void transpose8x8(const uint4 (&r)[8], uint4 (&c)[8])
         }
 }
 
+// DPP cross-lane add: v + v[permuted lane] in one VALU instruction (no LDS crossbar round trip)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the 16 quads of a wavefront of a value that is identical in the 4 lanes of each quad; result wave-uniform.
+// row_half_mirror and row_mirror fold the 4 quads of each 16-lane row, v_readlane picks the 4 row sums.
+__device__ __forceinline__ float wave_sum_of_quads(float v) {
+    v = dpp_add<0x141>(v);  // row_half_mirror: lane i += lane 7-i (within 8)
+    v = dpp_add<0x140>(v);  // row_mirror:      lane i += lane 15-i (within 16)
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // ---- GEMM launchers (vsde_gemm.hip) ----------------------------------------------------
 // C[m][n] = sum_k A(m,k) * Bt[n][k] (+ bias[n]);  Bt row-major [N][K] with leading dim ldb.
 int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int N, const float *bias,

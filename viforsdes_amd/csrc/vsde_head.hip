@@ -25,8 +25,10 @@ namespace vsde {
 // debug build only: cycle stamps of one wave for one time step (tools/trace_fwd.py)
 __device__ long long g_trace[64];
 #define VSDE_TP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && c == 1 && tt == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_trace[(k)] = clock64(); } } while (0)
+#define VSDE_TPB(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && c == 1 && (tt == 5 || ((k) == 31 && tt == 4))) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_trace[(k)] = clock64(); } } while (0)
 #else
 #define VSDE_TP(k) do { } while (0)
+#define VSDE_TPB(k) do { } while (0)
 #endif
 
 // ----------------------------------------------------------------------------- packing
@@ -824,31 +826,36 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 struct BwdV2Lds {
     int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, total;
 };
-__host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH) {
+__host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool two_act_buffers = false) {
     const int ntril = S * (S + 1) / 2, NO = S + ntril;
     BwdV2Lds o; int off = 0;
     auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
-    o.acts = take((CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
+    o.acts = take((two_act_buffers ? 2 : 1) * (CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
     o.gp = take(CH * S); o.gm = take(CH * S); o.gl = take(CH * S * S); o.raw = take(CH * ntril); o.eps = take(CH * S);
     o.owl = take(NO * 64); o.dxp = take(4 * 16);
     o.total = off;
     return o;
 }
 
-template <int L, int CH>
+// SS > 0: compile-time state dimension (loops over S / NO unroll).  DMA: the saved-activation records of the next
+// (earlier) chunk are copied global -> LDS by global_load_lds_dwordx4 into a second buffer while the current chunk's time
+// steps run (no registers, no wait until the chunk boundary); needs 16-byte aligned records (H % 4 == 0).
+template <int L, int CH, int SS, bool DMA>
 __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     static_assert(L >= 1 && L <= 2, "v2 keeps at most three 64x192 matrices in registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, u = lane >> 2, kq = lane & 3;
     const int i_unit = 16 * wave + u, k0 = 16 * kq;
     const int b = blockIdx.x;
-    const int H = p.H, S = p.S, T = p.T, NO = p.NO, ntril = p.ntril;
+    const int H = p.H, T = p.T;
+    const int S = SS > 0 ? SS : p.S, ntril = SS > 0 ? SS * (SS + 1) / 2 : p.ntril, NO = SS > 0 ? SS + SS * (SS + 1) / 2 : p.NO;
     const int I = S + p.C + p.P;
     const bool unit_ok = i_unit < H;
     const int orow = u;                       // every wave owns all emission rows (NO <= 16)
     const bool row_ok = orow < NO;
-    const BwdV2Lds lay = bwd_v2_lds(H, S, L, CH);
+    const BwdV2Lds lay = bwd_v2_lds(H, S, L, CH, DMA);
     float *s_acts = smem + lay.acts, *s_d4 = smem + lay.d4, *s_dO = smem + lay.dO;
+    float *const acts_buf0 = smem + lay.acts;
     float *s_gp = smem + lay.gp, *s_gm = smem + lay.gm, *s_gl = smem + lay.gl, *s_raw = smem + lay.raw, *s_eps = smem + lay.eps;
     float *owl = smem + lay.owl, *dxp = smem + lay.dxp;
     const int REC = L * 5 * H, DREC = L * 4 * H;
@@ -897,33 +904,77 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
 
     const int64_t bt0 = (int64_t)b * T;
     const int nchunks = (T + CH - 1) / CH;
-    // staged chunk loader (synchronous; its latency overlaps the previous chunk's flush)
-    auto load_chunk = [&](int t0, int n) {
-        // activation records t0-1 .. t0+n-1 (record -1 of the path is all zero)
+    const int ABUF = (CH + 1) * REC;  // floats of one activation buffer
+    // activation records t0-1 .. t0+n-1 (record -1 of the path is all zero)
+    auto load_acts_sync = [&](int t0, int n, float *dst) {
         const int nrec = (n + 1) * REC;
         const float *src = p.acts + (bt0 + t0 - 1) * REC;
 #pragma unroll 1
-        for (int e = tid; e < nrec; e += 256) s_acts[e] = (t0 == 0 && e < REC) ? 0.f : src[e];
+        for (int e = tid; e < nrec; e += 256) dst[e] = (t0 == 0 && e < REC) ? 0.f : src[e];
+    };
+    auto load_acts_dma = [&](int t0, int n, float *dst) {
+        const int skip = t0 == 0 ? REC : 0;  // record -1 does not exist: zero it by hand, copy the rest
+        if (skip) for (int e = tid; e < REC; e += 256) dst[e] = 0.f;
+        const char *src = (const char *)(p.acts + (bt0 + t0 - 1) * REC + skip);
+        const int nbytes = ((n + 1) * REC - skip) * 4;
 #pragma unroll 1
-        for (int e = tid; e < n * S; e += 256) {
-            s_gp[e] = p.g_paths[((int64_t)b * (T + 1) + t0 + 1) * S + e];
-            s_gm[e] = p.g_means[(bt0 + t0) * S + e];
-            s_eps[e] = p.eps[(bt0 + t0) * S + e];
+        for (int off = wave * 1024; off < nbytes; off += 4096) {  // one instruction: 64 lanes x 16 B -> 1 KB of LDS
+            if (off + lane * 16 < nbytes)
+                __builtin_amdgcn_global_load_lds((const void *)(src + off + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)((char *)(dst + skip) + off), 16, 0, 0);
         }
-#pragma unroll 1
-        for (int e = tid; e < n * S * S; e += 256) s_gl[e] = p.g_chol[(bt0 + t0) * S * S + e];
-#pragma unroll 1
-        for (int e = tid; e < n * ntril; e += 256) s_raw[e] = p.chol_raw[(bt0 + t0) * ntril + e];
+    };
+    // upstream gradients / eps / raw factors of a chunk: a few hundred floats, one or two per thread, prefetched in registers
+    const int small_per_step = 3 * S + S * S + ntril;
+    float sv[3] = {0.f, 0.f, 0.f};  // CH * (3S + S^2 + ntril) <= 16 * 38 floats
+    auto small_issue = [&](int t0, int n) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q;
+            float v = 0.f;
+            if (e < n * small_per_step) {
+                int r = e;
+                if (r < n * S) v = p.g_paths[((int64_t)b * (T + 1) + t0 + 1) * S + r];
+                else if ((r -= n * S) < n * S) v = p.g_means[(bt0 + t0) * S + r];
+                else if ((r -= n * S) < n * S) v = p.eps[(bt0 + t0) * S + r];
+                else if ((r -= n * S) < n * S * S) v = p.g_chol[(bt0 + t0) * S * S + r];
+                else { r -= n * S * S; v = p.chol_raw[(bt0 + t0) * ntril + r]; }
+            }
+            sv[q] = v;
+        }
+    };
+    auto small_commit = [&](int n) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q;
+            if (e < n * small_per_step) {
+                int r = e;
+                if (r < n * S) s_gp[r] = sv[q];
+                else if ((r -= n * S) < n * S) s_gm[r] = sv[q];
+                else if ((r -= n * S) < n * S) s_eps[r] = sv[q];
+                else if ((r -= n * S) < n * S * S) s_gl[r] = sv[q];
+                else { r -= n * S * S; s_raw[r] = sv[q]; }
+            }
+        }
     };
     {
         const int t0 = (nchunks - 1) * CH;
-        load_chunk(t0, T - t0);
+        s_acts = acts_buf0 + (DMA ? ((nchunks - 1) & 1) * ABUF : 0);
+        if (DMA) load_acts_dma(t0, T - t0, s_acts); else load_acts_sync(t0, T - t0, s_acts);
+        small_issue(t0, T - t0);
+        small_commit(T - t0);
+        if (DMA) __builtin_amdgcn_s_waitcnt(0);
     }
     __syncthreads();
 
     for (int c = nchunks - 1; c >= 0; --c) {
         const int t0 = c * CH, nsteps = min(CH, T - t0);
+        if (c > 0) {  // the next (earlier) chunk: its loads fly during this chunk's time steps
+            if (DMA) load_acts_dma(t0 - CH, CH, acts_buf0 + ((c - 1) & 1) * ABUF);
+            small_issue(t0 - CH, CH);
+        }
         for (int tt = nsteps - 1; tt >= 0; --tt) {
+            VSDE_TPB(tt == 5 ? 20 : 31);
             // ---- saved activations of this lane's unit (independent of the recurrence: issue first)
             float sr[L], su[L], sn[L], scn[L], shp[L];
 #pragma unroll
@@ -948,9 +999,11 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 dO = dL;
             }
             if (wave == 0 && kq == 0 && row_ok) s_dO[tt * NO + orow] = dO;
+            VSDE_TPB(21);
             float dcur = 0.f;  // d h_top[i] = sum_r dO_r out_W[r][i]
             for (int r = 0; r < NO; ++r)
                 dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
+            VSDE_TPB(22);
 
 #pragma unroll
             for (int l = L - 1; l >= 0; --l) {
@@ -971,42 +1024,56 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                     for (int i = 0; i < kMaxSRegV2; ++i) {
                         if (i < S) {
                             float v = wxr[i][0] * dr_pre + wxr[i][1] * du_pre + wxr[i][2] * dn_pre;
-                            v = wave_sum(v) * 0.25f;  // the four lanes of a quad hold identical values
+                            v = wave_sum_of_quads(v);  // the four lanes of a quad hold identical values
                             if (lane == 0) dxp[wave * 16 + i] = v;
                         }
                     }
                 }
+                VSDE_TPB(23 + 3 * (L - 1 - l));
                 __syncthreads();
-                // ---- transposed products over this lane's j-slice
-                const float4 *vr4 = (const float4 *)(D + k0), *vu4 = (const float4 *)(D + H + k0);
-                const float4 *vn4 = (const float4 *)(D + 2 * H + k0), *vc4 = (const float4 *)(D + 3 * H + k0);
-                float4 tr[4], tu[4], tn[4], tc[4];
+                VSDE_TPB(24 + 3 * (L - 1 - l));
+                // ---- transposed products over this lane's j-slice, 8 j's at a time: with three 64x192 matrices in
+                //      registers there is no room to hold all 64 staged values of the slice at once (scratch spills)
+                const float *Dk = D + k0;
+                f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { tr[q] = vr4[q]; tu[q] = vu4[q]; tc[q] = vc4[q]; if (l > 0) tn[q] = vn4[q]; }
-                const float *vr = (const float *)tr, *vu = (const float *)tu, *vn = (const float *)tn, *vc = (const float *)tc;
-                if (l > 0) {
-                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};  // (acc_h, acc_i) pairs
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 r0 = *(const float4 *)(Dk + 8 * hf), r1 = *(const float4 *)(Dk + 8 * hf + 4);
+                    const float4 u0 = *(const float4 *)(Dk + H + 8 * hf), u1 = *(const float4 *)(Dk + H + 8 * hf + 4);
+                    const float4 c0 = *(const float4 *)(Dk + 3 * H + 8 * hf), c1 = *(const float4 *)(Dk + 3 * H + 8 * hf + 4);
+                    const float vr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                    const float vu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                    const float vc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    if (l > 0) {  // (acc_h, acc_i) pairs
+                        const float4 n0 = *(const float4 *)(Dk + 2 * H + 8 * hf), n1 = *(const float4 *)(Dk + 2 * H + 8 * hf + 4);
+                        const float vn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
 #pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) {
-                        pa = __builtin_elementwise_fma((f32x2){vr[jj], vr[jj]}, (f32x2){whh[l][0][jj], wih[0][jj]}, pa);
-                        pb = __builtin_elementwise_fma((f32x2){vu[jj], vu[jj]}, (f32x2){whh[l][1][jj], wih[1][jj]}, pb);
-                        pc = __builtin_elementwise_fma((f32x2){vc[jj], vn[jj]}, (f32x2){whh[l][2][jj], wih[2][jj]}, pc);
+                        for (int j8 = 0; j8 < 8; ++j8) {
+                            const int jj = 8 * hf + j8;
+                            pa = __builtin_elementwise_fma((f32x2){vr[j8], vr[j8]}, (f32x2){whh[l][0][jj], wih[0][jj]}, pa);
+                            pb = __builtin_elementwise_fma((f32x2){vu[j8], vu[j8]}, (f32x2){whh[l][1][jj], wih[1][jj]}, pb);
+                            pc = __builtin_elementwise_fma((f32x2){vc[j8], vn[j8]}, (f32x2){whh[l][2][jj], wih[2][jj]}, pc);
+                        }
+                    } else {      // even/odd j pairs
+#pragma unroll
+                        for (int j8 = 0; j8 < 8; j8 += 2) {
+                            const int jj = 8 * hf + j8;
+                            pa = __builtin_elementwise_fma((f32x2){vr[j8], vr[j8 + 1]}, (f32x2){whh[0][0][jj], whh[0][0][jj + 1]}, pa);
+                            pb = __builtin_elementwise_fma((f32x2){vu[j8], vu[j8 + 1]}, (f32x2){whh[0][1][jj], whh[0][1][jj + 1]}, pb);
+                            pc = __builtin_elementwise_fma((f32x2){vc[j8], vc[j8 + 1]}, (f32x2){whh[0][2][jj], whh[0][2][jj + 1]}, pc);
+                        }
                     }
-                    pa += pb; pa += pc;
+                    if (hf == 0) __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads behind the first half's FMAs
+                }
+                pa += pb; pa += pc;
+                if (l > 0) {
                     dh[l] = carry + quad_sum(pa.x);
                     dcur = quad_sum(pa.y);
                 } else {
-                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};  // even/odd j pairs
-#pragma unroll
-                    for (int jj = 0; jj < 16; jj += 2) {
-                        pa = __builtin_elementwise_fma((f32x2){vr[jj], vr[jj + 1]}, (f32x2){whh[0][0][jj], whh[0][0][jj + 1]}, pa);
-                        pb = __builtin_elementwise_fma((f32x2){vu[jj], vu[jj + 1]}, (f32x2){whh[0][1][jj], whh[0][1][jj + 1]}, pb);
-                        pc = __builtin_elementwise_fma((f32x2){vc[jj], vc[jj + 1]}, (f32x2){whh[0][2][jj], whh[0][2][jj + 1]}, pc);
-                    }
-                    pa += pb; pa += pc;
                     dh[0] = carry + quad_sum(pa.x + pa.y);
                     if (lane < S) dxreg += dxp[lane] + dxp[16 + lane] + dxp[32 + lane] + dxp[48 + lane];
                 }
+                VSDE_TPB(25 + 3 * (L - 1 - l));
             }
         }
         __syncthreads();  // chunk done: D4 / DO staging final, input staging free
@@ -1024,7 +1091,11 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
 #pragma unroll 1
             for (int e = tid; e < nsteps * NO; e += 256) p.DO[(bt0 + t0) * NO + e] = s_dO[e];
         }
-        if (c > 0) load_chunk(t0 - CH, CH);
+        if (c > 0) {
+            small_commit(CH);
+            if (DMA) { s_acts = acts_buf0 + ((c - 1) & 1) * ABUF; __builtin_amdgcn_s_waitcnt(0); }
+            else load_acts_sync(t0 - CH, CH, s_acts);
+        }
         __syncthreads();
     }
     if (wave == 0 && lane < S) p.g_x0[(int64_t)b * S + lane] = dxreg + p.g_paths[(int64_t)b * (T + 1) * S + lane];  // :620-624
@@ -1577,16 +1648,53 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
         VSDE_CHECK_HIP(hipGetLastError());
         rc = 0;
     } else if (d->L <= 2 && NO <= 16 && !g_force_v1) {
-        int ch = 16;
-        while (ch > 4 && (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float) > 80 * 1024) --ch;
-        const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float);
         p.wpb = 1;
-#define VSDE_LAUNCH_BWD_V2(LL, CC)                                                                                  \
+        // DMA variant (16-byte aligned activation records): two activation buffers, chunk from {16, 10, 8}
+        const bool dma = (d->H % 4) == 0;
+        int ch = 16;
+        if (dma) {
+            const int cand[3] = {16, 10, 8};
+            int pick = 0;
+            for (int q = 0; q < 3 && !pick; ++q)
+                if ((size_t)bwd_v2_lds(d->H, d->S, d->L, cand[q], true).total * sizeof(float) <= 80 * 1024) pick = cand[q];
+            ch = pick;
+        }
+        if (dma && ch) {
+            const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch, true).total * sizeof(float);
+#define VSDE_LAUNCH_BWD_DMA(LL, CC, SM)                                                                             \
     do {                                                                                                            \
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_v2_kernel<LL, CC>,                                \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_v2_kernel<LL, CC, SM, true>,                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
         prof_mark(1, 0, s);                                                                                         \
-        hipLaunchKernelGGL((head_bwd_v2_kernel<LL, CC>), dim3(d->B), dim3(256), lds2, s, p);                        \
+        hipLaunchKernelGGL((head_bwd_v2_kernel<LL, CC, SM, true>), dim3(d->B), dim3(256), lds2, s, p);              \
+        prof_mark(1, 1, s);                                                                                         \
+    } while (0)
+#define VSDE_LAUNCH_BWD_DMA_S(LL, CC)                                                                               \
+    do {                                                                                                            \
+        if (d->S == 1) VSDE_LAUNCH_BWD_DMA(LL, CC, 1);                                                              \
+        else if (d->S == 2) VSDE_LAUNCH_BWD_DMA(LL, CC, 2);                                                         \
+        else VSDE_LAUNCH_BWD_DMA(LL, CC, 0);                                                                        \
+    } while (0)
+#define VSDE_LAUNCH_BWD_DMA_C(LL)                                                                                   \
+    do {                                                                                                            \
+        if (ch == 16) VSDE_LAUNCH_BWD_DMA_S(LL, 16);                                                                \
+        else if (ch == 10) VSDE_LAUNCH_BWD_DMA_S(LL, 10);                                                           \
+        else VSDE_LAUNCH_BWD_DMA_S(LL, 8);                                                                          \
+    } while (0)
+            if (d->L == 1) VSDE_LAUNCH_BWD_DMA_C(1); else VSDE_LAUNCH_BWD_DMA_C(2);
+#undef VSDE_LAUNCH_BWD_DMA_C
+#undef VSDE_LAUNCH_BWD_DMA_S
+#undef VSDE_LAUNCH_BWD_DMA
+        } else {
+        ch = 16;
+        while (ch > 4 && (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float) > 80 * 1024) --ch;
+        const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch).total * sizeof(float);
+#define VSDE_LAUNCH_BWD_V2(LL, CC)                                                                                  \
+    do {                                                                                                            \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_v2_kernel<LL, CC, 0, false>,                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        prof_mark(1, 0, s);                                                                                         \
+        hipLaunchKernelGGL((head_bwd_v2_kernel<LL, CC, 0, false>), dim3(d->B), dim3(256), lds2, s, p);              \
         prof_mark(1, 1, s);                                                                                         \
     } while (0)
 #define VSDE_LAUNCH_BWD_V2_L(LL)                                                                                    \
@@ -1604,6 +1712,7 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
         if (d->L == 1) VSDE_LAUNCH_BWD_V2_L(1); else VSDE_LAUNCH_BWD_V2_L(2);
 #undef VSDE_LAUNCH_BWD_V2_L
 #undef VSDE_LAUNCH_BWD_V2
+        }
         VSDE_CHECK_HIP(hipGetLastError());
         rc = 0;
     } else {
