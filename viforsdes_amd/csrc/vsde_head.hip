@@ -682,41 +682,48 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                 VSDE_TP(2 + 4 * l);
                 __syncthreads();
                 VSDE_TP(3 + 4 * l);
-                float4 hv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = *(const float4 *)&hb[l * 64 + k0 + 4 * q];
-                const float *hs = (const float *)hv;
                 // v_pk_fma_f32: two fp32 FMAs per issue slot (this loop is VALU-issue bound)
-                // six (four) independent accumulator chains: even/odd k, summed at the end
+                // six (four) independent accumulator chains: even/odd k, summed at the end.  The 16 staged h values (and the
+                // emission-row weights) are consumed 8 at a time: with three matrices in registers there is no room for more.
                 f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
                 VSDE_TP(4 + 4 * l);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 ha = *(const float4 *)&hb[l * 64 + k0 + 8 * hf], hc = *(const float4 *)&hb[l * 64 + k0 + 8 * hf + 4];
+                    const float hs[8] = {ha.x, ha.y, ha.z, ha.w, hc.x, hc.y, hc.z, hc.w};
+                    if (l < L - 1) {
+                        constexpr int ln = (L > 1) ? 1 : 0;
+#pragma unroll
+                        for (int i8 = 0; i8 < 8; i8 += 2) {
+                            const int i = 8 * hf + i8;
+                            const f32x2 hh = {hs[i8], hs[i8]}, hg = {hs[i8 + 1], hs[i8 + 1]};
+                            p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
+                            p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wi[ln][0][i]}, p1);
+                            p2 = __builtin_elementwise_fma(hh, (f32x2){wi[ln][1][i], wi[ln][2][i]}, p2);
+                            q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
+                            q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wi[ln][0][i + 1]}, q1);
+                            q2 = __builtin_elementwise_fma(hg, (f32x2){wi[ln][1][i + 1], wi[ln][2][i + 1]}, q2);
+                        }
+                    } else {
+                        const float4 wa = *(const float4 *)(wop + 8 * hf), wc = *(const float4 *)(wop + 8 * hf + 4);
+                        const float wo[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+                        for (int i8 = 0; i8 < 8; i8 += 2) {
+                            const int i = 8 * hf + i8;
+                            const f32x2 hh = {hs[i8], hs[i8]}, hg = {hs[i8 + 1], hs[i8 + 1]};
+                            p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
+                            p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wo[i8]}, p1);
+                            q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
+                            q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wo[i8 + 1]}, q1);
+                        }
+                    }
+                    if (hf == 0) __builtin_amdgcn_sched_barrier(0);  // second half's LDS reads stay behind the first half's FMAs
+                }
                 if (l < L - 1) {
                     constexpr int ln = (L > 1) ? 1 : 0;
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const f32x2 hh = {hs[i], hs[i]}, hg = {hs[i + 1], hs[i + 1]};
-                        p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
-                        p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wi[ln][0][i]}, p1);
-                        p2 = __builtin_elementwise_fma(hh, (f32x2){wi[ln][1][i], wi[ln][2][i]}, p2);
-                        q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
-                        q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wi[ln][0][i + 1]}, q1);
-                        q2 = __builtin_elementwise_fma(hg, (f32x2){wi[ln][1][i + 1], wi[ln][2][i + 1]}, q2);
-                    }
                     p0 += q0; p1 += q1; p2 += q2;
                     a[0] = bih[ln][0] + quad_sum(p1.y); a[1] = bih[ln][1] + quad_sum(p2.x); a[2] = bih[ln][2] + quad_sum(p2.y);
                 } else {
-                    float4 wv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wv[q] = *(const float4 *)(wop + 4 * q);
-                    const float *wo = (const float *)wv;
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const f32x2 hh = {hs[i], hs[i]}, hg = {hs[i + 1], hs[i + 1]};
-                        p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
-                        p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wo[i]}, p1);
-                        q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
-                        q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wo[i + 1]}, q1);
-                    }
                     if (!row_ok) { p1.y = 0.f; q1.y = 0.f; }
                     p0 += q0; p1 += q1;
                     o = outb + quad_sum(p1.y);
