@@ -244,3 +244,47 @@ def test_attention_kernel_large_scores_take_the_exact_path():
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     assert rel_err(o.float().cpu().numpy(), ref.cpu().numpy()) < 1e-2
     assert torch.allclose(lse, torch.logsumexp(s, -1), atol=1e-3, rtol=1e-5)
+
+
+def test_packed_weights_follow_parameter_updates():
+    """PackedWeight (cached bf16 GEMM operands) must never serve stale weights: in-place parameter updates are picked up
+    lazily (version check) and by refresh_all(); gradients come back per parameter piece."""
+    from viforsdes_amd.primitives import fused
+    from viforsdes_amd.primitives.mlp import SwiGLU
+    torch.manual_seed(0)
+    mlp = SwiGLU(256, 682).to(DEV)
+    x = torch.randn(16, 300, 256, device=DEV, dtype=torch.bfloat16)
+
+    def reference(inp):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            a, b_ = mlp.input_proj(inp).chunk(2, dim=-1)
+            return mlp.output_proj(torch.nn.functional.silu(a) * b_)
+
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = mlp(x)
+    assert hasattr(mlp, "_packs"), "large bf16 inputs should take the packed route"
+    assert rel_err(y0.float().detach().cpu().numpy(), reference(x).float().detach().cpu().numpy()) < 3e-2
+    with torch.no_grad():  # optimizer-style in-place update, no explicit refresh: the version check must catch it
+        mlp.input_proj.weight.mul_(0.5)
+        mlp.output_proj.bias.add_(1.0)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = mlp(x)
+    assert rel_err(y1.float().detach().cpu().numpy(), reference(x).float().detach().cpu().numpy()) < 3e-2
+    assert (y1 - y0).abs().max() > 0.5
+    with torch.no_grad():
+        mlp.output_proj.weight.mul_(2.0)
+    assert any(pk.stale() for pk in mlp._packs)
+    fused.PackedWeight.refresh_all()
+    assert not any(pk.stale() for pk in mlp._packs)
+    xg = x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = mlp(xg)
+    ref = reference(xg)
+    assert rel_err(y2.float().detach().cpu().numpy(), ref.float().detach().cpu().numpy()) < 3e-2
+    params = [mlp.input_proj.weight, mlp.input_proj.bias, mlp.output_proj.weight, mlp.output_proj.bias]
+    go = torch.randn_like(y2)
+    g_fused = torch.autograd.grad((y2.float() * go.float()).sum(), [xg] + params)
+    g_ref = torch.autograd.grad((ref.float() * go.float()).sum(), [xg] + params)
+    for name, a, b_ in zip(["x", "w_in", "b_in", "w_out", "b_out"], g_fused, g_ref):
+        assert a.shape == b_.shape, name
+        assert rel_err(a.float().cpu().numpy(), b_.float().cpu().numpy()) < 6e-2, name
