@@ -57,6 +57,9 @@ class TrainingContext:
                 dev = torch.device(f"cuda:{local_rank}")
                 torch.cuda.set_device(dev)
             init_process_group_if_needed(dev.type)
+        if dev.type == "cuda":
+            from ..accelerate import enable_tuned_gemms
+            enable_tuned_gemms()
         if seed is None and distributed:
             seed = DEFAULT_DISTRIBUTED_SEED
         if seed is not None:
