@@ -158,6 +158,15 @@ size_t vsde_colsum_workspace_bytes(int64_t B, int C);
 int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
                          const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* Gated residual fused with the LayerNorm-modulate that follows it (primitives/sit.py:73-79 + next norm):
+ *   xnew = x + gate*y;  h = LN(xnew)*(1+scale) + shift.   Backward: dxnew (optional) is the gradient reaching xnew from its
+ *   other consumers; dx = dxnew + LNbwd(dh) is the gradient of x, dy = gate*dx, dgate/dscale/dshift are token sums. */
+int vsde_residual_ln_fwd(int dtype, const void *x, const void *y, const void *gate, const void *scale, const void *shift,
+                         void *xnew, void *h, float *mean, float *rstd, int64_t B, int N, int C, double eps, void *stream);
+int vsde_residual_ln_bwd(int dtype, const void *xnew, const void *y, const void *gate, const void *scale, const void *dh,
+                         const void *dxnew, const float *mean, const float *rstd, void *dx, void *dy, void *dgate,
+                         void *dscale, void *dshift, int64_t B, int N, int C, void *workspace, size_t workspace_bytes,
+                         void *stream);
 int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N, int C,
                             void *stream);
 int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate, int64_t B,

@@ -288,3 +288,29 @@ def test_packed_weights_follow_parameter_updates():
     for name, a, b_ in zip(["x", "w_in", "b_in", "w_out", "b_out"], g_fused, g_ref):
         assert a.shape == b_.shape, name
         assert rel_err(a.float().cpu().numpy(), b_.float().cpu().numpy()) < 6e-2, name
+
+
+@pytest.mark.parametrize("C", [64, 192, 256, 512])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+def test_residual_norm_fused_op(C, dtype, tol):
+    """gated residual fused with the following LayerNorm-modulate (forward and the five gradients, including the gradient
+    that reaches xnew from another consumer) vs the torch chain in fp32."""
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(C + 1)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV, dtype)
+    B, N = 3, 41
+    leaves = [rn(B, N, C), rn(B, N, C), rn(B, C), rn(B, C) * 0.3, rn(B, C) * 0.3]
+    go_x, go_h = rn(B, N, C).float(), rn(B, N, C).float()
+
+    def run(use_fused):
+        x, y, gate, sc, sh = (t.clone().requires_grad_() if use_fused else t.clone().float().requires_grad_() for t in leaves)
+        if use_fused:
+            xnew, h = fused.residual_norm(x, y, gate, sc, sh, 1e-5)
+        else:
+            xnew = x + gate[:, None] * y
+            h = torch.nn.functional.layer_norm(xnew, (C,), eps=1e-5) * (1 + sc[:, None]) + sh[:, None]
+        grads = torch.autograd.grad((xnew.float() * go_x).sum() + (h.float() * go_h).sum(), [x, y, gate, sc, sh])
+        return [xnew.detach().float(), h.detach().float()] + [t.float() for t in grads]
+
+    for name, a, b_ in zip(["xnew", "h", "dx", "dy", "dgate", "dscale", "dshift"], run(True), run(False)):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < tol, name

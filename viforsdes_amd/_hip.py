@@ -55,7 +55,7 @@ EXPORTS = (
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
-    "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
+    "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
 )
 
@@ -327,6 +327,32 @@ def ln_modulate_bwd(x, scale, dy, mean, rstd, dres=None):
               _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()),
               _stream(dev))
     return dx, dscale, dshift
+
+
+def residual_ln_fwd(x, y, gate, scale, shift, eps):
+    """(xnew, h, mean, rstd) with xnew = x + gate*y and h = LN(xnew)*(1+scale)+shift."""
+    lib = load(); dev = _require_hip(x, y, gate, scale, shift)
+    B, N, C = x.shape
+    xnew = torch.empty_like(x); h = torch.empty_like(x)
+    mean = torch.empty(B * N, device=dev, dtype=torch.float32); rstd = torch.empty_like(mean)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_residual_ln_fwd, _dt(x), _ptr(x), _ptr(y), _ptr(gate), _ptr(scale), _ptr(shift), _ptr(xnew), _ptr(h),
+              _ptr(mean), _ptr(rstd), _i64(B), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps), _stream(dev))
+    return xnew, h, mean, rstd
+
+
+def residual_ln_bwd(xnew, y, gate, scale, dh, dxnew, mean, rstd):
+    """(dx, dy, dgate, dscale, dshift); dxnew may be None."""
+    lib = load(); dev = _require_hip(xnew, y, gate, scale, dh)
+    B, N, C = xnew.shape
+    dx = torch.empty_like(xnew); dy = torch.empty_like(xnew)
+    dgate = torch.empty_like(gate); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
+    ws = _colsum_workspace(lib, B, C, dev)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_residual_ln_bwd, _dt(xnew), _ptr(xnew), _ptr(y), _ptr(gate), _ptr(scale), _ptr(dh), _ptr(dxnew),
+              _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dy), _ptr(dgate), _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N),
+              ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
+    return dx, dy, dgate, dscale, dshift
 
 
 def gated_residual_fwd(x, y, gate):

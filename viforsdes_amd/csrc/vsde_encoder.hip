@@ -96,7 +96,10 @@ template <typename T, int V, int LPR, int NSLAB>
 __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ shift, T *__restrict__ y,
                                                          float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
-                                                         int N, int C, float eps) {
+                                                         int N, int C, float eps, const T *__restrict__ res_y,
+                                                         const T *__restrict__ res_gate, T *__restrict__ xnew) {
+    // res_y != nullptr: the input of the norm is the gated residual x + gate * res_y, which is also written to xnew
+    // (same rounding points as gated_residual followed by ln_modulate)
     const int lane = threadIdx.x & (LPR - 1);
     const int64_t m = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     if (m >= M) return;
@@ -108,6 +111,14 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
     for (int sl = 0; sl < NSLAB; ++sl)
         if (sl < nslab) {
             Pack<T, V>::load(x + m * C + (sl * LPR + lane) * V, v[sl]);
+            if (res_y) {
+                float ry[V], rg[V];
+                Pack<T, V>::load(res_y + m * C + (sl * LPR + lane) * V, ry);
+                Pack<T, V>::load(res_gate + b * C + (sl * LPR + lane) * V, rg);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[sl][e] = rnd<T>(v[sl][e] + rnd<T>(rg[e] * ry[e]));
+                Pack<T, V>::store(xnew + m * C + (sl * LPR + lane) * V, v[sl]);
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) s += v[sl][e];
         }
@@ -167,7 +178,11 @@ template <typename T, int V, int LPR, int NSLAB>
 __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                          const T *__restrict__ dy, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd, const T *__restrict__ dres,
-                                                         T *__restrict__ dx, float *__restrict__ part, int N, int C) {
+                                                         T *__restrict__ dx, float *__restrict__ part, int N, int C,
+                                                         const T *__restrict__ res_y, const T *__restrict__ res_gate,
+                                                         T *__restrict__ res_dy) {
+    // res_y != nullptr: x is the output of a gated residual x0 + gate * res_y; dx is then also the gradient of x0, and the
+    // kernel additionally writes res_dy = gate * dx and the partial sums of dx * res_y (part2: gradient of the gate)
     extern __shared__ float red[];
     constexpr int SLOTS = 256 / LPR;
     const int lane = threadIdx.x & (LPR - 1), slot = threadIdx.x / LPR;
@@ -175,16 +190,17 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
     const int CL = (N + nchunk - 1) / nchunk;
     const int n0 = blockIdx.x * CL, n1 = min(N, n0 + CL);
     constexpr int nslab = NSLAB;  // C == NSLAB * LPR * V
-    float sc1[NSLAB][V], a1[NSLAB][V], a2[NSLAB][V];
+    float sc1[NSLAB][V], a1[NSLAB][V], a2[NSLAB][V], a3[NSLAB][V], gt[NSLAB][V];
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         if (sl < nslab) {
             Pack<T, V>::load(scale + (int64_t)b * C + (sl * LPR + lane) * V, sc1[sl]);
 #pragma unroll
             for (int e = 0; e < V; ++e) sc1[sl][e] += 1.0f;
+            if (res_y) Pack<T, V>::load(res_gate + (int64_t)b * C + (sl * LPR + lane) * V, gt[sl]);
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) { a1[sl][e] = 0.f; a2[sl][e] = 0.f; }
+        for (int e = 0; e < V; ++e) { a1[sl][e] = 0.f; a2[sl][e] = 0.f; a3[sl][e] = 0.f; }
     }
     for (int n = n0 + slot; n < n1; n += SLOTS) {
         const int64_t m = (int64_t)b * N + n;
@@ -219,6 +235,13 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
                     for (int e = 0; e < V; ++e) o[e] += r[e];
                 }
                 Pack<T, V>::store(dx + m * C + c, o);
+                if (res_y) {
+                    float ry[V], od[V];
+                    Pack<T, V>::load(res_y + m * C + c, ry);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) { const float t = rnd<T>(o[e]); a3[sl][e] += t * ry[e]; od[e] = gt[sl][e] * t; }
+                    Pack<T, V>::store(res_dy + m * C + c, od);
+                }
             }
     }
     float *p0 = part + (((int64_t)0 * B + b) * nchunk + blockIdx.x) * C;
@@ -229,6 +252,10 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
             const int off = sl * LPR * V;
             colsum_block_reduce<V>(red, a1[sl], slot, SLOTS, lane * V, LPR * V, p0 + off, C - off);
             colsum_block_reduce<V>(red, a2[sl], slot, SLOTS, lane * V, LPR * V, p1 + off, C - off);
+            if (res_y) {
+                float *p2 = part + (((int64_t)2 * B + b) * nchunk + blockIdx.x) * C;
+                colsum_block_reduce<V>(red, a3[sl], slot, SLOTS, lane * V, LPR * V, p2 + off, C - off);
+            }
         }
 }
 
@@ -275,17 +302,19 @@ __global__ void __launch_bounds__(256) gated_residual_bwd_kernel(const T *__rest
 // r_k[b][c] = sum_chunk part[k][b][chunk][c]  (k < nout), converted to T
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restrict__ part, T *__restrict__ r0, T *__restrict__ r1,
-                                                            int64_t BC, int C, int nchunk) {
+                                                            T *__restrict__ r2, int64_t BC, int C, int nchunk) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BC) return;
     const int64_t b = i / C;
     const int c = (int)(i - b * C);
-    const int nout = r1 ? 2 : 1;
-    for (int k = 0; k < nout; ++k) {
+    T *const outs[3] = {r0, r1, r2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!outs[k]) continue;
         const float *p = part + ((int64_t)k * (BC / C) + b) * nchunk * C + c;
         float t = 0.f;
         for (int ch = 0; ch < nchunk; ++ch) t += p[(int64_t)ch * C];
-        (k == 0 ? r0 : r1)[i] = from_f32<T>(t);
+        outs[k][i] = from_f32<T>(t);
     }
 }
 
@@ -539,9 +568,16 @@ static inline int ew_grid(int64_t total, int per_block) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+struct LnResidual {  // optional gated residual fused in front of the norm (forward) / behind its backward
+    const void *y = nullptr;     // residual branch [B][N][C]
+    const void *gate = nullptr;  // [B][C]
+    void *out = nullptr;         // forward: x + gate*y; backward: gate * dx
+};
+
 template <typename T>
 static int ln_mod_dispatch(int which, const void *x, const void *scale, const void *shift_or_dy, const void *dres, void *out,
-                           float *mean, float *rstd, float *part, int64_t B, int N, int C, float eps, hipStream_t s) {
+                           float *mean, float *rstd, float *part, int64_t B, int N, int C, float eps, hipStream_t s,
+                           LnResidual res = LnResidual()) {
     VSDE_CHECK_ARG(C % 64 == 0 && C <= 1024, VSDE_E_BADARG, "ln_modulate needs C %% 64 == 0 and C <= 1024, got %d", C);
     constexpr int VF = VecOf<T>::v;  // 8 bf16 / 4 f32 = 16 bytes per lane
     const int64_t M = B * N;
@@ -551,11 +587,13 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
         if (which == 0) {                                                                                                     \
             dim3 grid((unsigned)((M + 256 / LPR - 1) / (256 / LPR)));                                                         \
             hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR, NS>), grid, block, 0, s, (const T *)x, (const T *)scale,         \
-                               (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps);                                   \
+                               (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps, (const T *)res.y,                  \
+                               (const T *)res.gate, (T *)res.out);                                                            \
         } else {                                                                                                              \
             hipLaunchKernelGGL((ln_mod_bwd_kernel<T, V, LPR, NS>), dim3(colsum_chunks(B, N), (unsigned)B), block,                   \
                                256 * V * sizeof(float), s, (const T *)x, (const T *)scale, (const T *)shift_or_dy,            \
-                               (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out, part, N, C);              \
+                               (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out, part, N, C,               \
+                               (const T *)res.y, (const T *)res.gate, (T *)res.out);                                          \
         }                                                                                                                     \
     } while (0)
 #define LNM(V, LPR)                                                                                                           \
@@ -599,7 +637,7 @@ extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale,
 }
 
 extern "C" size_t vsde_colsum_workspace_bytes(int64_t B, int C) {
-    return (size_t)2 * (size_t)B * kColsumChunksMax * (size_t)C * sizeof(float);
+    return (size_t)3 * (size_t)B * kColsumChunksMax * (size_t)C * sizeof(float);
 }
 
 extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
@@ -615,7 +653,39 @@ extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale,
         if (rc) return rc;
         const int64_t BC = B * C;
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dscale, (T *)dshift, BC, C, colsum_chunks(B, N));
+                           (T *)dscale, (T *)dshift, (T *)nullptr, BC, C, colsum_chunks(B, N));
+    });
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_residual_ln_fwd(int dtype, const void *x, const void *y, const void *gate, const void *scale, const void *shift,
+                                    void *xnew, void *h, float *mean, float *rstd, int64_t B, int N, int C, double eps,
+                                    void *stream) {
+    VSDE_CHECK_ARG(x && y && gate && scale && shift && xnew && h && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG,
+                   "bad residual_ln arguments");
+    LnResidual res; res.y = y; res.gate = gate; res.out = xnew;
+    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, h, mean, rstd, nullptr, B, N, C, (float)eps,
+                                                       (hipStream_t)stream, res));
+}
+
+extern "C" int vsde_residual_ln_bwd(int dtype, const void *xnew, const void *y, const void *gate, const void *scale, const void *dh,
+                                    const void *dxnew, const float *mean, const float *rstd, void *dx, void *dy, void *dgate,
+                                    void *dscale, void *dshift, int64_t B, int N, int C, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    VSDE_CHECK_ARG(xnew && y && gate && scale && dh && mean && rstd && dx && dy && dgate && dscale && dshift && B > 0 && N > 0,
+                   VSDE_E_BADARG, "bad residual_ln_bwd arguments");
+    VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C), VSDE_E_WORKSPACE,
+                   "residual_ln_bwd workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    LnResidual res; res.y = y; res.gate = gate; res.out = dy;
+    VSDE_DTYPE_SWITCH(dtype, {
+        int rc = ln_mod_dispatch<T>(1, xnew, scale, dh, dxnew, dx, (float *)mean, (float *)rstd, part, B, N, C, 0.f, s, res);
+        if (rc) return rc;
+        const int64_t BC = B * C;
+        hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
+                           (T *)dscale, (T *)dshift, (T *)dgate, BC, C, colsum_chunks(B, N));
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -654,7 +724,7 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
             hipLaunchKernelGGL((gated_residual_bwd_kernel<T, 4>), grid, dim3(256), 256 * 4 * sizeof(float), s, (const T *)y,
                                (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dgate, (T *)nullptr, BC, C, colsum_chunks(B, N));
+                           (T *)dgate, (T *)nullptr, (T *)nullptr, BC, C, colsum_chunks(B, N));
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;

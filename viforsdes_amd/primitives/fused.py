@@ -90,6 +90,33 @@ def gated_residual(x: Tensor, y: Tensor, gate: Tensor, link: Optional[GradLink] 
     return _GatedResidual.apply(x, y, gate, link)
 
 
+class _ResidualNorm(torch.autograd.Function):
+    """xnew = x + gate*y; h = LayerNorm(xnew)*(1+scale)+shift in one pass; the backward folds the gradient reaching xnew from
+    its other consumers, the norm backward, gate*dx and the three token sums into one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, y, gate, scale, shift, eps):
+        x = x.contiguous()
+        y, gate, scale, shift = (t.to(x.dtype).contiguous() for t in (y, gate, scale, shift))
+        xnew, h, mean, rstd = _hip.residual_ln_fwd(x, y, gate, scale, shift, eps)
+        ctx.save_for_backward(xnew, y, gate, scale, mean, rstd)
+        return xnew, h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dxnew, dh):
+        xnew, y, gate, scale, mean, rstd = ctx.saved_tensors
+        dh = torch.zeros_like(xnew) if dh is None else dh.to(xnew.dtype).contiguous()
+        dxnew = None if dxnew is None else dxnew.to(xnew.dtype).contiguous()
+        dx, dy, dgate, dscale, dshift = _hip.residual_ln_bwd(xnew, y, gate, scale, dh, dxnew, mean, rstd)
+        return dx, dy, dgate, dscale, dshift, None
+
+
+def residual_norm(x: Tensor, y: Tensor, gate: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> tuple[Tensor, Tensor]:
+    """``xnew = x + gate[:, None]*y`` and ``h = LayerNorm(xnew)*(1+scale[:, None]) + shift[:, None]`` -> (xnew, h)."""
+    return _ResidualNorm.apply(x, y, gate, scale, shift, eps)
+
+
 class _SwiGLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u):

@@ -59,11 +59,15 @@ class SiTBlock(nn.Module):
     def cond_params(self, *, cond: Tensor) -> tuple[CondBranch, ...]:
         return self._cond_modulator(cond=cond)
 
+    def fusable(self, hidden_states: Tensor, cond: Tensor, rotary: Optional[RotarySpec]) -> bool:
+        """Whether this block can take the fused HIP route (per-row conditioning, plain LayerNorms, gated QK-normed attention)."""
+        plain = lambda n: isinstance(n, nn.LayerNorm) and not n.elementwise_affine
+        return cond.ndim == 2 and plain(self.attn_norm) and plain(self.mlp_norm) and self.self_attn.fusable(hidden_states, rotary)
+
     def forward(self, hidden_states: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None,
                 v0: Optional[Tensor] = None) -> tuple[Tensor, Tensor]:
         """Returns ``(hidden_states, value_heads)``; the caller keeps block 0's values as ``v0``."""
-        if cond.ndim == 2 and isinstance(self.attn_norm, nn.LayerNorm) and not self.attn_norm.elementwise_affine \
-                and self.self_attn.fusable(hidden_states, rotary):
+        if self.fusable(hidden_states, cond, rotary):
             # fused HIP route: 6 fused passes + 5 GEMMs + 1 attention call per block
             sa, ha, ga, sm, hm, gm = self._cond_modulator.net(cond).chunk(6, dim=-1)
             # each stream tensor feeds a norm and the residual that follows it: one GradLink per such pair
@@ -96,8 +100,31 @@ class SiT(nn.Module):
         self.input_proj = init_linear_(nn.Linear(config.in_dim, config.hidden_dim, bias=config.bias))
         self.output_proj = init_linear_(nn.Linear(config.hidden_dim, config.out_dim, bias=config.bias))
 
+    def _forward_fused_chain(self, tokens: Tensor, cond: Tensor, rotary: RotarySpec) -> Tensor:
+        """All blocks on the fused route, with every gated residual fused into the LayerNorm that follows it -- the second
+        norm of the same block, and the first norm of the NEXT block (each stream tensor is then written once and read once
+        per direction): LN1 | attn | [res1+LN2] | mlp | [res2+next LN1] | attn | ..."""
+        blocks = self.blocks
+        mods = [blk._cond_modulator.net(cond).chunk(6, dim=-1) for blk in blocks]  # (sa, ha, ga, sm, hm, gm) per block
+        h1 = fused.ln_modulate(tokens, mods[0][0], mods[0][1], blocks[0].attn_norm.eps)
+        v0: Optional[Tensor] = None
+        for k, blk in enumerate(blocks):
+            _, _, ga, sm, hm, gm = mods[k]
+            attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0)
+            if v0 is None and self.config.attn_residual_v:
+                v0 = values
+            x1, h2 = fused.residual_norm(tokens, attn_out, ga, sm, hm, blk.mlp_norm.eps)
+            mlp_out = blk.mlp(h2)
+            if k + 1 < len(blocks):
+                tokens, h1 = fused.residual_norm(x1, mlp_out, gm, mods[k + 1][0], mods[k + 1][1], blocks[k + 1].attn_norm.eps)
+            else:
+                tokens = fused.gated_residual(x1, mlp_out, gm)
+        return tokens
+
     def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None) -> Tensor:
         tokens = self.input_proj(x)
+        if all(block.fusable(tokens, cond, rotary) for block in self.blocks):
+            return fused.linear(self._forward_fused_chain(tokens, cond, rotary), self.output_proj.weight, self.output_proj.bias)
         v0: Optional[Tensor] = None
         for block in self.blocks:
             tokens, values = block(tokens, cond=cond, rotary=rotary, v0=v0)
