@@ -36,7 +36,7 @@ def categories(path):
             k = "vsde attention"
         elif "vsde::" in n:
             k = "vsde " + ("head/gemm/elbo" if any(x in n for x in ("head_", "::tn_", "gemm_nt", "elbo", "pack_")) else "encoder fused")
-        elif n.startswith("Cijk_"):
+        elif "Cijk_" in n:
             k = "hipBLASLt GEMM"
         elif n in ("attn_fwd", "bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess", "bwd_postprocess") or "fmha_" in n:
             k = "attention (aotriton / aiter)"
@@ -48,5 +48,31 @@ def categories(path):
         print(f"{k:<32} {v/1e6:>10.3f} ms {100*v/tot:>6.2f}%")
 
 
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--categories":
+def busy(path, tail_frac=0.5):
+    """GPU busy fraction (union of kernel intervals / wall) over the last ``tail_frac`` of the trace, and the idle-gap histogram."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = sorted(cur.execute("select start, end from kernels").fetchall())
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    lo = t1 - (t1 - t0) * tail_frac
+    rows = [r for r in rows if r[0] >= lo]
+    busy_ns, cur_end, gaps = 0, rows[0][0], []
+    for st, en in rows:
+        if st > cur_end:
+            gaps.append(st - cur_end)
+            busy_ns += en - st
+            cur_end = en
+        elif en > cur_end:
+            busy_ns += en - cur_end
+            cur_end = en
+    wall = cur_end - rows[0][0]
+    print(f"window {wall/1e6:.1f} ms, kernels {len(rows)}, busy {100*busy_ns/wall:.1f} %, idle {(wall-busy_ns)/1e6:.2f} ms in {len(gaps)} gaps")
+    for lim in (2e3, 5e3, 1e4, 5e4, 1e9):
+        sel = [g for g in gaps if g <= lim]
+        print(f"  gaps <= {lim/1e3:.0f} us: {len(sel)} totalling {sum(sel)/1e6:.2f} ms")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--busy":
+    busy(sys.argv[1])
+elif __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--categories":
     categories(sys.argv[1])
