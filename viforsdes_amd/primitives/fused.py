@@ -426,7 +426,7 @@ def plain_pack(weight: Tensor, bias: Optional[Tensor]) -> PackedWeight:
         n = weight.shape[0]
         pk = PackedWeight(n, weight.shape[1], [(weight, 0, n, 0)], None if bias is None else [(bias, 0, n, 0)], weight.device)
         key = id(weight)
-        _PLAIN_PACKS[key] = (weakref.ref(weight, lambda _r, k=key: _PLAIN_PACKS.pop(k, None)), pk)
+        _PLAIN_PACKS[key] = (weakref.ref(weight, lambda _r, k=key, d=_PLAIN_PACKS: d.pop(k, None)), pk)
     return pk
 
 
