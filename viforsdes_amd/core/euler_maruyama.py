@@ -26,12 +26,26 @@ def euler_maruyama(sde: SDE, x0: Tensor, theta: Tensor, time_horizon: float, dt:
     root_dt = dt ** 0.5
     states = [x0]
     x = x0
+    floor = _floor_vector(pos, state_dim, x0.device, x0.dtype) if pos else None
     for k in range(n_steps):
         shock = torch.einsum("bij,bj->bi", sde.diffusion(x, theta), noise[:, k])
         x = x + sde.drift(x, theta) * dt + shock * root_dt
-        if pos:
-            floor = torch.full_like(x, -float("inf"))
-            floor[:, pos] = 1e-6
-            x = torch.maximum(x, floor)
+        if floor is not None:
+            x = torch.maximum(x, floor)  # 1e-6 on the positive dims, -inf elsewhere
         states.append(x)
     return torch.stack(states, dim=1)
+
+
+_FLOORS: dict = {}
+
+
+def _floor_vector(pos: list[int], state_dim: int, device: torch.device, dtype: torch.dtype) -> Tensor:
+    """[state_dim] clamp floor, built once per (dims, device): building it inside the time loop costs three kernels per Euler
+    step and an index upload that cannot be captured into a HIP graph."""
+    key = (tuple(pos), state_dim, str(device), dtype)
+    f = _FLOORS.get(key)
+    if f is None:
+        host = torch.full((state_dim,), -float("inf"), dtype=dtype)
+        host[pos] = 1e-6
+        f = _FLOORS[key] = host.to(device)
+    return f

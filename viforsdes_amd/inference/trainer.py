@@ -214,22 +214,38 @@ class VariationalInferenceTrainer:
         if free:
             mu.data[free] = cfg.init_scale * torch.randn(len(free), device=dev)
         log_sigma = nn.Parameter(torch.zeros(d, device=dev))
-        opt = torch.optim.Adam([mu, log_sigma], lr=cfg.learning_rate)
+        self._pretrain_opt = opt = torch.optim.Adam([mu, log_sigma], lr=cfg.learning_rate, capturable=dev.type == "cuda")
         best_mu, best_mse = mu.detach().clone(), float("inf")
         obs = self.ctx.observations
         obs_idx = (obs.times / self.config.time_step).round().long()
+        x0 = obs.values[0].unsqueeze(0).expand(cfg.batch_size, -1)
+        pos_host = torch.zeros(d, dtype=torch.bool)
+        pos_host[pos] = True
+        pos_mask = pos_host.to(dev)
+
+        def simulate():
+            """One stochastic evaluation of the matching loss for the current (mu, log_sigma)."""
+            sigma = log_sigma.exp()
+            log_theta = mu + sigma * torch.randn(cfg.batch_size, d, device=dev)
+            theta = torch.where(pos_mask, log_theta.exp(), log_theta) if pos else log_theta
+            paths = euler_maruyama(self.sde, x0, theta, self.time_horizon, self.config.time_step,
+                                   self.state_space.positive_dims)
+            return ((paths[:, obs_idx] - obs.values) ** 2).mean(), sigma.median()
+
+        replay = self._capture_pretrain_step(simulate, mu, log_sigma, cfg) if dev.type == "cuda" else None
         with self.console.pretrain_progress(cfg.n_iterations) as progress:
             for step in range(cfg.n_iterations):
+                if replay is not None:
+                    # the whole iteration (simulation, backward, clip, Adam) replays from a HIP graph: the T-step Python loop
+                    # is ~3 kernels per Euler step and entirely launch-bound.  The graph always applies the update; a
+                    # non-finite loss is undone from the snapshot it took first (same semantics as the eager branch below).
+                    value, finite, med, mu_before = replay()
+                    if finite and value < best_mse:
+                        best_mu, best_mse = mu_before, value
+                    progress.update(step, value, best_mse, med)
+                    continue
                 opt.zero_grad()
-                sigma = log_sigma.exp()
-                log_theta = mu + sigma * torch.randn(cfg.batch_size, d, device=dev)
-                theta = log_theta.clone()
-                if pos:
-                    theta[:, pos] = log_theta[:, pos].exp()
-                x0 = obs.values[0].unsqueeze(0).expand(cfg.batch_size, -1)
-                paths = euler_maruyama(self.sde, x0, theta, self.time_horizon, self.config.time_step,
-                                       self.state_space.positive_dims)
-                mse = ((paths[:, obs_idx] - obs.values) ** 2).mean()
+                mse, med_t = simulate()
                 finite = bool(torch.isfinite(mse))
                 value = mse.item()
                 if finite and value < best_mse:
@@ -238,8 +254,66 @@ class VariationalInferenceTrainer:
                     mse.backward()
                     nn.utils.clip_grad_norm_([mu, log_sigma], 1.0)
                     opt.step()
-                progress.update(step, value, best_mse, sigma.median().item())
+                progress.update(step, value, best_mse, med_t.item())
         return best_mu
+
+    def _capture_pretrain_step(self, simulate, mu: nn.Parameter, log_sigma: nn.Parameter, cfg: PretrainConfig):
+        """HIP graph of one pre-training iteration; returns ``replay() -> (loss, finite, median sigma, mu before the update)``
+        or ``None`` when capture is not possible (the caller then runs the eager loop)."""
+        opt = self._pretrain_opt
+        dev = mu.device
+        params = [mu, log_sigma]
+
+        def iteration():
+            opt.zero_grad(set_to_none=True)
+            mse, med = simulate()
+            mse.backward()
+            nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            return mse.detach(), med.detach()
+
+        try:
+            state0 = [p.detach().clone() for p in params]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                rng = torch.cuda.get_rng_state(dev)
+                iteration()  # warm-up: creates the optimizer state, allocator pools ...
+                torch.cuda.set_rng_state(rng, dev)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            with torch.no_grad():  # ... and is undone: the captured iterations start from the initial state
+                for p, s0 in zip(params, state0):
+                    p.copy_(s0)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            opt_tensors = [v for st in opt.state.values() for v in st.values() if torch.is_tensor(v)]
+            snap_p = [torch.empty_like(p) for p in params]
+            snap_o = [torch.empty_like(v) for v in opt_tensors]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                with torch.no_grad():
+                    torch._foreach_copy_(snap_p, [p.detach() for p in params])
+                    torch._foreach_copy_(snap_o, opt_tensors)
+                s_mse, s_med = iteration()
+                s_out = torch.stack([s_mse.float(), s_med.float()])
+        except Exception as err:  # capture is an optimisation, never a requirement
+            torch.cuda.synchronize(dev)
+            self.console.config_panel(f"pretrain HIP graph unavailable ({type(err).__name__}: {err}); running eagerly")
+            return None
+        self._pretrain_graph = graph
+
+        def replay():
+            graph.replay()
+            value, med = s_out.tolist()
+            finite = value == value and abs(value) != float("inf")
+            if not finite:  # the reference skips the update: restore what the graph changed
+                with torch.no_grad():
+                    torch._foreach_copy_([p.detach() for p in params], snap_p)
+                    torch._foreach_copy_(opt_tensors, snap_o)
+            return value, finite, med, snap_p[0].clone()
+        return replay
 
     def cleanup(self) -> None:
         self.ctx.cleanup()
