@@ -32,7 +32,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvsde_hip.so")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
+    # -fno-slp-vectorize: on gfx950 a wave64 v_pk_fma_f32 / v_pk_add_f32 issues in 8 cycles (no gain over two scalar ops) and the
+    # SLP vectorizer pays extra v_mov's to build the packed operands of the GRU step loops (measured: -7 % VALU issue cycles)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
            "-o", LIB_PATH] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -682,10 +682,12 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                 VSDE_TP(2 + 4 * l);
                 __syncthreads();
                 VSDE_TP(3 + 4 * l);
-                // v_pk_fma_f32: two fp32 FMAs per issue slot (this loop is VALU-issue bound)
-                // six (four) independent accumulator chains: even/odd k, summed at the end.  The 16 staged h values (and the
-                // emission-row weights) are consumed 8 at a time: with three matrices in registers there is no room for more.
-                f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+                // Plain v_fma_f32 chains (a wave64 v_pk_fma_f32 issues in 8 cycles = two v_fma_f32, and its broadcast operand
+                // costs an extra v_mov per h value): even/odd k accumulate separately and are summed at the end.  The 16
+                // staged h values (and the emission-row weights) are consumed 8 at a time: with three matrices in registers
+                // there is no room for more.
+                float eh[3] = {0.f, 0.f, 0.f}, oh[3] = {0.f, 0.f, 0.f};  // W_hh^l h^l: gate g, even / odd k
+                float ei[3] = {0.f, 0.f, 0.f}, oi[3] = {0.f, 0.f, 0.f};  // W_ih^{l+1} h^l, or [2] = emission row (last layer)
                 VSDE_TP(4 + 4 * l);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
@@ -696,13 +698,11 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 #pragma unroll
                         for (int i8 = 0; i8 < 8; i8 += 2) {
                             const int i = 8 * hf + i8;
-                            const f32x2 hh = {hs[i8], hs[i8]}, hg = {hs[i8 + 1], hs[i8 + 1]};
-                            p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
-                            p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wi[ln][0][i]}, p1);
-                            p2 = __builtin_elementwise_fma(hh, (f32x2){wi[ln][1][i], wi[ln][2][i]}, p2);
-                            q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
-                            q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wi[ln][0][i + 1]}, q1);
-                            q2 = __builtin_elementwise_fma(hg, (f32x2){wi[ln][1][i + 1], wi[ln][2][i + 1]}, q2);
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) {
+                                eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]); ei[g] = fmaf(hs[i8], wi[ln][g][i], ei[g]);
+                                oh[g] = fmaf(hs[i8 + 1], wh[l][g][i + 1], oh[g]); oi[g] = fmaf(hs[i8 + 1], wi[ln][g][i + 1], oi[g]);
+                            }
                         }
                     } else {
                         const float4 wa = *(const float4 *)(wop + 8 * hf), wc = *(const float4 *)(wop + 8 * hf + 4);
@@ -710,25 +710,25 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 #pragma unroll
                         for (int i8 = 0; i8 < 8; i8 += 2) {
                             const int i = 8 * hf + i8;
-                            const f32x2 hh = {hs[i8], hs[i8]}, hg = {hs[i8 + 1], hs[i8 + 1]};
-                            p0 = __builtin_elementwise_fma(hh, (f32x2){wh[l][0][i], wh[l][1][i]}, p0);
-                            p1 = __builtin_elementwise_fma(hh, (f32x2){wh[l][2][i], wo[i8]}, p1);
-                            q0 = __builtin_elementwise_fma(hg, (f32x2){wh[l][0][i + 1], wh[l][1][i + 1]}, q0);
-                            q1 = __builtin_elementwise_fma(hg, (f32x2){wh[l][2][i + 1], wo[i8 + 1]}, q1);
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) {
+                                eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]);
+                                oh[g] = fmaf(hs[i8 + 1], wh[l][g][i + 1], oh[g]);
+                            }
+                            ei[2] = fmaf(hs[i8], wo[i8], ei[2]); oi[2] = fmaf(hs[i8 + 1], wo[i8 + 1], oi[2]);
                         }
                     }
                     if (hf == 0) __builtin_amdgcn_sched_barrier(0);  // second half's LDS reads stay behind the first half's FMAs
                 }
                 if (l < L - 1) {
                     constexpr int ln = (L > 1) ? 1 : 0;
-                    p0 += q0; p1 += q1; p2 += q2;
-                    a[0] = bih[ln][0] + quad_sum(p1.y); a[1] = bih[ln][1] + quad_sum(p2.x); a[2] = bih[ln][2] + quad_sum(p2.y);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) a[g] = bih[ln][g] + quad_sum(ei[g] + oi[g]);
                 } else {
-                    if (!row_ok) { p1.y = 0.f; q1.y = 0.f; }
-                    p0 += q0; p1 += q1;
-                    o = outb + quad_sum(p1.y);
+                    o = outb + quad_sum(row_ok ? ei[2] + oi[2] : 0.f);
                 }
-                cc[l][0] = bhh[l][0] + quad_sum(p0.x); cc[l][1] = bhh[l][1] + quad_sum(p0.y); cc[l][2] = bhh[l][2] + quad_sum(p1.x);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) cc[l][g] = bhh[l][g] + quad_sum(eh[g] + oh[g]);
                 VSDE_TP(5 + 4 * l);
             }
             // ---- emission (forward.py:314-375)
