@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libvsde_trace.so"
 src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in ("vsde_gemm.hip", "vsde_head.hip", "vsde_elbo.hip", "vsde_encoder.hip", "vsde_wgrad.hip", "vsde_attn.hip")]
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
 import viforsdes_amd.build as b
 b.LIB_PATH = so
 from viforsdes_amd import _hip

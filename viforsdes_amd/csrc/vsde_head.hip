@@ -1042,7 +1042,9 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 // ---- transposed products over this lane's j-slice, 8 j's at a time: with three 64x192 matrices in
                 //      registers there is no room to hold all 64 staged values of the slice at once (scratch spills)
                 const float *Dk = D + k0;
-                f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f}, pc = {0.f, 0.f};
+                // plain v_fma_f32 chains (v_pk_fma_f32 has no rate advantage on gfx950 and needs operand moves);
+                // l > 0: (acc_h, acc_i) per gate; l == 0: even / odd j per gate
+                float ax[3] = {0.f, 0.f, 0.f}, ay[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const float4 r0 = *(const float4 *)(Dk + 8 * hf), r1 = *(const float4 *)(Dk + 8 * hf + 4);
@@ -1051,33 +1053,33 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                     const float vr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
                     const float vu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
                     const float vc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                    if (l > 0) {  // (acc_h, acc_i) pairs
+                    if (l > 0) {
                         const float4 n0 = *(const float4 *)(Dk + 2 * H + 8 * hf), n1 = *(const float4 *)(Dk + 2 * H + 8 * hf + 4);
                         const float vn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
 #pragma unroll
                         for (int j8 = 0; j8 < 8; ++j8) {
                             const int jj = 8 * hf + j8;
-                            pa = __builtin_elementwise_fma((f32x2){vr[j8], vr[j8]}, (f32x2){whh[l][0][jj], wih[0][jj]}, pa);
-                            pb = __builtin_elementwise_fma((f32x2){vu[j8], vu[j8]}, (f32x2){whh[l][1][jj], wih[1][jj]}, pb);
-                            pc = __builtin_elementwise_fma((f32x2){vc[j8], vn[j8]}, (f32x2){whh[l][2][jj], wih[2][jj]}, pc);
+                            ax[0] = fmaf(vr[j8], whh[l][0][jj], ax[0]); ay[0] = fmaf(vr[j8], wih[0][jj], ay[0]);
+                            ax[1] = fmaf(vu[j8], whh[l][1][jj], ax[1]); ay[1] = fmaf(vu[j8], wih[1][jj], ay[1]);
+                            ax[2] = fmaf(vc[j8], whh[l][2][jj], ax[2]); ay[2] = fmaf(vn[j8], wih[2][jj], ay[2]);
                         }
-                    } else {      // even/odd j pairs
+                    } else {
 #pragma unroll
                         for (int j8 = 0; j8 < 8; j8 += 2) {
                             const int jj = 8 * hf + j8;
-                            pa = __builtin_elementwise_fma((f32x2){vr[j8], vr[j8 + 1]}, (f32x2){whh[0][0][jj], whh[0][0][jj + 1]}, pa);
-                            pb = __builtin_elementwise_fma((f32x2){vu[j8], vu[j8 + 1]}, (f32x2){whh[0][1][jj], whh[0][1][jj + 1]}, pb);
-                            pc = __builtin_elementwise_fma((f32x2){vc[j8], vc[j8 + 1]}, (f32x2){whh[0][2][jj], whh[0][2][jj + 1]}, pc);
+                            ax[0] = fmaf(vr[j8], whh[0][0][jj], ax[0]); ay[0] = fmaf(vr[j8 + 1], whh[0][0][jj + 1], ay[0]);
+                            ax[1] = fmaf(vu[j8], whh[0][1][jj], ax[1]); ay[1] = fmaf(vu[j8 + 1], whh[0][1][jj + 1], ay[1]);
+                            ax[2] = fmaf(vc[j8], whh[0][2][jj], ax[2]); ay[2] = fmaf(vc[j8 + 1], whh[0][2][jj + 1], ay[2]);
                         }
                     }
                     if (hf == 0) __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads behind the first half's FMAs
                 }
-                pa += pb; pa += pc;
+                const float sx = (ax[0] + ax[1]) + ax[2], sy = (ay[0] + ay[1]) + ay[2];
                 if (l > 0) {
-                    dh[l] = carry + quad_sum(pa.x);
-                    dcur = quad_sum(pa.y);
+                    dh[l] = carry + quad_sum(sx);
+                    dcur = quad_sum(sy);
                 } else {
-                    dh[0] = carry + quad_sum(pa.x + pa.y);
+                    dh[0] = carry + quad_sum(sx + sy);
                     if (lane < S) dxreg += dxp[lane] + dxp[16 + lane] + dxp[32 + lane] + dxp[48 + lane];
                 }
                 VSDE_TPB(25 + 3 * (L - 1 - l));
