@@ -13,6 +13,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import torch
 from torch import Tensor, nn
 
 from . import fused
@@ -100,12 +101,29 @@ class SiT(nn.Module):
         self.input_proj = init_linear_(nn.Linear(config.in_dim, config.hidden_dim, bias=config.bias))
         self.output_proj = init_linear_(nn.Linear(config.hidden_dim, config.out_dim, bias=config.bias))
 
+    def _all_modulations(self, cond: Tensor) -> list[tuple[Tensor, ...]]:
+        """adaLN parameters of every block.  All blocks see the same conditioning vector, so their (SiLU -> Linear) modulators
+        are one SiLU and ONE GEMM against the row-stacked weights (cached bf16 operand) instead of ``depth`` small ones, forward
+        and backward."""
+        nets = [blk._cond_modulator.net for blk in self.blocks]
+        lin = [n[1] for n in nets]
+        per = lin[0].weight.shape[0]
+        if (cond.is_cuda and cond.dtype == torch.bfloat16 and fused.ENABLED and all(isinstance(n[0], nn.SiLU) for n in nets)
+                and all(l.bias is not None for l in lin) and per % 8 == 0 and cond.shape[-1] % 8 == 0):
+            pack = getattr(self, "_mods_pack", None)
+            if pack is None or pack.weight.device != cond.device:
+                pack = fused.row_pack([l.weight for l in lin], [l.bias for l in lin])
+                object.__setattr__(self, "_mods_pack", pack)
+            allm = fused.packed_linear(torch.nn.functional.silu(cond), pack)
+            return [allm[:, k * per:(k + 1) * per].chunk(6, dim=-1) for k in range(len(lin))]
+        return [n(cond).chunk(6, dim=-1) for n in nets]
+
     def _forward_fused_chain(self, tokens: Tensor, cond: Tensor, rotary: RotarySpec) -> Tensor:
         """All blocks on the fused route, with every gated residual fused into the LayerNorm that follows it -- the second
         norm of the same block, and the first norm of the NEXT block (each stream tensor is then written once and read once
         per direction): LN1 | attn | [res1+LN2] | mlp | [res2+next LN1] | attn | ..."""
         blocks = self.blocks
-        mods = [blk._cond_modulator.net(cond).chunk(6, dim=-1) for blk in blocks]  # (sa, ha, ga, sm, hm, gm) per block
+        mods = self._all_modulations(cond)  # (sa, ha, ga, sm, hm, gm) per block
         h1 = fused.ln_modulate(tokens, mods[0][0], mods[0][1], blocks[0].attn_norm.eps)
         v0: Optional[Tensor] = None
         for k, blk in enumerate(blocks):
