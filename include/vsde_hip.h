@@ -149,28 +149,32 @@ int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, const float *x
  * Replaces the unfused torch chains of primitives/sit.py:99-128 (LayerNorm -> (1+scale)x+shift,
  * gate*branch residual), primitives/attn.py:80-113 (QK RMS-norm, RoPE, value-residual mix, head
  * layout, sigmoid output gate) and primitives/mlp.py:21-24 (SwiGLU activation). */
+/* mod_pitch: row pitch (elements) of the per-batch-row vectors scale / shift / gate AND of their gradient outputs; 0 = C
+ * (contiguous [B][C]).  A pitch > C lets all of them be column ranges of one [B][pitch] buffer -- the output of the single
+ * GEMM that produces every block's adaLN parameters, and its gradient -- with no copies in either direction. */
 int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
-                         float *rstd, int64_t B, int N, int C, double eps, void *stream);
+                         float *rstd, int64_t B, int N, int C, double eps, int64_t mod_pitch, void *stream);
 /* The two backward passes below also produce per-(batch row, channel) sums over the tokens (dscale/dshift, dgate);
  * they need vsde_colsum_workspace_bytes(B, C) bytes of device scratch for the fp32 partials. */
 size_t vsde_colsum_workspace_bytes(int64_t B, int C);
 /* dres (optional, [B][N][C]) is added to dx: the gradient reaching x through the residual branch */
 int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
                          const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B, int N, int C,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         int64_t mod_pitch, void *workspace, size_t workspace_bytes, void *stream);
 /* Gated residual fused with the LayerNorm-modulate that follows it (primitives/sit.py:73-79 + next norm):
  *   xnew = x + gate*y;  h = LN(xnew)*(1+scale) + shift.   Backward: dxnew (optional) is the gradient reaching xnew from its
  *   other consumers; dx = dxnew + LNbwd(dh) is the gradient of x, dy = gate*dx, dgate/dscale/dshift are token sums. */
 int vsde_residual_ln_fwd(int dtype, const void *x, const void *y, const void *gate, const void *scale, const void *shift,
-                         void *xnew, void *h, float *mean, float *rstd, int64_t B, int N, int C, double eps, void *stream);
+                         void *xnew, void *h, float *mean, float *rstd, int64_t B, int N, int C, double eps, int64_t mod_pitch,
+                         void *stream);
 int vsde_residual_ln_bwd(int dtype, const void *xnew, const void *y, const void *gate, const void *scale, const void *dh,
                          const void *dxnew, const float *mean, const float *rstd, void *dx, void *dy, void *dgate,
-                         void *dscale, void *dshift, int64_t B, int N, int C, void *workspace, size_t workspace_bytes,
-                         void *stream);
+                         void *dscale, void *dshift, int64_t B, int N, int C, int64_t mod_pitch, void *workspace,
+                         size_t workspace_bytes, void *stream);
 int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N, int C,
-                            void *stream);
+                            int64_t mod_pitch, void *stream);
 int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate, int64_t B,
-                            int N, int C, void *workspace, size_t workspace_bytes, void *stream);
+                            int N, int C, int64_t mod_pitch, void *workspace, size_t workspace_bytes, void *stream);
 int vsde_swiglu_fwd(int dtype, const void *u, void *out, int64_t M, int H2, void *stream);
 int vsde_swiglu_bwd(int dtype, const void *u, const void *dout, void *du, int64_t M, int H2, void *stream);
 /* token_major selects the memory layout of the per-head tensors (attn, dattn, q, k, v, v0, dq, dk, dv, dv0):

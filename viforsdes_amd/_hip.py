@@ -300,6 +300,25 @@ def _i64(v):
     return ctypes.c_int64(int(v))
 
 
+def _mod_pitch(C, *vecs):
+    """Common row pitch of per-batch-row vectors [B, C] (contiguous, or column ranges of one [B, pitch] buffer)."""
+    pitch = None
+    for v in vecs:
+        if v is None:
+            continue
+        if v.ndim != 2 or v.shape[1] != C or v.stride(1) != 1 or v.stride(0) < C:
+            raise ValueError(f"expected a [B,{C}] row-pitched vector, got shape {tuple(v.shape)} strides {v.stride()}")
+        if pitch is None:
+            pitch = v.stride(0)
+        elif v.stride(0) != pitch:
+            raise ValueError("scale / shift / gate and their gradient outputs must share one row pitch")
+    return pitch
+
+
+def _like_vec(v):
+    return torch.empty_strided(v.shape, v.stride(), device=v.device, dtype=v.dtype)
+
+
 def ln_modulate_fwd(x, scale, shift, eps):
     lib = load(); dev = _require_hip(x, scale, shift)
     B, N, C = x.shape
@@ -307,7 +326,7 @@ def ln_modulate_fwd(x, scale, shift, eps):
     mean = torch.empty(B, N, device=dev, dtype=torch.float32); rstd = torch.empty_like(mean)
     with torch.cuda.device(dev):
         _call(lib.vsde_ln_modulate_fwd, _dt(x), _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(mean), _ptr(rstd), _i64(B),
-              ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps), _stream(dev))
+              ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps), _i64(_mod_pitch(C, scale, shift)), _stream(dev))
     return y, mean, rstd
 
 
@@ -316,16 +335,19 @@ def _colsum_workspace(lib, B, C, dev):
     return torch.empty(max(int(nbytes), 1), device=dev, dtype=torch.uint8)
 
 
-def ln_modulate_bwd(x, scale, dy, mean, rstd, dres=None):
-    """dres (optional, same shape as x) is added to dx inside the kernel."""
+def ln_modulate_bwd(x, scale, dy, mean, rstd, dres=None, dscale=None, dshift=None):
+    """dres (optional, same shape as x) is added to dx inside the kernel; dscale / dshift: optional destinations with the row
+    pitch of ``scale`` (column ranges of a shared gradient buffer)."""
     lib = load(); dev = _require_hip(x, scale, dy)
     B, N, C = x.shape
-    dx = torch.empty_like(x); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
+    dx = torch.empty_like(x)
+    dscale = _like_vec(scale) if dscale is None else dscale
+    dshift = _like_vec(scale) if dshift is None else dshift
     ws = _colsum_workspace(lib, B, C, dev)
     with torch.cuda.device(dev):
         _call(lib.vsde_ln_modulate_bwd, _dt(x), _ptr(x), _ptr(scale), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-              _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()),
-              _stream(dev))
+              _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N), ctypes.c_int(C), _i64(_mod_pitch(C, scale, dscale, dshift)),
+              _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
     return dx, dscale, dshift
 
 
@@ -337,21 +359,25 @@ def residual_ln_fwd(x, y, gate, scale, shift, eps):
     mean = torch.empty(B * N, device=dev, dtype=torch.float32); rstd = torch.empty_like(mean)
     with torch.cuda.device(dev):
         _call(lib.vsde_residual_ln_fwd, _dt(x), _ptr(x), _ptr(y), _ptr(gate), _ptr(scale), _ptr(shift), _ptr(xnew), _ptr(h),
-              _ptr(mean), _ptr(rstd), _i64(B), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps), _stream(dev))
+              _ptr(mean), _ptr(rstd), _i64(B), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_double(eps),
+              _i64(_mod_pitch(C, gate, scale, shift)), _stream(dev))
     return xnew, h, mean, rstd
 
 
-def residual_ln_bwd(xnew, y, gate, scale, dh, dxnew, mean, rstd):
-    """(dx, dy, dgate, dscale, dshift); dxnew may be None."""
+def residual_ln_bwd(xnew, y, gate, scale, dh, dxnew, mean, rstd, dgate=None, dscale=None, dshift=None):
+    """(dx, dy, dgate, dscale, dshift); dxnew may be None; optional preallocated d-vector destinations (pitch of ``gate``)."""
     lib = load(); dev = _require_hip(xnew, y, gate, scale, dh)
     B, N, C = xnew.shape
     dx = torch.empty_like(xnew); dy = torch.empty_like(xnew)
-    dgate = torch.empty_like(gate); dscale = torch.empty_like(scale); dshift = torch.empty_like(scale)
+    dgate = _like_vec(gate) if dgate is None else dgate
+    dscale = _like_vec(scale) if dscale is None else dscale
+    dshift = _like_vec(scale) if dshift is None else dshift
     ws = _colsum_workspace(lib, B, C, dev)
     with torch.cuda.device(dev):
         _call(lib.vsde_residual_ln_bwd, _dt(xnew), _ptr(xnew), _ptr(y), _ptr(gate), _ptr(scale), _ptr(dh), _ptr(dxnew),
               _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dy), _ptr(dgate), _ptr(dscale), _ptr(dshift), _i64(B), ctypes.c_int(N),
-              ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
+              ctypes.c_int(C), _i64(_mod_pitch(C, gate, scale, dgate, dscale, dshift)), _ptr(ws), ctypes.c_size_t(ws.numel()),
+              _stream(dev))
     return dx, dy, dgate, dscale, dshift
 
 
@@ -361,18 +387,20 @@ def gated_residual_fwd(x, y, gate):
     out = torch.empty_like(x)
     with torch.cuda.device(dev):
         _call(lib.vsde_gated_residual_fwd, _dt(x), _ptr(x), _ptr(y), _ptr(gate), _ptr(out), _i64(B), ctypes.c_int(N),
-              ctypes.c_int(C), _stream(dev))
+              ctypes.c_int(C), _i64(_mod_pitch(C, gate)), _stream(dev))
     return out
 
 
-def gated_residual_bwd(y, gate, dout):
+def gated_residual_bwd(y, gate, dout, dgate=None):
     lib = load(); dev = _require_hip(y, gate, dout)
     B, N, C = y.shape
-    dy = torch.empty_like(y); dgate = torch.empty_like(gate)
+    dy = torch.empty_like(y)
+    dgate = _like_vec(gate) if dgate is None else dgate
     ws = _colsum_workspace(lib, B, C, dev)
     with torch.cuda.device(dev):
         _call(lib.vsde_gated_residual_bwd, _dt(y), _ptr(y), _ptr(gate), _ptr(dout), _ptr(dy), _ptr(dgate), _i64(B),
-              ctypes.c_int(N), ctypes.c_int(C), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
+              ctypes.c_int(N), ctypes.c_int(C), _i64(_mod_pitch(C, gate, dgate)), _ptr(ws), ctypes.c_size_t(ws.numel()),
+              _stream(dev))
     return dy, dgate
 
 

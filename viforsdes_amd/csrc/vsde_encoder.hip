@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
                                                          const T *__restrict__ shift, T *__restrict__ y,
                                                          float *__restrict__ mean, float *__restrict__ rstd, int64_t M,
                                                          int N, int C, float eps, const T *__restrict__ res_y,
-                                                         const T *__restrict__ res_gate, T *__restrict__ xnew) {
+                                                         const T *__restrict__ res_gate, T *__restrict__ xnew, int64_t mp) {
     // res_y != nullptr: the input of the norm is the gated residual x + gate * res_y, which is also written to xnew
     // (same rounding points as gated_residual followed by ln_modulate)
     const int lane = threadIdx.x & (LPR - 1);
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
             if (res_y) {
                 float ry[V], rg[V];
                 Pack<T, V>::load(res_y + m * C + (sl * LPR + lane) * V, ry);
-                Pack<T, V>::load(res_gate + b * C + (sl * LPR + lane) * V, rg);
+                Pack<T, V>::load(res_gate + b * mp + (sl * LPR + lane) * V, rg);
 #pragma unroll
                 for (int e = 0; e < V; ++e) v[sl][e] = rnd<T>(v[sl][e] + rnd<T>(rg[e] * ry[e]));
                 Pack<T, V>::store(xnew + m * C + (sl * LPR + lane) * V, v[sl]);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
         if (sl < nslab) {
             const int c = (sl * LPR + lane) * V;
             float sc[V], sh[V], o[V];
-            Pack<T, V>::load(scale + b * C + c, sc); Pack<T, V>::load(shift + b * C + c, sh);
+            Pack<T, V>::load(scale + b * mp + c, sc); Pack<T, V>::load(shift + b * mp + c, sh);
 #pragma unroll
             for (int e = 0; e < V; ++e) o[e] = (v[sl][e] - mu) * rs * (1.0f + sc[e]) + sh[e];
             Pack<T, V>::store(y + m * C + c, o);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
                                                          const float *__restrict__ rstd, const T *__restrict__ dres,
                                                          T *__restrict__ dx, float *__restrict__ part, int N, int C,
                                                          const T *__restrict__ res_y, const T *__restrict__ res_gate,
-                                                         T *__restrict__ res_dy) {
+                                                         T *__restrict__ res_dy, int64_t mp) {
     // res_y != nullptr: x is the output of a gated residual x0 + gate * res_y; dx is then also the gradient of x0, and the
     // kernel additionally writes res_dy = gate * dx and the partial sums of dx * res_y (part2: gradient of the gate)
     extern __shared__ float red[];
@@ -194,10 +194,10 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         if (sl < nslab) {
-            Pack<T, V>::load(scale + (int64_t)b * C + (sl * LPR + lane) * V, sc1[sl]);
+            Pack<T, V>::load(scale + (int64_t)b * mp + (sl * LPR + lane) * V, sc1[sl]);
 #pragma unroll
             for (int e = 0; e < V; ++e) sc1[sl][e] += 1.0f;
-            if (res_y) Pack<T, V>::load(res_gate + (int64_t)b * C + (sl * LPR + lane) * V, gt[sl]);
+            if (res_y) Pack<T, V>::load(res_gate + (int64_t)b * mp + (sl * LPR + lane) * V, gt[sl]);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) { a1[sl][e] = 0.f; a2[sl][e] = 0.f; a3[sl][e] = 0.f; }
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) ln_mod_bwd_kernel(const T *__restrict__ x
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gated_residual_bwd_kernel(const T *__restrict__ y, const T *__restrict__ gate,
                                                                  const T *__restrict__ dout, T *__restrict__ dy,
-                                                                 float *__restrict__ part, int N, int C) {
+                                                                 float *__restrict__ part, int N, int C, int64_t mp) {
     extern __shared__ float red[];
     const int lpt = C / V;                 // lanes per token
     const int slots = 256 / lpt;           // tokens in flight per block (threads beyond slots*lpt idle)
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) gated_residual_bwd_kernel(const T *__rest
     float gv[V], acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { gv[e] = 0.f; acc[e] = 0.f; }
-    if (live) Pack<T, V>::load(gate + (int64_t)b * C + lane * V, gv);
+    if (live) Pack<T, V>::load(gate + (int64_t)b * mp + lane * V, gv);
     if (live)
         for (int n = n0 + slot; n < n1; n += slots) {
             const int64_t o = ((int64_t)b * N + n) * C + lane * V;
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) gated_residual_bwd_kernel(const T *__rest
 // r_k[b][c] = sum_chunk part[k][b][chunk][c]  (k < nout), converted to T
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restrict__ part, T *__restrict__ r0, T *__restrict__ r1,
-                                                            T *__restrict__ r2, int64_t BC, int C, int nchunk) {
+                                                            T *__restrict__ r2, int64_t BC, int C, int nchunk, int64_t mp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BC) return;
     const int64_t b = i / C;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
         const float *p = part + ((int64_t)k * (BC / C) + b) * nchunk * C + c;
         float t = 0.f;
         for (int ch = 0; ch < nchunk; ++ch) t += p[(int64_t)ch * C];
-        outs[k][i] = from_f32<T>(t);
+        outs[k][b * mp + c] = from_f32<T>(t);
     }
 }
 
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
 template <typename T, int V>
 __global__ void __launch_bounds__(256) gated_residual_kernel(const T *__restrict__ x, const T *__restrict__ y,
                                                              const T *__restrict__ gate, T *__restrict__ out, int64_t total,
-                                                             int N, int C, int mode) {
+                                                             int N, int C, int mode, int64_t mp) {
     // mode 0: out = x + gate*y ; mode 1: out = gate * y   (backward: dy = gate * dout, x unused)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i0 < total; i0 += stride) {
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) gated_residual_kernel(const T *__restrict
         const int c = (int)(i0 - m * C);
         const int64_t b = m / N;
         float gv[V], yv[V], xv[V], o[V];
-        Pack<T, V>::load(gate + b * C + c, gv); Pack<T, V>::load(y + i0, yv);
+        Pack<T, V>::load(gate + b * mp + c, gv); Pack<T, V>::load(y + i0, yv);
         if (mode == 0) Pack<T, V>::load(x + i0, xv);
 #pragma unroll
         for (int e = 0; e < V; ++e) { const float g = gv[e] * yv[e]; o[e] = mode == 0 ? xv[e] + rnd<T>(g) : g; }
@@ -572,6 +572,7 @@ struct LnResidual {  // optional gated residual fused in front of the norm (forw
     const void *y = nullptr;     // residual branch [B][N][C]
     const void *gate = nullptr;  // [B][C]
     void *out = nullptr;         // forward: x + gate*y; backward: gate * dx
+    int64_t mp = 0;              // row pitch (elements) of scale / shift / gate and of their gradients; 0 = C (contiguous)
 };
 
 template <typename T>
@@ -588,12 +589,12 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
             dim3 grid((unsigned)((M + 256 / LPR - 1) / (256 / LPR)));                                                         \
             hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR, NS>), grid, block, 0, s, (const T *)x, (const T *)scale,         \
                                (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps, (const T *)res.y,                  \
-                               (const T *)res.gate, (T *)res.out);                                                            \
+                               (const T *)res.gate, (T *)res.out, res.mp ? res.mp : (int64_t)C);                              \
         } else {                                                                                                              \
             hipLaunchKernelGGL((ln_mod_bwd_kernel<T, V, LPR, NS>), dim3(colsum_chunks(B, N), (unsigned)B), block,                   \
                                256 * V * sizeof(float), s, (const T *)x, (const T *)scale, (const T *)shift_or_dy,            \
                                (const float *)mean, (const float *)rstd, (const T *)dres, (T *)out, part, N, C,               \
-                               (const T *)res.y, (const T *)res.gate, (T *)res.out);                                          \
+                               (const T *)res.y, (const T *)res.gate, (T *)res.out, res.mp ? res.mp : (int64_t)C);            \
         }                                                                                                                     \
     } while (0)
 #define LNM(V, LPR)                                                                                                           \
@@ -630,10 +631,16 @@ using namespace vsde;
         else { set_error("dtype must be 0 (f32) or 1 (bf16), got %d", (dtype)); return VSDE_E_BADARG; }      \
     } while (0)
 
+// per-batch-row vectors (scale, shift, gate and their gradients) may be column ranges of one wider [B][pitch] buffer
+#define MOD_PITCH_OK(mp, C) ((mp) == 0 || ((mp) >= (C) && (mp) % 8 == 0))
+
 extern "C" int vsde_ln_modulate_fwd(int dtype, const void *x, const void *scale, const void *shift, void *y, float *mean,
-                                    float *rstd, int64_t B, int N, int C, double eps, void *stream) {
-    VSDE_CHECK_ARG(x && scale && shift && y && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate arguments");
-    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, y, mean, rstd, nullptr, B, N, C, (float)eps, (hipStream_t)stream));
+                                    float *rstd, int64_t B, int N, int C, double eps, int64_t mod_pitch, void *stream) {
+    VSDE_CHECK_ARG(x && scale && shift && y && mean && rstd && B > 0 && N > 0 && MOD_PITCH_OK(mod_pitch, C), VSDE_E_BADARG,
+                   "bad ln_modulate arguments");
+    LnResidual res; res.mp = mod_pitch;
+    VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, y, mean, rstd, nullptr, B, N, C, (float)eps,
+                                                       (hipStream_t)stream, res));
 }
 
 extern "C" size_t vsde_colsum_workspace_bytes(int64_t B, int C) {
@@ -642,18 +649,20 @@ extern "C" size_t vsde_colsum_workspace_bytes(int64_t B, int C) {
 
 extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale, const void *dy, const float *mean,
                                     const float *rstd, const void *dres, void *dx, void *dscale, void *dshift, int64_t B,
-                                    int N, int C, void *workspace, size_t workspace_bytes, void *stream) {
-    VSDE_CHECK_ARG(x && scale && dy && mean && rstd && dx && dscale && dshift && B > 0 && N > 0, VSDE_E_BADARG, "bad ln_modulate_bwd arguments");
+                                    int N, int C, int64_t mod_pitch, void *workspace, size_t workspace_bytes, void *stream) {
+    VSDE_CHECK_ARG(x && scale && dy && mean && rstd && dx && dscale && dshift && B > 0 && N > 0 && MOD_PITCH_OK(mod_pitch, C),
+                   VSDE_E_BADARG, "bad ln_modulate_bwd arguments");
     VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C), VSDE_E_WORKSPACE,
                    "ln_modulate_bwd workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)workspace;
     VSDE_DTYPE_SWITCH(dtype, {
-        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dres, dx, (float *)mean, (float *)rstd, part, B, N, C, 0.f, s);
+        LnResidual res; res.mp = mod_pitch;
+        int rc = ln_mod_dispatch<T>(1, x, scale, dy, dres, dx, (float *)mean, (float *)rstd, part, B, N, C, 0.f, s, res);
         if (rc) return rc;
         const int64_t BC = B * C;
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dscale, (T *)dshift, (T *)nullptr, BC, C, colsum_chunks(B, N));
+                           (T *)dscale, (T *)dshift, (T *)nullptr, BC, C, colsum_chunks(B, N), mod_pitch ? mod_pitch : (int64_t)C);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -661,54 +670,57 @@ extern "C" int vsde_ln_modulate_bwd(int dtype, const void *x, const void *scale,
 
 extern "C" int vsde_residual_ln_fwd(int dtype, const void *x, const void *y, const void *gate, const void *scale, const void *shift,
                                     void *xnew, void *h, float *mean, float *rstd, int64_t B, int N, int C, double eps,
-                                    void *stream) {
-    VSDE_CHECK_ARG(x && y && gate && scale && shift && xnew && h && mean && rstd && B > 0 && N > 0, VSDE_E_BADARG,
-                   "bad residual_ln arguments");
-    LnResidual res; res.y = y; res.gate = gate; res.out = xnew;
+                                    int64_t mod_pitch, void *stream) {
+    VSDE_CHECK_ARG(x && y && gate && scale && shift && xnew && h && mean && rstd && B > 0 && N > 0 && MOD_PITCH_OK(mod_pitch, C),
+                   VSDE_E_BADARG, "bad residual_ln arguments");
+    LnResidual res; res.y = y; res.gate = gate; res.out = xnew; res.mp = mod_pitch;
     VSDE_DTYPE_SWITCH(dtype, return ln_mod_dispatch<T>(0, x, scale, shift, nullptr, h, mean, rstd, nullptr, B, N, C, (float)eps,
                                                        (hipStream_t)stream, res));
 }
 
 extern "C" int vsde_residual_ln_bwd(int dtype, const void *xnew, const void *y, const void *gate, const void *scale, const void *dh,
                                     const void *dxnew, const float *mean, const float *rstd, void *dx, void *dy, void *dgate,
-                                    void *dscale, void *dshift, int64_t B, int N, int C, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
-    VSDE_CHECK_ARG(xnew && y && gate && scale && dh && mean && rstd && dx && dy && dgate && dscale && dshift && B > 0 && N > 0,
-                   VSDE_E_BADARG, "bad residual_ln_bwd arguments");
+                                    void *dscale, void *dshift, int64_t B, int N, int C, int64_t mod_pitch, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    VSDE_CHECK_ARG(xnew && y && gate && scale && dh && mean && rstd && dx && dy && dgate && dscale && dshift && B > 0 && N > 0 &&
+                       MOD_PITCH_OK(mod_pitch, C), VSDE_E_BADARG, "bad residual_ln_bwd arguments");
     VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C), VSDE_E_WORKSPACE,
                    "residual_ln_bwd workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)workspace;
-    LnResidual res; res.y = y; res.gate = gate; res.out = dy;
+    LnResidual res; res.y = y; res.gate = gate; res.out = dy; res.mp = mod_pitch;
     VSDE_DTYPE_SWITCH(dtype, {
         int rc = ln_mod_dispatch<T>(1, xnew, scale, dh, dxnew, dx, (float *)mean, (float *)rstd, part, B, N, C, 0.f, s, res);
         if (rc) return rc;
         const int64_t BC = B * C;
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dscale, (T *)dshift, (T *)dgate, BC, C, colsum_chunks(B, N));
+                           (T *)dscale, (T *)dshift, (T *)dgate, BC, C, colsum_chunks(B, N), mod_pitch ? mod_pitch : (int64_t)C);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int vsde_gated_residual_fwd(int dtype, const void *x, const void *y, const void *gate, void *out, int64_t B, int N,
-                                       int C, void *stream) {
-    VSDE_CHECK_ARG(x && y && gate && out && C % 4 == 0, VSDE_E_BADARG, "bad gated_residual arguments");
-    const int64_t total = B * N * C;
+                                       int C, int64_t mod_pitch, void *stream) {
+    VSDE_CHECK_ARG(x && y && gate && out && C % 4 == 0 && MOD_PITCH_OK(mod_pitch, C), VSDE_E_BADARG, "bad gated_residual arguments");
+    const int64_t total = B * N * C, mp = mod_pitch ? mod_pitch : (int64_t)C;
     VSDE_DTYPE_SWITCH(dtype, {
         constexpr int VF = VecOf<T>::v;
         if (C % VF == 0) hipLaunchKernelGGL((gated_residual_kernel<T, VF>), dim3(ew_grid(total, 256 * VF)), dim3(256), 0, (hipStream_t)stream,
-                                            (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0);
+                                            (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0, mp);
         else hipLaunchKernelGGL((gated_residual_kernel<T, 4>), dim3(ew_grid(total, 1024)), dim3(256), 0, (hipStream_t)stream,
-                                (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0);
+                                (const T *)x, (const T *)y, (const T *)gate, (T *)out, total, N, C, 0, mp);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gate, const void *dout, void *dy, void *dgate,
-                                       int64_t B, int N, int C, void *workspace, size_t workspace_bytes, void *stream) {
-    VSDE_CHECK_ARG(y && gate && dout && dy && dgate && C % 4 == 0 && C <= 2048, VSDE_E_BADARG, "bad gated_residual_bwd arguments");
+                                       int64_t B, int N, int C, int64_t mod_pitch, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    VSDE_CHECK_ARG(y && gate && dout && dy && dgate && C % 4 == 0 && C <= 2048 && MOD_PITCH_OK(mod_pitch, C), VSDE_E_BADARG,
+                   "bad gated_residual_bwd arguments");
+    const int64_t mp = mod_pitch ? mod_pitch : (int64_t)C;
     VSDE_CHECK_ARG(workspace && workspace_bytes >= vsde_colsum_workspace_bytes(B, C) / 2, VSDE_E_WORKSPACE,
                    "gated_residual_bwd workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -719,12 +731,12 @@ extern "C" int vsde_gated_residual_bwd(int dtype, const void *y, const void *gat
         dim3 grid(colsum_chunks(B, N), (unsigned)B);
         if (C % VF == 0 && C / VF <= 256)
             hipLaunchKernelGGL((gated_residual_bwd_kernel<T, VF>), grid, dim3(256), 256 * VF * sizeof(float), s, (const T *)y,
-                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
+                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C, mp);
         else
             hipLaunchKernelGGL((gated_residual_bwd_kernel<T, 4>), grid, dim3(256), 256 * 4 * sizeof(float), s, (const T *)y,
-                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C);
+                               (const T *)gate, (const T *)dout, (T *)dy, part, N, C, mp);
         hipLaunchKernelGGL((colsum_finish_kernel<T>), dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, s, (const float *)part,
-                           (T *)dgate, (T *)nullptr, (T *)nullptr, BC, C, colsum_chunks(B, N));
+                           (T *)dgate, (T *)nullptr, (T *)nullptr, BC, C, colsum_chunks(B, N), mp);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;

@@ -117,6 +117,105 @@ def residual_norm(x: Tensor, y: Tensor, gate: Tensor, scale: Tensor, shift: Tens
     return _ResidualNorm.apply(x, y, gate, scale, shift, eps)
 
 
+class Modulations:
+    """The adaLN parameters of ALL blocks as one [B, depth*6*C] tensor (output of a single GEMM) plus the gradient buffer
+    that the consuming ops fill in place.
+
+    The ``*_m`` ops below read their scale / shift / gate straight out of ``allm`` (row pitch = its width: no chunk copies)
+    and their backward passes write dscale / dshift / dgate straight into ``grad``; the op that ran FIRST in the forward
+    pass (``final=True``: its backward runs last, everything downstream depends on it) hands ``grad`` to autograd as the
+    gradient of ``allm``.  Every chunk is consumed by exactly one op, so the buffer is complete at that point."""
+
+    def __init__(self, allm: Tensor, channels: int) -> None:
+        self.allm, self.C, self.grad = allm, channels, None
+
+    def vec(self, block: int, j: int) -> Tensor:
+        o = (6 * block + j) * self.C
+        return self.allm.detach()[:, o:o + self.C]
+
+    def gvec(self, block: int, j: int) -> Tensor:
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.allm)
+        o = (6 * block + j) * self.C
+        return self.grad[:, o:o + self.C]
+
+    def take_grad(self) -> Tensor:
+        g, self.grad = (self.grad if self.grad is not None else torch.zeros_like(self.allm)), None
+        return g
+
+
+class _LnModulateM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, allm, mods, sc, sh, eps, final):
+        x = x.contiguous()
+        y, mean, rstd = _hip.ln_modulate_fwd(x, mods.vec(*sc), mods.vec(*sh), eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.meta = (mods, sc, sh, final)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        mods, sc, sh, final = ctx.meta
+        dx, _, _ = _hip.ln_modulate_bwd(x, mods.vec(*sc), dy.to(x.dtype).contiguous(), mean, rstd, None,
+                                        dscale=mods.gvec(*sc), dshift=mods.gvec(*sh))
+        return dx, (mods.take_grad() if final else None), None, None, None, None, None
+
+
+class _ResidualNormM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, allm, mods, gt, sc, sh, eps):
+        x = x.contiguous(); y = y.to(x.dtype).contiguous()
+        xnew, h, mean, rstd = _hip.residual_ln_fwd(x, y, mods.vec(*gt), mods.vec(*sc), mods.vec(*sh), eps)
+        ctx.save_for_backward(xnew, y, mean, rstd)
+        ctx.meta = (mods, gt, sc, sh)
+        return xnew, h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dxnew, dh):
+        xnew, y, mean, rstd = ctx.saved_tensors
+        mods, gt, sc, sh = ctx.meta
+        dh = torch.zeros_like(xnew) if dh is None else dh.to(xnew.dtype).contiguous()
+        dxnew = None if dxnew is None else dxnew.to(xnew.dtype).contiguous()
+        dx, dy, _, _, _ = _hip.residual_ln_bwd(xnew, y, mods.vec(*gt), mods.vec(*sc), dh, dxnew, mean, rstd,
+                                               dgate=mods.gvec(*gt), dscale=mods.gvec(*sc), dshift=mods.gvec(*sh))
+        return dx, dy, None, None, None, None, None, None
+
+
+class _GatedResidualM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, allm, mods, gt):
+        x = x.contiguous(); y = y.to(x.dtype).contiguous()
+        ctx.save_for_backward(y)
+        ctx.meta = (mods, gt)
+        return _hip.gated_residual_fwd(x, y, mods.vec(*gt))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        mods, gt = ctx.meta
+        dout = dout.to(y.dtype).contiguous()
+        dy, _ = _hip.gated_residual_bwd(y, mods.vec(*gt), dout, dgate=mods.gvec(*gt))
+        return dout, dy, None, None, None
+
+
+def ln_modulate_m(x: Tensor, mods: Modulations, scale: tuple[int, int], shift: tuple[int, int], eps: float, final: bool = False) -> Tensor:
+    """``ln_modulate`` with scale / shift = chunks ``(block, j)`` of ``mods`` (see ``Modulations``)."""
+    return _LnModulateM.apply(x, mods.allm, mods, scale, shift, eps, final)
+
+
+def residual_norm_m(x: Tensor, y: Tensor, mods: Modulations, gate: tuple[int, int], scale: tuple[int, int], shift: tuple[int, int],
+                    eps: float) -> tuple[Tensor, Tensor]:
+    return _ResidualNormM.apply(x, y, mods.allm, mods, gate, scale, shift, eps)
+
+
+def gated_residual_m(x: Tensor, y: Tensor, mods: Modulations, gate: tuple[int, int]) -> Tensor:
+    return _GatedResidualM.apply(x, y, mods.allm, mods, gate)
+
+
 class _SwiGLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u):

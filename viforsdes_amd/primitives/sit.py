@@ -101,42 +101,55 @@ class SiT(nn.Module):
         self.input_proj = init_linear_(nn.Linear(config.in_dim, config.hidden_dim, bias=config.bias))
         self.output_proj = init_linear_(nn.Linear(config.hidden_dim, config.out_dim, bias=config.bias))
 
-    def _all_modulations(self, cond: Tensor) -> list[tuple[Tensor, ...]]:
-        """adaLN parameters of every block.  All blocks see the same conditioning vector, so their (SiLU -> Linear) modulators
-        are one SiLU and ONE GEMM against the row-stacked weights (cached bf16 operand) instead of ``depth`` small ones, forward
-        and backward."""
+    def _packed_modulations(self, cond: Tensor) -> Optional["fused.Modulations"]:
+        """adaLN parameters of every block from ONE GEMM.  All blocks see the same conditioning vector, so their
+        (SiLU -> Linear) modulators are one SiLU and one product against the row-stacked weights (cached bf16 operand); the
+        result stays one [B, depth*6*C] tensor that the fused ops index by column range (``fused.Modulations``)."""
         nets = [blk._cond_modulator.net for blk in self.blocks]
         lin = [n[1] for n in nets]
         per = lin[0].weight.shape[0]
-        if (cond.is_cuda and cond.dtype == torch.bfloat16 and fused.ENABLED and all(isinstance(n[0], nn.SiLU) for n in nets)
-                and all(l.bias is not None for l in lin) and per % 8 == 0 and cond.shape[-1] % 8 == 0):
-            pack = getattr(self, "_mods_pack", None)
-            if pack is None or pack.weight.device != cond.device:
-                pack = fused.row_pack([l.weight for l in lin], [l.bias for l in lin])
-                object.__setattr__(self, "_mods_pack", pack)
-            allm = fused.packed_linear(torch.nn.functional.silu(cond), pack)
-            return [allm[:, k * per:(k + 1) * per].chunk(6, dim=-1) for k in range(len(lin))]
-        return [n(cond).chunk(6, dim=-1) for n in nets]
+        C = self.config.hidden_dim
+        if not (cond.is_cuda and cond.dtype == torch.bfloat16 and fused.ENABLED and all(isinstance(n[0], nn.SiLU) for n in nets)
+                and all(l.bias is not None and l.weight.shape[0] == 6 * C for l in lin) and C % 8 == 0 and cond.shape[-1] % 8 == 0):
+            return None
+        pack = getattr(self, "_mods_pack", None)
+        if pack is None or pack.weight.device != cond.device:
+            pack = fused.row_pack([l.weight for l in lin], [l.bias for l in lin])
+            object.__setattr__(self, "_mods_pack", pack)
+        return fused.Modulations(fused.packed_linear(torch.nn.functional.silu(cond), pack), C)
 
     def _forward_fused_chain(self, tokens: Tensor, cond: Tensor, rotary: RotarySpec) -> Tensor:
         """All blocks on the fused route, with every gated residual fused into the LayerNorm that follows it -- the second
         norm of the same block, and the first norm of the NEXT block (each stream tensor is then written once and read once
         per direction): LN1 | attn | [res1+LN2] | mlp | [res2+next LN1] | attn | ..."""
         blocks = self.blocks
-        mods = self._all_modulations(cond)  # (sa, ha, ga, sm, hm, gm) per block
-        h1 = fused.ln_modulate(tokens, mods[0][0], mods[0][1], blocks[0].attn_norm.eps)
+        nb = len(blocks)
+        mods = self._packed_modulations(cond)
+        SA, HA, GA, SM, HM, GM = range(6)  # chunk order of a block's modulator output (primitives/sit.py:72)
+        if mods is None:
+            ml = [blk._cond_modulator.net(cond).chunk(6, dim=-1) for blk in blocks]
+            h1 = fused.ln_modulate(tokens, ml[0][SA], ml[0][HA], blocks[0].attn_norm.eps)
+        else:
+            h1 = fused.ln_modulate_m(tokens, mods, (0, SA), (0, HA), blocks[0].attn_norm.eps, final=True)
         v0: Optional[Tensor] = None
         for k, blk in enumerate(blocks):
-            _, _, ga, sm, hm, gm = mods[k]
             attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0)
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
-            x1, h2 = fused.residual_norm(tokens, attn_out, ga, sm, hm, blk.mlp_norm.eps)
-            mlp_out = blk.mlp(h2)
-            if k + 1 < len(blocks):
-                tokens, h1 = fused.residual_norm(x1, mlp_out, gm, mods[k + 1][0], mods[k + 1][1], blocks[k + 1].attn_norm.eps)
+            if mods is None:
+                x1, h2 = fused.residual_norm(tokens, attn_out, ml[k][GA], ml[k][SM], ml[k][HM], blk.mlp_norm.eps)
             else:
-                tokens = fused.gated_residual(x1, mlp_out, gm)
+                x1, h2 = fused.residual_norm_m(tokens, attn_out, mods, (k, GA), (k, SM), (k, HM), blk.mlp_norm.eps)
+            mlp_out = blk.mlp(h2)
+            if k + 1 < nb:
+                eps = blocks[k + 1].attn_norm.eps
+                if mods is None:
+                    tokens, h1 = fused.residual_norm(x1, mlp_out, ml[k][GM], ml[k + 1][SA], ml[k + 1][HA], eps)
+                else:
+                    tokens, h1 = fused.residual_norm_m(x1, mlp_out, mods, (k, GM), (k + 1, SA), (k + 1, HA), eps)
+            else:
+                tokens = (fused.gated_residual(x1, mlp_out, ml[k][GM]) if mods is None
+                          else fused.gated_residual_m(x1, mlp_out, mods, (k, GM)))
         return tokens
 
     def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None) -> Tensor:
