@@ -24,7 +24,7 @@ def main():
             step()
         torch.cuda.synchronize()
     print(prof.key_averages(group_by_input_shape=True).table(
-        sort_by="self_cuda_time_total", row_limit=50, max_name_column_width=45, max_shapes_column_width=80))
+        sort_by="self_cuda_time_total", row_limit=int(os.environ.get("OPPROF_ROWS", "50")), max_name_column_width=45, max_shapes_column_width=80))
 
 
 if __name__ == "__main__":
