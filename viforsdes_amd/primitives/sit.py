@@ -124,6 +124,7 @@ class SiT(nn.Module):
         per direction): LN1 | attn | [res1+LN2] | mlp | [res2+next LN1] | attn | ..."""
         blocks = self.blocks
         nb = len(blocks)
+        tokens = tokens.contiguous()  # a broadcast input is materialised once, not by each consumer
         mods = self._packed_modulations(cond)
         SA, HA, GA, SM, HM, GM = range(6)  # chunk order of a block's modulator output (primitives/sit.py:72)
         if mods is None:
@@ -153,7 +154,11 @@ class SiT(nn.Module):
         return tokens
 
     def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None) -> Tensor:
-        tokens = self.input_proj(x)
+        if x.ndim == 3 and x.stride(0) == 0 and x.shape[0] > 1:
+            # the same token sequence for every batch row (the observation grid): project it once, then broadcast
+            tokens = self.input_proj(x[0]).unsqueeze(0).expand(x.shape[0], -1, -1)
+        else:
+            tokens = self.input_proj(x)
         if all(block.fusable(tokens, cond, rotary) for block in self.blocks):
             return fused.linear(self._forward_fused_chain(tokens, cond, rotary), self.output_proj.weight, self.output_proj.bias)
         v0: Optional[Tensor] = None
