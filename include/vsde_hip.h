@@ -194,7 +194,9 @@ int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, int d);
 int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq, const float *wk,
                           const void *v0, const float *lam, const void *dq, const void *dk, const void *dv, void *dqkv,
                           void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d, double eps, int token_major,
-                          int64_t row_stride, void *stream);
+                          int64_t row_stride, int dv0_accumulate, const void *dv_extra, void *stream);
+/* dv0_accumulate != 0: dv0 += (1-lam) dv (all blocks' value-residual gradients collect in one buffer); dv_extra (optional,
+ * layout of dv) is added to dv first -- the block that produced v0 gets that buffer next to its own attention's dv. */
 
 /* Attention core for the encoder's shape class (bf16, head_dim 64, N <= vsde_attention_max_tokens() so that K and V of
  * one (batch, head) stay in LDS):  o = softmax(scale * q k^T) v  with q, k, v, o token-major [B][N][H][64];

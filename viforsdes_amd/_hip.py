@@ -481,8 +481,10 @@ def qk_norm_rope_fwd(qkv, cos, sin, wq, wk, v0, lam, heads, eps, token_major=Fal
     return q, k, v
 
 
-def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, token_major=False, dqkv=None):
-    """dqkv: optional preallocated destination with the same row pitch as qkv (a column range of a shared buffer)."""
+def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, token_major=False, dqkv=None, dv0=None,
+                     dv_extra=None):
+    """dqkv: optional preallocated destination with the same row pitch as qkv (a column range of a shared buffer);
+    dv0: optional existing buffer to ACCUMULATE the value-residual gradient into; dv_extra: added to dv first."""
     lib = load(); dev = _require_hip(qkv, dq, dk, dv)
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
@@ -491,13 +493,16 @@ def qk_norm_rope_bwd(qkv, cos, sin, wq, wk, v0, lam, dq, dk, dv, heads, eps, tok
         dqkv = torch.empty_like(qkv) if qkv.is_contiguous() else torch.empty_strided(qkv.shape, qkv.stride(), device=dev, dtype=qkv.dtype)
     if _row_pitch(dqkv, C3) != pitch:
         raise ValueError("dqkv must have the row pitch of qkv")
-    dv0 = torch.empty_like(dv) if v0 is not None else None
+    accumulate = dv0 is not None
+    if v0 is not None and dv0 is None:
+        dv0 = torch.empty_like(dv)
     nparts = lib.vsde_qk_norm_rope_bwd_partials(_i64(B), ctypes.c_int(N), ctypes.c_int(heads), ctypes.c_int(d))
     parts = torch.empty(nparts, device=dev, dtype=torch.float32) if v0 is not None else None
     with torch.cuda.device(dev):
         _call(lib.vsde_qk_norm_rope_bwd, _dt(qkv), _ptr(qkv), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(dv0), _ptr(parts), _i64(B), ctypes.c_int(N), ctypes.c_int(heads),
-              ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _i64(pitch), _stream(dev))
+              ctypes.c_int(d), ctypes.c_double(eps), ctypes.c_int(int(token_major)), _i64(pitch), ctypes.c_int(int(accumulate)),
+              _ptr(dv_extra), _stream(dev))
     dlam = parts.sum() if parts is not None else None
     return dqkv, dv0, dlam
 

@@ -492,7 +492,10 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
                                                                const T *__restrict__ dk, const T *__restrict__ dv,
                                                                T *__restrict__ dqkv, T *__restrict__ dv0,
                                                                float *__restrict__ dlam_partial, int64_t M, int N, int heads, int d,
-                                                               float eps, int token_major, int64_t rstride) {
+                                                               float eps, int token_major, int64_t rstride, int dv0_accumulate,
+                                                               const T *__restrict__ dv_extra) {
+    // dv0_accumulate: dv0 += (1 - lam) dv instead of dv0 = ... (the value-residual gradient of all blocks collects in ONE buffer);
+    // dv_extra: added to dv first (block 0 receives that buffer next to the gradient of its own attention)
     __shared__ float red[4];
     const int half = d >> 1, C = heads * d, tph = half / PV, TPT = heads * tph;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,6 +524,12 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
             for (int e = 0; e < PV; ++e) { gy[2 * t][e] = g0[e] * cs[e] + g1[e] * sn[e]; gy[2 * t + 1][e] = -g0[e] * sn[e] + g1[e] * cs[e]; }  // inverse rotation
         }
         Pack<T, PV>::load(dv + o, g0); Pack<T, PV>::load(dv + o + half, g1);
+        if (dv_extra) {
+            float e0[PV], e1[PV];
+            Pack<T, PV>::load(dv_extra + o, e0); Pack<T, PV>::load(dv_extra + o + half, e1);
+#pragma unroll
+            for (int e = 0; e < PV; ++e) { g0[e] = rnd<T>(g0[e] + e0[e]); g1[e] = rnd<T>(g1[e] + e1[e]); }
+        }
         if (v0) {
             const float l = lam[0];
             float a0[PV], a1[PV], p0[PV], p1[PV], z0[PV], z1[PV];
@@ -530,6 +539,12 @@ __global__ void __launch_bounds__(256) qk_norm_rope_bwd_kernel(const T *__restri
             for (int e = 0; e < PV; ++e) {
                 dlam += g0[e] * (a0[e] - p0[e]) + g1[e] * (a1[e] - p1[e]);
                 z0[e] = (1.0f - l) * g0[e]; z1[e] = (1.0f - l) * g1[e]; g0[e] *= l; g1[e] *= l;
+            }
+            if (dv0_accumulate) {
+                float y0[PV], y1[PV];
+                Pack<T, PV>::load(dv0 + o, y0); Pack<T, PV>::load(dv0 + o + half, y1);
+#pragma unroll
+                for (int e = 0; e < PV; ++e) { z0[e] = y0[e] + rnd<T>(z0[e]); z1[e] = y1[e] + rnd<T>(z1[e]); }
             }
             Pack<T, PV>::store(dv0 + o, z0); Pack<T, PV>::store(dv0 + o + half, z1);
         }
@@ -842,7 +857,8 @@ extern "C" int64_t vsde_qk_norm_rope_bwd_partials(int64_t B, int N, int heads, i
 extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const float *sinT, const float *wq,
                                      const float *wk, const void *v0, const float *lam, const void *dq, const void *dk,
                                      const void *dv, void *dqkv, void *dv0, float *dlam_partial, int64_t B, int N, int heads, int d,
-                                     double eps, int token_major, int64_t row_stride, void *stream) {
+                                     double eps, int token_major, int64_t row_stride, int dv0_accumulate, const void *dv_extra,
+                                     void *stream) {
     VSDE_CHECK_ARG(qkv && cosT && sinT && wq && wk && dq && dk && dv && dqkv && (!v0 || (lam && dv0 && dlam_partial)) &&
                        row_stride >= 3 * (int64_t)heads * d, VSDE_E_BADARG,
                    "bad qk_norm_rope_bwd arguments");
@@ -854,11 +870,11 @@ extern "C" int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *co
         if (pv == 4) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                         (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                        (float)eps, token_major, row_stride);
+                                        (float)eps, token_major, row_stride, dv0_accumulate, (const T *)dv_extra);
         else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<T, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                                 (hipStream_t)stream, (const T *)qkv, cosT, sinT, wq, wk, (const T *)v0, lam, (const T *)dq,
                                 (const T *)dk, (const T *)dv, (T *)dqkv, (T *)dv0, v0 ? dlam_partial : nullptr, B * N, N, heads, d,
-                                (float)eps, token_major, row_stride);
+                                (float)eps, token_major, row_stride, dv0_accumulate, (const T *)dv_extra);
     });
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;

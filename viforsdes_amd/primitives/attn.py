@@ -57,7 +57,8 @@ class Attention(nn.Module):
                 and not self.q_norm.weight.requires_grad and not self.k_norm.weight.requires_grad
                 and fused.usable(hidden_states, self.embed_dim, self.head_dim))
 
-    def forward_fused(self, hidden_states: Tensor, *, rotary: RotarySpec, v0: Optional[Tensor]) -> tuple[Tensor, Tensor]:
+    def forward_fused(self, hidden_states: Tensor, *, rotary: RotarySpec, v0: Optional[Tensor],
+                      v0link: Optional["fused.GradLink"] = None) -> tuple[Tensor, Tensor]:
         """Same map as ``forward(..., return_value=True)`` with the elementwise chains as fused HIP ops:
         qkv GEMM -> [RMS + RoPE + value mix + head layout] -> SDPA -> [sigmoid gate + merge heads] -> out GEMM.
 
@@ -86,7 +87,7 @@ class Attention(nn.Module):
         q, k, v = fused.attention_projection_split(y, cos, sin, self.q_norm.weight, self.k_norm.weight,
                                                    v0.transpose(1, 2) if mix else None,
                                                    self.v_residual_lambda if mix else None, self.num_heads,
-                                                   self.q_norm.eps, True, link)
+                                                   self.q_norm.eps, True, link, v0link)
         if fused.attention_usable(q):
             out_tm = fused.attention(q, k, v, self.head_dim ** -0.5)  # token-major in, token-major out
         else:

@@ -284,35 +284,43 @@ class _GateMergeJoint(torch.autograd.Function):
 
 class _QkNormRopeJoint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, cos, sin, wq, wk, v0, lam, heads, eps, token_major, width, link):
+    def forward(ctx, y, cos, sin, wq, wk, v0, lam, heads, eps, token_major, width, link, v0link):
         v0c = v0.to(y.dtype).contiguous() if v0 is not None else None
         lamc = lam.detach().float().reshape(1).contiguous() if lam is not None else None
         q, k, v = _hip.qk_norm_rope_fwd(y[..., :width], cos, sin, wq, wk, v0c, lamc, heads, eps, token_major)
         ctx.save_for_backward(y, cos, sin, wq, wk, v0c, lamc)
-        ctx.meta = (heads, eps, lam.dtype if lam is not None else None, token_major, width, link)
+        ctx.meta = (heads, eps, lam.dtype if lam is not None else None, token_major, width, link, v0link)
         return q, k, v
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dq, dk, dv):
         y, cos, sin, wq, wk, v0, lam = ctx.saved_tensors
-        heads, eps, lam_dtype, token_major, width, link = ctx.meta
+        heads, eps, lam_dtype, token_major, width, link, v0link = ctx.meta
         dy = link.take()
         if dy is None:  # the gate branch did not take part in this backward pass
             dy = torch.zeros_like(y)
         c = lambda t: t.to(y.dtype).contiguous()
+        # value-residual gradient: every consumer block adds its share into ONE buffer (v0link) inside its kernel and reports
+        # None; the block that produced v0 (v0 is None here) runs last and folds the buffer into its own dv
+        acc = v0link.value if (v0link is not None and v0 is not None) else None
+        extra = v0link.take() if (v0link is not None and v0 is None) else None
         _, dv0, dlam = _hip.qk_norm_rope_bwd(y[..., :width], cos, sin, wq, wk, v0, lam, c(dq), c(dk), c(dv), heads, eps,
-                                             token_major, dqkv=dy[..., :width])
+                                             token_major, dqkv=dy[..., :width], dv0=acc, dv_extra=extra)
+        if v0link is not None and v0 is not None:
+            v0link.value, dv0 = dv0, None
         if dlam is not None:
             dlam = dlam.to(lam_dtype).reshape(())
-        return dy, None, None, None, None, dv0, dlam, None, None, None, None, None
+        return dy, None, None, None, None, dv0, dlam, None, None, None, None, None, None
 
 
 def attention_projection_split(y: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor],
-                               lam: Optional[Tensor], heads: int, eps: float, token_major: bool, link: GradLink):
-    """(q, k, v) from the first 3C columns of the merged [qkv | gate] projection ``y`` [B,N,3C+d]."""
+                               lam: Optional[Tensor], heads: int, eps: float, token_major: bool, link: GradLink,
+                               v0link: Optional[GradLink] = None):
+    """(q, k, v) from the first 3C columns of the merged [qkv | gate] projection ``y`` [B,N,3C+d].  ``v0link``: shared by
+    the block that produces the residual values (called with ``v0=None``) and every block that mixes them in."""
     d = y.shape[-1] // (3 * heads + 1)
-    return _QkNormRopeJoint.apply(y.contiguous(), cos, sin, wq, wk, v0, lam, heads, eps, token_major, 3 * heads * d, link)
+    return _QkNormRopeJoint.apply(y.contiguous(), cos, sin, wq, wk, v0, lam, heads, eps, token_major, 3 * heads * d, link, v0link)
 
 
 def gate_merge_joint(attn: Tensor, y: Tensor, heads: int, token_major: bool, link: GradLink) -> Tensor:

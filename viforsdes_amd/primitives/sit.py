@@ -133,8 +133,9 @@ class SiT(nn.Module):
         else:
             h1 = fused.ln_modulate_m(tokens, mods, (0, SA), (0, HA), blocks[0].attn_norm.eps, final=True)
         v0: Optional[Tensor] = None
+        v0link = fused.GradLink() if self.config.attn_residual_v else None  # one buffer for the value-residual gradient
         for k, blk in enumerate(blocks):
-            attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0)
+            attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0, v0link=v0link)
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
             if mods is None:
