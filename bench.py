@@ -257,6 +257,11 @@ def main():
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(args.workload, args.batch),
                      "avg_ms": fwd_ms_avg, "algorithmic_bytes": fwd_bytes, "bytes_per_path_step": fwd_bytes_step,
+                     # SURVEY 8(d) prices the forward with the raw C-float context read (4*[C + S + 2S + S^2 + ntril + 5LH]); this
+                     # kernel streams the 3H-float projected record instead (the context itself is read by the projection GEMM)
+                     "survey_bytes_per_path_step": 4 * (C + S + (2 * S + S * S + ntril) + 5 * L * H),
+                     "frac_with_survey_bytes": 4 * (C + S + (2 * S + S * S + ntril) + 5 * L * H) * args.batch * T
+                                               / (fwd_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "bwd_kernel_avg_ms": bwd_ms_avg,
                      "bwd_achieved_GBs": bwd_bytes_step * args.batch * T / (bwd_ms_avg * 1e-3) / 1e9},
     }

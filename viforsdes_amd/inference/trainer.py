@@ -315,5 +315,28 @@ class VariationalInferenceTrainer:
             return value, finite, med, snap_p[0].clone()
         return replay
 
+    # ------------------------------------------------------------------------- resumable state
+    def training_state_dict(self) -> dict:
+        """Everything needed to continue an interrupted run bit-for-bit on the same hardware: parameters, EMA shadow, AdamW
+        moments, loss-scaler state and the RNG streams (additive: the reference checkpoints parameters and EMA only,
+        ``posterior/variational_posterior.py:150-192``)."""
+        ctx = self.ctx
+        state = {"model": ctx.model.state_dict(), "ema": ctx.ema.state_dict(), "optimizer": ctx.optimizer.state_dict(),
+                 "scaler": ctx.scaler.state_dict(), "rng_cpu": torch.get_rng_state()}
+        if ctx.device.type == "cuda":
+            state["rng_cuda"] = torch.cuda.get_rng_state(ctx.device)
+        return state
+
+    def load_training_state_dict(self, state: dict) -> None:
+        ctx = self.ctx
+        ctx.model.load_state_dict(state["model"])
+        for name, t in state["ema"].items():
+            ctx.ema.shadow[name].copy_(t)
+        ctx.optimizer.load_state_dict(state["optimizer"])
+        ctx.scaler.load_state_dict(state["scaler"])
+        torch.set_rng_state(state["rng_cpu"])
+        if ctx.device.type == "cuda" and "rng_cuda" in state:
+            torch.cuda.set_rng_state(state["rng_cuda"], ctx.device)
+
     def cleanup(self) -> None:
         self.ctx.cleanup()
