@@ -63,10 +63,10 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
 
 def pmc_traffic_bytes(workload, batch):
     """HBM bytes per launch of the serial forward kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_head_lv.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512).  The
+    (profiles/r01_pmc_head_lv_v2.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512).  The
     kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
     counter is used; null for other workloads."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_head_lv.txt")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_head_lv_v2.txt")
     if workload != "lv" or batch != 512 or not os.path.exists(path):
         return None
     vals = {}
