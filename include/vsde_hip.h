@@ -109,6 +109,11 @@ typedef struct vsde_head_grads {
     float *W_ih_l0, *W_hh_l0, *b_ih_l0, *b_hh_l0;
     float *W_ih_stack, *W_hh_stack, *b_ih_stack, *b_hh_stack; /* unused when L == 1 */
     float *out_weight, *out_bias;
+    /* placement of the context gradient (0, 0 = fp32 [B][T][C] contiguous): dtype 1 writes bf16 through the same pointer;
+     * a batch stride (elements, >= T*C) lets it be the leading T rows of every slab of a [B][T+1][C] buffer, i.e. the
+     * gradient of the encoder output itself, whose last token the head never reads (diffusion_path_sampler.py:66). */
+    int context_dtype;
+    int64_t context_batch_stride;
 } vsde_head_grads;
 
 size_t vsde_head_backward_workspace_bytes(const vsde_head_dims *d);

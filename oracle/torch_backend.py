@@ -37,13 +37,18 @@ class OracleBackend:
                 self._t(f.chol_raw) if save else None, self._t(f.acts) if save else None)
 
     def head_backward(self, g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, acts, ws, time_step,
-                      diag_min=vo.DIAG_MIN):
+                      diag_min=vo.DIAG_MIN, context_grad_out=None):
         w = vo.HeadWeights(*[_np(t, self.dtype) for t in ws])
         f = vo.FwdResult(_np(paths, self.dtype), None, None, _np(chol_raw, self.dtype), _np(acts, self.dtype))
         g = vo.head_backward(_np(g_paths, self.dtype), _np(g_means, self.dtype), _np(g_chol, self.dtype),
                              _np(ctx, self.dtype), _np(theta, self.dtype), _np(eps, self.dtype), f, w, float(time_step),
                              self.dtype, diag_min)
-        return tuple(self._t(a) for a in g)
+        out = [self._t(a) for a in g]
+        if context_grad_out is not None:  # same contract as _hip.head_backward: first T steps, caller's dtype
+            T = out[1].shape[1]
+            context_grad_out[:, :T].copy_(out[1])
+            out[1] = context_grad_out
+        return tuple(out)
 
     def elbo_path_terms(self, z, x, means, chol, drift, diffusion, positive_dims, time_step):
         out = vo.elbo_path_terms(*[_np(t, self.dtype) for t in (z, x, means, chol, drift, diffusion)],

@@ -43,7 +43,8 @@ class _CtxView(ctypes.Structure):
 class _Grads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "x0", "context", "theta", "W_ih_l0", "W_hh_l0", "b_ih_l0", "b_hh_l0",
-        "W_ih_stack", "W_hh_stack", "b_ih_stack", "b_hh_stack", "out_weight", "out_bias")]
+        "W_ih_stack", "W_hh_stack", "b_ih_stack", "b_hh_stack", "out_weight", "out_bias")] + [
+        ("context_dtype", ctypes.c_int), ("context_batch_stride", ctypes.c_int64)]
 
 
 EXPORTS = (
@@ -190,8 +191,12 @@ def head_forward(x0, ctx, theta, eps, ws, time_step: float, save: bool, diag_min
 
 
 def head_backward(g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, acts, ws,
-                  time_step: float, diag_min: float = DIAG_MIN):
-    """-> 13 fp32 gradients in launch_bwd order (reference kernels/backward.py:766-784)."""
+                  time_step: float, diag_min: float = DIAG_MIN, context_grad_out=None):
+    """-> 13 fp32 gradients in launch_bwd order (reference kernels/backward.py:766-784).
+
+    ``context_grad_out``: optional contiguous [B, T+1, C] (f32 or bf16) tensor; the context gradient is then written
+    straight into its first T steps (in its dtype) and returned in place of the fp32 [B,T,C] tensor; its last step is
+    the caller's to zero."""
     lib = load()
     dev = _require_hip(g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, acts, *ws)
     g_paths = _f32c(g_paths); g_means = _f32c(g_means); g_chol = _f32c(g_chol)
@@ -206,7 +211,15 @@ def head_backward(g_paths, g_means, g_chol, ctx, theta, eps, paths, chol_raw, ac
         mk = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         g = [mk(B, S), mk(B, T, C), mk(B, P), mk(3 * H, S + C + P), mk(3 * H, H), mk(3 * H), mk(3 * H),
              mk(L - 1, 3 * H, H), mk(L - 1, 3 * H, H), mk(L - 1, 3 * H), mk(L - 1, 3 * H), mk(NO, H), mk(NO)]
-        gstruct = _Grads(*[_ptr(t) for t in g])
+        cdt, cbs = 0, 0
+        if context_grad_out is not None:
+            o = context_grad_out
+            if (not o.is_contiguous() or o.ndim != 3 or o.shape[0] != B or o.shape[1] < T or o.shape[2] != C
+                    or o.dtype not in (torch.float32, torch.bfloat16) or o.device != dev):
+                raise ValueError("context_grad_out must be a contiguous [B, >=T, C] f32/bf16 tensor on the same device")
+            g[1] = o
+            cdt, cbs = int(o.dtype == torch.bfloat16), o.shape[1] * C
+        gstruct = _Grads(*[_ptr(t) for t in g], cdt, cbs)
         nbytes = lib.vsde_head_backward_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
             _raise(-1)

@@ -119,7 +119,7 @@ __device__ __forceinline__ float wave_sum_of_quads(float v) {
 // ---- GEMM launchers (vsde_gemm.hip) ----------------------------------------------------
 // C[m][n] = sum_k A(m,k) * Bt[n][k] (+ bias[n]);  Bt row-major [N][K] with leading dim ldb.
 int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int N, const float *bias,
-                   float *C, int64_t ldc, hipStream_t stream);
+                   float *C, int64_t ldc, hipStream_t stream, int out_rpb = 0, int64_t out_bstride = 0, int out_dtype = 0);
 
 // Grouped "X^T Y" reductions over the row index:  out[n][col_off + k] = sum_m X(m,n) * Y(m,k)
 // and, when bias_out != nullptr, bias_out[n] = sum_m X(m,n).

@@ -38,6 +38,11 @@ struct NtParams {
     int64_t ldc;
     int a_vec;  // A rows may be read with 16-byte (f32) / 8-byte (bf16) vector loads
     int b_vec;
+    // output placement: row m = b*out_rpb + t lands at C + b*out_bstride + t*ldc when out_rpb > 0 (lets the result be the
+    // leading T rows of every [T+1, N] batch slab); out_dtype 0 = f32, 1 = bf16 (round to nearest even)
+    int out_rpb;
+    int64_t out_bstride;
+    int out_dtype;
 };
 
 __device__ __forceinline__ float4 load_a4(const RowView &A, int64_t off, bool valid, int k, int K, int vec) {
@@ -123,7 +128,17 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int m = m_blk + 16 * wave + 4 * fq + r;
-            if (m < p.M) p.C[(int64_t)m * p.ldc + n] = acc[nt][r] + bias;
+            if (m < p.M) {
+                int64_t off = (int64_t)m * p.ldc;
+                if (p.out_rpb > 0) { const int bb = m / p.out_rpb; off = (int64_t)bb * p.out_bstride + (int64_t)(m - bb * p.out_rpb) * p.ldc; }
+                const float val = acc[nt][r] + bias;
+                if (p.out_dtype == 0) p.C[off + n] = val;
+                else {
+                    uint32_t u = __float_as_uint(val);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    ((uint16_t *)p.C)[off + n] = (uint16_t)(u >> 16);
+                }
+            }
         }
     }
 }
@@ -135,10 +150,11 @@ static bool rowview_vec_ok(const RowView &v, int K) {
 }
 
 int launch_gemm_nt(const RowView &A, int M, int K, const float *Bt, int ldb, int N, const float *bias,
-                   float *C, int64_t ldc, hipStream_t stream) {
+                   float *C, int64_t ldc, hipStream_t stream, int out_rpb, int64_t out_bstride, int out_dtype) {
     if (M <= 0 || N <= 0) return 0;
     NtParams p;
     p.A = A; p.M = M; p.K = K; p.N = N; p.Bt = Bt; p.ldb = ldb; p.bias = bias; p.C = C; p.ldc = ldc;
+    p.out_rpb = out_rpb; p.out_bstride = out_bstride; p.out_dtype = out_dtype;
     p.a_vec = rowview_vec_ok(A, K) ? 1 : 0;
     p.b_vec = ((uintptr_t)Bt % 16 == 0 && ldb % 4 == 0) ? 1 : 0;
     dim3 grid((M + NT_BM - 1) / NT_BM, (N + NT_BN - 1) / NT_BN);

@@ -1743,7 +1743,11 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     // grad_context[m][c] = sum_n d_pre0(m, n) W_ih_l0[n][S + c]   (backward.py:550-564)
     RowView dv; dv.base = p.D4; dv.batch_stride = (int64_t)d->T * d->L * 4 * d->H; dv.row_stride = (int64_t)d->L * 4 * d->H;
     dv.rows_per_batch = d->T; dv.shift = 0; dv.col_split = 3 * d->H; dv.col_skip = 0; dv.dtype = 0;
-    rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s);
+    VSDE_CHECK_ARG(g->context_dtype == 0 || g->context_dtype == 1, VSDE_E_BADARG, "grads->context_dtype must be 0 (f32) or 1 (bf16)");
+    VSDE_CHECK_ARG(g->context_batch_stride == 0 || g->context_batch_stride >= (int64_t)d->T * d->C, VSDE_E_BADARG,
+                   "grads->context_batch_stride smaller than T*C");
+    rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s,
+                        g->context_batch_stride ? d->T : 0, g->context_batch_stride, g->context_dtype);
     if (rc) return rc;
 
     TnProblem pr[kMaxTnProblems];

@@ -36,5 +36,9 @@ def sample_diffusion_paths(encoder: EncoderProtocol, head: HeadProtocol, observa
     elif tuple(noise.shape) != (B, n_steps, S):
         raise ValueError(f"noise must have shape {(B, n_steps, S)}, got {tuple(noise.shape)}")
     z0 = state_space.to_latent(x0)
-    paths, means, chol = head.sample_diffusion_paths(z0, context[:, :-1], sde_parameters, noise, time_step)
+    if getattr(head, "accepts_full_context", False):  # our head: reads the first T steps in place, gradient written in place
+        paths, means, chol = head.sample_diffusion_paths(z0, context, sde_parameters, noise, time_step,
+                                                         context_has_extra_step=True)
+    else:
+        paths, means, chol = head.sample_diffusion_paths(z0, context[:, :-1], sde_parameters, noise, time_step)
     return DiffusionPathSample(z=paths, transition_means=means, transition_cholesky=chol, state_space=state_space)

@@ -68,9 +68,20 @@ class DiffusionTransitionHead(nn.Module):
         return first + tuple(torch.stack([getattr(g, f"{kind}_l{k}") for k in upper])
                              for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
 
+    accepts_full_context = True  # sample_diffusion_paths(..., context_has_extra_step=True) takes the encoder output unsliced
+
     def sample_diffusion_paths(self, x0: Tensor, context: Tensor, sde_parameters: Tensor, standard_noise: Tensor,
-                               time_step: float) -> tuple[Tensor, Tensor, Tensor]:
-        """``(paths[B,T+1,S], transition_means[B,T,S], transition_cholesky[B,T,S,S])``."""
+                               time_step: float, context_has_extra_step: bool = False) -> tuple[Tensor, Tensor, Tensor]:
+        """``(paths[B,T+1,S], transition_means[B,T,S], transition_cholesky[B,T,S,S])``.
+
+        ``context_has_extra_step`` (additive): ``context`` is ``[B, T+1, C]`` and only its first T steps are used -- what
+        the sampler has anyway (``diffusion_path_sampler.py:66`` slices ``[:, :-1]``); saves the slice's backward copy."""
+        if self.training and context_has_extra_step:
+            return _SDEFunction.apply(x0, context, sde_parameters, standard_noise, time_step, self.hidden_dim,
+                                      self.context_dim, self.sde_param_dim, self.state_dim, self.num_layers,
+                                      *self._extract_gru_weights(), self.out_proj.weight, self.out_proj.bias, True)
+        if context_has_extra_step:
+            context = context[:, :-1]
         if self.training:
             return _SDEFunction.apply(x0, context, sde_parameters, standard_noise, time_step, self.hidden_dim,
                                       self.context_dim, self.sde_param_dim, self.state_dim, self.num_layers,
