@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *(uint32_t *)&r;
 }
 
-__global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
+__global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     uint16_t *Ks = asmem;                      // [npad][AT_KLD]
     uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
@@ -57,16 +57,17 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
     const uint16_t *qb = p.q + base, *kb = p.k + base, *vb = p.v + base;
     // ---- stage K [key][d] and V^T [d][key]: every global load of the workgroup is issued before the first use -----
-    constexpr int KIT = (AT_MAXN * 8 + 511) / 512, VIT = (AT_MAXN + 511) / 512;
+    constexpr int NT = 768, NW = NT / 64;
+    constexpr int KIT = (AT_MAXN * 8 + NT - 1) / NT, VIT = (AT_MAXN + NT - 1) / NT;
     uint4 kreg[KIT], vreg[VIT][8];
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        const int i = tid + it * NT, n = i >> 3, c = i & 7;
         kreg[it] = (i < npad * 8 && n < N) ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {  // (npad/8 key blocks) x (8 d-chunks); lanes c = 0..7 read one full 128-byte row
-        const int i = tid + it * 512, kblk = i >> 3, c = i & 7;
+        const int i = tid + it * NT, kblk = i >> 3, c = i & 7;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int n = kblk * 8 + j;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     float kss_max = 0.f;  // max_j |k_j|^2 (8 adjacent lanes hold one key row)
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        const int i = tid + it * NT, n = i >> 3, c = i & 7;
         if (i < npad * 8) *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
         const uint32_t w[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
         float ss = 0.f;
@@ -90,11 +91,11 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kss_max = fmaxf(kss_max, __shfl_xor(kss_max, off, 64));
-    __shared__ float kred[8];
+    __shared__ float kred[NW];
     if (lane == 0) kred[wave] = kss_max;
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
-        const int i = tid + it * 512, kblk = i >> 3, c = i & 7;
+        const int i = tid + it * NT, kblk = i >> 3, c = i & 7;
         uint4 ct[8];
         transpose8x8(vreg[it], ct);
         if (i < npad) {
@@ -108,13 +109,13 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(AttnParams p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 8; ++w) kss_max = fmaxf(kss_max, kred[w]);
+    for (int w = 0; w < NW; ++w) kss_max = fmaxf(kss_max, kred[w]);
     const float kmax = sqrtf(kss_max);
 
     const int fr = lane & 31, h2 = lane >> 5;
     const int nkt = npad >> 5, nqb = npad >> 5;
     const bool ragged = (N & 31) != 0;
-    for (int qblk = wave; qblk < nqb; qblk += 8) {
+    for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int query = qblk * 32 + fr;
         const bool qok = query < N;
         bf16x8 qf[4];  // B operand of S^T = K Q^T: column = query, k = d
@@ -480,7 +481,7 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(768), lds, (hipStream_t)stream, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
