@@ -831,15 +831,16 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 // the kernel's output), one workgroup barrier per layer.  All global traffic (saved activations,
 // upstream gradients in; D4/DO out) is staged per chunk of CH steps as contiguous bursts.
 struct BwdV2Lds {
-    int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, total;
+    int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, wxl, total;
 };
-__host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool two_act_buffers = false) {
+__host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool two_act_buffers = false, bool wide = false) {
     const int ntril = S * (S + 1) / 2, NO = S + ntril;
     BwdV2Lds o; int off = 0;
     auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
     o.acts = take((two_act_buffers ? 2 : 1) * (CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
     o.gp = take(CH * S); o.gm = take(CH * S); o.gl = take(CH * S * S); o.raw = take(CH * ntril); o.eps = take(CH * S);
     o.owl = take(NO * 64); o.dxp = take(4 * 16);
+    o.wxl = take(wide ? S * 3 * 64 : 0);  // wide variant: state rows of W_ih_l0 live in LDS
     o.total = off;
     return o;
 }
@@ -847,7 +848,10 @@ __host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool
 // SS > 0: compile-time state dimension (loops over S / NO unroll).  DMA: the saved-activation records of the next
 // (earlier) chunk are copied global -> LDS by global_load_lds_dwordx4 into a second buffer while the current chunk's time
 // steps run (no registers, no wait until the chunk boundary); needs 16-byte aligned records (H % 4 == 0).
-template <int L, int CH, int SS, bool DMA>
+// WIDE: up to 64 emission rows / 16 state dims (e.g. S = 8: NO = 44).  The rows are spread over the four waves
+// (row = 16*wave + quad) instead of replicated in every wave, so the emission gradients cross waves through the staged dO
+// record (one more barrier per step) and the state rows of W_ih_l0 come from LDS instead of registers.
+template <int L, int CH, int SS, bool DMA, bool WIDE = false>
 __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     static_assert(L >= 1 && L <= 2, "v2 keeps at most three 64x192 matrices in registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -858,13 +862,13 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     const int S = SS > 0 ? SS : p.S, ntril = SS > 0 ? SS * (SS + 1) / 2 : p.ntril, NO = SS > 0 ? SS + SS * (SS + 1) / 2 : p.NO;
     const int I = S + p.C + p.P;
     const bool unit_ok = i_unit < H;
-    const int orow = u;                       // every wave owns all emission rows (NO <= 16)
+    const int orow = WIDE ? 16 * wave + u : u;  // !WIDE: every wave owns all emission rows (NO <= 16)
     const bool row_ok = orow < NO;
-    const BwdV2Lds lay = bwd_v2_lds(H, S, L, CH, DMA);
+    const BwdV2Lds lay = bwd_v2_lds(H, S, L, CH, DMA, WIDE);
     float *s_acts = smem + lay.acts, *s_d4 = smem + lay.d4, *s_dO = smem + lay.dO;
     float *const acts_buf0 = smem + lay.acts;
     float *s_gp = smem + lay.gp, *s_gm = smem + lay.gm, *s_gl = smem + lay.gl, *s_raw = smem + lay.raw, *s_eps = smem + lay.eps;
-    float *owl = smem + lay.owl, *dxp = smem + lay.dxp;
+    float *owl = smem + lay.owl, *dxp = smem + lay.dxp, *wxl = smem + lay.wxl;
     const int REC = L * 5 * H, DREC = L * 4 * H;
     // For H < 64 a lane's 16-wide j-slice can reach past the H valid entries of a staged record; its
     // weights are zero there, so the data only has to be finite: start from an all-zero LDS image.
@@ -894,7 +898,12 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int i = 0; i < kMaxSRegV2; ++i) wxr[i][g] = (unit_ok && i < S) ? p.W_ih0[(int64_t)(g * H + i_unit) * I + i] : 0.f;
+        for (int i = 0; i < kMaxSRegV2; ++i) wxr[i][g] = (!WIDE && unit_ok && i < S) ? p.W_ih0[(int64_t)(g * H + i_unit) * I + i] : 0.f;
+    if (WIDE)
+        for (int e = tid; e < S * 3 * 64; e += 256) {  // wxl[i][g][unit]
+            const int un = e & 63, g = (e >> 6) % 3, i = e / 192;
+            wxl[e] = un < H ? p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
+        }
     int trow = 0, tcol = 0;
     if (orow >= S && orow < NO) {
         int q = orow - S, r = 0;
@@ -933,10 +942,13 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     };
     // upstream gradients / eps / raw factors of a chunk: a few hundred floats, one or two per thread, prefetched in registers
     const int small_per_step = 3 * S + S * S + ntril;
-    float sv[3] = {0.f, 0.f, 0.f};  // CH * (3S + S^2 + ntril) <= 16 * 38 floats
+    constexpr int NSV = WIDE ? 8 : 3;  // CH * (3S + S^2 + ntril) floats: <= 16 * 38 (S <= 4), <= 2048 in the wide variant
+    float sv[NSV];
+#pragma unroll
+    for (int q = 0; q < NSV; ++q) sv[q] = 0.f;
     auto small_issue = [&](int t0, int n) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NSV; ++q) {
             const int e = tid + 256 * q;
             float v = 0.f;
             if (e < n * small_per_step) {
@@ -952,7 +964,7 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     };
     auto small_commit = [&](int n) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NSV; ++q) {
             const int e = tid + 256 * q;
             if (e < n * small_per_step) {
                 int r = e;
@@ -1005,11 +1017,16 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 if (is_diag && !(raw >= p.diag_min || dL < 0.f)) dL = 0.f;  // bounds.py:20 / backward.py:331-334
                 dO = dL;
             }
-            if (wave == 0 && kq == 0 && row_ok) s_dO[tt * NO + orow] = dO;
+            if ((WIDE || wave == 0) && kq == 0 && row_ok) s_dO[tt * NO + orow] = dO;
             VSDE_TPB(21);
             float dcur = 0.f;  // d h_top[i] = sum_r dO_r out_W[r][i]
-            for (int r = 0; r < NO; ++r)
-                dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
+            if (WIDE) {
+                __syncthreads();  // the rows live in different waves: exchange through the staged record
+                for (int r = 0; r < NO; ++r) dcur = fmaf(s_dO[tt * NO + r], owl[r * 64 + i_unit], dcur);
+            } else {
+                for (int r = 0; r < NO; ++r)
+                    dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
+            }
             VSDE_TPB(22);
 
 #pragma unroll
@@ -1027,12 +1044,21 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 if (l == 0) {
                     spi[0] += dr_pre; spi[1] += du_pre; spi[2] += dn_pre;
                     // d z_t += W_ih_l0[:, state rows]^T . d_pre (backward.py:494-509): per-wave partial sums
-#pragma unroll
-                    for (int i = 0; i < kMaxSRegV2; ++i) {
-                        if (i < S) {
-                            float v = wxr[i][0] * dr_pre + wxr[i][1] * du_pre + wxr[i][2] * dn_pre;
-                            v = wave_sum_of_quads(v);  // the four lanes of a quad hold identical values
+                    if (WIDE) {
+                        for (int i = 0; i < S; ++i) {
+                            const float *wx = wxl + i * 192 + i_unit;
+                            float v = wx[0] * dr_pre + wx[64] * du_pre + wx[128] * dn_pre;
+                            v = wave_sum_of_quads(v);
                             if (lane == 0) dxp[wave * 16 + i] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kMaxSRegV2; ++i) {
+                            if (i < S) {
+                                float v = wxr[i][0] * dr_pre + wxr[i][1] * du_pre + wxr[i][2] * dn_pre;
+                                v = wave_sum_of_quads(v);  // the four lanes of a quad hold identical values
+                                if (lane == 0) dxp[wave * 16 + i] = v;
+                            }
                         }
                     }
                 }
@@ -1656,7 +1682,37 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
         hipLaunchKernelGGL(head_bwd_wide_kernel, dim3(d->B), dim3(block), ldsw, s, p, d->L);
         VSDE_CHECK_HIP(hipGetLastError());
         rc = 0;
-    } else if (d->L <= 2 && NO <= 16 && !g_force_v1) {
+    } else if (d->L <= 2 && (d->H % 4) == 0 && (NO > 16 || d->S > kMaxSRegV2) && d->S <= 16 && !g_force_v1) {
+        // wide variant: emission rows spread over the waves (NO <= 64 here), always with LDS-DMA activation chunks;
+        // one workgroup per CU is acceptable when the staging does not fit in half the LDS
+        p.wpb = 1;
+        const int cand[3] = {16, 10, 8};
+        int ch = 0;
+        for (int pass = 0; pass < 2 && !ch; ++pass)
+            for (int q = 0; q < 3 && !ch; ++q)
+                if ((size_t)bwd_v2_lds(d->H, d->S, d->L, cand[q], true, true).total * sizeof(float) <= (pass == 0 ? 80u : 150u) * 1024) ch = cand[q];
+        VSDE_CHECK_ARG(ch != 0, VSDE_E_STATE, "LDS budget exceeded for the wide backward kernel");
+        const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch, true, true).total * sizeof(float);
+#define VSDE_LAUNCH_BWD_WIDE(LL, CC)                                                                                \
+    do {                                                                                                            \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)head_bwd_v2_kernel<LL, CC, 0, true, true>,                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        prof_mark(1, 0, s);                                                                                         \
+        hipLaunchKernelGGL((head_bwd_v2_kernel<LL, CC, 0, true, true>), dim3(d->B), dim3(256), lds2, s, p);         \
+        prof_mark(1, 1, s);                                                                                         \
+    } while (0)
+#define VSDE_LAUNCH_BWD_WIDE_C(LL)                                                                                  \
+    do {                                                                                                            \
+        if (ch == 16) VSDE_LAUNCH_BWD_WIDE(LL, 16);                                                                 \
+        else if (ch == 10) VSDE_LAUNCH_BWD_WIDE(LL, 10);                                                            \
+        else VSDE_LAUNCH_BWD_WIDE(LL, 8);                                                                           \
+    } while (0)
+        if (d->L == 1) VSDE_LAUNCH_BWD_WIDE_C(1); else VSDE_LAUNCH_BWD_WIDE_C(2);
+#undef VSDE_LAUNCH_BWD_WIDE_C
+#undef VSDE_LAUNCH_BWD_WIDE
+        VSDE_CHECK_HIP(hipGetLastError());
+        rc = 0;
+    } else if (d->L <= 2 && NO <= 16 && d->S <= kMaxSRegV2 && !g_force_v1) {
         p.wpb = 1;
         // DMA variant (16-byte aligned activation records): two activation buffers, chunk from {16, 10, 8}
         const bool dma = (d->H % 4) == 0;
