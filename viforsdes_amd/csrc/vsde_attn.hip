@@ -312,21 +312,22 @@ __device__ __forceinline__ void store_transposed(uint16_t *row, int h2, const f3
 }
 
 // ---- staging of whole row-major operands [npad][64] -> LDS [npad][AT_KLD]; all global loads issued before first use ---
-constexpr int AT_SIT = (AT_MAXN * 8 + 511) / 512;  // 16-byte chunks per thread and operand
+constexpr int AT_BT = 768;                                 // threads of a backward workgroup (12 waves: 3 per SIMD)
+constexpr int AT_SIT = (AT_MAXN * 8 + AT_BT - 1) / AT_BT;  // 16-byte chunks per thread and operand
 
 __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2, int64_t ts, int N, int npad, int tid,
                                           uint16_t *sa, uint16_t *sb) {
     uint4 ra[AT_SIT], rb[AT_SIT];
 #pragma unroll
     for (int it = 0; it < AT_SIT; ++it) {
-        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        const int i = tid + it * AT_BT, n = i >> 3, c = i & 7;
         const bool ok = i < npad * 8 && n < N;
         ra[it] = ok ? *(const uint4 *)(a + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
         rb[it] = ok ? *(const uint4 *)(b2 + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < AT_SIT; ++it) {
-        const int i = tid + it * 512, n = i >> 3, c = i & 7;
+        const int i = tid + it * AT_BT, n = i >> 3, c = i & 7;
         if (i < npad * 8) {
             *(uint4 *)(sa + n * AT_KLD + c * 8) = ra[it];
             *(uint4 *)(sb + n * AT_KLD + c * 8) = rb[it];
@@ -340,7 +341,7 @@ __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2,
 // first round's before the operand staging, the next round's before the tile loop -- and only waited for at use.
 
 // dq: one workgroup per (batch, head); K and V resident in LDS, a wavefront owns 32 queries at a time.
-__global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
+__global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
@@ -362,7 +363,8 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
     __syncthreads();
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
-    for (int qblk = wave; qblk < p.ntile; qblk += 8) {
+    for (int qblk = wave; qblk < p.ntile; qblk += AT_BT / 64) {
+        if (qblk != wave) request(qblk);  // later rounds are rare with 12 waves (N <= 384 needs none): fetch on demand
         const int query = qblk * 32 + fr;
         const bool qok = query < N;
         bf16x8 qf[4], dof[4];
@@ -377,7 +379,6 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
         dsum += __shfl_xor(dsum, 32, 64);
         const float lse2 = lsen * 1.4426950408889634f;
         if (qok && h2 == 0) p.delta[srow + query] = dsum;
-        request(qblk + 8);
         f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll 1
         for (int kt = 0; kt < p.ntile; ++kt) {
@@ -401,7 +402,7 @@ __global__ void __launch_bounds__(512) attn_bwd_dq_kernel(AttnBwdParams p) {
 }
 
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
-__global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(AttnBwdParams p) {
+__global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
@@ -418,19 +419,19 @@ __global__ void __launch_bounds__(512) attn_bwd_dkv_kernel(AttnBwdParams p) {
     };
     request(wave);
     stage_two(p.q + base, p.dout + base, ts, N, npad, tid, Qs, Os);
-    for (int i = tid; i < npad; i += 512) {  // padded queries: lse = +inf -> P = 0
+    for (int i = tid; i < npad; i += AT_BT) {  // padded queries: lse = +inf -> P = 0
         lse2s[i] = i < N ? p.lse[srow + i] * 1.4426950408889634f : INFINITY;
         dels[i] = i < N ? p.delta[srow + i] : 0.f;
     }
     __syncthreads();
     const float c2 = p.scale_log2e;
-    for (int kblk = wave; kblk < p.ntile; kblk += 8) {
+    for (int kblk = wave; kblk < p.ntile; kblk += AT_BT / 64) {
+        if (kblk != wave) request(kblk);
         const int key = kblk * 32 + fr;
         const bool kok = key < N;
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
-        request(kblk + 8);
         f32x16 dk0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
 #pragma unroll 1
         for (int qt = 0; qt < p.ntile; ++qt) {
@@ -504,8 +505,8 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);   // also writes delta, read by the next kernel
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(512), lds_dkv, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);   // also writes delta, read by the next kernel
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
