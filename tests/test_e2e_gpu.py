@@ -1,4 +1,6 @@
 """GPU end-to-end: autograd boundary (_SDEFunction), head module, trainer trajectory, sampling."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -125,3 +127,41 @@ def test_infer_end_to_end_small_ou(tmp_path):
     fresh = VariationalSDEPosterior(1, 1, 3, cfg.encoder, cfg.head, tp)
     again = VariationalPosterior.load(tmp_path / "p.pt", fresh, prior, obs, torch.device(DEV))
     assert again.summary(32).diffusion_path_mean.shape == (101, 1)
+
+
+def test_flat_gradient_allreduce_over_rccl_single_rank():
+    """The multi-GPU gradient path on one device: pack -> all-reduce over the nccl (= RCCL) backend -> .grad views -> fused
+    capturable AdamW.  One rank cannot test the exchange itself, but it does catch API / dtype / stream errors of the path the
+    driver's multi-GPU runs take."""
+    import socket
+    import torch.distributed as dist
+    from viforsdes_amd.inference.data_parallel import FlatGradientAllReduce
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.SiLU(), torch.nn.Linear(128, 8)).to(DEV)
+        frozen = torch.nn.Parameter(torch.ones(3, device=DEV))  # never receives a gradient: its slot must read zero
+        params = list(net.parameters()) + [frozen]
+        sync = FlatGradientAllReduce(params, force_buffer=True)
+        opt = torch.optim.AdamW(params, lr=1e-2, fused=True, capturable=True)
+        x = torch.randn(32, 64, device=DEV)
+        sync.zero_grad()
+        net(x).square().mean().backward()
+        ref = [p.grad.clone() for p in net.parameters()]
+        sync.all_reduce()
+        dist.barrier()
+        for p, r in zip(net.parameters(), ref):
+            assert p.grad.data_ptr() >= sync.flat.data_ptr() and torch.equal(p.grad, r)
+        assert torch.count_nonzero(frozen.grad) == 0
+        before = [p.detach().clone() for p in net.parameters()]
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        torch.cuda.synchronize()
+        assert all(not torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    finally:
+        dist.destroy_process_group()

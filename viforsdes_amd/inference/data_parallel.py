@@ -53,7 +53,7 @@ class FlatGradientAllReduce:
     is all-reduced in at most ``max_buckets`` pieces and ``.grad`` is re-pointed at its views (what unscale / clip / the
     optimizer then read)."""
 
-    def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2) -> None:
+    def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2, force_buffer: bool = False) -> None:
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -62,7 +62,8 @@ class FlatGradientAllReduce:
         self.flat: Optional[Tensor] = None
         self._views: list[Tensor] = []
         self.buckets: list[Tensor] = []
-        if self.world_size > 1:
+        self.active = self.world_size > 1 or force_buffer  # force_buffer: exercise the packed path on one rank (tests)
+        if self.active:
             self._allocate()
 
     def _allocate(self) -> None:
@@ -90,7 +91,7 @@ class FlatGradientAllReduce:
 
     @torch.no_grad()
     def all_reduce(self) -> None:
-        if self.world_size <= 1:
+        if not self.active:
             return
         have = [(v, p.grad) for p, v in zip(self.params, self._views) if p.grad is not None]
         missing = [v for p, v in zip(self.params, self._views) if p.grad is None]
