@@ -267,3 +267,49 @@ def theta_log_probs(theta, q_mean, q_log_std, positive_dims, prior_is_lognormal,
        _p(_mask(positive_dims, P)), ctypes.c_int(int(bool(prior_is_lognormal))),
        ctypes.c_double(prior_mean), ctypes.c_double(prior_std), _p(prior_lp), _p(post_lp))
     return prior_lp, post_lp
+
+
+def head_steps_teacher_forced(paths, acts, ctx, theta, eps, w: HeadWeights, dt: float, diag_min: float = DIAG_MIN):
+    """One-step-ahead ("teacher-forced") float64 evaluation of the head, vectorised over (B, T).
+
+    Step t of forward.py:195-365 is re-evaluated from a GIVEN history -- z_t = ``paths[:, t]`` and
+    h^l_{t-1} = ``acts[:, t-1, l, 0]`` (zeros at t = 0, forward.py:143) -- instead of the oracle's own, so a
+    kernel's per-step arithmetic can be scored without the error amplification of a free-running path.
+    Returns (acts_ref [B,T,L,5,H], means_ref [B,T,S], chol_raw_ref [B,T,ntril], next_ref [B,T,S]) where
+    ``next_ref[:, t]`` is z_{t+1} computed from z_t with the Euler-Maruyama update (forward.py:352-365)."""
+    f8 = np.float64
+    paths = np.asarray(paths, f8); acts = np.asarray(acts, f8); ctx = np.asarray(ctx, f8)
+    theta = np.asarray(theta, f8); eps = np.asarray(eps, f8)
+    W = [np.asarray(a, f8) for a in w]
+    B, T, L, _, H = acts.shape
+    S = paths.shape[2]
+    C = ctx.shape[2]
+    ntril = S * (S + 1) // 2
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    hprev = np.concatenate([np.zeros((B, 1, L, H)), acts[:, :-1, :, 0]], axis=1)      # h^l_{t-1}
+    z = paths[:, :-1]
+    Wi0, Wh0, bi0, bh0 = W[0], W[1], W[2], W[3]
+    a = (bi0 + theta @ Wi0[:, S + C:].T)[:, None] + z @ Wi0[:, :S].T + ctx @ Wi0[:, S:S + C].T
+    out = np.empty((B, T, L, 5, H))
+    inp = None
+    for l in range(L):
+        if l > 0:
+            a = W[6][l - 1] + inp @ W[4][l - 1].T
+            c = W[7][l - 1] + hprev[:, :, l] @ W[5][l - 1].T
+        else:
+            c = bh0 + hprev[:, :, 0] @ Wh0.T
+        r = sig(a[..., :H] + c[..., :H]); u = sig(a[..., H:2 * H] + c[..., H:2 * H])
+        n = np.tanh(a[..., 2 * H:] + r * c[..., 2 * H:])
+        h = (1.0 - u) * n + u * hprev[:, :, l]
+        out[:, :, l, 0], out[:, :, l, 1], out[:, :, l, 2], out[:, :, l, 3], out[:, :, l, 4] = h, r, u, n, c[..., 2 * H:]
+        inp = h
+    o = W[9] + inp @ W[8].T
+    means = o[..., :S]
+    raw = o[..., S:]
+    Lm = np.zeros((B, T, S, S))
+    ii, jj = np.tril_indices(S)                                                     # row-major tril order, head.py:88-97
+    Lm[..., ii, jj] = raw
+    d = np.arange(S)
+    Lm[..., d, d] = np.maximum(Lm[..., d, d], diag_min)                            # forward.py:346-351
+    nxt = z + means * dt + np.einsum("btij,btj->bti", Lm, eps) * np.sqrt(dt)
+    return out, means, raw, nxt

@@ -19,6 +19,8 @@ What is recorded (inputs and expected outputs only -- no reference source text):
                   scalar and autograd gradients.
 * encoder_tiny.npz  ``ObservationContextEncoder`` forward + gradients for a tiny config.
 * state_dict_manifest.json  key -> [shape, dtype] of ``VariationalSDEPosterior.state_dict()``.
+* fused_dims.npz   encoder forward/gradients and a K=20-step trainer trajectory from one initial state at dims
+                  where the build's fused encoder route is active (hidden 128, 2 heads, depth 2, batch 104).
 * trajectory_tiny.npz  a K-step ``VariationalInferenceTrainer`` run on CPU with the head's
                   kernel call replaced by O1 and every ``torch.randn`` draw recorded.
 """
@@ -368,6 +370,100 @@ def make_trajectory():
     print("wrote trajectory_tiny.npz; elbo[0], elbo[-1] =", elbos[0], elbos[-1])
 
 
+# --------------------------------------------------- fused-eligible dims: encoder case + trajectory from ONE init
+def make_fused_dims():
+    """Encoder hidden 128 / 2 heads (head_dim 64) / depth 2, head GRU 64 x 2, LV, 41 grid tokens, batch 104
+    (104 * 41 = 4264 token rows >= the 4096-row threshold of the packed bf16 GEMM / weight-gradient kernels): the
+    dims at which the build's fused encoder route, its own attention kernels and its packed Linears are all active.
+    One initial ``state_dict`` serves (a) an encoder forward/gradient case and (b) a K=20-step trainer trajectory
+    (reference CPU path, fp32, O1 head, every ``torch.randn`` draw recorded).  The upstream context gradient is
+    ``RandomState(seed).randn`` (a frozen stream), regenerated by the test instead of being stored."""
+    from variational_sde.inference.trainer import VariationalInferenceTrainer
+    from variational_sde.console import Console
+    _, lv = example_sdes()
+    K, B, dt, horizon = 20, 104, 0.05, 2.0
+    obs = Observations(times=torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0]),
+                       values=torch.tensor([[1.2, 0.7], [0.9, 1.1], [0.6, 1.4], [0.8, 1.0], [1.1, 0.8]]))
+    prior = Prior(type=PriorType.LOG_NORMAL, mean=0.0, std=1.5, dim=3)
+
+    def patched(self, x0, context, sde_parameters, standard_noise, time_step):
+        return o1(self, x0, context, sde_parameters, standard_noise, time_step)
+
+    DiffusionTransitionHead.sample_diffusion_paths = patched
+    torch.manual_seed(4242)
+    tr = VariationalInferenceTrainer(
+        sde=lv, observations=obs, observation_likelihood=GaussianObservationLikelihood(variance=0.25),
+        prior=prior, time_horizon=horizon,
+        config=TrainingConfig(time_step=dt, batch_size=B, n_iterations=K, learning_rate=1e-3, sde_param_lr=1e-2),
+        encoder_config=EncoderConfig(hidden_dim=128, cond_dim=16, num_heads=2, depth=2),
+        head_config=HeadConfig(hidden_dim=64, num_layers=2),
+        state_positive_dims=[0, 1], sde_param_positive_dims=[0, 1, 2], device="cpu",
+        mixed_precision=False, console=Console(enabled=False), accelerator=None)
+    model = tr.ctx.model
+    g = torch.Generator().manual_seed(9)
+    randomize_(model.encoder, g, 0.1)
+    with torch.no_grad():
+        model.head.out_proj.weight.add_(torch.randn(model.head.out_proj.weight.shape, generator=g) * 0.2)
+    tr.ctx.ema._init_shadow()
+    rec = {}
+    for k, v in model.state_dict().items():
+        rec["init::" + k] = torch.view_as_real(v).numpy().copy() if v.is_complex() else v.numpy().copy()
+
+    # (a) encoder forward + gradients at the initial weights
+    enc = model.encoder
+    theta = (torch.randn(B, 3, generator=g).abs() + 0.2).requires_grad_(True)
+    ctx = enc(obs.values, obs.times, theta, horizon, dt)
+    seed_g = 31337
+    gout = torch.from_numpy(np.random.RandomState(seed_g).randn(*ctx.shape).astype(np.float32))
+    names = [n for n, p in enc.named_parameters() if p.requires_grad]
+    params = [p for n, p in enc.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad((ctx * gout).sum(), [theta] + params)
+    rec["enc_theta"] = theta.detach().numpy().copy()
+    rec["enc_context_rows"] = np.arange(0, B, 13)                    # stored rows of the context (the rest is covered
+    rec["enc_context"] = ctx.detach().numpy()[::13].copy()           # through the gradients of the shared weights)
+    rec["enc_g_context_seed"] = np.array(seed_g)
+    rec["enc_grad_theta"] = grads[0].numpy().copy()
+    for n, gr in zip(names, grads[1:]):
+        rec["enc_grad::" + n] = gr.numpy().copy()
+
+    # (b) K-step trajectory
+    draws = []
+    real_randn = torch.randn
+
+    def rec_randn(*a, **kw):
+        t = real_randn(*a, **kw)
+        draws.append(t.detach().clone())
+        return t
+
+    torch.randn = rec_randn
+    elbos, comps, gnorms = [], [], []
+    try:
+        model.train()
+        for step in range(K):
+            r = tr._train_step(model)
+            tr.ctx.ema.update()
+            elbos.append(r.elbo_result.evidence_lower_bound.item())
+            c = r.elbo_result.components
+            comps.append([c.observation_log_prob.item(), c.sde_log_prob.item(), c.generative_log_prob.item(),
+                          c.prior_log_prob.item(), c.posterior_log_prob.item()])
+            gnorms.append(r.grad_norm)
+    finally:
+        torch.randn = real_randn
+    assert len(draws) == 2 * K
+    rec["theta_eps"] = torch.stack(draws[0::2]).numpy()
+    rec["path_noise"] = torch.stack(draws[1::2]).numpy().astype(np.float32)
+    rec["elbo"] = np.array(elbos); rec["components"] = np.array(comps); rec["grad_norm"] = np.array(gnorms)
+    post = model.sde_parameter_posterior
+    rec["final_mean"] = post.mean.detach().numpy().copy()
+    rec["final_log_std"] = post.log_std.detach().numpy().copy()
+    rec["final_expected_value"] = post.expected_value.detach().numpy().copy()
+    rec["ema_mean"] = tr.ctx.ema.shadow["sde_parameter_posterior.mean"].numpy().copy()
+    rec["cfg"] = np.array([K, B]); rec["dt"] = np.array(dt); rec["horizon"] = np.array(horizon)
+    rec["obs_times"] = obs.times.numpy(); rec["obs_values"] = obs.values.numpy()
+    np.savez_compressed(os.path.join(OUT, "fused_dims.npz"), **rec)
+    print("wrote fused_dims.npz; elbo[0], elbo[-1] =", elbos[0], elbos[-1], "grad_norm", gnorms[0], gnorms[-1])
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"head", "elbo", "encoder", "manifest", "trajectory"}
     if "head" in which:
@@ -400,3 +496,5 @@ if __name__ == "__main__":
         make_manifest()
     if "trajectory" in which:
         make_trajectory()
+    if "fused_dims" in which:
+        make_fused_dims()

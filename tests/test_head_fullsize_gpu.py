@@ -1,0 +1,103 @@
+"""GPU parity of the fused head AT THE BENCHMARK SIZES against the float64 CPU oracle.
+
+Two workloads: Lotka-Volterra (B=512 launched, T=400, S=2, P=3, C=256, H=64, L=2, bf16 context)
+and the synthetic stress config (B=256 launched, T=1000, S=8, P=16, C=512, H=64, L=2).  The oracle scores a sub-batch
+of the launched paths (each path is independent: forward.py:91-135 runs one program per path).
+
+Each workload is checked two ways, because a T-step recurrence amplifies rounding:
+
+* teacher-forced -- every step re-evaluated in float64 from the kernel's OWN history (z_t, h_{t-1}), which scores the
+  per-step arithmetic of the forward with no amplification, and the reverse-time backward run by the float64 oracle on the
+  kernel's OWN saved activations, which scores the backward arithmetic alone;
+* free-running -- kernel vs the oracle's own float64 trajectory from the same inputs: includes the amplification of fp32
+  rounding (incl. v_exp/v_rcp based sigmoid/tanh) through T steps, hence the looser, stated tolerances.
+
+Tolerances are relative to the max magnitude of the compared tensor:
+  teacher-forced forward 2e-5, backward 2e-4 (the small-case tolerances of test_head_gpu.py);
+  free-running forward 5e-4 (LV, T=400) / 2e-3 (synthetic, T=1000), backward 2e-3 / 5e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import G_NAMES, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+WORKLOADS = {
+    # name: (B launched, sub-batch scored, T, S, C, P, H, L, dt, bf16 context, free-running fwd tol, bwd tol)
+    "lv": (512, 64, 400, 2, 256, 3, 64, 2, 0.1, True, 5e-4, 2e-3),
+    "synthetic": (256, 32, 1000, 8, 512, 16, 64, 2, 0.01, True, 2e-3, 5e-3),
+}
+TF_FWD_TOL, TF_BWD_TOL = 2e-5, 2e-4
+
+
+def _inputs(B, T, S, C, P, H, L, seed, bf16_ctx):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    NO = S + S * (S + 1) // 2
+    bias = torch.zeros(NO)
+    for k in range(S):
+        bias[S + k * (k + 3) // 2] = 1.0          # default emission bias: unit diagonal (head.py:60-66)
+    ws = [rn(3 * H, S + C + P, sc=0.08), rn(3 * H, H, sc=0.12), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1),
+          rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1),
+          rn(NO, H, sc=0.1), bias]
+    ctx = rn(B, T + 1, C)
+    if bf16_ctx:
+        ctx = ctx.to(torch.bfloat16)              # what the autocast encoder hands over; both sides read these values
+    return ws, rn(B, S), ctx, rn(B, P).abs(), rn(B, T, S), rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+
+
+@pytest.mark.parametrize("name", list(WORKLOADS))
+def test_head_full_size_vs_f64_oracle(name):
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    B, Bs, T, S, C, P, H, L, dt, bf16_ctx, fr_fwd, fr_bwd = WORKLOADS[name]
+    ws, x0, ctx_full, theta, eps, gp, gm, gl = _inputs(B, T, S, C, P, H, L, 100 + len(name), bf16_ctx)
+    d = lambda t: t.to(DEV)
+    wd = [d(w) for w in ws]
+    ctx_d = d(ctx_full)[:, :-1]
+    # full launch (the benchmark's grid) ...
+    paths, means, chol, chol_raw, acts = _hip.head_forward(d(x0), ctx_d, d(theta), d(eps), wd, dt, True)
+    grads = _hip.head_backward(d(gp), d(gm), d(gl), ctx_d, d(theta), d(eps), paths, chol_raw, acts, wd, dt)
+    # ... and the scored sub-batch launched alone, for the weight gradients (sums over the launched paths)
+    sub = slice(B // 4, B // 4 + Bs)
+    fs = _hip.head_forward(d(x0)[sub], ctx_d[sub], d(theta)[sub], d(eps)[sub], wd, dt, True)
+    gs = _hip.head_backward(d(gp)[sub], d(gm)[sub], d(gl)[sub], ctx_d[sub], d(theta)[sub], d(eps)[sub], fs[0], fs[3], fs[4],
+                            wd, dt)
+    torch.cuda.synchronize()
+    for a, b_ in zip(fs[:3], (paths, means, chol)):
+        assert torch.equal(a, b_[sub]), "a path must not depend on which launch it is part of"
+    for i in (0, 1, 2):  # per-path gradients: x0, context, theta
+        assert torch.equal(gs[i], grads[i][sub])
+
+    n = lambda t: t.detach().cpu().numpy()
+    w = vo.HeadWeights(*[n(t) for t in ws])
+    ctx_np = n(ctx_full.float())[sub, :-1]
+    x0n, thn, epn = n(x0)[sub], n(theta)[sub], n(eps)[sub]
+    gpn, gmn, gln = n(gp)[sub], n(gm)[sub], n(gl)[sub]
+    k_paths, k_means, k_chol, k_raw, k_acts = (n(t)[sub] for t in (paths, means, chol, chol_raw, acts))
+
+    # ---- teacher-forced forward: every step from the kernel's own (z_t, h_{t-1}) in float64
+    a_ref, m_ref, raw_ref, nxt_ref = vo.head_steps_teacher_forced(k_paths, k_acts, ctx_np, thn, epn, w, dt)
+    errs = {"tf_acts": rel_err(k_acts, a_ref), "tf_means": rel_err(k_means, m_ref), "tf_chol_raw": rel_err(k_raw, raw_ref),
+            "tf_next_state": rel_err(k_paths[:, 1:], nxt_ref)}
+    # ---- teacher-forced backward: the float64 oracle on the kernel's saved tensors
+    saved = vo.FwdResult(k_paths, k_means, k_chol, k_raw, k_acts)
+    g_tf = vo.head_backward(gpn, gmn, gln, ctx_np, thn, epn, saved, w, dt, np.float64)
+    for gname, a, b_ in zip(G_NAMES, gs, g_tf):
+        if b_.size:
+            errs["tf_grad_" + gname] = rel_err(n(a), b_)
+    # ---- free-running: the oracle's own float64 trajectory
+    f = vo.head_forward(x0n, ctx_np, thn, epn, w, dt, True, np.float64)
+    g_fr = vo.head_backward(gpn, gmn, gln, ctx_np, thn, epn, f, w, dt, np.float64)
+    errs.update(fr_paths=rel_err(k_paths, f.paths), fr_means=rel_err(k_means, f.means), fr_chol=rel_err(k_chol, f.chol))
+    for gname, a, b_ in zip(G_NAMES, gs, g_fr):
+        if b_.size:
+            errs["fr_grad_" + gname] = rel_err(n(a), b_)
+    print(f"\n[{name}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert np.isfinite(k_paths).all() and float(np.abs(f.paths).max()) < 1e6, "synthetic weights must give bounded paths"
+    for k, v in errs.items():
+        tol = (TF_FWD_TOL if "grad" not in k else TF_BWD_TOL) if k.startswith("tf_") else (fr_fwd if "grad" not in k else fr_bwd)
+        assert v < tol, (k, v, tol)

@@ -5,10 +5,11 @@ hipBLASLt GEMMs), so ``optimize`` returns the module unchanged; the dataclass ex
 from __future__ import annotations
 
 import os
+import sys
 from contextlib import contextmanager
 from dataclasses import dataclass
 from enum import Enum
-from typing import Iterator
+from typing import Iterator, Optional
 
 import torch
 from torch import nn
@@ -56,8 +57,14 @@ class CompileMode(Enum):
 class Accelerator:
     compile: bool = False
     compile_mode: CompileMode = CompileMode.DEFAULT
+    compile_fullgraph: bool = False       # accepted for configs written for the reference (accelerate.py:47-62); ignored
+    compile_dynamic: Optional[bool] = None
 
     def optimize(self, module: nn.Module) -> nn.Module:
+        if self.compile and not _tuned_state.get("compile_notice"):
+            _tuned_state["compile_notice"] = True
+            print("viforsdes_amd: Accelerator(compile=True) is ignored -- the hot path is hand-written HIP kernels, "
+                  "no tracing compiler is used", file=sys.stderr)
         return module
 
 

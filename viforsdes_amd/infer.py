@@ -90,6 +90,12 @@ def infer(sde: SDE, observations: Observations, observation_likelihood: Observat
     if cfg.pretrain and cfg.sde_param_init_mean is None:
         pre_cfg = cfg.pretrain if isinstance(cfg.pretrain, PretrainConfig) else None
         best = trainer.pretrain_sde_parameters(pre_cfg)
+        if trainer.ctx.is_distributed:
+            # every rank pre-trains on its own draws (seed + rank); all of them must start the ELBO phase from ONE mean,
+            # otherwise the replicas never agree again (gradient averaging does not remove a parameter offset)
+            import torch.distributed as dist
+            best = best.contiguous()
+            dist.broadcast(best, src=0)
         with torch.no_grad():
             trainer.ctx.model.sde_parameter_posterior.mean.copy_(best)
             trainer.ctx.ema._init_shadow()

@@ -39,7 +39,8 @@ def init_process_group_if_needed(device_type: str) -> bool:
         return False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, needed by RCCL on this driver) is launcher environment: it is read when
+        # HSA initialises, long before this point; viforsdes_amd/__init__.py defaults it at import time
         dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo")
     return True
 
@@ -90,21 +91,36 @@ class FlatGradientAllReduce:
             p.grad = None
 
     @torch.no_grad()
-    def all_reduce(self) -> None:
-        if not self.active:
-            return
-        have = [(v, p.grad) for p, v in zip(self.params, self._views) if p.grad is not None]
+    def pack(self) -> None:
+        """Gather every ``p.grad`` into the flat buffer (one multi-tensor copy; absent gradients become zeros)."""
+        have = [(v, p.grad) for p, v in zip(self.params, self._views) if p.grad is not None and p.grad is not v]
         missing = [v for p, v in zip(self.params, self._views) if p.grad is None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v in missing:
             v.zero_()
-        handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
-        for h in handles:
-            h.wait()
-        self.flat.mul_(1.0 / self.world_size)
+
+    @torch.no_grad()
+    def reduce(self) -> None:
+        """Average the flat buffer over the ranks: at most ``max_buckets`` RCCL all-reduces, then one scale."""
+        if self.world_size > 1:
+            handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+            for h in handles:
+                h.wait()
+            self.flat.mul_(1.0 / self.world_size)
+
+    def attach(self) -> None:
+        """Point ``p.grad`` at the views of the flat buffer (what unscale / clip / the optimizer read)."""
         for p, v in zip(self.params, self._views):
             p.grad = v
+
+    @torch.no_grad()
+    def all_reduce(self) -> None:
+        if not self.active:
+            return
+        self.pack()
+        self.reduce()
+        self.attach()
 
 
 @torch.no_grad()

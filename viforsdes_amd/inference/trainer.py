@@ -77,8 +77,9 @@ class VariationalInferenceTrainer:
         return self.ctx.device
 
     # ------------------------------------------------------------------------------ one step
-    def _train_step(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,
-                    path_noise: Optional[Tensor] = None) -> TrainStepResult:
+    def _forward_backward(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,
+                          path_noise: Optional[Tensor] = None) -> EvidenceLowerBoundResult:
+        """theta ~ q -> encoder -> head -> ELBO -> backward; leaves the (loss-scaled) gradients in ``p.grad``."""
         ctx, cfg = self.ctx, self.config
         ctx.grad_sync.zero_grad()
         sde_parameters = model.sde_parameter_posterior.rsample(cfg.batch_size, eps=theta_eps)
@@ -88,31 +89,51 @@ class VariationalInferenceTrainer:
             result = compute_evidence_lower_bound(self.sde, ctx.observations, self.observation_likelihood, self.prior,
                                                   model.sde_parameter_posterior, sde_parameters, sample, cfg.time_step)
         ctx.scaler.scale(-result.evidence_lower_bound).backward()
-        ctx.grad_sync.all_reduce()          # mean over ranks of the (still loss-scaled) gradients
+        # hand out detached scalars: nothing the caller keeps may hold this step's autograd graph (and its AccumulateGrad
+        # nodes) alive across steps or across a HIP-graph capture; the reference returns host floats (trainer.py:199-206)
+        c = result.components
+        return EvidenceLowerBoundResult(
+            evidence_lower_bound=result.evidence_lower_bound.detach(),
+            components=type(c)(**{f: getattr(c, f).detach() for f in c.__dataclass_fields__}))
+
+    def _optimizer_step(self) -> Tensor:
+        """unscale -> clip (global norm) -> AdamW -> scaler update -> refresh of the cached bf16 GEMM operands."""
+        ctx, cfg = self.ctx, self.config
         ctx.scaler.unscale_(ctx.optimizer)
         grad_norm = nn.utils.clip_grad_norm_(ctx.model.parameters(), cfg.grad_clip_norm)
         ctx.scaler.step(ctx.optimizer)
         ctx.scaler.update()
         if ctx.device.type == "cuda":
             fused.PackedWeight.refresh_all()  # bf16 GEMM operands of the encoder follow the updated parameters
-        return TrainStepResult(elbo_result=result, grad_norm=grad_norm)
+        return grad_norm.detach()
+
+    def _train_step(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,
+                    path_noise: Optional[Tensor] = None) -> TrainStepResult:
+        result = self._forward_backward(model, theta_eps, path_noise)
+        self.ctx.grad_sync.all_reduce()     # mean over ranks of the (still loss-scaled) gradients
+        return TrainStepResult(elbo_result=result, grad_norm=self._optimizer_step())
 
     # ------------------------------------------------------------------------------ HIP graph
     def capture_step_graph(self, warmup: int = 3, warm_results: Optional[list] = None
                            ) -> Optional[Callable[[], TrainStepResult]]:
-        """Capture one full optimizer step (+ EMA update) into a HIP graph and return a ``replay()`` callable.
+        """Capture one full optimizer step (+ EMA update) into HIP graph(s) and return a ``replay()`` callable.
 
         The OU-size step is launch-bound (~900 small kernels): replaying a graph removes the per-kernel host
         cost (28.7 -> 9.6 ms/step measured); at LV size the GPU is busy either way and the eager queue is ~3 %
         faster than graph replay (44.8 vs 46.1 ms), so callers should prefer eager stepping there.
+        Single process: ONE graph holds the whole step.  Data parallel (or ``grad_sync.active``): TWO graphs -- [theta draw
+        ... backward, gradients packed into the flat buffer] and [unscale, clip, AdamW, EMA] -- with the RCCL all-reduce
+        of the flat buffer issued eagerly between them, so the collective never sits inside a captured region and a
+        small-batch replica is not launch-bound either.
         ``warmup`` eager steps run first (optimizer state, allocator pools, lazily built caches); they are real
         training steps (their results are appended to ``warm_results`` when given).  Returns ``None`` when
-        capture is not applicable (CPU, multi-process) or fails, in which case the caller keeps stepping
-        eagerly.  Each replay draws fresh noise (graph-safe Philox offsets)."""
+        capture is not applicable (CPU) or fails, in which case the caller keeps stepping eagerly.  Each replay draws
+        fresh noise (graph-safe Philox offsets)."""
         ctx = self.ctx
-        if ctx.device.type != "cuda" or ctx.is_distributed:
+        if ctx.device.type != "cuda":
             return None
         model = ctx.model
+        split = ctx.grad_sync.active
         try:
             side = torch.cuda.Stream(device=ctx.device)
             side.wait_stream(torch.cuda.current_stream(ctx.device))
@@ -123,19 +144,40 @@ class VariationalInferenceTrainer:
                     if warm_results is not None:
                         warm_results.append(r)
             torch.cuda.current_stream(ctx.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static = self._train_step(model)
-                ctx.ema.update()
+            if not split:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static = self._train_step(model)
+                    ctx.ema.update()
+                graphs = (graph,)
+            else:
+                g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb):
+                    elbo = self._forward_backward(model)
+                    ctx.grad_sync.pack()                 # gradients -> flat buffer (static addresses)
+                ctx.grad_sync.reduce()                   # eager RCCL all-reduce of the flat buffer (a real step)
+                ctx.grad_sync.attach()                   # p.grad = views of the flat buffer: what graph 2 reads
+                with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+                    gnorm = self._optimizer_step()
+                    ctx.ema.update()
+                static = TrainStepResult(elbo_result=elbo, grad_norm=gnorm)
+                graphs = (g_fb, g_opt)
         except Exception as err:  # capture is an optimisation, never a requirement
             torch.cuda.synchronize(ctx.device)
             self.console.config_panel(f"HIP graph capture unavailable ({type(err).__name__}: {err}); running eagerly")
             return None
-        self._graph = graph  # keep alive
+        self._graph = graphs  # keep alive
 
-        def replay() -> TrainStepResult:
-            graph.replay()
-            return static
+        if not split:
+            def replay() -> TrainStepResult:
+                graphs[0].replay()
+                return static
+        else:
+            def replay() -> TrainStepResult:
+                graphs[0].replay()
+                ctx.grad_sync.reduce()
+                graphs[1].replay()
+                return static
         return replay
 
     # ----------------------------------------------------------------------------- main loop
