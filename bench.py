@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Lotka-Volterra (S=2, T=400, batch 512 per GPU), full ELBO gradient step.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 launches its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -15,16 +15,24 @@ observations.  Weak scaling: every rank draws its own 512 paths.
 
 Rank 0 prints ONE JSON line.  value = sample paths pushed through a full ELBO step per second over
 all ranks (= global_batch * ELBO-iters/s); ELBO-iters/s and the no-grad sampled-paths/s (encoder +
-head, the VariationalPosterior.sample path) are extra fields.  `roofline` describes the dominant
-hand-written kernel (the serial GRU time-stepping forward, training variant), timed with HIP
-events on its launch stream; `cpu_baseline` times the same step with the CPU oracle standing in
-for the HIP kernels on a bounded sample (rank 0, N=1 only).
+head, the VariationalPosterior.sample path) are extra fields.
+
+* ``roofline``: the serial GRU time-stepping forward (training variant), HIP events on its launch stream, priced with
+  SURVEY 8(d)'s algorithmic bytes (bf16 context); ``frac_incl_projection`` also charges the hoisted context-projection
+  GEMM that does the context read for it; ``backward`` is the same for the reverse-time path.
+* ``mfma_util``: encoder FLOPs (forward + backward = 3 x forward) / encoder time / 2.5 PFLOP/s bf16 dense.
+* ``parity``: the ELBO and the posterior means (``expected_value``) of a few GPU optimizer steps against the CPU oracle
+  path (torch-CPU encoder + C oracle head/ELBO, fp32) from the same initial state on identical injected theta-eps / path
+  noise, with the tolerance.
+* ``cpu_baseline``: the same ELBO step timed on the host cores on a bounded sample (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +42,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X datasheet HBM3E bandwidth (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256, enc_depth=8, heads=4, head_hidden=64,
@@ -62,20 +71,20 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
 
 
 def pmc_traffic_bytes(workload, batch):
-    """HBM bytes per launch of the serial forward kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_head_lv_v2.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512).  The
-    kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
-    counter is used; null for other workloads."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_head_lv_v2.txt")
-    if workload != "lv" or batch != 512 or not os.path.exists(path):
+    """HBM bytes per launch of the serial forward kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in KiB, separate passes, LV B=512; newest profiles/r*_pmc_head_lv*.txt).  The kernel reads with 4-byte
+    loads, for which the guide gives no FETCH_SIZE correction, so the raw counter is used; null for other workloads."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_head_lv*.txt")))
+    if workload != "lv" or batch != 512 or not files:
         return None
     vals = {}
-    for line in open(path):
-        if "head_fwd_v2_kernel" in line:
+    for line in open(files[-1]):
+        if "head_fwd_v2_kernel" in line or "head_fwd_" in line:
             parts = line.split()
             ctr = [p for p in parts if p in ("FETCH_SIZE", "WRITE_SIZE")]
-            if ctr:
-                vals[ctr[0]] = float(line.split("mean=")[1])
+            if ctr and "mean=" in line:
+                vals[ctr[0]] = float(line.split("mean=")[1].split()[0])
     if len(vals) != 2:
         return None
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
@@ -107,25 +116,126 @@ def timed(fn, steps, warmup, device, distributed):
     return dt
 
 
-def cpu_baseline(problem, sample_batch, steps):
-    """The same ELBO step on the host CPUs: torch-CPU encoder + the C oracle for head/ELBO ops."""
+# ------------------------------------------------------------------------------------------------------ CPU legs
+def _cpu_trainer(problem, batch, seed, **enc):
     from oracle.torch_backend import OracleBackend
     from viforsdes_amd.kernels.backend import set_backend
     set_backend(OracleBackend())
+    return build_trainer(problem, batch, torch.device("cpu"), False, seed=seed, **enc)
+
+
+def cpu_baseline(lv, ou, lv_micro_batch, enc):
+    """The same ELBO step on the host CPUs: torch-CPU encoder + the C oracle for head/ELBO ops.
+    LV: ONE 64-path micro-batch of the B=512 step (the full batch is 8 such micro-batches with gradient accumulation; its
+    autograd footprint does not fit a host otherwise) -- about 15 s; OU: the full B=128 step."""
+    from viforsdes_amd.kernels.backend import set_backend
+    out = {}
     try:
-        tr = build_trainer(problem, sample_batch, torch.device("cpu"), False, seed=1234)
-        tr._train_step(tr.ctx.model)  # warm-up (thread pools, allocator)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for name, problem, batch in (("lv", lv, lv_micro_batch), ("ou", ou, 128)):
+            warm = _cpu_trainer(problem, 2, 1234, **enc)
+            warm._train_step(warm.ctx.model)  # thread pools, allocator, oracle library
+            tr = _cpu_trainer(problem, batch, 1234, **enc)
+            t0 = time.perf_counter()
             tr._train_step(tr.ctx.model)
             tr.ctx.ema.update()
-        dt = time.perf_counter() - t0
+            out[name] = (batch, time.perf_counter() - t0)
     finally:
         set_backend(None)
-    return {"value": sample_batch * steps / dt, "unit": "paths/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"LV T=400 S=2 full ELBO step, batch {sample_batch} x {steps} steps, fp32, torch-CPU encoder + "
-                      f"C oracle head/ELBO ({os.cpu_count()} logical CPUs on the host)",
-            "elbo_iters_per_sec_at_sample_batch": steps / dt}
+    (bl, tl), (bo, to) = out["lv"], out["ou"]
+    return {"value": bl / tl, "unit": "paths/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"LV T=400 S=2 full ELBO step on ONE {bl}-path micro-batch of the 512-path step (8 micro-batches with "
+                      f"gradient accumulation = one step), fp32, torch-CPU encoder + C oracle head/ELBO; "
+                      f"{os.cpu_count()} logical CPUs on the host, {torch.get_num_threads()} torch threads",
+            "lv_seconds_per_micro_batch": tl, "lv_elbo_iters_per_sec_at_512": 1.0 / (tl * 512 / bl),
+            "ou": {"value": bo / to, "unit": "paths/s", "elbo_iters_per_sec": 1.0 / to,
+                   "sample": "OU T=100 S=1 full ELBO step, B=128 (the whole batch), fp32"}}
+
+
+def parity_gate(problem, enc, device, batch=16, steps=3):
+    """ELBO per step and theta ``expected_value`` after ``steps`` optimizer steps: GPU (fp32 and bf16-autocast encoder) vs
+    the CPU oracle path, same initial state, identical injected theta-eps and path noise."""
+    from viforsdes_amd.kernels.backend import set_backend
+    sde, obs, like, prior, horizon, dt, *_ = problem
+    T, S, P = int(round(horizon / dt)), sde.state_dim, sde.sde_param_dim
+    g = torch.Generator(device="cpu").manual_seed(99)
+    teps = [torch.randn(batch, P, generator=g) for _ in range(steps)]
+    noise = [torch.randn(batch, T, S, generator=g) for _ in range(steps)]
+
+    def run(tr, dev):
+        elbos = []
+        for k in range(steps):
+            r = tr._train_step(tr.ctx.model, theta_eps=teps[k].to(dev), path_noise=noise[k].to(dev))
+            elbos.append(float(r.elbo_result.evidence_lower_bound))
+        return elbos, tr.ctx.model.sde_parameter_posterior.expected_value.detach().cpu().tolist()
+
+    try:
+        cpu_tr = _cpu_trainer(problem, batch, 4321, **enc)
+        init = {k: v.clone() for k, v in cpu_tr.ctx.model.state_dict().items()}
+        e_cpu, ev_cpu = run(cpu_tr, torch.device("cpu"))
+    finally:
+        set_backend(None)
+    res = {"workload": f"LV T={T} batch {batch}, {steps} optimizer steps from one initial state, injected noise",
+           "reference": "CPU oracle path (torch-CPU encoder + C oracle head/ELBO, fp32)",
+           "elbo_cpu": e_cpu, "expected_value_cpu": ev_cpu}
+    rel = lambda a, b: max(abs(x - y) / max(abs(y), 1e-12) for x, y in zip(a, b))
+    tols = {"fp32": (2e-3, 1e-3), "bf16": (5e-2, 1e-2)}
+    ok = True
+    for tag, mp in (("fp32", False), ("bf16", True)):
+        tr = build_trainer(problem, batch, device, mp, seed=4321, **enc)
+        tr.ctx.model.load_state_dict(init)
+        tr.ctx.ema._init_shadow()
+        e, ev = run(tr, device)
+        te, tv = tols[tag]
+        res[f"elbo_gpu_{tag}"] = e
+        res[f"elbo_max_rel_diff_{tag}"] = rel(e, e_cpu)
+        res[f"expected_value_max_rel_diff_{tag}"] = rel(ev, ev_cpu)
+        res[f"tolerance_{tag}"] = {"elbo_rel": te, "expected_value_rel": tv}
+        ok = ok and res[f"elbo_max_rel_diff_{tag}"] < te and res[f"expected_value_max_rel_diff_{tag}"] < tv
+        del tr
+    res["pass"] = bool(ok)
+    return res
+
+
+# --------------------------------------------------------------------------------------------- multi-GPU launcher
+def self_launch(n, argv, script=None):
+    """``python bench.py --gpus N`` without a torchrun environment: start N ranks as fresh child processes (this parent
+    never touches the GPU), relay rank 0's JSON line, exit non-zero if any rank fails."""
+    if torch.cuda.device_count() < n:  # counting devices does not initialise the GPU
+        raise SystemExit(f"--gpus {n} requested but only {torch.cuda.device_count()} GPU(s) are visible")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                rc = rc or code
+                for q in pending:  # a failed rank would leave the others hanging in a collective
+                    procs[q].terminate()
+        time.sleep(0.2)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    raise SystemExit(rc if rc else 0)
+
+
+def encoder_flops_per_step(B, N, C, depth, heads, mlp_hidden, cond_dim):
+    """Algorithmic FLOPs of the encoder for one ELBO step (forward + backward = 3 x forward), SURVEY 8(d): per token and block
+    the qkv / gate / out projections, the SwiGLU pair and the attention products; the output projection; per batch row the
+    adaLN modulator.  The shared grid tokens are projected once (input_proj), not per row."""
+    d = C // heads
+    per_token_block = 2 * C * 3 * C + 2 * C * d + 2 * C * C + 2 * C * 2 * mlp_hidden + 2 * mlp_hidden * C + 4 * N * C
+    fwd = B * N * (depth * per_token_block + 2 * C * C) + B * depth * 2 * cond_dim * 6 * C + N * 2 * C * C
+    return 3.0 * fwd
 
 
 def main():
@@ -135,26 +245,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="sample paths per GPU")
     ap.add_argument("--workload", default="lv", choices=["lv", "ou", "synthetic"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline and parity legs (host CPU work)")
     ap.add_argument("--no-hip-graph", action="store_true", help="step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--hip-graph", action="store_true", help="always replay the captured HIP graph (default: whichever of "
                     "eager / replay is faster in a 3-step probe before the warm-up; same kernels and work either way)")
-    ap.add_argument("--cpu-sample-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-micro-batch", type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("launch multi-GPU runs with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the fused kernels have no CPU fallback)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if distributed and not dist.is_initialized():
@@ -183,10 +291,11 @@ def main():
         tr._train_step(model)
         ctx.ema.update()
 
-    # single-process runs may replay the whole step (same kernels, same work) from a HIP graph: a win when the step is
-    # launch-bound (OU), a small loss when it is GPU-bound (graph nodes dispatch with a larger gap than a busy eager queue)
+    # the step may replay from HIP graph(s) (same kernels, same work): a win when the step is launch-bound (OU), a small
+    # loss when it is GPU-bound (graph nodes dispatch with a larger gap than a busy eager queue).  Under data parallelism
+    # the graph is split around the eager RCCL all-reduce (trainer.capture_step_graph).
     graph_mode = False
-    if not distributed and not args.no_hip_graph:
+    if not args.no_hip_graph:
         def probe(fn, n=3):
             fn(); sync(device)
             t0 = time.perf_counter()
@@ -198,7 +307,12 @@ def main():
             train_step()
         t_eager = probe(train_step)
         replay = tr.capture_step_graph(warmup=3)
-        if replay is not None and (args.hip_graph or probe(replay) < t_eager):
+        use = replay is not None and (args.hip_graph or probe(replay) < t_eager)
+        if distributed:  # every rank must take the same route
+            flag = torch.tensor([1 if use else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use = bool(flag.item())
+        if use:
             train_step, graph_mode = replay, True
         elif replay is not None:  # drop the graph and its private memory pool
             del replay
@@ -206,6 +320,8 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
+            for p in model.parameters():
+                p.grad = None
 
     elapsed = timed(train_step, args.steps, args.warmup, device, distributed)
     iters_per_sec = args.steps / elapsed
@@ -223,25 +339,63 @@ def main():
     s_elapsed = timed(sample_step, args.steps, max(2, args.warmup // 2), device, distributed)
     model.train()
 
-    # per-kernel timing of the dominant hand-written kernel (HIP events on the launch stream)
+    # gradient all-reduce alone (RCCL over xGMI), HIP events on the current stream
+    allreduce_ms = None
+    if distributed:
+        ctx.grad_sync.all_reduce()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync(device); dist.barrier()
+        e0.record()
+        for _ in range(10):
+            ctx.grad_sync.reduce()
+        e1.record(); sync(device)
+        allreduce_ms = e0.elapsed_time(e1) / 10
+
+    # per-kernel timing of the hand-written head kernels (HIP events on the launch stream) -- eager steps
     H, L, C = model.head.hidden_dim, model.head.num_layers, model.head.context_dim
     ntril = S * (S + 1) // 2
     _hip.profile_enable(True)
-    fwd_ms, bwd_ms = [], []
+    slots = {k: [] for k in range(7)}
     for _ in range(5):
         tr._train_step(model)
-        fwd_ms.append(_hip.profile_elapsed_ms(0))
-        bwd_ms.append(_hip.profile_elapsed_ms(1))
+        for k in slots:
+            slots[k].append(_hip.profile_elapsed_ms(k))
     _hip.profile_enable(False)
-    fwd_ms_avg = sum(fwd_ms) / len(fwd_ms)
-    bwd_ms_avg = sum(bwd_ms) / len(bwd_ms)
-    # algorithmic bytes per path-step of the serial forward (training variant), SURVEY 8(d) with the
-    # context term replaced by the 3H-float projected record this kernel actually consumes:
-    #   4 * [3H + S + (2S + S^2 + n_tril) + 5 L H]
-    fwd_bytes_step = 4 * (3 * H + S + (2 * S + S * S + ntril) + 5 * L * H)
-    bwd_bytes_step = 4 * (4 * S + S * S + ntril + 5 * L * H + 4 * L * H + (S + ntril))
-    fwd_bytes = fwd_bytes_step * args.batch * T
-    achieved = fwd_bytes / (fwd_ms_avg * 1e-3) / 1e9
+    avg = {k: sum(v) / len(v) for k, v in slots.items()}
+    fwd_ms, bwd_ms = avg[0], avg[1]
+    # SURVEY 8(d) algorithmic bytes per path-step, bf16 context (C/2 floats): what the path must move whatever the kernel split
+    #   forward (train): 4 * [C/2 + S + (2S + S^2 + n_tril) + 5 L H]     backward: 4 * [C/2 + C/2 + 4S + S^2 + n_tril + 5 L H]
+    fwd_bytes_step = 4 * (C // 2 + S + (2 * S + S * S + ntril) + 5 * L * H)
+    bwd_bytes_step = 4 * (C // 2 + C // 2 + 4 * S + S * S + ntril + 5 * L * H)
+    steps_per_launch = args.batch * T
+    gbs = lambda bytes_step, ms: bytes_step * steps_per_launch / (ms * 1e-3) / 1e9
+    achieved = gbs(fwd_bytes_step, fwd_ms)
+
+    # encoder alone: forward + backward of the context (bf16 autocast), for the MFMA utilisation figure
+    enc_mod = model.encoder
+    mlp_hidden = enc_mod.sit.blocks[0].mlp.hidden_dim
+    cond_dim = enc_mod.sde_param_proj[0].out_features
+    depth, heads = len(enc_mod.sit.blocks), enc_mod.num_heads
+    gout = torch.randn(args.batch, T + 1, C, device=device, dtype=torch.bfloat16)
+
+    def enc_step():
+        for p in model.parameters():
+            p.grad = None
+        theta = model.sde_parameter_posterior.rsample(args.batch)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            c = enc_mod(ctx.observations.values, ctx.observations.times, theta, horizon, dt)
+        c.backward(gout)
+    for _ in range(2):
+        enc_step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync(device); e0.record()
+    for _ in range(5):
+        enc_step()
+    e1.record(); sync(device)
+    enc_ms = e0.elapsed_time(e1) / 5
+    enc_flops = encoder_flops_per_step(args.batch, T + 1, C, depth, heads, mlp_hidden, cond_dim)
+    for p in model.parameters():
+        p.grad = None
 
     out = {
         "metric": "sampled-paths/sec + ELBO-iters/sec (full ELBO gradient step; value = global_batch * ELBO-iters/s)",
@@ -253,21 +407,32 @@ def main():
                    "global_batch": global_batch, "parallelism": f"dp{world}", "hip_graph": graph_mode},
         "elbo_iters_per_sec": iters_per_sec,
         "sampled_paths_per_sec": global_batch * args.steps / s_elapsed,
-        "roofline": {"kernel": f"vsde::head_fwd_v2_kernel<{L}, true, ...> (serial GRU time-stepping forward, training variant)",
+        "rccl_ranks": dist.get_world_size() if distributed else 1,
+        "allreduce_ms_per_step": allreduce_ms,
+        "roofline": {"kernel": f"vsde head forward, serial GRU time-stepping kernel (training variant, L={L})",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(args.workload, args.batch),
-                     "avg_ms": fwd_ms_avg, "algorithmic_bytes": fwd_bytes, "bytes_per_path_step": fwd_bytes_step,
-                     # SURVEY 8(d) prices the forward with the raw C-float context read (4*[C + S + 2S + S^2 + ntril + 5LH]); this
-                     # kernel streams the 3H-float projected record instead (the context itself is read by the projection GEMM)
-                     "survey_bytes_per_path_step": 4 * (C + S + (2 * S + S * S + ntril) + 5 * L * H),
-                     "frac_with_survey_bytes": 4 * (C + S + (2 * S + S * S + ntril) + 5 * L * H) * args.batch * T
-                                               / (fwd_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "bwd_kernel_avg_ms": bwd_ms_avg,
-                     "bwd_achieved_GBs": bwd_bytes_step * args.batch * T / (bwd_ms_avg * 1e-3) / 1e9},
+                     "avg_ms": fwd_ms, "algorithmic_bytes": fwd_bytes_step * steps_per_launch,
+                     "bytes_per_path_step": fwd_bytes_step, "path_steps_per_launch": steps_per_launch,
+                     # the context read is done by the hoisted projection GEMM: the whole forward path priced with the same bytes
+                     "projection_gemm_ms": avg[4], "forward_path_ms": avg[2],
+                     "frac_incl_projection": gbs(fwd_bytes_step, avg[2]) / HBM_PEAK_GBS,
+                     "backward": {"serial_kernel_ms": bwd_ms, "grad_context_gemm_ms": avg[5], "weight_grad_reduction_ms": avg[6],
+                                  "backward_path_ms": avg[3], "bytes_per_path_step": bwd_bytes_step,
+                                  "achieved": gbs(bwd_bytes_step, bwd_ms), "frac": gbs(bwd_bytes_step, bwd_ms) / HBM_PEAK_GBS,
+                                  "frac_whole_path": gbs(bwd_bytes_step, avg[3]) / HBM_PEAK_GBS}},
+        "mfma_util": {"encoder_flops_per_step": enc_flops, "encoder_fwd_bwd_ms": enc_ms,
+                      "achieved_tflops": enc_flops / (enc_ms * 1e-3) / 1e12, "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                      "frac": enc_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                      "frac_of_whole_step": enc_flops / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "lv":
-        out["cpu_baseline"] = cpu_baseline(problem, args.cpu_sample_batch, args.cpu_steps)
+        del tr, model, ctx
+        torch.cuda.empty_cache()
+        out["parity"] = parity_gate(problem, enc, device)
+        out["cpu_baseline"] = cpu_baseline(problem, ou_problem(), args.cpu_micro_batch, enc)
     elif rank == 0:
+        out["parity"] = None
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -224,9 +224,11 @@ size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
                            size_t workspace_bytes, void *stream);
 
-/* Measurement aid (no reference counterpart): when enabled, the launchers bracket the serial
- * time-stepping kernel with hipEvents on the launch stream.  which: 0 = forward (training
- * variant), 1 = backward.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */
+/* Measurement aid (no reference counterpart): when enabled, the launchers bracket their kernels with hipEvents on the
+ * launch stream.  which: 0 = serial time-stepping forward kernel (training variant), 1 = serial backward kernel,
+ * 2 = everything vsde_head_forward enqueues (training variant), 3 = everything vsde_head_backward enqueues,
+ * 4 = the forward's context-projection GEMM, 5 = the backward's grad_context GEMM, 6 = the grouped weight-gradient
+ * reduction.  vsde_profile_elapsed_ms waits for the end event of the LAST such launch. */
 int vsde_profile_enable(int on);
 /* Test hook: route L <= 2 through the LDS-resident one-wave-per-path kernels that serve L = 3, 4. */
 int vsde_debug_force_v1(int on);

@@ -136,3 +136,48 @@ def test_training_state_resume_is_bit_exact():
             assert torch.equal(a.ctx.ema.shadow[n], b.ctx.ema.shadow[n]), n
     finally:
         set_backend(None)
+
+
+def _pretrain_worker(rank, world, port, out_dir):
+    """infer(pretrain=True) on two ranks: each rank pre-trains on its own draws (seed + rank), so without the broadcast of the
+    pre-trained mean the replicas would start -- and stay -- apart."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.torch_backend import OracleBackend
+    from viforsdes_amd import EncoderConfig, HeadConfig, InferenceConfig, PretrainConfig, TrainingConfig, infer
+    from viforsdes_amd.console import Console
+    from viforsdes_amd.examples.sdes import ou_problem
+    from viforsdes_amd.kernels.backend import set_backend
+    set_backend(OracleBackend())
+    sde, obs, like, prior, horizon, dt, sp, tp = ou_problem()
+    captured = {}
+    from viforsdes_amd.inference import trainer as infer_mod
+    real_cleanup = infer_mod.VariationalInferenceTrainer.cleanup
+
+    def gather_then_cleanup(self):  # compare the replicas while the process group is still up
+        flat = torch.cat([p.detach().reshape(-1) for p in self.ctx.model.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        captured["same"] = all(torch.equal(both[0], b) for b in both)
+        ema = self.ctx.ema.shadow["sde_parameter_posterior.mean"].clone()
+        emas = [torch.zeros_like(ema) for _ in range(world)]
+        dist.all_gather(emas, ema)
+        captured["ema_same"] = all(torch.equal(emas[0], e) for e in emas)
+        real_cleanup(self)
+
+    infer_mod.VariationalInferenceTrainer.cleanup = gather_then_cleanup
+    cfg = InferenceConfig(training=TrainingConfig(time_step=0.25, batch_size=4, n_iterations=3),
+                          encoder=EncoderConfig(hidden_dim=16, cond_dim=8, num_heads=2, depth=1),
+                          head=HeadConfig(hidden_dim=8, num_layers=2), sde_param_positive_dims=tp, device="cpu",
+                          mixed_precision=False, console=Console(enabled=False), seed=5,
+                          pretrain=PretrainConfig(n_iterations=5, batch_size=32))
+    infer(sde, obs, like, prior, horizon, cfg)
+    assert captured["same"], "replicas diverged: the pre-trained mean was not broadcast"
+    assert captured["ema_same"]
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_pretrain_keeps_replicas_identical(tmp_path):
+    mp.spawn(_pretrain_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

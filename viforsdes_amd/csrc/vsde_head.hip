@@ -1343,13 +1343,16 @@ __global__ void head_bwd_wide_kernel(BwdParams p, int L) {
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline block).
 static bool g_force_v1 = false;  // test hook: run L<=2 through the LDS-resident v1 kernels
 static bool g_prof_on = false;
-static hipEvent_t g_prof_ev[2][2];
+// which: 0 = serial forward kernel (training variant), 1 = serial backward kernel, 2 = whole vsde_head_forward (training),
+// 3 = whole vsde_head_backward, 4 = forward context-projection GEMM, 5 = grad_context GEMM, 6 = grouped weight-gradient reduction
+constexpr int kProfSlots = 7;
+static hipEvent_t g_prof_ev[kProfSlots][2];
 static bool g_prof_init = false;
-static bool g_prof_valid[2] = {false, false};
+static bool g_prof_valid[kProfSlots] = {};
 static void prof_mark(int which, int edge, hipStream_t s) {
     if (!g_prof_on) return;
     if (!g_prof_init) {
-        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) (void)hipEventCreate(&g_prof_ev[i][j]);
+        for (int i = 0; i < kProfSlots; ++i) for (int j = 0; j < 2; ++j) (void)hipEventCreate(&g_prof_ev[i][j]);
         g_prof_init = true;
     }
     (void)hipEventRecord(g_prof_ev[which][edge], s);
@@ -1443,12 +1446,12 @@ extern "C" int vsde_debug_force_v1(int on) {
 
 extern "C" int vsde_profile_enable(int on) {
     g_prof_on = on != 0;
-    g_prof_valid[0] = g_prof_valid[1] = false;
+    for (int i = 0; i < kProfSlots; ++i) g_prof_valid[i] = false;
     return 0;
 }
 
 extern "C" int vsde_profile_elapsed_ms(int which, float *ms) {
-    VSDE_CHECK_ARG(which >= 0 && which < 2 && ms, VSDE_E_BADARG, "bad profile query");
+    VSDE_CHECK_ARG(which >= 0 && which < kProfSlots && ms, VSDE_E_BADARG, "bad profile query");
     VSDE_CHECK_ARG(g_prof_valid[which], VSDE_E_BADARG, "no timed launch of kernel %d recorded", which);
     VSDE_CHECK_HIP(hipEventSynchronize(g_prof_ev[which][1]));
     VSDE_CHECK_HIP(hipEventElapsedTime(ms, g_prof_ev[which][0], g_prof_ev[which][1]));
@@ -1485,11 +1488,14 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     const bool wide = d->H > kHP || NO > kWave;
     if (!wide) { pk.packF = (float4 *)(ws + lay.packF); pk.packO = (float4 *)(ws + lay.packO); }
     pk.Wc = (float *)(ws + lay.Wc);
+    if (save) prof_mark(2, 0, s);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
     VSDE_CHECK_HIP(hipGetLastError());
 
     float *G = (float *)(ws + lay.G);
+    if (save) prof_mark(4, 0, s);
     rc = launch_gemm_nt(ctx_rowview(ctx, d->T, d->C), d->B * d->T, d->C, pk.Wc, d->C, 3 * d->H, w->b_ih_l0, G, 3 * d->H, s);
+    if (save) prof_mark(4, 1, s);
     if (rc) return rc;
 
     FwdParams p = {};
@@ -1506,6 +1512,7 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
         if (save) hipLaunchKernelGGL((head_fwd_wide_kernel<true>), dim3(d->B), dim3(block), ldsw, s, p, d->L);
         else hipLaunchKernelGGL((head_fwd_wide_kernel<false>), dim3(d->B), dim3(block), ldsw, s, p, d->L);
         VSDE_CHECK_HIP(hipGetLastError());
+        if (save) prof_mark(2, 1, s);
         return 0;
     }
     if (d->L <= 2 && !g_force_v1) {  // register-resident 4-waves-per-path kernels
@@ -1539,6 +1546,7 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
 #undef VSDE_LAUNCH_FWD_V2
 #undef VSDE_LAUNCH_FWD_V2_
         VSDE_CHECK_HIP(hipGetLastError());
+        if (save) prof_mark(2, 1, s);
         return 0;
     }
     const size_t lds_fixed = (size_t)fwd_lds_matrices(d->L) * kMatF4 * sizeof(float4) + (size_t)kChunks * NO * sizeof(float4);
@@ -1548,11 +1556,13 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     VSDE_CHECK_ARG(lds <= 160 * 1024, VSDE_E_STATE, "LDS budget exceeded (%zu B)", lds);
     const int grid = (d->B + p.wpb - 1) / p.wpb, block = 64 * p.wpb;
     switch (d->L) {
-        case 1: return launch_fwd_L<1>(p, save != 0, grid, block, lds, s);
-        case 2: return launch_fwd_L<2>(p, save != 0, grid, block, lds, s);
-        case 3: return launch_fwd_L<3>(p, save != 0, grid, block, lds, s);
-        default: return launch_fwd_L<4>(p, save != 0, grid, block, lds, s);
+        case 1: rc = launch_fwd_L<1>(p, save != 0, grid, block, lds, s); break;
+        case 2: rc = launch_fwd_L<2>(p, save != 0, grid, block, lds, s); break;
+        case 3: rc = launch_fwd_L<3>(p, save != 0, grid, block, lds, s); break;
+        default: rc = launch_fwd_L<4>(p, save != 0, grid, block, lds, s); break;
     }
+    if (save && rc == 0) prof_mark(2, 1, s);
+    return rc;
 }
 
 namespace vsde {
@@ -1666,6 +1676,7 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     pk.W_ih0 = w->W_ih_l0; pk.W_hh0 = w->W_hh_l0; pk.W_ih_st = w->W_ih_stack; pk.W_hh_st = w->W_hh_stack; pk.out_W = w->out_weight;
     if (!(d->H > kHP || NO > kWave)) pk.packB = (float4 *)(ws + lay.packB);
     pk.WcT = (float *)(ws + lay.WcT);
+    prof_mark(3, 0, s);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(64), dim3(256), 0, s, pk);
     VSDE_CHECK_HIP(hipGetLastError());
 
@@ -1802,11 +1813,17 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     VSDE_CHECK_ARG(g->context_dtype == 0 || g->context_dtype == 1, VSDE_E_BADARG, "grads->context_dtype must be 0 (f32) or 1 (bf16)");
     VSDE_CHECK_ARG(g->context_batch_stride == 0 || g->context_batch_stride >= (int64_t)d->T * d->C, VSDE_E_BADARG,
                    "grads->context_batch_stride smaller than T*C");
+    prof_mark(5, 0, s);
     rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s,
                         g->context_batch_stride ? d->T : 0, g->context_batch_stride, g->context_dtype);
+    prof_mark(5, 1, s);
     if (rc) return rc;
 
     TnProblem pr[kMaxTnProblems];
     int n = build_tn(d, ctx, theta, paths, acts, p.D4, p.DO, g, pr);
-    return launch_tn_grouped(pr, n, M, ws + lay.tn, lay.total - lay.tn, s);
+    prof_mark(6, 0, s);
+    rc = launch_tn_grouped(pr, n, M, ws + lay.tn, lay.total - lay.tn, s);
+    prof_mark(6, 1, s);
+    prof_mark(3, 1, s);
+    return rc;
 }
