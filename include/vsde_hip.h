@@ -224,6 +224,24 @@ size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- Batched Euler-Maruyama simulator of the MODEL SDE (parameter pre-training stage) --------------------------------
+ * Replaces the T-step Python loop of core/euler_maruyama.py:11-45 (called from trainer.py:246-259 with 4096 paths) for
+ * SDEs whose drift / diffusion are built in:
+ *   VSDE_SDE_OU               f = kappa (mu - x), G = sigma                        examples/ornstein_uhlenbeck.py:18-30
+ *   VSDE_SDE_LOTKA_VOLTERRA   analytic 2x2 Cholesky diffusion, three 1e-6 clamps   examples/lotka_volterra.py:18-46
+ *   VSDE_SDE_LINEAR_DIAGONAL  f = -a x, G = diag(softplus(b) + 1e-3), theta=(a,b)  (BASELINE.json config 5)
+ * x0[B][S], theta[B][P], noise[B][T][S] -> traj[B][T+1][S] with traj[:,0] = x0 and the positive dims (positive_mask: S
+ * bytes on the HOST) clamped at 1e-6 after every step.  _bwd: g_traj[B][T+1][S] -> g_x0[B][S], g_theta[B][P] (reverse-mode
+ * derivative of exactly that recursion; a clamped entry passes no gradient).  User-defined SDEs keep the torch loop. */
+#define VSDE_SDE_OU 1
+#define VSDE_SDE_LOTKA_VOLTERRA 2
+#define VSDE_SDE_LINEAR_DIAGONAL 3
+int vsde_euler_maruyama_fwd(int kind, int B, int T, int S, int P, const float *x0, const float *theta, const float *noise,
+                            double time_step, const uint8_t *positive_mask_host, float *traj, void *stream);
+int vsde_euler_maruyama_bwd(int kind, int B, int T, int S, int P, const float *theta, const float *noise, const float *traj,
+                            const float *g_traj, double time_step, const uint8_t *positive_mask_host, float *g_x0,
+                            float *g_theta, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, the launchers bracket their kernels with hipEvents on the
  * launch stream.  which: 0 = serial time-stepping forward kernel (training variant), 1 = serial backward kernel,
  * 2 = everything vsde_head_forward enqueues (training variant), 3 = everything vsde_head_backward enqueues,

@@ -313,3 +313,31 @@ def head_steps_teacher_forced(paths, acts, ctx, theta, eps, w: HeadWeights, dt: 
     Lm[..., d, d] = np.maximum(Lm[..., d, d], diag_min)                            # forward.py:346-351
     nxt = z + means * dt + np.einsum("btij,btj->bti", Lm, eps) * np.sqrt(dt)
     return out, means, raw, nxt
+
+
+EM_KINDS = {"ou": 1, "lv": 2, "linear_diagonal": 3}
+
+
+def euler_maruyama(kind: str, x0, theta, noise, dt: float, positive_dims=(), dtype=np.float32):
+    """core/euler_maruyama.py:11-45 for the built-in model SDEs (``kind`` in EM_KINDS) -> trajectory [B, T+1, S]."""
+    sfx, _ = _dt(dtype)
+    x0 = _c(x0, dtype); theta = _c(theta, dtype); noise = _c(noise, dtype)
+    B, T, S = noise.shape
+    traj = np.empty((B, T + 1, S), dtype)
+    fn = getattr(lib(), "vsde_oracle_em_fwd" + sfx); fn.restype = None
+    fn(ctypes.c_int(EM_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S), ctypes.c_int(theta.shape[1]),
+       _p(x0), _p(theta), _p(noise), ctypes.c_double(dt), _p(_mask(positive_dims, S)), _p(traj))
+    return traj
+
+
+def euler_maruyama_bwd(kind: str, theta, noise, traj, g_traj, dt: float, positive_dims=(), dtype=np.float32):
+    """Reverse-mode gradient of ``euler_maruyama`` -> (g_x0 [B,S], g_theta [B,P])."""
+    sfx, _ = _dt(dtype)
+    theta = _c(theta, dtype); noise = _c(noise, dtype); traj = _c(traj, dtype); g_traj = _c(g_traj, dtype)
+    B, T, S = noise.shape
+    assert S <= 64
+    g_x0 = np.empty((B, S), dtype); g_theta = np.empty_like(theta)
+    fn = getattr(lib(), "vsde_oracle_em_bwd" + sfx); fn.restype = None
+    fn(ctypes.c_int(EM_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S), ctypes.c_int(theta.shape[1]),
+       _p(theta), _p(noise), _p(traj), _p(g_traj), ctypes.c_double(dt), _p(_mask(positive_dims, S)), _p(g_x0), _p(g_theta))
+    return g_x0, g_theta

@@ -442,6 +442,112 @@ void FN(vsde_oracle_theta_log_probs)(
     }
 }
 
+/* ------------------------------------------------- Euler-Maruyama simulator of the MODEL SDE (pre-training stage)
+ * core/euler_maruyama.py:11-45:  x <- x + f(x, theta) dt + (G(x, theta) eps_t) sqrt(dt);  x[positive_dims] <- max(x, 1e-6).
+ * The reference takes f and G as user callables; restated here for the SDEs of its two example scripts and the
+ * benchmark's synthetic config:
+ *   kind 1  Ornstein-Uhlenbeck   examples/ornstein_uhlenbeck.py:18-30   f = kappa (mu - x),  G = sigma
+ *   kind 2  Lotka-Volterra       examples/lotka_volterra.py:18-46       f = (t1 u - t2 u v, t2 u v - t3 v), G = analytic 2x2
+ *                                Cholesky factor with three clamp(min=1e-6)
+ *   kind 3  linear, diagonal     (BASELINE config 5)                     f = -a x,  G = diag(softplus(b) + 1e-3), theta = (a, b)
+ * traj[B][T+1][S].  The backward is the reverse-mode derivative of exactly this recursion (what torch autograd computes for
+ * trainer.py:208-259): clamp(min) passes the gradient where its input >= the floor; a clamped trajectory entry is
+ * recognised by its value (== 1e-6 exactly). */
+static void FN(em_step)(int kind, int S, const REAL *x, const REAL *th, const REAL *e, REAL dt, REAL sqdt, REAL *y)
+{
+    if (kind == 1) {
+        y[0] = x[0] + th[0] * (th[1] - x[0]) * dt + th[2] * e[0] * sqdt;
+    } else if (kind == 2) {
+        const REAL u = x[0], v = x[1], t1 = th[0], t2 = th[1], t3 = th[2], floor = (REAL)1e-6;
+        const REAL uv = t2 * u * v;
+        REAL q00 = t1 * u + uv; if (q00 < floor) q00 = floor;
+        const REAL l00 = (REAL)sqrt((double)q00);
+        const REAL c = l00 < floor ? floor : l00;
+        const REAL l10 = -uv / c;
+        REAL q11 = t3 * v + uv - l10 * l10; if (q11 < floor) q11 = floor;
+        const REAL l11 = (REAL)sqrt((double)q11);
+        y[0] = u + (t1 * u - uv) * dt + (l00 * e[0]) * sqdt;
+        y[1] = v + (uv - t3 * v) * dt + (l10 * e[0] + l11 * e[1]) * sqdt;
+    } else {
+        for (int i = 0; i < S; ++i) {
+            const REAL b = th[S + i];
+            const REAL sp = (b > (REAL)20 ? b : LOG1P(EXP(b))) + (REAL)1e-3;
+            y[i] = x[i] + (-th[i] * x[i]) * dt + (sp * e[i]) * sqdt;
+        }
+    }
+}
+
+void FN(vsde_oracle_em_fwd)(int kind, int B, int T, int S, int P, const REAL *x0, const REAL *theta, const REAL *noise,
+                            double dt_d, const unsigned char *pos_mask, REAL *traj)
+{
+    const REAL dt = (REAL)dt_d, sqdt = (REAL)POW(dt_d, 0.5);
+    for (int b = 0; b < B; ++b) {
+        REAL *tr = traj + (long)b * (T + 1) * S;
+        for (int i = 0; i < S; ++i) tr[i] = x0[(long)b * S + i];
+        for (int t = 0; t < T; ++t) {
+            REAL *y = tr + (long)(t + 1) * S;
+            FN(em_step)(kind, S, tr + (long)t * S, theta + (long)b * P, noise + ((long)b * T + t) * S, dt, sqdt, y);
+            for (int i = 0; i < S; ++i) if (pos_mask[i] && y[i] < (REAL)1e-6) y[i] = (REAL)1e-6;
+        }
+    }
+}
+
+void FN(vsde_oracle_em_bwd)(int kind, int B, int T, int S, int P, const REAL *theta, const REAL *noise, const REAL *traj,
+                            const REAL *g_traj, double dt_d, const unsigned char *pos_mask, REAL *g_x0, REAL *g_theta)
+{
+    const REAL dt = (REAL)dt_d, sqdt = (REAL)POW(dt_d, 0.5), floor = (REAL)1e-6;
+    REAL a[64], ax[64];
+    for (int b = 0; b < B; ++b) {
+        const REAL *th = theta + (long)b * P;
+        REAL *gth = g_theta + (long)b * P;
+        for (int p = 0; p < P; ++p) gth[p] = 0;
+        for (int i = 0; i < S; ++i) a[i] = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            const REAL *x = traj + ((long)b * (T + 1) + t) * S, *xn = x + S, *e = noise + ((long)b * T + t) * S;
+            for (int i = 0; i < S; ++i) {
+                a[i] += g_traj[((long)b * (T + 1) + t + 1) * S + i];
+                if (pos_mask[i] && xn[i] == floor) a[i] = 0;           /* clamped: no gradient through this entry */
+            }
+            if (kind == 1) {
+                gth[0] += a[0] * (th[1] - x[0]) * dt; gth[1] += a[0] * th[0] * dt; gth[2] += a[0] * e[0] * sqdt;
+                ax[0] = a[0] * ((REAL)1 - th[0] * dt);
+            } else if (kind == 2) {
+                const REAL u = x[0], v = x[1], t1 = th[0], t2 = th[1], t3 = th[2];
+                const REAL uv = t2 * u * v;
+                const REAL q00r = t1 * u + uv, q00 = q00r < floor ? floor : q00r, l00 = (REAL)sqrt((double)q00);
+                const REAL c = l00 < floor ? floor : l00, l10 = -uv / c;
+                const REAL q11r = t3 * v + uv - l10 * l10, q11 = q11r < floor ? floor : q11r, l11 = (REAL)sqrt((double)q11);
+                const REAL d_f0 = a[0] * dt, d_f1 = a[1] * dt;
+                REAL d_l00 = a[0] * e[0] * sqdt, d_l10 = a[1] * e[0] * sqdt;
+                const REAL d_l11 = a[1] * e[1] * sqdt;
+                REAL d_u = a[0], d_v = a[1], d_uv = 0, d_t1 = 0, d_t2 = 0, d_t3 = 0;
+                const REAL d_q11 = q11r >= floor ? d_l11 / ((REAL)2 * l11) : (REAL)0;
+                d_t3 += d_q11 * v; d_v += d_q11 * t3; d_uv += d_q11; d_l10 += (REAL)(-2) * l10 * d_q11;
+                d_uv += -d_l10 / c;
+                const REAL d_c = d_l10 * uv / (c * c);
+                if (l00 >= floor) d_l00 += d_c;
+                const REAL d_q00 = q00r >= floor ? d_l00 / ((REAL)2 * l00) : (REAL)0;
+                d_t1 += d_q00 * u; d_u += d_q00 * t1; d_uv += d_q00;
+                d_t1 += d_f0 * u; d_u += d_f0 * t1; d_uv -= d_f0;
+                d_uv += d_f1; d_t3 -= d_f1 * v; d_v -= d_f1 * t3;
+                d_t2 += d_uv * u * v; d_u += d_uv * t2 * v; d_v += d_uv * t2 * u;
+                gth[0] += d_t1; gth[1] += d_t2; gth[2] += d_t3;
+                ax[0] = d_u; ax[1] = d_v;
+            } else {
+                for (int i = 0; i < S; ++i) {
+                    const REAL bb = th[S + i];
+                    const REAL sg = (REAL)1 / ((REAL)1 + EXP(-bb));    /* d softplus(b) / db (threshold branch: 1) */
+                    gth[i] += a[i] * (-x[i]) * dt;
+                    gth[S + i] += a[i] * (bb > (REAL)20 ? (REAL)1 : sg) * e[i] * sqdt;
+                    ax[i] = a[i] * ((REAL)1 - th[i] * dt);
+                }
+            }
+            for (int i = 0; i < S; ++i) a[i] = ax[i];
+        }
+        for (int i = 0; i < S; ++i) g_x0[(long)b * S + i] = a[i] + g_traj[((long)b * (T + 1)) * S + i];
+    }
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

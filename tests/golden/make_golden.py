@@ -21,6 +21,7 @@ What is recorded (inputs and expected outputs only -- no reference source text):
 * state_dict_manifest.json  key -> [shape, dtype] of ``VariationalSDEPosterior.state_dict()``.
 * fused_dims.npz   encoder forward/gradients and a K=20-step trainer trajectory from one initial state at dims
                   where the build's fused encoder route is active (hidden 128, 2 heads, depth 2, batch 104).
+* euler_maruyama.npz  ``euler_maruyama`` trajectories + gradients for the example OU / LV SDEs with injected noise.
 * trajectory_tiny.npz  a K-step ``VariationalInferenceTrainer`` run on CPU with the head's
                   kernel call replaced by O1 and every ``torch.randn`` draw recorded.
 """
@@ -464,6 +465,36 @@ def make_fused_dims():
     print("wrote fused_dims.npz; elbo[0], elbo[-1] =", elbos[0], elbos[-1], "grad_norm", gnorms[0], gnorms[-1])
 
 
+# ------------------------------------------------------------------- Euler-Maruyama simulator of the model SDE
+def make_em_cases():
+    """``euler_maruyama`` (core/euler_maruyama.py:11-45) with the example OU / LV SDEs, injected noise: trajectory and the
+    gradients of <trajectory, g> with respect to theta and x0 (what ``pretrain_sde_parameters`` differentiates,
+    trainer.py:208-259).  The LV case starts two rows next to zero so that the positive-dims clamp (1e-6) fires."""
+    from variational_sde.core.euler_maruyama import euler_maruyama
+    ou, lv = example_sdes()
+    rec = {}
+    for name, sde, B, horizon, dt, pos in (("ou", ou, 5, 5.0, 0.05, []), ("lv", lv, 6, 4.0, 0.1, [0, 1])):
+        g = torch.Generator().manual_seed(500 + len(name) + B)
+        S, P = sde.state_dim, sde.sde_param_dim
+        T = round(horizon / dt)
+        theta = (torch.rand(B, P, generator=g) * 0.8 + 0.1).requires_grad_(True)
+        x0 = (torch.rand(B, S, generator=g) * 2.0 + 0.5)
+        if name == "lv":
+            x0[0] = torch.tensor([2e-3, 1e-3]); x0[1] = torch.tensor([5e-3, 3.0])
+        x0.requires_grad_(True)
+        noise = torch.randn(B, T, S, generator=g)
+        traj = euler_maruyama(sde, x0, theta, horizon, dt, pos, noise=noise)
+        gw = torch.randn(traj.shape, generator=g)
+        gth, gx0 = torch.autograd.grad((traj * gw).sum(), [theta, x0])
+        n_clamped = int((traj[:, 1:][..., pos] == 1e-6).sum()) if pos else 0
+        print(f"  em_{name}: T={T}, clamped entries {n_clamped}, |traj|max {float(traj.abs().max()):.3g}")
+        for k, v in dict(theta=theta, x0=x0, noise=noise, traj=traj, g_traj=gw, grad_theta=gth, grad_x0=gx0).items():
+            rec[f"{name}_{k}"] = v.detach().numpy().copy()
+        rec[f"{name}_cfg"] = np.array([horizon, dt]); rec[f"{name}_pos"] = np.array(pos, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "euler_maruyama.npz"), **rec)
+    print("wrote euler_maruyama.npz")
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"head", "elbo", "encoder", "manifest", "trajectory"}
     if "head" in which:
@@ -498,3 +529,5 @@ if __name__ == "__main__":
         make_trajectory()
     if "fused_dims" in which:
         make_fused_dims()
+    if "em" in which:
+        make_em_cases()

@@ -14,7 +14,8 @@ Each workload is checked two ways, because a T-step recurrence amplifies roundin
 
 Tolerances are relative to the max magnitude of the compared tensor:
   teacher-forced forward 2e-5, backward 2e-4 (the small-case tolerances of test_head_gpu.py);
-  free-running forward 5e-4 (LV, T=400) / 2e-3 (synthetic, T=1000), backward 2e-3 / 5e-3.
+  free-running forward 5e-5, backward 2e-4 at both sizes (measured on MI355X: forward <= 1e-6, backward <= 2e-6 -- the
+  GRU is contractive at these weight scales, so T = 400 / 1000 steps do not amplify the fp32 rounding).
 """
 import numpy as np
 import pytest
@@ -27,8 +28,8 @@ DEV = "cuda:0"
 
 WORKLOADS = {
     # name: (B launched, sub-batch scored, T, S, C, P, H, L, dt, bf16 context, free-running fwd tol, bwd tol)
-    "lv": (512, 64, 400, 2, 256, 3, 64, 2, 0.1, True, 5e-4, 2e-3),
-    "synthetic": (256, 32, 1000, 8, 512, 16, 64, 2, 0.01, True, 2e-3, 5e-3),
+    "lv": (512, 64, 400, 2, 256, 3, 64, 2, 0.1, True, 5e-5, 2e-4),
+    "synthetic": (256, 32, 1000, 8, 512, 16, 64, 2, 0.01, True, 5e-5, 2e-4),
 }
 TF_FWD_TOL, TF_BWD_TOL = 2e-5, 2e-4
 

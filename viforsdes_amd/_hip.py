@@ -58,6 +58,7 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -273,6 +274,38 @@ def elbo_path_terms_bwd(z, x, means, chol, drift, diffusion, positive_dims, time
     if rc != 0:
         _raise(rc)
     return tuple(outs)
+
+
+SDE_KINDS = {"ornstein_uhlenbeck": 1, "lotka_volterra": 2, "linear_diagonal": 3}
+
+
+def euler_maruyama_fwd(kind: str, x0, theta, noise, time_step: float, positive_dims=()):
+    """Trajectory [B, T+1, S] of a built-in model SDE (``kind`` in SDE_KINDS) for given noise [B, T, S]."""
+    lib = load()
+    dev = _require_hip(x0, theta, noise)
+    x0, theta, noise = _f32c(x0), _f32c(theta), _f32c(noise)
+    B, T, S = noise.shape
+    with torch.cuda.device(dev):
+        traj = torch.empty(B, T + 1, S, device=dev, dtype=torch.float32)
+        _call(lib.vsde_euler_maruyama_fwd, ctypes.c_int(SDE_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S),
+              ctypes.c_int(theta.shape[1]), _ptr(x0), _ptr(theta), _ptr(noise), ctypes.c_double(time_step),
+              _mask_bytes(positive_dims, S), _ptr(traj), _stream(dev))
+    return traj
+
+
+def euler_maruyama_bwd(kind: str, theta, noise, traj, g_traj, time_step: float, positive_dims=()):
+    """(g_x0 [B,S], g_theta [B,P]) of ``euler_maruyama_fwd`` for the upstream gradient g_traj [B, T+1, S]."""
+    lib = load()
+    dev = _require_hip(theta, noise, traj, g_traj)
+    theta, noise, traj, g_traj = _f32c(theta), _f32c(noise), _f32c(traj), _f32c(g_traj)
+    B, T, S = noise.shape
+    with torch.cuda.device(dev):
+        g_x0 = torch.empty(B, S, device=dev, dtype=torch.float32)
+        g_theta = torch.empty_like(theta)
+        _call(lib.vsde_euler_maruyama_bwd, ctypes.c_int(SDE_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S),
+              ctypes.c_int(theta.shape[1]), _ptr(theta), _ptr(noise), _ptr(traj), _ptr(g_traj), ctypes.c_double(time_step),
+              _mask_bytes(positive_dims, S), _ptr(g_x0), _ptr(g_theta), _stream(dev))
+    return g_x0, g_theta
 
 
 def profile_enable(on: bool) -> None:

@@ -15,6 +15,7 @@ class OrnsteinUhlenbeck:
 
     state_dim = 1
     sde_param_dim = 3
+    builtin_kind = "ornstein_uhlenbeck"  # drift / diffusion also exist inside the HIP simulator (csrc/vsde_sde.hip)
 
     def drift(self, x: Tensor, sde_parameters: Tensor) -> Tensor:
         return sde_parameters[..., 0:1] * (sde_parameters[..., 1:2] - x)
@@ -31,6 +32,7 @@ class LotkaVolterra:
 
     state_dim = 2
     sde_param_dim = 3
+    builtin_kind = "lotka_volterra"
 
     def drift(self, x: Tensor, sde_parameters: Tensor) -> Tensor:
         u, v = x.unbind(-1)
@@ -52,6 +54,8 @@ class LotkaVolterra:
 class LinearDiagonalSDE:
     """Synthetic stress workload (BASELINE config 5): dx = -a * x dt + diag(softplus(b)) dW,
     theta = (a[S], b[S])."""
+
+    builtin_kind = "linear_diagonal"
 
     def __init__(self, state_dim: int = 8) -> None:
         self.state_dim = state_dim
