@@ -225,4 +225,7 @@ def test_resume_reproduces_the_run_on_gpu():
     print("\nresume: ELBO max rel diff", max(abs(a - b) / abs(a) for a, b in zip(e1, e2)), "bit-equal params:",
           sum(int(torch.equal(a, b)) for a, b in zip(p1, p2)), "of", len(p1))
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(e1, e2)), (e1, e2)
-    assert all(torch.allclose(a, b, rtol=1e-3, atol=1e-6) for a, b in zip(p1, p2))
+    # parameters: AdamW's first steps move every weight by ~lr * sign(gradient), so last-bit noise on a near-zero gradient
+    # (zero-initialised gates / modulators) shows up as an O(lr) difference: compare with an absolute bound of a few lr
+    lr = tr.config.sde_param_lr
+    assert all(float((a - b).abs().max()) <= 3 * 3 * lr for a, b in zip(p1, p2))
