@@ -224,6 +224,26 @@ size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- Dense contractions of the encoder on bf16 MFMA ----------------------------------------------------------------
+ * y[M][N] = x[M][K] w[N][K]^T + bias[N]   (x, w, bias, y bf16; fp32 accumulation).  Replaces the hipBLASLt GEMMs behind
+ * nn.Linear in primitives/attn.py:46-47,54,113 (qkv / gate / out projections), primitives/mlp.py:41-54 (SwiGLU pair) and
+ * primitives/sit.py:186 (output projection), and -- called with the transposed weight -- their input gradients.
+ * ldx / ldy: row pitches in elements (multiples of 8; 16-byte aligned bases).  epilogue:
+ *   VSDE_EPI_PLAIN        y = acc + bias
+ *   VSDE_EPI_SWIGLU       w packs the SwiGLU input projection with its two halves interleaved in blocks of 32 rows
+ *                         ([a_0..31 | b_0..31 | a_32..63 | ...]); u = acc + bias goes to y (may be NULL when the caller
+ *                         does not need it), s_out[M][N/2] = silu(a) * b  (mlp.py:21-24)
+ *   VSDE_EPI_SWIGLU_BWD   acc is ds (gradient of s, N = width of s); u_in[M][2N] is the saved interleaved u and
+ *                         y[M][2N] receives du = (da | db) in the same interleaved layout
+ * vsde_linear_bf16_supported returns 0 when the shape is outside the compiled kernels (K in {128, 256, 512} with N % 64
+ * == 0, or K % 64 == 0 with N % 128 == 0 for the plain epilogue); callers then keep their library GEMM. */
+#define VSDE_EPI_PLAIN 0
+#define VSDE_EPI_SWIGLU 1
+#define VSDE_EPI_SWIGLU_BWD 2
+int vsde_linear_bf16_supported(int64_t M, int N, int K, int epilogue);
+int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias, void *y, int64_t ldy, int64_t M, int N, int K,
+                     int epilogue, void *s_out, int64_t lds, const void *u_in, int64_t ldu, void *stream);
+
 /* ---- Batched Euler-Maruyama simulator of the MODEL SDE (parameter pre-training stage) --------------------------------
  * Replaces the T-step Python loop of core/euler_maruyama.py:11-45 (called from trainer.py:246-259 with 4096 paths) for
  * SDEs whose drift / diffusion are built in:

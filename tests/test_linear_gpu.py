@@ -1,0 +1,79 @@
+"""GPU: the encoder's bf16 MFMA GEMM kernels (csrc/vsde_linear.hip) against an fp32 torch reference of the same op.
+
+y = x W^T + b with bf16 inputs, fp32 accumulation, bf16 output: tolerance 1e-2 relative to the output's max magnitude
+(one bf16 rounding of the result, |y| <= ~40 here); the SwiGLU epilogues are checked against the unfused chain of
+primitives/mlp.py:21-24 evaluated in fp32 from the same bf16-rounded intermediates (2e-2)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(torch.bfloat16)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+
+# (M, N, K): the LV encoder's forward and input-gradient shapes, the C=128 fixture's, the synthetic C=512 ones, ragged M
+SHAPES = [(4264, 448, 128), (4264, 128, 128), (4264, 128, 384), (4264, 128, 448), (4264, 128, 768),
+          (20000, 832, 256), (20000, 256, 256), (20000, 256, 768), (20000, 256, 832), (20000, 256, 1536),
+          (3000, 1664, 512), (3000, 512, 1408), (3000, 512, 1664), (257, 256, 256), (31, 128, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_plain_linear_matches_fp32_reference(M, N, K):
+    from viforsdes_amd import _hip
+    assert _hip.linear_supported(M, N, K)
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, scale=K ** -0.5, seed=2), _rand(N, seed=3)
+    ref = x.float() @ w.float().t() + b.float()
+    y = _hip.linear_bf16(x, w, b)
+    assert _rel(y, ref) < 1e-2
+    y2 = _hip.linear_bf16(x, w, None)
+    assert _rel(y2, x.float() @ w.float().t()) < 1e-2
+    # row-pitched input (a column range of a wider buffer) and a row-pitched output
+    wide = _rand(M, K + 64, seed=4)
+    out = torch.zeros(M, N + 8, device=DEV, dtype=torch.bfloat16)
+    _hip.linear_bf16(wide[:, 32:32 + K] if (32 * 2) % 16 == 0 else wide[:, :K], w, b, out=out[:, :N])
+    assert _rel(out[:, :N], wide[:, 32:32 + K].float() @ w.float().t() + b.float()) < 1e-2 and float(out[:, N:].abs().max()) == 0.0
+
+
+def _interleave(w_a, w_b):
+    """Packed row order of the SwiGLU input projection: blocks of 32 rows, a then b (see primitives/fused.py)."""
+    H = w_a.shape[0]
+    return torch.stack([w_a.reshape(H // 32, 32, -1), w_b.reshape(H // 32, 32, -1)], dim=1).reshape(2 * H, -1)
+
+
+@pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (3000, 1408, 512), (300, 64, 128)])
+def test_swiglu_epilogues(M, H, K):
+    from viforsdes_amd import _hip
+    x = _rand(M, K, seed=5)
+    w_a, w_b = _rand(H, K, scale=K ** -0.5, seed=6), _rand(H, K, scale=K ** -0.5, seed=7)
+    b_a, b_b = _rand(H, seed=8), _rand(H, seed=9)
+    w = _interleave(w_a, w_b).contiguous()
+    bias = _interleave(b_a[:, None], b_b[:, None]).reshape(-1).contiguous()
+    u, s = _hip.linear_swiglu_bf16(x, w, bias)
+    a_ref = (x.float() @ w_a.float().t() + b_a.float()).to(torch.bfloat16).float()
+    b_ref = (x.float() @ w_b.float().t() + b_b.float()).to(torch.bfloat16).float()
+    u_ref = _interleave(a_ref.t(), b_ref.t()).t()
+    assert _rel(u, u_ref) < 1e-2
+    # s from the kernel's own u (isolates the epilogue arithmetic from the GEMM rounding)
+    ua = u.float().reshape(M, H // 32, 2, 32)[:, :, 0].reshape(M, H)
+    ub = u.float().reshape(M, H // 32, 2, 32)[:, :, 1].reshape(M, H)
+    s_ref = (ua * torch.sigmoid(ua)).to(torch.bfloat16).float() * ub
+    assert _rel(s, s_ref) < 1e-2
+    _, s_only = _hip.linear_swiglu_bf16(x, w, bias, want_u=False)
+    assert torch.equal(s_only, s)
+    # backward epilogue: du = swiglu'(u) * (dy W2) with W2 [K2, H] the output projection
+    K2 = K
+    dy, w2 = _rand(M, K2, seed=10), _rand(K2, H, scale=H ** -0.5, seed=11)
+    du = _hip.linear_swiglu_bwd_bf16(dy, w2.t().contiguous(), u)
+    ds = dy.float() @ w2.float()
+    sg = torch.sigmoid(ua)
+    da, db = ds * ub * sg * (1 + ua * (1 - sg)), ds * ua * sg
+    du_ref = _interleave(da.t(), db.t()).t()
+    assert _rel(du, du_ref) < 2e-2

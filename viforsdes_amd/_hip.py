@@ -58,7 +58,7 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
-    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -600,3 +600,58 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
         _call(lib.vsde_linear_wgrad_bf16, _ptr(dy), _ptr(x), _i64(M), ctypes.c_int(N), ctypes.c_int(K), _ptr(dW), _ptr(db),
               _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
     return dW, db
+
+
+EPI_PLAIN, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2
+
+
+def linear_supported(M: int, N: int, K: int, epilogue: int = EPI_PLAIN) -> bool:
+    return bool(load().vsde_linear_bf16_supported(_i64(M), ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(epilogue)))
+
+
+def _rows2d(t: torch.Tensor):
+    """(tensor, row pitch) of a bf16 matrix whose rows are contiguous (a column range of a wider buffer is fine)."""
+    if t.dtype != torch.bfloat16 or t.ndim != 2 or t.stride(1) != 1:
+        raise ValueError(f"expected a row-pitched bf16 matrix, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t, t.stride(0)
+
+
+def linear_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None):
+    """y = x w^T + bias on the MFMA kernels: x [M,K] (row-pitched), w [N,K] contiguous, bias [N] or None -> y [M,N] bf16."""
+    lib = load(); dev = _require_hip(x, w)
+    x, ldx = _rows2d(x)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if out is None else out
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _ptr(y), _i64(y.stride(0)), _i64(M), ctypes.c_int(N),
+              ctypes.c_int(K), ctypes.c_int(EPI_PLAIN), None, _i64(0), None, _i64(0), _stream(dev))
+    return y
+
+
+def linear_swiglu_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], want_u: bool = True):
+    """(u [M,N] or None, s [M,N/2]) for the interleaved-packed SwiGLU input projection w [N,K]."""
+    lib = load(); dev = _require_hip(x, w)
+    x, ldx = _rows2d(x)
+    M, K = x.shape
+    N = w.shape[0]
+    u = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if want_u else None
+    s = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _ptr(u), _i64(N), _i64(M), ctypes.c_int(N),
+              ctypes.c_int(K), ctypes.c_int(EPI_SWIGLU), _ptr(s), _i64(N // 2), None, _i64(0), _stream(dev))
+    return u, s
+
+
+def linear_swiglu_bwd_bf16(dy: torch.Tensor, w_t: torch.Tensor, u: torch.Tensor):
+    """du [M,2H] (interleaved, like u) from dy [M,K] and w_t [H,K] = the SwiGLU output projection transposed: the product
+    ds = dy w_t^T never leaves the registers."""
+    lib = load(); dev = _require_hip(dy, w_t, u)
+    dy, ldx = _rows2d(dy)
+    M, K = dy.shape
+    H = w_t.shape[0]
+    du = torch.empty(M, 2 * H, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_bf16, _ptr(dy), _i64(ldx), _ptr(w_t), None, _ptr(du), _i64(2 * H), _i64(M), ctypes.c_int(H),
+              ctypes.c_int(K), ctypes.c_int(EPI_SWIGLU_BWD), None, _i64(0), _ptr(u), _i64(u.stride(0)), _stream(dev))
+    return du
