@@ -235,8 +235,8 @@ int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int 
  *                         does not need it), s_out[M][N/2] = silu(a) * b  (mlp.py:21-24)
  *   VSDE_EPI_SWIGLU_BWD   acc is ds (gradient of s, N = width of s); u_in[M][2N] is the saved interleaved u and
  *                         y[M][2N] receives du = (da | db) in the same interleaved layout
- * vsde_linear_bf16_supported returns 0 when the shape is outside the compiled kernels (K in {128, 256, 512} with N % 64
- * == 0, or K % 64 == 0 with N % 128 == 0 for the plain epilogue); callers then keep their library GEMM. */
+ * vsde_linear_bf16_supported returns 0 when the shape is outside the compiled kernels (K in {128, 256} with N % 64 == 0;
+ * for the plain epilogue also any K % 64 == 0 with N % 128 == 0); callers then keep their library GEMM. */
 #define VSDE_EPI_PLAIN 0
 #define VSDE_EPI_SWIGLU 1
 #define VSDE_EPI_SWIGLU_BWD 2

@@ -7,7 +7,7 @@
 // activation matrix is what streams.  One workgroup = 8 wavefronts x 32 rows = a 256-row stripe; a wave keeps ITS rows'
 // operand / accumulators in registers and the weight streams through LDS in 32 KB tiles (double-buffered, one barrier per
 // tile, 32 v_mfma_f32_32x32x16_bf16 per wave and tile):
-//   * rows kernel ("A-stationary", K in {128, 256, 512}): the wave's 32 x K slice of x sits in VGPRs for the whole stripe,
+//   * rows kernel ("A-stationary", K in {128, 256}): the wave's 32 x K slice of x sits in VGPRs for the whole stripe,
 //     the loop runs over 64-column tiles of W ([64][K]); x is read from HBM exactly once, y written once.
 //   * cols kernel ("C-stationary", N tile of 128 / 256, any K % 64 == 0): the wave's 32 x N accumulators stay in VGPRs, the
 //     loop runs over 64-deep K chunks of W ([N][64]) and of x (fragment loads straight to registers).
@@ -51,6 +51,11 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 __device__ __forceinline__ float rbf(float x) {   // value of x after rounding to bf16
     uint32_t a = __float_as_uint(x); a += 0x7fffu + ((a >> 16) & 1u); return __uint_as_float(a & 0xffff0000u);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a release fence for GLOBAL memory, i.e. an
+// s_waitcnt vmcnt(0): in these loops that would drain the tile's output stores (HBM write latency) and the operand loads
+// issued for the next iterations at every tile.  LDS operations are tracked by lgkmcnt alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float sigm_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
 // 32 rows x 64 columns of bf16 out of the wave's staging buffer (row stride SLD elements) as full 128-byte row segments
@@ -180,13 +185,10 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
     // the wave's 32 x KC slice of the activations, as MFMA operand fragments (lane: row r, k-half h)
     bf16x8 afr[KS];
     {
-        const int64_t m = row0 + r;
+        const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one; they are never stored
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (m < p.M) afr[ks] = *(const bf16x8 *)(src + ks * 16);
-            else afr[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int ks = 0; ks < KS; ++ks) afr[ks] = *(const bf16x8 *)(src + ks * 16);
     }
     const int ntiles = p.N / 64;
     u32x4 breg[NLD];
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
     } while (0)
     VSDE_TILE_LOAD(0);
     VSDE_TILE_STORE(lsm);
-    __syncthreads();
+    lds_barrier();
     if (ntiles > 1) VSDE_TILE_LOAD(1);
     for (int nt = 0; nt < ntiles; ++nt) {
         const uint16_t *Bs = lsm + (nt & 1) * TILE;
@@ -212,16 +214,33 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+        // weight fragments are fetched a group (4 k-steps x 2 column blocks = 8 ds_read_b128) ahead of the MFMAs that use them
+        constexpr int GK = 4, NG = KS / GK;
+        const uint16_t *bsrc = Bs + r * LDB + 8 * h;
+        bf16x8 bq[2][GK][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int k = 0; k < GK; ++k)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const bf16x8 bfr = *(const bf16x8 *)(Bs + (nb * 32 + r) * LDB + ks * 16 + 8 * h);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, afr[ks], acc[nb], 0, 0, 0);
-            }
+            for (int nb = 0; nb < 2; ++nb) bq[0][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + k * 16);
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+            if (gk + 1 < NG)
+#pragma unroll
+                for (int k = 0; k < GK; ++k)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        bq[(gk + 1) & 1][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + ((gk + 1) * GK + k) * 16);
+            __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+            for (int k = 0; k < GK; ++k)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k][nb], afr[gk * GK + k], acc[nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         tile_epilogue<EPI>(p, acc, Bs + 64 * LDB, stage, row0, nt * 64, lane);
         if (nt + 1 < ntiles) VSDE_TILE_STORE(lsm + ((nt + 1) & 1) * TILE);   // that buffer was last read in iteration nt - 1
-        __syncthreads();
+        lds_barrier();
         if (nt + 2 < ntiles) VSDE_TILE_LOAD(nt + 2);
     }
 #undef VSDE_TILE_LOAD
@@ -239,19 +258,15 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     uint16_t *stage = lsm + 2 * TILE + wave * stage_elems<EPI_PLAIN>();
     const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS + wave * 32;
     const int nbase = blockIdx.y * NT;
-    const int64_t m = row0 + r;
-    const bool mok = m < p.M;
+    const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one; they are never stored
     const uint16_t *asrc = p.A + m * p.lda + 8 * h;
     const int ktiles = p.K / 64;
 
     u32x4 breg[NLD];
     bf16x8 afr[4], anext[4];
     const uint16_t *wsrc = p.W + (int64_t)nbase * p.K;
-#define VSDE_A_LOAD(kt_, dst_)                                                              \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                      \
-        if (mok) dst_[ks] = *(const bf16x8 *)(asrc + (kt_) * 64 + ks * 16);                 \
-        else dst_[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};                                   \
-    }
+#define VSDE_A_LOAD(kt_, dst_) \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) dst_[ks] = *(const bf16x8 *)(asrc + (kt_) * 64 + ks * 16);
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -260,20 +275,36 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     wtile_load<NLD, 64>(breg, wsrc, p.K, tid);
     VSDE_A_LOAD(0, afr)
     wtile_store<NLD, 64, LDB>(breg, lsm, tid);
-    __syncthreads();
+    lds_barrier();
     if (ktiles > 1) wtile_load<NLD, 64>(breg, wsrc + 64, p.K, tid);
     for (int kt = 0; kt < ktiles; ++kt) {
         const uint16_t *Bs = lsm + (kt & 1) * TILE;
         if (kt + 1 < ktiles) { VSDE_A_LOAD(kt + 1, anext) }
+        // the tile's 4 NB (k-step, column block) products in order; the weight fragments of a group of 4 are fetched while the
+        // MFMAs of the previous group run
+        constexpr int G = 4, NGRP = 4 * NB / G;
+        const uint16_t *bsrc = Bs + r * LDB + 8 * h;
+        bf16x8 bq[2][G];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * LDB + (i / NB) * 16);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 bfr = *(const bf16x8 *)(Bs + (nb * 32 + r) * LDB + ks * 16 + 8 * h);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, afr[ks], acc[nb], 0, 0, 0);
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP)
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int q = (g + 1) * G + i;
+                    bq[(g + 1) & 1][i] = *(const bf16x8 *)(bsrc + (q % NB) * 32 * LDB + (q / NB) * 16);
+                }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int q = g * G + i;
+                acc[q % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g & 1][i], afr[q / NB], acc[q % NB], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (kt + 1 < ktiles) wtile_store<NLD, 64, LDB>(breg, lsm + ((kt + 1) & 1) * TILE, tid);
-        __syncthreads();
+        lds_barrier();
         if (kt + 2 < ktiles) wtile_load<NLD, 64>(breg, wsrc + (kt + 2) * 64, p.K, tid);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) afr[ks] = anext[ks];
@@ -281,7 +312,7 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
 #undef VSDE_A_LOAD
     // epilogue: 64 columns at a time through the wave's staging buffer; the bias row is staged in the (now free) tile buffer 0
     if (tid < NT / 2) *(uint32_t *)(lsm + 2 * tid) = p.bias ? *(const uint32_t *)(p.bias + nbase + 2 * tid) : 0u;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < NB / 2; ++q) {
         f32x16 pair[2] = {acc[2 * q], acc[2 * q + 1]};
@@ -303,11 +334,7 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
 
 template <int EPI>
 static int launch_rows_k(const LinParams &p, hipStream_t s) {
-    switch (p.K) {
-        case 128: return launch_rows<128, EPI>(p, s);
-        case 256: return launch_rows<256, EPI>(p, s);
-        default: return launch_rows<512, EPI>(p, s);
-    }
+    return p.K == 128 ? launch_rows<128, EPI>(p, s) : launch_rows<256, EPI>(p, s);
 }
 
 template <int NB>
@@ -321,7 +348,7 @@ static int launch_cols(const LinParams &p, hipStream_t s) {
 
 // 1 = rows kernel, 2 = cols kernel, 0 = shape not covered (the caller keeps its library GEMM)
 static int lin_variant(int N, int K, int epilogue) {
-    const bool rows_ok = (K == 128 || K == 256 || K == 512) && N % 64 == 0;
+    const bool rows_ok = (K == 128 || K == 256) && N % 64 == 0;   // K = 512 would need 172 KB of LDS: cols kernel
     const bool cols_ok = K % 64 == 0 && N % 128 == 0 && epilogue == EPI_PLAIN;
     if (epilogue != EPI_PLAIN) return rows_ok ? 1 : 0;
     // both fit: the rows kernel reads the activations once and suits wide outputs; the cols kernel suits deep reductions
