@@ -41,16 +41,15 @@ struct LinParams {
     int64_t M; int N, K;
 };
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // round to nearest even, two at a time
-    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {   // v_cvt_pk_bf16_f32: round to nearest even, two at a time
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2));
 }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ float rbf(float x) {   // value of x after rounding to bf16
-    uint32_t a = __float_as_uint(x); a += 0x7fffu + ((a >> 16) & 1u); return __uint_as_float(a & 0xffff0000u);
-}
+__device__ __forceinline__ float rbf(float x) { return (float)(__bf16)x; }   // value of x after rounding to bf16
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a release fence for GLOBAL memory, i.e. an
 // s_waitcnt vmcnt(0): in these loops that would drain the tile's output stores (HBM write latency) and the operand loads
 // issued for the next iterations at every tile.  LDS operations are tracked by lgkmcnt alone.
@@ -172,6 +171,38 @@ __device__ __forceinline__ void wtile_store(const u32x4 (&breg)[NLD], uint16_t *
     }
 }
 
+// The 2 x KS products of one 64-column tile for the wave's 32 rows.  Weight fragments are fetched a group (4 k-steps x 2
+// column blocks = 8 ds_read_b128) ahead of the MFMAs that use them.  bsrc = tile + r * LDB + 8 h.
+template <int KC>
+__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&afr)[KC / 16], const uint16_t *bsrc) {
+    constexpr int KS = KC / 16, LDB = KC + 8, GK = 4, NG = KS / GK;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+    bf16x8 bq[2][GK][2];
+#pragma unroll
+    for (int k = 0; k < GK; ++k)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bq[0][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + k * 16);
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) {
+        if (gk + 1 < NG)
+#pragma unroll
+            for (int k = 0; k < GK; ++k)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    bq[(gk + 1) & 1][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + ((gk + 1) * GK + k) * 16);
+        __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+        for (int k = 0; k < GK; ++k)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k][nb], afr[gk * GK + k], acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ rows kernel
 template <int KC, int EPI>
 __global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
@@ -191,60 +222,72 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
         for (int ks = 0; ks < KS; ++ks) afr[ks] = *(const bf16x8 *)(src + ks * 16);
     }
     const int ntiles = p.N / 64;
-    u32x4 breg[NLD];
-    uint32_t biasreg = 0;
-#define VSDE_TILE_LOAD(nt_)                                                                                   \
+    // Tiles are visited in a rotated order (first tile = workgroup index mod ntiles): the workgroups of a launch then pull
+    // DIFFERENT 32 KB tiles of W out of L2 at any moment instead of all hammering the same lines (same channels).
+    const int rot = blockIdx.x % ntiles;
+    // Two register sets: tile t travels in breg[t & 1]; its loads are issued two iterations before its LDS store.
+    u32x4 breg[2][NLD];
+    uint32_t biasreg[2] = {0u, 0u};
+#define VSDE_TILE_LOAD(t_, set_)                                                                              \
     do {                                                                                                      \
-        wtile_load<NLD, KC>(breg, p.W + (int64_t)(nt_) * 64 * KC, KC, tid);                                   \
-        if (tid < 32) biasreg = p.bias ? *(const uint32_t *)(p.bias + (nt_) * 64 + 2 * tid) : 0u;             \
+        const int tile_ = ((t_) + rot) % ntiles;                                                              \
+        wtile_load<NLD, KC>(breg[set_], p.W + (int64_t)tile_ * 64 * KC, KC, tid);                             \
+        if (tid < 32) biasreg[set_] = p.bias ? *(const uint32_t *)(p.bias + tile_ * 64 + 2 * tid) : 0u;       \
     } while (0)
-#define VSDE_TILE_STORE(Bs_)                                                                                  \
+#define VSDE_TILE_STORE(Bs_, set_)                                                                            \
     do {                                                                                                      \
-        wtile_store<NLD, KC, LDB>(breg, (Bs_), tid);                                                          \
-        if (tid < 32) *(uint32_t *)((Bs_) + 64 * LDB + 2 * tid) = biasreg;                                    \
+        wtile_store<NLD, KC, LDB>(breg[set_], (Bs_), tid);                                                    \
+        if (tid < 32) *(uint32_t *)((Bs_) + 64 * LDB + 2 * tid) = biasreg[set_];                              \
     } while (0)
-    VSDE_TILE_LOAD(0);
-    VSDE_TILE_STORE(lsm);
+// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (register set 1 - PAR_) goes to the other buffer
+#define VSDE_ROWS_BODY(t_, PAR_)                                                                              \
+    do {                                                                                                      \
+        const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
+        f32x16 acc[2];                                                                                        \
+        rows_tile_mfma<KC>(acc, afr, Bs + r * LDB + 8 * h);                                                   \
+        tile_epilogue<EPI>(p, acc, Bs + 64 * LDB, stage, row0, (((t_) + rot) % ntiles) * 64, lane);           \
+        if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE, 1 - (PAR_));                        \
+        lds_barrier();                                                                                        \
+        if ((t_) + 3 < ntiles) VSDE_TILE_LOAD((t_) + 3, 1 - (PAR_));                                          \
+    } while (0)
+    VSDE_TILE_LOAD(0, 0);
+    VSDE_TILE_STORE(lsm, 0);
     lds_barrier();
-    if (ntiles > 1) VSDE_TILE_LOAD(1);
-    for (int nt = 0; nt < ntiles; ++nt) {
-        const uint16_t *Bs = lsm + (nt & 1) * TILE;
-        f32x16 acc[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-        // weight fragments are fetched a group (4 k-steps x 2 column blocks = 8 ds_read_b128) ahead of the MFMAs that use them
-        constexpr int GK = 4, NG = KS / GK;
-        const uint16_t *bsrc = Bs + r * LDB + 8 * h;
-        bf16x8 bq[2][GK][2];
-#pragma unroll
-        for (int k = 0; k < GK; ++k)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) bq[0][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + k * 16);
-#pragma unroll
-        for (int gk = 0; gk < NG; ++gk) {
-            if (gk + 1 < NG)
-#pragma unroll
-                for (int k = 0; k < GK; ++k)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        bq[(gk + 1) & 1][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + ((gk + 1) * GK + k) * 16);
-            __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
-#pragma unroll
-            for (int k = 0; k < GK; ++k)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k][nb], afr[gk * GK + k], acc[nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tile_epilogue<EPI>(p, acc, Bs + 64 * LDB, stage, row0, nt * 64, lane);
-        if (nt + 1 < ntiles) VSDE_TILE_STORE(lsm + ((nt + 1) & 1) * TILE);   // that buffer was last read in iteration nt - 1
-        lds_barrier();
-        if (nt + 2 < ntiles) VSDE_TILE_LOAD(nt + 2);
+    if (ntiles > 1) VSDE_TILE_LOAD(1, 1);
+    if (ntiles > 2) VSDE_TILE_LOAD(2, 0);
+    for (int nt = 0; nt < ntiles; nt += 2) {
+        VSDE_ROWS_BODY(nt, 0);
+        if (nt + 1 < ntiles) VSDE_ROWS_BODY(nt + 1, 1);
     }
+#undef VSDE_ROWS_BODY
 #undef VSDE_TILE_LOAD
 #undef VSDE_TILE_STORE
+}
+
+// The 4 x NB (k-step, column block) products of one 64-deep chunk for the wave's 32 rows; the weight fragments of a group of
+// 4 are fetched while the MFMAs of the previous group run.  bsrc = tile + r * 72 + 8 h.
+template <int NB>
+__device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (&afr)[4], const uint16_t *bsrc) {
+    constexpr int G = 4, NGRP = 4 * NB / G, LDB = 72;
+    bf16x8 bq[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * LDB + (i / NB) * 16);
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        if (g + 1 < NGRP)
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int q = (g + 1) * G + i;
+                bq[(g + 1) & 1][i] = *(const bf16x8 *)(bsrc + (q % NB) * 32 * LDB + (q / NB) * 16);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = g * G + i;
+            acc[q % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g & 1][i], afr[q / NB], acc[q % NB], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ cols kernel
@@ -262,54 +305,41 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     const uint16_t *asrc = p.A + m * p.lda + 8 * h;
     const int ktiles = p.K / 64;
 
-    u32x4 breg[NLD];
-    bf16x8 afr[4], anext[4];
+    // K chunks are visited in a rotated order (see the rows kernel); chunk t travels in breg[t & 1], loaded two iterations
+    // before its LDS store; the activation fragments of chunk t + 1 are fetched during the MFMAs of chunk t.
+    const int rot = blockIdx.x % ktiles;
+    u32x4 breg[2][NLD];
+    bf16x8 afr[2][4];
     const uint16_t *wsrc = p.W + (int64_t)nbase * p.K;
-#define VSDE_A_LOAD(kt_, dst_) \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) dst_[ks] = *(const bf16x8 *)(asrc + (kt_) * 64 + ks * 16);
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-    wtile_load<NLD, 64>(breg, wsrc, p.K, tid);
-    VSDE_A_LOAD(0, afr)
-    wtile_store<NLD, 64, LDB>(breg, lsm, tid);
+#define VSDE_CHUNK(t_) ((((t_) + rot) % ktiles) * 64)
+#define VSDE_A_LOAD(t_, set_) \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) afr[set_][ks] = *(const bf16x8 *)(asrc + VSDE_CHUNK(t_) + ks * 16);
+#define VSDE_COLS_BODY(t_, PAR_)                                                                              \
+    do {                                                                                                      \
+        if ((t_) + 1 < ktiles) { VSDE_A_LOAD((t_) + 1, 1 - (PAR_)) }                                          \
+        cols_tile_mfma<NB>(acc, afr[PAR_], lsm + (PAR_) * TILE + r * LDB + 8 * h);                            \
+        if ((t_) + 1 < ktiles) wtile_store<NLD, 64, LDB>(breg[1 - (PAR_)], lsm + (1 - (PAR_)) * TILE, tid);   \
+        lds_barrier();                                                                                        \
+        if ((t_) + 3 < ktiles) wtile_load<NLD, 64>(breg[1 - (PAR_)], wsrc + VSDE_CHUNK((t_) + 3), p.K, tid);  \
+    } while (0)
+    wtile_load<NLD, 64>(breg[0], wsrc + VSDE_CHUNK(0), p.K, tid);
+    VSDE_A_LOAD(0, 0)
+    wtile_store<NLD, 64, LDB>(breg[0], lsm, tid);
     lds_barrier();
-    if (ktiles > 1) wtile_load<NLD, 64>(breg, wsrc + 64, p.K, tid);
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const uint16_t *Bs = lsm + (kt & 1) * TILE;
-        if (kt + 1 < ktiles) { VSDE_A_LOAD(kt + 1, anext) }
-        // the tile's 4 NB (k-step, column block) products in order; the weight fragments of a group of 4 are fetched while the
-        // MFMAs of the previous group run
-        constexpr int G = 4, NGRP = 4 * NB / G;
-        const uint16_t *bsrc = Bs + r * LDB + 8 * h;
-        bf16x8 bq[2][G];
-#pragma unroll
-        for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * LDB + (i / NB) * 16);
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            if (g + 1 < NGRP)
-#pragma unroll
-                for (int i = 0; i < G; ++i) {
-                    const int q = (g + 1) * G + i;
-                    bq[(g + 1) & 1][i] = *(const bf16x8 *)(bsrc + (q % NB) * 32 * LDB + (q / NB) * 16);
-                }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
-#pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int q = g * G + i;
-                acc[q % NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g & 1][i], afr[q / NB], acc[q % NB], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kt + 1 < ktiles) wtile_store<NLD, 64, LDB>(breg, lsm + ((kt + 1) & 1) * TILE, tid);
-        lds_barrier();
-        if (kt + 2 < ktiles) wtile_load<NLD, 64>(breg, wsrc + (kt + 2) * 64, p.K, tid);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) afr[ks] = anext[ks];
+    if (ktiles > 1) wtile_load<NLD, 64>(breg[1], wsrc + VSDE_CHUNK(1), p.K, tid);
+    if (ktiles > 2) wtile_load<NLD, 64>(breg[0], wsrc + VSDE_CHUNK(2), p.K, tid);
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        VSDE_COLS_BODY(kt, 0);
+        if (kt + 1 < ktiles) VSDE_COLS_BODY(kt + 1, 1);
     }
+#undef VSDE_COLS_BODY
 #undef VSDE_A_LOAD
+#undef VSDE_CHUNK
     // epilogue: 64 columns at a time through the wave's staging buffer; the bias row is staged in the (now free) tile buffer 0
     if (tid < NT / 2) *(uint32_t *)(lsm + 2 * tid) = p.bias ? *(const uint32_t *)(p.bias + nbase + 2 * tid) : 0u;
     lds_barrier();
