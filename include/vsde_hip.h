@@ -230,8 +230,8 @@ int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int 
  * primitives/sit.py:186 (output projection), and -- called with the transposed weight -- their input gradients.
  * ldx / ldy: row pitches in elements (multiples of 8; 16-byte aligned bases).  epilogue:
  *   VSDE_EPI_PLAIN        y = acc + bias
- *   VSDE_EPI_SWIGLU       w packs the SwiGLU input projection with its two halves interleaved in blocks of 32 rows
- *                         ([a_0..31 | b_0..31 | a_32..63 | ...]); u = acc + bias goes to y (may be NULL when the caller
+ *   VSDE_EPI_SWIGLU       w packs the SwiGLU input projection with its two halves interleaved in blocks of 16 rows
+ *                         ([a_0..15 | b_0..15 | a_16..31 | ...]); u = acc + bias goes to y (may be NULL when the caller
  *                         does not need it), s_out[M][N/2] = silu(a) * b  (mlp.py:21-24)
  *   VSDE_EPI_SWIGLU_BWD   acc is ds (gradient of s, N = width of s); u_in[M][2N] is the saved interleaved u and
  *                         y[M][2N] receives du = (da | db) in the same interleaved layout

@@ -43,9 +43,9 @@ def test_plain_linear_matches_fp32_reference(M, N, K):
 
 
 def _interleave(w_a, w_b):
-    """Packed row order of the SwiGLU input projection: blocks of 32 rows, a then b (see primitives/fused.py)."""
+    """Packed row order of the SwiGLU input projection: blocks of 16 rows, a then b (see primitives/fused.py)."""
     H = w_a.shape[0]
-    return torch.stack([w_a.reshape(H // 32, 32, -1), w_b.reshape(H // 32, 32, -1)], dim=1).reshape(2 * H, -1)
+    return torch.stack([w_a.reshape(H // 16, 16, -1), w_b.reshape(H // 16, 16, -1)], dim=1).reshape(2 * H, -1)
 
 
 @pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128)])
@@ -62,8 +62,8 @@ def test_swiglu_epilogues(M, H, K):
     u_ref = _interleave(a_ref.t(), b_ref.t()).t()
     assert _rel(u, u_ref) < 1e-2
     # s from the kernel's own u (isolates the epilogue arithmetic from the GEMM rounding)
-    ua = u.float().reshape(M, H // 32, 2, 32)[:, :, 0].reshape(M, H)
-    ub = u.float().reshape(M, H // 32, 2, 32)[:, :, 1].reshape(M, H)
+    ua = u.float().reshape(M, H // 16, 2, 16)[:, :, 0].reshape(M, H)
+    ub = u.float().reshape(M, H // 16, 2, 16)[:, :, 1].reshape(M, H)
     s_ref = (ua * torch.sigmoid(ua)).to(torch.bfloat16).float() * ub
     assert _rel(s, s_ref) < 1e-2
     _, s_only = _hip.linear_swiglu_bf16(x, w, bias, want_u=False)

@@ -16,8 +16,8 @@
 // are then lane-local register math, and the tile leaves through a per-wave LDS staging buffer as full 128-byte row segments.
 // Epilogues:
 //   EPI_PLAIN        y = acc + bias                                                       (bf16)
-//   EPI_SWIGLU       u = acc + bias (kept for the backward), s = silu(a) * b   with [a | b] the two 32-column halves of a
-//                    64-column tile: the packed weight interleaves the SwiGLU halves in blocks of 32 rows (primitives/fused.py)
+//   EPI_SWIGLU       u = acc + bias (kept for the backward), s = silu(a) * b   with [a | b] the two 16-column halves of a
+//                    32-column tile: the packed weight interleaves the SwiGLU halves in blocks of 16 rows (primitives/fused.py)
 //   EPI_SWIGLU_BWD   acc = ds (gradient of s); reads u, writes du = (da | db) in the same interleaved layout
 #include "vsde_common.h"
 
@@ -30,6 +30,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte regis
 constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2;
 constexpr int LIN_ROWS = 256;   // rows per workgroup (8 waves x 32)
 constexpr int LIN_THREADS = 512;
+constexpr int R2_THREADS = 256, R2_ROWS = 256, R2_SLD = 72;   // rows kernel: 4 waves x 64 rows, staging rows of 64 + 8 elements
 
 struct LinParams {
     const uint16_t *A; int64_t lda;    // activations [M][lda] bf16 (row pitch in elements)
@@ -57,83 +58,112 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float sigm_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
-// 32 rows x 64 columns of bf16 out of the wave's staging buffer (row stride SLD elements) as full 128-byte row segments
-template <int SLD>
+// R rows x 64 columns of bf16 out of a wave's staging buffer (row stride SLD elements) as full 128-byte row segments
+template <int SLD, int R>
 __device__ __forceinline__ void flush_rows64(const uint16_t *stage, uint16_t *dst, int64_t ld, int64_t row0, int64_t M, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R / 8; ++i) {
         const int row = (lane >> 3) + 8 * i, c = lane & 7;
         const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
         if (row0 + row < M) *(uint4 *)(dst + (row0 + row) * ld + c * 8) = v;
     }
 }
+// R rows x 32 columns (64-byte row segments: 4 lanes per row)
+template <int SLD, int R>
+__device__ __forceinline__ void flush_rows32(const uint16_t *stage, uint16_t *dst, int64_t ld, int64_t row0, int64_t M, int lane) {
+#pragma unroll
+    for (int i = 0; i < R / 16; ++i) {
+        const int row = (lane >> 2) + 16 * i, c = lane & 3;
+        const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
+        if (row0 + row < M) *(uint4 *)(dst + (row0 + row) * ld + c * 8) = v;
+    }
+}
 
-// Epilogue of one 64-column tile held as acc[0], acc[1] (32 columns each) for the wave's 32 rows.
-// brow: LDS row with the tile's 64 bias values (bf16; zeros without a bias).  n0: first output column of the tile.
-template <int EPI>
-__device__ __forceinline__ void tile_epilogue(const LinParams &p, f32x16 (&acc)[2], const uint16_t *brow, uint16_t *stage,
+// acc (one 32x32 MFMA block: this lane holds row r, columns 8 g + 4 h + i) + bias -> bf16 into the staging row
+__device__ __forceinline__ void stage_block(const f32x16 &acc, const uint16_t *bias32, uint16_t *dst_row, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+        *(uint2 *)(dst_row + 8 * g + 4 * h) = make_uint2(pack_bf16x2(acc[4 * g + 0] + bf_lo(bb.x), acc[4 * g + 1] + bf_hi(bb.x)),
+                                                        pack_bf16x2(acc[4 * g + 2] + bf_lo(bb.y), acc[4 * g + 3] + bf_hi(bb.y)));
+    }
+}
+
+// weight tile [ROWS][KW] (row pitch ldw in global memory) <-> registers <-> LDS rows of LDB elements, THREADS threads
+template <int NLD, int KW, int THREADS>
+__device__ __forceinline__ void wtile_load(u32x4 (&breg)[NLD], const uint16_t *W, int64_t ldw, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + THREADS * i, row = idx / (KW / 8), c = idx % (KW / 8);
+        breg[i] = *(const u32x4 *)(W + (int64_t)row * ldw + c * 8);
+    }
+}
+template <int NLD, int KW, int LDB, int THREADS>
+__device__ __forceinline__ void wtile_store(const u32x4 (&breg)[NLD], uint16_t *Bs, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + THREADS * i, row = idx / (KW / 8), c = idx % (KW / 8);
+        *(u32x4 *)(Bs + row * LDB + c * 8) = breg[i];
+    }
+}
+
+// Epilogue of one 32-column tile (acc[rb]: the wave's two 32-row blocks) of the rows kernel.  PAR = parity of the tile: tiles
+// leave in pairs (2q, 2q + 1) = 64 output columns.  bias32: LDS row with the tile's 32 bias values; n0: the tile's first column.
+//   EPI_SWIGLU      the packed weight interleaves the SwiGLU halves in blocks of 16 rows, so a 32-column tile is [a_16 | b_16]:
+//                   this lane's register quads g = 0, 1 hold a_j and g = 2, 3 the matching b_j; a pair of tiles gives 32 columns of s.
+//   EPI_SWIGLU_BWD  acc = ds for 32 columns j; u / du tile: 64 interleaved columns [a_16 | b_16 | a_16 | b_16]; no pairing.
+template <int EPI, int PAR>
+__device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[2], const uint16_t *bias32, uint16_t *stage,
                                               int64_t row0, int n0, int lane) {
     const int r = lane & 31, h = lane >> 5;
+    constexpr int SLD = R2_SLD;
     if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU) {
-        constexpr int SLD = 72;   // 64 + 8 elements: 144-byte rows
-        uint32_t sp[2][4];        // EPI_SWIGLU: packed s values per register quad
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[2][4];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const uint2 bb = *(const uint2 *)(brow + nb * 32 + 8 * g + 4 * h);
-                v[nb][0] = acc[nb][4 * g + 0] + bf_lo(bb.x); v[nb][1] = acc[nb][4 * g + 1] + bf_hi(bb.x);
-                v[nb][2] = acc[nb][4 * g + 2] + bf_lo(bb.y); v[nb][3] = acc[nb][4 * g + 3] + bf_hi(bb.y);
-                *(uint2 *)(stage + r * SLD + nb * 32 + 8 * g + 4 * h) = make_uint2(pack_bf16x2(v[nb][0], v[nb][1]), pack_bf16x2(v[nb][2], v[nb][3]));
-            }
+        for (int rb = 0; rb < 2; ++rb) {
+            stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
             if constexpr (EPI == EPI_SWIGLU) {
-                float s[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {   // from the bf16-rounded u, as the unfused chain (mlp.py:21-24 under autocast)
-                    const float a = rbf(v[0][i]), b = rbf(v[1][i]);
-                    s[i] = rbf(a * sigm_f(a)) * b;
+                for (int g = 0; g < 2; ++g) {
+                    const uint2 ba = *(const uint2 *)(bias32 + 8 * g + 4 * h), bb = *(const uint2 *)(bias32 + 16 + 8 * g + 4 * h);
+                    const float av[4] = {bf_lo(ba.x), bf_hi(ba.x), bf_lo(ba.y), bf_hi(ba.y)};
+                    const float bv[4] = {bf_lo(bb.x), bf_hi(bb.x), bf_lo(bb.y), bf_hi(bb.y)};
+                    float sv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {   // from the bf16-rounded u, as the unfused chain (mlp.py:21-24 under autocast)
+                        const float a = rbf(acc[rb][4 * g + i] + av[i]), b = rbf(acc[rb][4 * (g + 2) + i] + bv[i]);
+                        sv[i] = rbf(a * sigm_f(a)) * b;
+                    }
+                    // s leaves straight from the registers: 8 bytes per lane, the two half-waves complete 16 bytes of a row
+                    if (row0 + rb * 32 + r < p.M)
+                        *(uint2 *)(p.S + (row0 + rb * 32 + r) * p.lds_ + (n0 >> 1) + 8 * g + 4 * h) = make_uint2(pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3]));
                 }
-                sp[0][g] = pack_bf16x2(s[0], s[1]); sp[1][g] = pack_bf16x2(s[2], s[3]);
             }
         }
-        wave_lds_fence();
-        if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD>(stage, p.C + n0, p.ldc, row0, p.M, lane);
-        if constexpr (EPI == EPI_SWIGLU) {
+        if constexpr (PAR == 1) {
             wave_lds_fence();
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(uint2 *)(stage + r * SLD + 8 * g + 4 * h) = make_uint2(sp[0][g], sp[1][g]);
+            if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD, 64>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
             wave_lds_fence();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {   // 32 columns of s = 64 bytes per row: 4 lanes per row, 16 rows per instruction
-                const int row = (lane >> 2) + 16 * i, c = lane & 3;
-                const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
-                if (row0 + row < p.M) *(uint4 *)(p.S + (row0 + row) * p.lds_ + (n0 >> 1) + c * 8) = v;
-            }
         }
-        wave_lds_fence();
     } else {
-        // acc[nb] = ds for columns j = n0 + 32 nb + ..; u / du tile: 128 interleaved columns [a(32) | b(32) | a(32) | b(32)]
-        constexpr int SLD = 136;  // 128 + 8 elements
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {   // coalesced load of the wave's 32 x 128 slice of u: 4 rows x 256 bytes per instruction
-            const int row = (lane >> 4) + 4 * i, c = lane & 15;
+        for (int i = 0; i < 8; ++i) {   // coalesced load of the wave's 64 x 64 slice of u: 8 rows x 128 bytes per instruction
+            const int row = (lane >> 3) + 8 * i, c = lane & 7;
             const uint4 v = row0 + row < p.M ? *(const uint4 *)(p.U + (row0 + row) * p.ldu + 2 * n0 + c * 8) : make_uint4(0, 0, 0, 0);
             *(uint4 *)(stage + row * SLD + c * 8) = v;
         }
         wave_lds_fence();
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint16_t *pa = stage + r * SLD + nb * 64 + 8 * g + 4 * h, *pb = pa + 32;
+            for (int g = 0; g < 4; ++g) {   // ds column 8 g + 4 h + i  <->  u columns 32 (g / 2) + 8 (g % 2) + 4 h + i (a), + 16 (b)
+                uint16_t *pa = stage + (rb * 32 + r) * SLD + 32 * (g >> 1) + 8 * (g & 1) + 4 * h, *pb = pa + 16;
                 const uint2 ua = *(const uint2 *)pa, ub = *(const uint2 *)pb;
                 const float a[4] = {bf_lo(ua.x), bf_hi(ua.x), bf_lo(ua.y), bf_hi(ua.y)};
                 const float b[4] = {bf_lo(ub.x), bf_hi(ub.x), bf_lo(ub.y), bf_hi(ub.y)};
                 float da[4], db[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float gs = acc[nb][4 * g + i], sg = sigm_f(a[i]);
+                    const float gs = acc[rb][4 * g + i], sg = sigm_f(a[i]);
                     da[i] = gs * b[i] * sg * (1.0f + a[i] * (1.0f - sg));
                     db[i] = gs * a[i] * sg;
                 }
@@ -141,123 +171,97 @@ __device__ __forceinline__ void tile_epilogue(const LinParams &p, f32x16 (&acc)[
                 *(uint2 *)pb = make_uint2(pack_bf16x2(db[0], db[1]), pack_bf16x2(db[2], db[3]));
             }
         wave_lds_fence();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (lane >> 4) + 4 * i, c = lane & 15;
-            const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
-            if (row0 + row < p.M) *(uint4 *)(p.C + (row0 + row) * p.ldc + 2 * n0 + c * 8) = v;
-        }
+        flush_rows64<SLD, 64>(stage, p.C + 2 * n0, p.ldc, row0, p.M, lane);
         wave_lds_fence();
     }
 }
 
-template <int EPI> constexpr int stage_elems() { return EPI == EPI_SWIGLU_BWD ? 32 * 136 : 32 * 72; }
+// ------------------------------------------------------------------------------------------------ rows kernel
+// Workgroup = 4 waves x 64 rows (two 32-row MFMA blocks per wave, their K-slices resident in VGPRs); the weight streams
+// through LDS in tiles of 32 output columns ([32][KC] + a bias row, double-buffered, one barrier per tile, 32 MFMAs per wave and
+// tile, every weight fragment feeds two MFMAs).  ~72 KB of LDS and <= 256 VGPRs: TWO workgroups per CU, whose phases (MFMA
+// burst / epilogue / tile refill) drift apart and overlap -- one 8-wave workgroup in lockstep ran the matrix pipe at 25 %.
+// Tiles are visited in a rotated order (first tile pair = workgroup index): the workgroups of a launch pull DIFFERENT tiles of W
+// out of L2 at any moment; the next tile's loads are in flight during the current tile's MFMAs and epilogue.
+// Outputs leave in pairs of tiles (64 columns = 128-byte row segments) through the wave's staging buffer.
+template <int EPI> constexpr int r2_stage_elems() { return 64 * R2_SLD; }
 
-// weight tile [ROWS][KW] (row pitch ldw in global memory) <-> registers <-> LDS rows of LDB elements
-template <int NLD, int KW>
-__device__ __forceinline__ void wtile_load(u32x4 (&breg)[NLD], const uint16_t *W, int64_t ldw, int tid) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + LIN_THREADS * i, row = idx / (KW / 8), c = idx % (KW / 8);
-        breg[i] = *(const u32x4 *)(W + (int64_t)row * ldw + c * 8);
-    }
-}
-template <int NLD, int KW, int LDB>
-__device__ __forceinline__ void wtile_store(const u32x4 (&breg)[NLD], uint16_t *Bs, int tid) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + LIN_THREADS * i, row = idx / (KW / 8), c = idx % (KW / 8);
-        *(u32x4 *)(Bs + row * LDB + c * 8) = breg[i];
-    }
-}
-
-// The 2 x KS products of one 64-column tile for the wave's 32 rows.  Weight fragments are fetched a group (4 k-steps x 2
-// column blocks = 8 ds_read_b128) ahead of the MFMAs that use them.  bsrc = tile + r * LDB + 8 h.
 template <int KC>
-__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&afr)[KC / 16], const uint16_t *bsrc) {
-    constexpr int KS = KC / 16, LDB = KC + 8, GK = 4, NG = KS / GK;
+__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&afr)[2][KC / 16], const uint16_t *bsrc) {
+    constexpr int KS = KC / 16, GK = 2, NG = KS / GK;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-    bf16x8 bq[2][GK][2];
+        for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+    bf16x8 bq[2][GK];
 #pragma unroll
-    for (int k = 0; k < GK; ++k)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bq[0][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + k * 16);
+    for (int k = 0; k < GK; ++k) bq[0][k] = *(const bf16x8 *)(bsrc + k * 16);
 #pragma unroll
     for (int gk = 0; gk < NG; ++gk) {
         if (gk + 1 < NG)
 #pragma unroll
-            for (int k = 0; k < GK; ++k)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    bq[(gk + 1) & 1][k][nb] = *(const bf16x8 *)(bsrc + nb * 32 * LDB + ((gk + 1) * GK + k) * 16);
+            for (int k = 0; k < GK; ++k) bq[(gk + 1) & 1][k] = *(const bf16x8 *)(bsrc + ((gk + 1) * GK + k) * 16);
         __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
         for (int k = 0; k < GK; ++k)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k][nb], afr[gk * GK + k], acc[nb], 0, 0, 0);
+            for (int rb = 0; rb < 2; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], afr[rb][gk * GK + k], acc[rb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// ------------------------------------------------------------------------------------------------ rows kernel
 template <int KC, int EPI>
-__global__ void __launch_bounds__(LIN_THREADS) lin_rows_kernel(LinParams p) {
-    constexpr int KS = KC / 16, LDB = KC + 8, TILE = 65 * LDB;   // 64 weight rows + 1 bias row
-    constexpr int NLD = 64 * KC / 8 / LIN_THREADS;               // 16-byte loads per thread and tile
+__global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
+    constexpr int KS = KC / 16, LDB = KC + 8, TILE = 33 * LDB;   // 32 weight rows + 1 bias row
+    constexpr int NLD = 32 * KC / 8 / R2_THREADS;                // 16-byte loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    uint16_t *stage = lsm + 2 * TILE + wave * stage_elems<EPI>();
-    const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS + wave * 32;
+    uint16_t *stage = lsm + 2 * TILE + wave * r2_stage_elems<EPI>();
+    const int64_t row0 = (int64_t)blockIdx.x * R2_ROWS + wave * 64;
 
-    // the wave's 32 x KC slice of the activations, as MFMA operand fragments (lane: row r, k-half h)
-    bf16x8 afr[KS];
-    {
-        const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one; they are never stored
+    bf16x8 afr[2][KS];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int64_t m = row0 + rb * 32 + r < p.M ? row0 + rb * 32 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afr[ks] = *(const bf16x8 *)(src + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
     }
-    const int ntiles = p.N / 64;
-    // Tiles are visited in a rotated order (first tile = workgroup index mod ntiles): the workgroups of a launch then pull
-    // DIFFERENT 32 KB tiles of W out of L2 at any moment instead of all hammering the same lines (same channels).
-    const int rot = blockIdx.x % ntiles;
-    // Two register sets: tile t travels in breg[t & 1]; its loads are issued two iterations before its LDS store.
-    u32x4 breg[2][NLD];
-    uint32_t biasreg[2] = {0u, 0u};
-#define VSDE_TILE_LOAD(t_, set_)                                                                              \
+    const int ntiles = p.N / 32;
+    const int rot = 2 * (blockIdx.x % (ntiles / 2));
+    u32x4 breg[NLD];          // the next tile on its way from L2 to LDS (loaded one iteration before its LDS store)
+    uint32_t biasreg = 0u;
+#define VSDE_TILE_LOAD(t_)                                                                                    \
     do {                                                                                                      \
         const int tile_ = ((t_) + rot) % ntiles;                                                              \
-        wtile_load<NLD, KC>(breg[set_], p.W + (int64_t)tile_ * 64 * KC, KC, tid);                             \
-        if (tid < 32) biasreg[set_] = p.bias ? *(const uint32_t *)(p.bias + tile_ * 64 + 2 * tid) : 0u;       \
+        wtile_load<NLD, KC, R2_THREADS>(breg, p.W + (int64_t)tile_ * 32 * KC, KC, tid);                       \
+        if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * tid) : 0u;             \
     } while (0)
-#define VSDE_TILE_STORE(Bs_, set_)                                                                            \
+#define VSDE_TILE_STORE(Bs_)                                                                                  \
     do {                                                                                                      \
-        wtile_store<NLD, KC, LDB>(breg[set_], (Bs_), tid);                                                    \
-        if (tid < 32) *(uint32_t *)((Bs_) + 64 * LDB + 2 * tid) = biasreg[set_];                              \
+        wtile_store<NLD, KC, LDB, R2_THREADS>(breg, (Bs_), tid);                                              \
+        if (tid < 16) *(uint32_t *)((Bs_) + 32 * LDB + 2 * tid) = biasreg;                                    \
     } while (0)
-// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (register set 1 - PAR_) goes to the other buffer
+// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (register set 1 - PAR_) goes to the other buffer.
+// t and the tile index have the same parity (rot is even): PAR_ = 1 closes a pair of tiles.
 #define VSDE_ROWS_BODY(t_, PAR_)                                                                              \
     do {                                                                                                      \
         const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
         f32x16 acc[2];                                                                                        \
         rows_tile_mfma<KC>(acc, afr, Bs + r * LDB + 8 * h);                                                   \
-        tile_epilogue<EPI>(p, acc, Bs + 64 * LDB, stage, row0, (((t_) + rot) % ntiles) * 64, lane);           \
-        if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE, 1 - (PAR_));                        \
+        rows_epilogue<EPI, PAR_>(p, acc, Bs + 32 * LDB, stage, row0, (((t_) + rot) % ntiles) * 32, lane);       \
+        if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE);                                    \
         lds_barrier();                                                                                        \
-        if ((t_) + 3 < ntiles) VSDE_TILE_LOAD((t_) + 3, 1 - (PAR_));                                          \
+        if ((t_) + 2 < ntiles) VSDE_TILE_LOAD((t_) + 2);                                                      \
     } while (0)
-    VSDE_TILE_LOAD(0, 0);
-    VSDE_TILE_STORE(lsm, 0);
+    VSDE_TILE_LOAD(0);
+    VSDE_TILE_STORE(lsm);
     lds_barrier();
-    if (ntiles > 1) VSDE_TILE_LOAD(1, 1);
-    if (ntiles > 2) VSDE_TILE_LOAD(2, 0);
+    VSDE_TILE_LOAD(1);
     for (int nt = 0; nt < ntiles; nt += 2) {
         VSDE_ROWS_BODY(nt, 0);
-        if (nt + 1 < ntiles) VSDE_ROWS_BODY(nt + 1, 1);
+        VSDE_ROWS_BODY(nt + 1, 1);
     }
 #undef VSDE_ROWS_BODY
 #undef VSDE_TILE_LOAD
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     constexpr int NLD = NT * 64 / 8 / LIN_THREADS;               // 16-byte loads per thread and tile (2 or 4)
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    uint16_t *stage = lsm + 2 * TILE + wave * stage_elems<EPI_PLAIN>();
+    uint16_t *stage = lsm + 2 * TILE + wave * (32 * 72);
     const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS + wave * 32;
     const int nbase = blockIdx.y * NT;
     const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one; they are never stored
@@ -323,16 +327,16 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     do {                                                                                                      \
         if ((t_) + 1 < ktiles) { VSDE_A_LOAD((t_) + 1, 1 - (PAR_)) }                                          \
         cols_tile_mfma<NB>(acc, afr[PAR_], lsm + (PAR_) * TILE + r * LDB + 8 * h);                            \
-        if ((t_) + 1 < ktiles) wtile_store<NLD, 64, LDB>(breg[1 - (PAR_)], lsm + (1 - (PAR_)) * TILE, tid);   \
+        if ((t_) + 1 < ktiles) wtile_store<NLD, 64, LDB, LIN_THREADS>(breg[1 - (PAR_)], lsm + (1 - (PAR_)) * TILE, tid);   \
         lds_barrier();                                                                                        \
-        if ((t_) + 3 < ktiles) wtile_load<NLD, 64>(breg[1 - (PAR_)], wsrc + VSDE_CHUNK((t_) + 3), p.K, tid);  \
+        if ((t_) + 3 < ktiles) wtile_load<NLD, 64, LIN_THREADS>(breg[1 - (PAR_)], wsrc + VSDE_CHUNK((t_) + 3), p.K, tid);  \
     } while (0)
-    wtile_load<NLD, 64>(breg[0], wsrc + VSDE_CHUNK(0), p.K, tid);
+    wtile_load<NLD, 64, LIN_THREADS>(breg[0], wsrc + VSDE_CHUNK(0), p.K, tid);
     VSDE_A_LOAD(0, 0)
-    wtile_store<NLD, 64, LDB>(breg[0], lsm, tid);
+    wtile_store<NLD, 64, LDB, LIN_THREADS>(breg[0], lsm, tid);
     lds_barrier();
-    if (ktiles > 1) wtile_load<NLD, 64>(breg[1], wsrc + VSDE_CHUNK(1), p.K, tid);
-    if (ktiles > 2) wtile_load<NLD, 64>(breg[0], wsrc + VSDE_CHUNK(2), p.K, tid);
+    if (ktiles > 1) wtile_load<NLD, 64, LIN_THREADS>(breg[1], wsrc + VSDE_CHUNK(1), p.K, tid);
+    if (ktiles > 2) wtile_load<NLD, 64, LIN_THREADS>(breg[0], wsrc + VSDE_CHUNK(2), p.K, tid);
     for (int kt = 0; kt < ktiles; kt += 2) {
         VSDE_COLS_BODY(kt, 0);
         if (kt + 1 < ktiles) VSDE_COLS_BODY(kt + 1, 1);
@@ -345,19 +349,22 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < NB / 2; ++q) {
-        f32x16 pair[2] = {acc[2 * q], acc[2 * q + 1]};
-        tile_epilogue<EPI_PLAIN>(p, pair, lsm + 64 * q, stage, row0, nbase + 64 * q, lane);
+        stage_block(acc[2 * q], lsm + 64 * q, stage + r * 72, h);
+        stage_block(acc[2 * q + 1], lsm + 64 * q + 32, stage + r * 72 + 32, h);
+        wave_lds_fence();
+        flush_rows64<72, 32>(stage, p.C + nbase + 64 * q, p.ldc, row0, p.M, lane);
+        wave_lds_fence();
     }
 }
 
-template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 65 * (KC + 8) + 8 * stage_elems<EPI>()) * sizeof(uint16_t); }
-template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * 72 + 8 * stage_elems<EPI_PLAIN>()) * sizeof(uint16_t); }
+template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * r2_stage_elems<EPI>()) * sizeof(uint16_t); }
+template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * 72 + 8 * 32 * 72) * sizeof(uint16_t); }
 
 template <int KC, int EPI>
 static int launch_rows(const LinParams &p, hipStream_t s) {
     const size_t lds = rows_lds_bytes<KC, EPI>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)((p.M + LIN_ROWS - 1) / LIN_ROWS)), dim3(LIN_THREADS), lds, s, p);
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)((p.M + R2_ROWS - 1) / R2_ROWS)), dim3(R2_THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
