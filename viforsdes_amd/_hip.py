@@ -605,8 +605,13 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
 EPI_PLAIN, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2
 
 
+def linear_variant(M: int, N: int, K: int, epilogue: int = EPI_PLAIN) -> int:
+    """0 = shape not covered, 1 = rows kernel (K in {128, 256}), 2 = cols kernel (deep reductions)."""
+    return int(load().vsde_linear_bf16_supported(_i64(M), ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(epilogue)))
+
+
 def linear_supported(M: int, N: int, K: int, epilogue: int = EPI_PLAIN) -> bool:
-    return bool(load().vsde_linear_bf16_supported(_i64(M), ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(epilogue)))
+    return linear_variant(M, N, K, epilogue) != 0
 
 
 def _rows2d(t: torch.Tensor):

@@ -19,6 +19,8 @@
 //   EPI_SWIGLU       u = acc + bias (kept for the backward), s = silu(a) * b   with [a | b] the two 16-column halves of a
 //                    32-column tile: the packed weight interleaves the SwiGLU halves in blocks of 16 rows (primitives/fused.py)
 //   EPI_SWIGLU_BWD   acc = ds (gradient of s); reads u, writes du = (da | db) in the same interleaved layout
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -30,7 +32,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte regis
 constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2;
 constexpr int LIN_ROWS = 256;   // rows per workgroup (8 waves x 32)
 constexpr int LIN_THREADS = 512;
-constexpr int R2_THREADS = 256, R2_ROWS = 256, R2_SLD = 72;   // rows kernel: 4 waves x 64 rows, staging rows of 64 + 8 elements
+constexpr int R2_THREADS = 256, R2_ROWS = 256, R2_SLD = 88;   // rows kernel: 4 waves x 64 rows, staging rows of 64 + 16 (+ 8 pad) elements
 
 struct LinParams {
     const uint16_t *A; int64_t lda;    // activations [M][lda] bf16 (row pitch in elements)
@@ -40,6 +42,7 @@ struct LinParams {
     uint16_t *S; int64_t lds_;         // EPI_SWIGLU: s [M][N/2]
     const uint16_t *U; int64_t ldu;    // EPI_SWIGLU_BWD: saved u [M][2N]
     int64_t M; int N, K;
+    int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
 };
 
 typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -64,8 +67,10 @@ __device__ __forceinline__ void flush_rows64(const uint16_t *stage, uint16_t *ds
 #pragma unroll
     for (int i = 0; i < R / 8; ++i) {
         const int row = (lane >> 3) + 8 * i, c = lane & 7;
-        const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
-        if (row0 + row < M) *(uint4 *)(dst + (row0 + row) * ld + c * 8) = v;
+        const u32x4 v = *(const u32x4 *)(stage + row * SLD + c * 8);
+        // streaming output, never re-read by this kernel: a non-temporal store keeps it from evicting the weight tiles (and the
+        // activation rows still to be read) out of L2
+        if (row0 + row < M) __builtin_nontemporal_store(v, (u32x4 *)(dst + (row0 + row) * ld + c * 8));
     }
 }
 // R rows x 32 columns (64-byte row segments: 4 lanes per row)
@@ -74,8 +79,8 @@ __device__ __forceinline__ void flush_rows32(const uint16_t *stage, uint16_t *ds
 #pragma unroll
     for (int i = 0; i < R / 16; ++i) {
         const int row = (lane >> 2) + 16 * i, c = lane & 3;
-        const uint4 v = *(const uint4 *)(stage + row * SLD + c * 8);
-        if (row0 + row < M) *(uint4 *)(dst + (row0 + row) * ld + c * 8) = v;
+        const u32x4 v = *(const u32x4 *)(stage + row * SLD + c * 8);
+        if (row0 + row < M) __builtin_nontemporal_store(v, (u32x4 *)(dst + (row0 + row) * ld + c * 8));
     }
 }
 
@@ -112,6 +117,23 @@ __device__ __forceinline__ void wtile_store(const u32x4 (&breg)[NLD], uint16_t *
 //   EPI_SWIGLU      the packed weight interleaves the SwiGLU halves in blocks of 16 rows, so a 32-column tile is [a_16 | b_16]:
 //                   this lane's register quads g = 0, 1 hold a_j and g = 2, 3 the matching b_j; a pair of tiles gives 32 columns of s.
 //   EPI_SWIGLU_BWD  acc = ds for 32 columns j; u / du tile: 64 interleaved columns [a_16 | b_16 | a_16 | b_16]; no pairing.
+// packed s = silu(a) * b of one tile for row block rb: quads g = 0, 1 of acc are a_j, g = 2, 3 the matching b_j
+__device__ __forceinline__ void swiglu_quads(const f32x16 &acc, const uint16_t *bias32, int h, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint2 ba = *(const uint2 *)(bias32 + 8 * g + 4 * h), bb = *(const uint2 *)(bias32 + 16 + 8 * g + 4 * h);
+        const float av[4] = {bf_lo(ba.x), bf_hi(ba.x), bf_lo(ba.y), bf_hi(ba.y)};
+        const float bv[4] = {bf_lo(bb.x), bf_hi(bb.x), bf_lo(bb.y), bf_hi(bb.y)};
+        float sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // from the bf16-rounded u, as the unfused chain (mlp.py:21-24 under autocast)
+            const float a = rbf(acc[4 * g + i] + av[i]), b = rbf(acc[4 * (g + 2) + i] + bv[i]);
+            sv[i] = rbf(a * sigm_f(a)) * b;
+        }
+        out[2 * g] = pack_bf16x2(sv[0], sv[1]); out[2 * g + 1] = pack_bf16x2(sv[2], sv[3]);
+    }
+}
+
 template <int EPI, int PAR>
 __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[2], const uint16_t *bias32, uint16_t *stage,
                                               int64_t row0, int n0, int lane) {
@@ -121,27 +143,33 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
-            if constexpr (EPI == EPI_SWIGLU) {
+            if constexpr (EPI == EPI_SWIGLU && PAR == 0) {   // the first tile's s waits in columns 64..79 of the staging row
+                uint32_t s0[4];
+                swiglu_quads(acc[rb], bias32, h, s0);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const uint2 ba = *(const uint2 *)(bias32 + 8 * g + 4 * h), bb = *(const uint2 *)(bias32 + 16 + 8 * g + 4 * h);
-                    const float av[4] = {bf_lo(ba.x), bf_hi(ba.x), bf_lo(ba.y), bf_hi(ba.y)};
-                    const float bv[4] = {bf_lo(bb.x), bf_hi(bb.x), bf_lo(bb.y), bf_hi(bb.y)};
-                    float sv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {   // from the bf16-rounded u, as the unfused chain (mlp.py:21-24 under autocast)
-                        const float a = rbf(acc[rb][4 * g + i] + av[i]), b = rbf(acc[rb][4 * (g + 2) + i] + bv[i]);
-                        sv[i] = rbf(a * sigm_f(a)) * b;
-                    }
-                    // s leaves straight from the registers: 8 bytes per lane, the two half-waves complete 16 bytes of a row
-                    if (row0 + rb * 32 + r < p.M)
-                        *(uint2 *)(p.S + (row0 + rb * 32 + r) * p.lds_ + (n0 >> 1) + 8 * g + 4 * h) = make_uint2(pack_bf16x2(sv[0], sv[1]), pack_bf16x2(sv[2], sv[3]));
-                }
+                for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 64 + 8 * g + 4 * h) = make_uint2(s0[2 * g], s0[2 * g + 1]);
             }
         }
         if constexpr (PAR == 1) {
             wave_lds_fence();
-            if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD, 64>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
+            if ((EPI == EPI_PLAIN || p.C != nullptr) && !(p.dbg & 1)) flush_rows64<SLD, 64>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
+            if constexpr (EPI == EPI_SWIGLU) {   // second tile's s (acc is still live) into columns 0..15, then 32 columns of s per row
+                wave_lds_fence();
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    uint32_t s1[4];
+                    swiglu_quads(acc[rb], bias32, h, s1);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 8 * g + 4 * h) = make_uint2(s1[2 * g], s1[2 * g + 1]);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // 64 bytes of s per row: lanes c = 0, 1 take the first tile's half, c = 2, 3 the second's
+                    const int row = (lane >> 2) + 16 * i, c = lane & 3;
+                    const u32x4 v = *(const u32x4 *)(stage + row * SLD + (c < 2 ? 64 + 8 * c : 8 * (c - 2)));
+                    if (row0 + row < p.M) __builtin_nontemporal_store(v, (u32x4 *)(p.S + (row0 + row) * p.lds_ + ((n0 - 32) >> 1) + c * 8));
+                }
+            }
             wave_lds_fence();
         }
     } else {
@@ -196,6 +224,10 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&
     bf16x8 bq[2][GK];
 #pragma unroll
     for (int k = 0; k < GK; ++k) bq[0][k] = *(const bf16x8 *)(bsrc + k * 16);
+    // The waves sharing a SIMD (one per co-resident workgroup) run the same program: left alone they stay in phase, both
+    // queueing for the matrix pipe and then both leaving it idle.  Priority while in the MFMA burst makes one of them finish its
+    // burst first, after which the bursts of one overlap the epilogue / refill of the other.
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gk = 0; gk < NG; ++gk) {
         if (gk + 1 < NG)
@@ -209,6 +241,7 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], afr[rb][gk * GK + k], acc[rb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 template <int KC, int EPI>
@@ -276,6 +309,7 @@ __device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (
     bf16x8 bq[2][G];
 #pragma unroll
     for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * LDB + (i / NB) * 16);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
         if (g + 1 < NGRP)
@@ -292,6 +326,7 @@ __device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // ------------------------------------------------------------------------------------------------ cols kernel
@@ -414,6 +449,7 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
     p.A = (const uint16_t *)x; p.lda = ldx; p.W = (const uint16_t *)w; p.bias = (const uint16_t *)bias;
     p.C = (uint16_t *)y; p.ldc = ldy; p.M = M; p.N = N; p.K = K;
     p.S = (uint16_t *)s_out; p.lds_ = lds; p.U = (const uint16_t *)u_in; p.ldu = ldu;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_LIN_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
     if (epilogue == EPI_PLAIN) {
         VSDE_CHECK_ARG(y && ldy >= N && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0, VSDE_E_BADARG, "bad linear output");

@@ -5,6 +5,7 @@ primitives/{sit,attn,mlp}.py (which remain the eager specification and the CPU p
 encoder).  ``usable(x)`` decides whether a tensor can take the fused route."""
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -406,10 +407,14 @@ class PackedWeight:
 
     _live = weakref.WeakSet()
 
-    def __init__(self, rows: int, cols: int, weight_pieces, bias_pieces, device) -> None:
+    def __init__(self, rows: int, cols: int, weight_pieces, bias_pieces, device, grad_rows: Optional[Tensor] = None) -> None:
         self.weight = torch.zeros(rows, cols, device=device, dtype=torch.bfloat16)
         self.bias = torch.zeros(rows, device=device, dtype=torch.bfloat16) if bias_pieces else None
         self.weight_pieces, self.bias_pieces = list(weight_pieces), list(bias_pieces or [])
+        self.weight_t: Optional[Tensor] = None   # [cols, rows] copy for the input-gradient GEMM, kept in step by refresh_all()
+        self._t_versions: Optional[list[int]] = None
+        # packs whose rows are a permutation of ONE parameter (interleaved SwiGLU halves): packed row of every parameter row
+        self.grad_rows = grad_rows
         self.params: list[Tensor] = []
         for p, *_ in self.weight_pieces + self.bias_pieces:
             if not any(p is q for q in self.params):
@@ -439,9 +444,22 @@ class PackedWeight:
             self.mark_fresh()
         return self.weight, self.bias
 
+    @torch.no_grad()
+    def transposed(self) -> Tensor:
+        """The packed weight as [cols, rows] (what ``dx = dy W`` needs as an ``x W^T`` GEMM operand)."""
+        self.operands()
+        if self.weight_t is None:
+            self.weight_t = torch.empty(self.weight.shape[1], self.weight.shape[0], device=self.weight.device, dtype=torch.bfloat16)
+        if self._t_versions != self._versions:
+            self.weight_t.copy_(self.weight.t())
+            self._t_versions = list(self._versions)
+        return self.weight_t
+
     def split_grads(self, dW: Tensor, db: Optional[Tensor]) -> list[Optional[Tensor]]:
         """fp32 gradient of the packed operand -> one gradient per entry of ``self.params`` (a view when the parameter is
-        one whole row block, otherwise its row blocks concatenated)."""
+        one whole row block, otherwise its row blocks concatenated; a row gather for permuted packs)."""
+        if self.grad_rows is not None:   # params = [weight] or [weight, bias], rows permuted
+            return [dW.index_select(0, self.grad_rows) if q.ndim == 2 else db.index_select(0, self.grad_rows) for q in self.params]
         out: list[Optional[Tensor]] = []
         for q in self.params:
             blocks = [dW[d0:d0 + n, :p.shape[1]] for p, s0, n, d0 in sorted(self.weight_pieces, key=lambda t: t[1]) if p is q]
@@ -462,16 +480,41 @@ class PackedWeight:
             torch._foreach_copy_(dst, src)
             for pk in packs:
                 pk.mark_fresh()
+                if pk.weight_t is not None:
+                    pk.weight_t.copy_(pk.weight.t())
+                    pk._t_versions = list(pk._versions)
+
+
+# the MFMA GEMM kernels of csrc/vsde_linear.hip for the shapes they cover (VSDE_OWN_GEMM=0: library GEMMs everywhere, for A/B runs)
+OWN_GEMM = os.environ.get("VSDE_OWN_GEMM", "1") != "0"
+# also their deep-reduction variant (K > 256), currently slower than the tuned hipBLASLt solutions
+OWN_GEMM_COLS = os.environ.get("VSDE_OWN_GEMM_COLS", "0") == "1"
+
+
+def own_gemm(M: int, N: int, K: int, epilogue: int = 0) -> bool:
+    """Whether y[M,N] = x[M,K] W[N,K]^T runs on the own MFMA kernels."""
+    if not (ENABLED and OWN_GEMM) or M < 4096:
+        return False
+    variant = _hip.linear_variant(M, N, K, epilogue)
+    return variant == 1 or (variant == 2 and OWN_GEMM_COLS)
+
+
+def _mm_nt(x2: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """x2 [M,K] @ w[N,K]^T (+ bias) in bf16: own kernel when the shape is covered, hipBLASLt otherwise."""
+    if x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and own_gemm(x2.shape[0], w.shape[0], w.shape[1]):
+        return _hip.linear_bf16(x2, w, bias)
+    return torch.nn.functional.linear(x2, w, bias)
 
 
 class _PackedLinear(torch.autograd.Function):
-    """y = x W^T + b with a ``PackedWeight``: hipBLASLt forward / input gradient, HIP weight-gradient kernel, gradients
-    returned per parameter piece."""
+    """y = x W^T + b with a ``PackedWeight``: forward and input gradient on the MFMA GEMM kernels of csrc/vsde_linear.hip
+    where the shape is covered (hipBLASLt otherwise), HIP weight-gradient kernel, gradients returned per parameter piece."""
 
     @staticmethod
     def forward(ctx, x, pack, *params):
         wb, bb = pack.operands()
-        y = torch.nn.functional.linear(x, wb, bb)
+        x2 = x.reshape(-1, x.shape[-1])
+        y = _mm_nt(x2, wb, bb).reshape(*x.shape[:-1], wb.shape[0])
         ctx.save_for_backward(x, wb)
         ctx.pack = pack
         return y
@@ -483,7 +526,10 @@ class _PackedLinear(torch.autograd.Function):
         pack = ctx.pack
         dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        dx = (dy2 @ wb).reshape(x.shape)
+        if own_gemm(dy2.shape[0], wb.shape[1], wb.shape[0]):
+            dx = _hip.linear_bf16(dy2, pack.transposed(), None).reshape(x.shape)   # dx = dy W as an x W^T product with W^T
+        else:
+            dx = (dy2 @ wb).reshape(x.shape)
         dW, db = _hip.linear_wgrad(dy2, x2, pack.bias is not None)
         return (dx, None, *pack.split_grads(dW, db))
 
@@ -550,6 +596,50 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class _SwiGLUMLP(torch.autograd.Function):
+    """SwiGLU feed-forward ``W_out (silu(a) * b) + b_out`` with ``[a | b] = W_in x + b_in`` (mlp.py:50-54) around two GEMM
+    kernels with fused epilogues: the input projection writes u (for the backward) and s = silu(a) * b in one pass, the
+    backward computes ds = dy W_out inside the kernel that turns it into du = swiglu'(u) ds.  ``pin`` packs W_in with its
+    halves interleaved in blocks of 16 rows (``swiglu_packs(..., interleave=True)``)."""
+
+    @staticmethod
+    def forward(ctx, x, pin, pout, *params):
+        w1, b1 = pin.operands()
+        w2, b2 = pout.operands()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        u, s_ = _hip.linear_swiglu_bf16(x2, w1, b1)
+        y = _mm_nt(s_, w2, b2)
+        ctx.save_for_backward(x2, u, s_, w1)
+        ctx.packs = (pin, pout)
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, u, s_, w1 = ctx.saved_tensors
+        pin, pout = ctx.packs
+        dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
+        du = _hip.linear_swiglu_bwd_bf16(dy2, pout.transposed(), u)
+        if own_gemm(du.shape[0], w1.shape[1], w1.shape[0]):
+            dx = _hip.linear_bf16(du, pin.transposed(), None)
+        else:
+            dx = du @ w1
+        dW1, db1 = _hip.linear_wgrad(du, x2, pin.bias is not None)
+        dW2, db2 = _hip.linear_wgrad(dy2, s_, pout.bias is not None)
+        return (dx.reshape(ctx.xshape), None, None, *pin.split_grads(dW1, db1), *pout.split_grads(dW2, db2))
+
+
+def swiglu_mlp_usable(x: Tensor, width: int) -> bool:
+    rows = x.numel() // x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and own_gemm(rows, 2 * width, x.shape[-1], _hip.EPI_SWIGLU)
+            and own_gemm(rows, width, x.shape[-1], _hip.EPI_SWIGLU_BWD))
+
+
+def swiglu_mlp(x: Tensor, pin: PackedWeight, pout: PackedWeight) -> Tensor:
+    return _SwiGLUMLP.apply(x, pin, pout, *pin.params, *pout.params)
+
+
 def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Optional[int] = None) -> PackedWeight:
     """Pack of several Linears that share their input, stacked along the output rows ([qkv | gate])."""
     rows = sum(w.shape[0] for w in weights)
@@ -562,12 +652,27 @@ def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Opti
     return PackedWeight(pad_to or rows, weights[0].shape[1], wp, bp or None, weights[0].device)
 
 
-def swiglu_packs(w_in: Tensor, b_in: Optional[Tensor], w_out: Tensor, b_out: Optional[Tensor], width: int):
+def swiglu_packs(w_in: Tensor, b_in: Optional[Tensor], w_out: Tensor, b_out: Optional[Tensor], width: int,
+                 interleave: bool = False):
     """Packs of a SwiGLU MLP whose hidden size h is zero-padded to ``width``: input projection [2h, K] -> [2*width, K] (the
-    two halves start at rows 0 and ``width``), output projection [K, h] -> [K, width] (extra columns zero)."""
+    two halves start at rows 0 and ``width``), output projection [K, h] -> [K, width] (extra columns zero).
+    ``interleave``: the input projection's halves alternate in blocks of 16 rows ([a_0..15 | b_0..15 | a_16..31 | ...]), the
+    layout the fused-SwiGLU GEMM epilogues work on (csrc/vsde_linear.hip)."""
     h = w_out.shape[1]
-    pin = PackedWeight(2 * width, w_in.shape[1], [(w_in, 0, h, 0), (w_in, h, h, width)],
-                       None if b_in is None else [(b_in, 0, h, 0), (b_in, h, h, width)], w_in.device)
+    if interleave:
+        wp, bp, rows = [], [], []
+        for half in (0, 1):
+            for j0 in range(0, h, 16):
+                n, dst = min(16, h - j0), 32 * (j0 // 16) + 16 * half
+                wp.append((w_in, half * h + j0, n, dst))
+                if b_in is not None:
+                    bp.append((b_in, half * h + j0, n, dst))
+                rows.extend(range(dst, dst + n))
+        pin = PackedWeight(2 * width, w_in.shape[1], wp, bp or None, w_in.device,
+                           grad_rows=torch.tensor(rows, device=w_in.device, dtype=torch.long))
+    else:
+        pin = PackedWeight(2 * width, w_in.shape[1], [(w_in, 0, h, 0), (w_in, h, h, width)],
+                           None if b_in is None else [(b_in, 0, h, 0), (b_in, h, h, width)], w_in.device)
     n = w_out.shape[0]
     pout = PackedWeight(n, width, [(w_out, 0, n, 0)], None if b_out is None else [(b_out, 0, n, 0)], w_out.device)
     return pin, pout

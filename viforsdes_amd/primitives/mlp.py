@@ -29,11 +29,15 @@ class SwiGLU(nn.Module):
             width = -(-self.hidden_dim // 128) * 128
             if fused.packed_linear_usable(x, 2 * width, self.in_dim):
                 # bf16 operands of both projections (padded to `width`) live in a cache refreshed once per optimizer step
+                fused_mlp = fused.swiglu_mlp_usable(x, width)   # both GEMMs with the SwiGLU math in their epilogues
                 packs = getattr(self, "_packs", None)
-                if packs is None or packs[0].weight.device != x.device or packs[0].weight.shape[0] != 2 * width:
+                if (packs is None or packs[0].weight.device != x.device or packs[0].weight.shape[0] != 2 * width
+                        or (packs[0].grad_rows is not None) != fused_mlp):
                     packs = fused.swiglu_packs(self.input_proj.weight, self.input_proj.bias, self.output_proj.weight,
-                                               self.output_proj.bias, width)
+                                               self.output_proj.bias, width, interleave=fused_mlp)
                     object.__setattr__(self, "_packs", packs)
+                if fused_mlp:
+                    return fused.swiglu_mlp(x, packs[0], packs[1])
                 return fused.packed_linear(fused.swiglu(fused.packed_linear(x, packs[0])), packs[1])
             if width != self.hidden_dim:
                 w1, b1, w2 = self._padded_weights(width)
