@@ -203,8 +203,9 @@ int vsde_qk_norm_rope_bwd(int dtype, const void *qkv, const float *cosT, const f
 /* dv0_accumulate != 0: dv0 += (1-lam) dv (all blocks' value-residual gradients collect in one buffer); dv_extra (optional,
  * layout of dv) is added to dv first -- the block that produced v0 gets that buffer next to its own attention's dv. */
 
-/* Attention core for the encoder's shape class (bf16, head_dim 64, N <= vsde_attention_max_tokens() so that K and V of
- * one (batch, head) stay in LDS):  o = softmax(scale * q k^T) v  with q, k, v, o token-major [B][N][H][64];
+/* Attention core (bf16, head_dim 64 or 128).  head_dim 64 with N <= vsde_attention_max_tokens() runs the kernels that keep K
+ * and V of one (batch, head) resident in LDS (the encoder's shape class at the OU / LV grids); longer sequences and head_dim
+ * 128 (the 1001-token, 512 / 4-head stress configuration) run the kernels that stream 32-token tiles through LDS:  o = softmax(scale * q k^T) v  with q, k, v, o token-major [B][N][H][64];
  * lse [B][H][N] = natural-log sum-exp of the scaled scores (what a flash-attention backward consumes).
  * Replaces F.scaled_dot_product_attention at primitives/attn.py:104-106 for these shapes. */
 int vsde_attention_max_tokens(void);

@@ -558,11 +558,11 @@ def attention_max_tokens() -> int:
 
 
 def attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
-    """softmax(scale q k^T) v for token-major bf16 heads [B,N,H,64]; returns (o [B,N,H,64], lse [B,H,N] fp32)."""
+    """softmax(scale q k^T) v for token-major bf16 heads [B,N,H,d], d in (64, 128); returns (o, lse [B,H,N] fp32)."""
     lib = load(); dev = _require_hip(q, k, v)
     B, N, H, d = q.shape
     if q.dtype != torch.bfloat16 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
-        raise ValueError("attention_fwd needs contiguous bf16 [B,N,H,64] tensors")
+        raise ValueError("attention_fwd needs contiguous bf16 [B,N,H,d] tensors")
     o = torch.empty_like(q)
     lse = torch.empty(B, H, N, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
@@ -577,7 +577,7 @@ def attention_bwd(dout, q, k, v, o, lse, scale: float):
     B, N, H, d = q.shape
     for t in (dout, q, k, v, o):
         if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.shape != q.shape:
-            raise ValueError("attention_bwd needs contiguous bf16 [B,N,H,64] tensors of one shape")
+            raise ValueError("attention_bwd needs contiguous bf16 [B,N,H,d] tensors of one shape")
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(B, H, N, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):

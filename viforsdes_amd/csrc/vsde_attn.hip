@@ -473,9 +473,10 @@ extern "C" int vsde_attention_max_tokens(void) { return AT_MAXN; }
 extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
                                        int head_dim, double scale, void *stream) {
     VSDE_CHECK_ARG(q && k && v && o && lse && B > 0 && N > 0 && H > 0, VSDE_E_BADARG, "bad attention arguments");
-    VSDE_CHECK_ARG(head_dim == AT_D, VSDE_E_BADARG, "attention kernel is built for head_dim 64, got %d", head_dim);
-    VSDE_CHECK_ARG(N <= AT_MAXN, VSDE_E_BADARG, "attention kernel keeps K and V of one head in LDS: N <= %d, got %d", AT_MAXN, N);
+    VSDE_CHECK_ARG(head_dim == 64 || head_dim == 128, VSDE_E_BADARG, "attention kernels are built for head_dim 64 and 128, got %d", head_dim);
     VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
+    if (head_dim != AT_D || N > AT_MAXN)   // does not fit the LDS-resident kernel: K / V stream through LDS (vsde_attn_stream.hip)
+        return launch_attention_stream_fwd(q, k, v, o, lse, B, N, H, head_dim, scale, (hipStream_t)stream);
     AttnParams p;
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (uint16_t *)o; p.lse = lse;
     p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
@@ -492,9 +493,10 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
                                        double scale, void *stream) {
     VSDE_CHECK_ARG(dout && q && k && v && o && lse && dq && dk && dv && delta && B > 0 && N > 0 && H > 0, VSDE_E_BADARG,
                    "bad attention_bwd arguments");
-    VSDE_CHECK_ARG(head_dim == AT_D, VSDE_E_BADARG, "attention kernels are built for head_dim 64, got %d", head_dim);
-    VSDE_CHECK_ARG(N <= AT_MAXN, VSDE_E_BADARG, "attention kernels keep a whole head in LDS: N <= %d, got %d", AT_MAXN, N);
+    VSDE_CHECK_ARG(head_dim == 64 || head_dim == 128, VSDE_E_BADARG, "attention kernels are built for head_dim 64 and 128, got %d", head_dim);
     VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
+    if (head_dim != AT_D || N > AT_MAXN)
+        return launch_attention_stream_bwd(dout, q, k, v, o, lse, dq, dk, dv, delta, B, N, H, head_dim, scale, (hipStream_t)stream);
     AttnBwdParams p;
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o;
     p.dout = (const uint16_t *)dout; p.lse = lse; p.delta = delta;

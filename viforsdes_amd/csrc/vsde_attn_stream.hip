@@ -1,0 +1,353 @@
+// Self-attention core for sequences that do not fit the LDS-resident kernels of vsde_attn.hip (N > 544 tokens) or for
+// head_dim 128 -- the synthetic stress configuration (1001 grid tokens, encoder 512 / 4 heads).  Same math, same token-major
+// layout [B][N][H][D] and the same lane = token orientation of the products (see vsde_attn.hip), but the "other side" of the
+// product streams through LDS in tiles of 32 tokens (double-buffered, one barrier per tile) and the forward keeps a running
+// maximum (online softmax; the rescale of the accumulators is skipped while the maximum grows by < 2^8, so it runs once or
+// twice per query).  D in {64, 128}; reference: F.scaled_dot_product_attention at primitives/attn.py:104-106.
+//   forward   workgroup = (batch, head, 128 queries): 4 waves x 32 queries; K and V tiles stream.
+//   dq        same ownership; K and V tiles stream; also emits delta_i = <dO_i, O_i>.
+//   dk / dv   workgroup = (batch, head, 128 keys); Q and dO tiles (+ their lse, delta) stream.
+// Deterministic: every output element has one owner, no atomics.
+#include "vsde_common.h"
+
+namespace vsde {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32v2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AS_THREADS = 256, AS_TOK = 128;   // 4 waves x 32 owned tokens per workgroup
+
+template <int D> struct ASCfg {
+    static constexpr int KS = D / 16;            // k-steps of a product contracting over the channels
+    static constexpr int DB = D / 32;            // 32-channel blocks of an accumulator
+    static constexpr int LD = D == 64 ? 72 : 144;   // LDS row stride (bf16): conflict-free ds_read_b64_tr_b16, <= 2-way ds_read_b128
+    static constexpr int CH = D / 8;             // 16-byte chunks per row
+    static constexpr int NLD = 32 * CH / AS_THREADS;   // chunks per thread and 32-row tile (1 or 2)
+};
+
+struct ASParams {
+    const uint16_t *q, *k, *v, *o, *dout;   // [B][N][H][D] bf16
+    uint16_t *out, *dq, *dk, *dv;
+    float *lse;                             // [B][H][N]
+    const float *lse_in;
+    float *delta;                           // [B][H][N]
+    int N, H, ntile;
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ uint32_t as_pack(float a, float b) {
+    const f32v2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hbf16x2));
+}
+__device__ __forceinline__ void as_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint2 as_read_tr(const uint16_t *ptr) {
+    bf16x4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s *)ptr);
+    return *(uint2 *)&r;
+}
+
+// [32 rows][D] tile (row stride LD) times the B fragments "column = owned token, k = channel": T[row][token]
+template <int D>
+__device__ __forceinline__ f32x16 as_product(const uint16_t *arow, const bf16x8 (&bfrag)[D / 16]) {
+    f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(arow + ks * 16), bfrag[ks], t, 0, 0, 0);
+    return t;
+}
+
+// acc[db] += X^T B for a row-major LDS tile X [32 tokens][D]: A operand (row = channel, contraction over the tile's tokens in
+// the order B's registers hold them: 4 h2 + {0..3, 8..11 | 16..19, 24..27}) read with the hardware transpose.
+template <int D>
+__device__ __forceinline__ void as_accumulate_t(const uint16_t *tile, int lane, const bf16x8 &b0, const bf16x8 &b1, f32x16 (&acc)[D / 32]) {
+    constexpr int LD = ASCfg<D>::LD;
+    const int h2 = lane >> 5, m = lane & 15;
+    const uint16_t *src = tile + (4 * h2 + (m >> 2)) * LD + ((lane >> 4) & 1) * 16 + (m & 3) * 4;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) {
+        const uint2 a0 = as_read_tr(src + db * 32), a1 = as_read_tr(src + db * 32 + 8 * LD);
+        const uint2 a2 = as_read_tr(src + db * 32 + 16 * LD), a3 = as_read_tr(src + db * 32 + 24 * LD);
+        uint4 w0 = make_uint4(a0.x, a0.y, a1.x, a1.y), w1 = make_uint4(a2.x, a2.y, a3.x, a3.y);
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w0, b0, acc[db], 0, 0, 0);
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w1, b1, acc[db], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void as_pack_tile(const float (&x)[16], bf16x8 &b0, bf16x8 &b1) {
+    uint4 w0 = make_uint4(as_pack(x[0], x[1]), as_pack(x[2], x[3]), as_pack(x[4], x[5]), as_pack(x[6], x[7]));
+    uint4 w1 = make_uint4(as_pack(x[8], x[9]), as_pack(x[10], x[11]), as_pack(x[12], x[13]), as_pack(x[14], x[15]));
+    b0 = *(bf16x8 *)&w0; b1 = *(bf16x8 *)&w1;
+}
+
+// B fragments of one owned token row (zero when the token is padding)
+template <int D>
+__device__ __forceinline__ void as_load_frag(const uint16_t *base, int64_t ts, int row, bool ok, int h2, bf16x8 (&f)[D / 16]) {
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if (ok) t = *(const uint4 *)(base + row * ts + ks * 16 + h2 * 8);
+        f[ks] = *(bf16x8 *)&t;
+    }
+}
+
+// accumulator blocks (rows = channels, column = owned token) -> that token's bf16 row, scaled
+template <int D>
+__device__ __forceinline__ void as_store_t(uint16_t *row, int h2, const f32x16 (&a)[D / 32], float mul) {
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(uint2 *)(row + db * 32 + 8 * g + 4 * h2) = make_uint2(as_pack(a[db][4 * g] * mul, a[db][4 * g + 1] * mul),
+                                                                    as_pack(a[db][4 * g + 2] * mul, a[db][4 * g + 3] * mul));
+}
+
+// tile `t` (32 token rows, zero beyond N) of two row-major operands: global -> registers / registers -> LDS
+template <int D>
+__device__ __forceinline__ void as_tile_load(u32x4 (&ra)[ASCfg<D>::NLD], u32x4 (&rb)[ASCfg<D>::NLD], const uint16_t *a, const uint16_t *b,
+                                             int64_t ts, int t, int N, int tid) {
+    constexpr int CH = ASCfg<D>::CH;
+#pragma unroll
+    for (int i = 0; i < ASCfg<D>::NLD; ++i) {
+        const int idx = tid + AS_THREADS * i, row = idx / CH, c = idx % CH, n = t * 32 + row;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        ra[i] = n < N ? *(const u32x4 *)(a + n * ts + c * 8) : z;
+        rb[i] = n < N ? *(const u32x4 *)(b + n * ts + c * 8) : z;
+    }
+}
+template <int D>
+__device__ __forceinline__ void as_tile_store(const u32x4 (&ra)[ASCfg<D>::NLD], const u32x4 (&rb)[ASCfg<D>::NLD], uint16_t *sa, uint16_t *sb, int tid) {
+    constexpr int CH = ASCfg<D>::CH, LD = ASCfg<D>::LD;
+#pragma unroll
+    for (int i = 0; i < ASCfg<D>::NLD; ++i) {
+        const int idx = tid + AS_THREADS * i, row = idx / CH, c = idx % CH;
+        *(u32x4 *)(sa + row * LD + c * 8) = ra[i];
+        *(u32x4 *)(sb + row * LD + c * 8) = rb[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ void __launch_bounds__(AS_THREADS) attn_fwd_stream_kernel(ASParams p) {
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D;
+    const uint16_t *kb = p.k + base, *vb = p.v + base;
+    const int query = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const bool qok = query < N;
+    bf16x8 qf[D / 16];
+    as_load_frag<D>(p.q + base, ts, query, qok, h2, qf);
+    u32x4 rk[ASCfg<D>::NLD], rv[ASCfg<D>::NLD];
+    as_tile_load<D>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D>(rk, rv, Ks, Vs, tid);
+    as_barrier();
+    if (p.ntile > 1) as_tile_load<D>(rk, rv, kb, vb, ts, 1, N, tid);
+    const float c2 = p.scale_log2e;
+    float m = -INFINITY, lsum = 0.f;   // running maximum (log2 units, equal in the two lanes of a query) and this lane's share of the sum
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+    const bool ragged = (N & 31) != 0;
+    for (int kt = 0; kt < p.ntile; ++kt) {
+        const uint16_t *kt_ = Ks + (kt & 1) * TILE, *vt_ = Vs + (kt & 1) * TILE;
+        f32x16 s = as_product<D>(kt_ + fr * LD + h2 * 8, qf);   // S^T [key][query]
+        float t[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[r] = s[r] * c2;
+            if (ragged && kt == p.ntile - 1 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) t[r] = -INFINITY;
+            mx = fmaxf(mx, t[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx > m + 8.0f)) {   // wave-uniform: rescale every accumulator of the wave (factor 1 where the maximum held)
+            const float mn = fmaxf(m, mx), alpha = fast_exp2(m - mn);   // m = -inf: alpha = 0
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            m = mn;
+        }
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(t[r] - m); lsum += pr[r]; }
+        bf16x8 pb0, pb1;
+        as_pack_tile(pr, pb0, pb1);
+        as_accumulate_t<D>(vt_, lane, pb0, pb1, o);   // O^T += V^T P^T
+        if (kt + 1 < p.ntile) as_tile_store<D>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+        as_barrier();
+        if (kt + 2 < p.ntile) as_tile_load<D>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qok) {
+        as_store_t<D>(p.out + base + query * ts, h2, o, 1.0f / lsum);
+        if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = (m + __log2f(lsum)) * 0.6931471805599453f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ backward: dq
+template <int D>
+__global__ void __launch_bounds__(AS_THREADS) attn_bwd_dq_stream_kernel(ASParams p) {
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
+    const uint16_t *kb = p.k + base, *vb = p.v + base;
+    const int query = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const bool qok = query < N;
+    bf16x8 qf[D / 16], dof[D / 16];
+    float dsum = 0.f;   // delta_i = <dO_i, O_i>: this lane holds half of the channels of its query
+    {
+        bf16x8 of[D / 16];
+        as_load_frag<D>(p.q + base, ts, query, qok, h2, qf);
+        as_load_frag<D>(p.dout + base, ts, query, qok, h2, dof);
+        as_load_frag<D>(p.o + base, ts, query, qok, h2, of);
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)dof[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)of[ks][e]) << 16), dsum);
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (qok && h2 == 0) p.delta[srow + query] = dsum;
+    const float lse2 = (qok ? p.lse_in[srow + query] : INFINITY) * 1.4426950408889634f;   // padded queries: P = 0
+    u32x4 rk[ASCfg<D>::NLD], rv[ASCfg<D>::NLD];
+    as_tile_load<D>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D>(rk, rv, Ks, Vs, tid);
+    as_barrier();
+    if (p.ntile > 1) as_tile_load<D>(rk, rv, kb, vb, ts, 1, N, tid);
+    const float c2 = p.scale_log2e;
+    const bool ragged = (N & 31) != 0;
+    f32x16 acc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[db][e] = 0.f;
+    for (int kt = 0; kt < p.ntile; ++kt) {
+        const uint16_t *kt_ = Ks + (kt & 1) * TILE, *vt_ = Vs + (kt & 1) * TILE;
+        const f32x16 stl = as_product<D>(kt_ + fr * LD + h2 * 8, qf);    // S^T  [key][query]
+        const f32x16 dpt = as_product<D>(vt_ + fr * LD + h2 * 8, dof);   // dP^T [key][query]
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
+            if (ragged && kt == p.ntile - 1 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;   // zero rows of K: P != 0
+        }
+        bf16x8 b0, b1;
+        as_pack_tile(ds, b0, b1);
+        as_accumulate_t<D>(kt_, lane, b0, b1, acc);   // dQ^T += K^T dS^T
+        if (kt + 1 < p.ntile) as_tile_store<D>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+        as_barrier();
+        if (kt + 2 < p.ntile) as_tile_load<D>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+    }
+    if (qok) as_store_t<D>(p.dq + base + query * ts, h2, acc, p.scale);
+}
+
+// ------------------------------------------------------------------------------------------------- backward: dk, dv
+template <int D>
+__global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParams p) {
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    __shared__ __attribute__((aligned(16))) uint16_t Qs[2 * TILE], Os[2 * TILE];
+    __shared__ __attribute__((aligned(16))) float lse2s[2 * 32], dels[2 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
+    const uint16_t *qb = p.q + base, *dob = p.dout + base;
+    const int key = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const bool kok = key < N;
+    bf16x8 kf[D / 16], vf[D / 16];
+    as_load_frag<D>(p.k + base, ts, key, kok, h2, kf);
+    as_load_frag<D>(p.v + base, ts, key, kok, h2, vf);
+    u32x4 rq[ASCfg<D>::NLD], rdo[ASCfg<D>::NLD];
+    float rl = 0.f, rd = 0.f;   // per-query statistics of the tile in flight (threads 0..31)
+    auto stat_load = [&](int t) {
+        if (tid < 32) {
+            const int n = t * 32 + tid;
+            rl = n < N ? p.lse_in[srow + n] * 1.4426950408889634f : INFINITY;   // padded queries: P = 0
+            rd = n < N ? p.delta[srow + n] : 0.f;
+        }
+    };
+    auto stat_store = [&](int buf) { if (tid < 32) { lse2s[buf * 32 + tid] = rl; dels[buf * 32 + tid] = rd; } };
+    as_tile_load<D>(rq, rdo, qb, dob, ts, 0, N, tid); stat_load(0);
+    as_tile_store<D>(rq, rdo, Qs, Os, tid); stat_store(0);
+    as_barrier();
+    if (p.ntile > 1) { as_tile_load<D>(rq, rdo, qb, dob, ts, 1, N, tid); stat_load(1); }
+    const float c2 = p.scale_log2e;
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[db][e] = 0.f; dv[db][e] = 0.f; }
+    for (int qt = 0; qt < p.ntile; ++qt) {
+        const int buf = qt & 1;
+        const uint16_t *qt_ = Qs + buf * TILE, *dot_ = Os + buf * TILE;
+        const f32x16 sc = as_product<D>(qt_ + fr * LD + h2 * 8, kf);     // S  [query][key]
+        const f32x16 dp = as_product<D>(dot_ + fr * LD + h2 * 8, vf);    // dP [query][key]
+        float pr[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {   // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
+            const float4 l4 = *(const float4 *)(lse2s + buf * 32 + 8 * g + 4 * h2);
+            const float4 d4 = *(const float4 *)(dels + buf * 32 + 8 * g + 4 * h2);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                pr[r] = fast_exp2(fmaf(sc[r], c2, -lv[e]));
+                ds[r] = pr[r] * (dp[r] - dl[e]);
+            }
+        }
+        bf16x8 p0, p1, s0, s1;
+        as_pack_tile(pr, p0, p1);
+        as_pack_tile(ds, s0, s1);
+        as_accumulate_t<D>(dot_, lane, p0, p1, dv);   // dV^T += dO^T P
+        as_accumulate_t<D>(qt_, lane, s0, s1, dk);    // dK^T += Q^T dS
+        if (qt + 1 < p.ntile) { as_tile_store<D>(rq, rdo, Qs + (1 - buf) * TILE, Os + (1 - buf) * TILE, tid); stat_store(1 - buf); }
+        as_barrier();
+        if (qt + 2 < p.ntile) { as_tile_load<D>(rq, rdo, qb, dob, ts, qt + 2, N, tid); stat_load(qt + 2); }
+    }
+    if (kok) {
+        as_store_t<D>(p.dk + base + key * ts, h2, dk, p.scale);
+        as_store_t<D>(p.dv + base + key * ts, h2, dv, 1.0f);
+    }
+}
+
+template <int D>
+static int as_forward(const ASParams &p, int64_t BH, hipStream_t s) {
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<D>), dim3((unsigned)BH, (p.N + AS_TOK - 1) / AS_TOK), dim3(AS_THREADS), 0, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int D>
+static int as_backward(const ASParams &p, int64_t BH, hipStream_t s) {
+    const dim3 grid((unsigned)BH, (p.N + AS_TOK - 1) / AS_TOK);
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D>), grid, dim3(AS_THREADS), 0, s, p);    // also writes delta, read by the next kernel
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D>), grid, dim3(AS_THREADS), 0, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
+                                double scale, hipStream_t s) {
+    ASParams p = {};
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.out = (uint16_t *)o; p.lse = lse;
+    p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    return D == 64 ? as_forward<64>(p, B * H, s) : as_forward<128>(p, B * H, s);
+}
+
+int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse, void *dq,
+                                void *dk, void *dv, float *delta, int64_t B, int N, int H, int D, double scale, hipStream_t s) {
+    ASParams p = {};
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o; p.dout = (const uint16_t *)dout;
+    p.lse_in = lse; p.delta = delta; p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
+    p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    return D == 64 ? as_backward<64>(p, B * H, s) : as_backward<128>(p, B * H, s);
+}
+
+}  // namespace vsde

@@ -137,4 +137,10 @@ size_t tn_workspace_bytes(const TnProblem *probs, int nprob, int M);
 int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes,
                       hipStream_t stream);
 
+// ---- streamed attention kernels (vsde_attn_stream.hip): any N, head_dim 64 or 128 ------------
+int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
+                                double scale, hipStream_t s);
+int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse, void *dq,
+                                void *dk, void *dv, float *delta, int64_t B, int N, int H, int D, double scale, hipStream_t s);
+
 }  // namespace vsde

@@ -381,9 +381,9 @@ class _Attention(torch.autograd.Function):
 
 
 def attention_usable(q: Tensor) -> bool:
-    """q token-major [B,N,H,d]: bf16, head_dim 64, sequence short enough for the LDS-resident kernel."""
-    return (ENABLED and q.is_cuda and q.dtype == torch.bfloat16 and q.ndim == 4 and q.shape[-1] == 64
-            and q.shape[1] <= _hip.attention_max_tokens())
+    """q token-major [B,N,H,d]: bf16, head_dim 64 or 128 (any sequence length: short head_dim-64 sequences run the LDS-resident
+    kernels, everything else the kernels that stream K / V tiles)."""
+    return ENABLED and q.is_cuda and q.dtype == torch.bfloat16 and q.ndim == 4 and q.shape[-1] in (64, 128)
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
