@@ -32,7 +32,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte regis
 constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2;
 constexpr int LIN_ROWS = 256;   // rows per workgroup (8 waves x 32)
 constexpr int LIN_THREADS = 512;
-constexpr int R2_THREADS = 256, R2_ROWS = 256, R2_SLD = 88;   // rows kernel: 4 waves x 64 rows, staging rows of 64 + 16 (+ 8 pad) elements
+constexpr int R2_THREADS = 256, R2_SLD = 88;   // rows kernel: 4 waves, staging rows of 64 + 16 (+ 8 pad) elements
 
 struct LinParams {
     const uint16_t *A; int64_t lda;    // activations [M][lda] bf16 (row pitch in elements)
@@ -134,14 +134,14 @@ __device__ __forceinline__ void swiglu_quads(const f32x16 &acc, const uint16_t *
     }
 }
 
-template <int EPI, int PAR>
-__device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[2], const uint16_t *bias32, uint16_t *stage,
-                                              int64_t row0, int n0, int lane) {
+template <int EPI, int PAR, int RB>
+__device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[RB], const uint16_t *bias32, uint16_t *stage,
+                                              const u32x4 (&ureg)[4 * RB], int64_t row0, int n0, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    constexpr int SLD = R2_SLD;
+    constexpr int SLD = R2_SLD, R = 32 * RB;
     if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
             stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
             if constexpr (EPI == EPI_SWIGLU && PAR == 0) {   // the first tile's s waits in columns 64..79 of the staging row
                 uint32_t s0[4];
@@ -152,11 +152,11 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
         }
         if constexpr (PAR == 1) {
             wave_lds_fence();
-            if ((EPI == EPI_PLAIN || p.C != nullptr) && !(p.dbg & 1)) flush_rows64<SLD, 64>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
+            if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD, R>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
             if constexpr (EPI == EPI_SWIGLU) {   // second tile's s (acc is still live) into columns 0..15, then 32 columns of s per row
                 wave_lds_fence();
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
+                for (int rb = 0; rb < RB; ++rb) {
                     uint32_t s1[4];
                     swiglu_quads(acc[rb], bias32, h, s1);
 #pragma unroll
@@ -164,7 +164,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 }
                 wave_lds_fence();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {   // 64 bytes of s per row: lanes c = 0, 1 take the first tile's half, c = 2, 3 the second's
+                for (int i = 0; i < R / 16; ++i) {   // 64 bytes of s per row: lanes c = 0, 1 take the first tile's half, c = 2, 3 the second's
                     const int row = (lane >> 2) + 16 * i, c = lane & 3;
                     const u32x4 v = *(const u32x4 *)(stage + row * SLD + (c < 2 ? 64 + 8 * c : 8 * (c - 2)));
                     if (row0 + row < p.M) __builtin_nontemporal_store(v, (u32x4 *)(p.S + (row0 + row) * p.lds_ + ((n0 - 32) >> 1) + c * 8));
@@ -173,15 +173,15 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
             wave_lds_fence();
         }
     } else {
+        // ureg: the wave's R x 64 slice of u for THIS tile (8 rows x 128 bytes per register quad), requested a tile ago
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {   // coalesced load of the wave's 64 x 64 slice of u: 8 rows x 128 bytes per instruction
+        for (int i = 0; i < 4 * RB; ++i) {
             const int row = (lane >> 3) + 8 * i, c = lane & 7;
-            const uint4 v = row0 + row < p.M ? *(const uint4 *)(p.U + (row0 + row) * p.ldu + 2 * n0 + c * 8) : make_uint4(0, 0, 0, 0);
-            *(uint4 *)(stage + row * SLD + c * 8) = v;
+            *(u32x4 *)(stage + row * SLD + c * 8) = ureg[i];
         }
         wave_lds_fence();
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {   // ds column 8 g + 4 h + i  <->  u columns 32 (g / 2) + 8 (g % 2) + 4 h + i (a), + 16 (b)
                 uint16_t *pa = stage + (rb * 32 + r) * SLD + 32 * (g >> 1) + 8 * (g & 1) + 4 * h, *pb = pa + 16;
@@ -199,34 +199,34 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 *(uint2 *)pb = make_uint2(pack_bf16x2(db[0], db[1]), pack_bf16x2(db[2], db[3]));
             }
         wave_lds_fence();
-        flush_rows64<SLD, 64>(stage, p.C + 2 * n0, p.ldc, row0, p.M, lane);
+        flush_rows64<SLD, R>(stage, p.C + 2 * n0, p.ldc, row0, p.M, lane);
         wave_lds_fence();
     }
 }
 
 // ------------------------------------------------------------------------------------------------ rows kernel
-// Workgroup = 4 waves x 64 rows (two 32-row MFMA blocks per wave, their K-slices resident in VGPRs); the weight streams
-// through LDS in tiles of 32 output columns ([32][KC] + a bias row, double-buffered, one barrier per tile, 32 MFMAs per wave and
-// tile, every weight fragment feeds two MFMAs).  ~72 KB of LDS and <= 256 VGPRs: TWO workgroups per CU, whose phases (MFMA
-// burst / epilogue / tile refill) drift apart and overlap -- one 8-wave workgroup in lockstep ran the matrix pipe at 25 %.
+// Workgroup = 4 waves x RB 32-row MFMA blocks (RB = 2: 256-row stripes; RB = 1: 128-row stripes), the waves' K-slices of x
+// resident in VGPRs; the weight streams through LDS in tiles of 32 output columns ([32][KC] + a bias row, double-buffered, one
+// barrier per tile, 16 RB MFMAs per wave and tile, every weight fragment feeds RB MFMAs).  <= 80 KB of LDS and <= 256 VGPRs: at
+// least TWO workgroups per CU, whose phases (MFMA burst / epilogue / tile refill) drift apart and overlap -- one 8-wave
+// workgroup in lockstep ran the matrix pipe at 25 %.
 // Tiles are visited in a rotated order (first tile pair = workgroup index): the workgroups of a launch pull DIFFERENT tiles of W
 // out of L2 at any moment; the next tile's loads are in flight during the current tile's MFMAs and epilogue.
-// Outputs leave in pairs of tiles (64 columns = 128-byte row segments) through the wave's staging buffer.
-template <int EPI> constexpr int r2_stage_elems() { return 64 * R2_SLD; }
+// Outputs leave in pairs of tiles (64 columns = 128-byte row segments, non-temporal) through the wave's staging buffer.
+// EPI_SWIGLU_BWD runs with RB = 1: the tile's slice of the saved u is requested a tile ahead into registers, so its HBM
+// latency is hidden behind the MFMAs (with RB = 2 there are no registers left for that and every tile waited for its u).
+template <int EPI> constexpr int rows_rb() { return EPI == EPI_SWIGLU_BWD ? 1 : 2; }
 
-template <int KC>
-__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&afr)[2][KC / 16], const uint16_t *bsrc) {
-    constexpr int KS = KC / 16, GK = 2, NG = KS / GK;
+template <int KC, int RB>
+__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (&afr)[RB][KC / 16], const uint16_t *bsrc) {
+    constexpr int KS = KC / 16, GK = RB == 1 ? 4 : 2, NG = KS / GK;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
     bf16x8 bq[2][GK];
 #pragma unroll
     for (int k = 0; k < GK; ++k) bq[0][k] = *(const bf16x8 *)(bsrc + k * 16);
-    // The waves sharing a SIMD (one per co-resident workgroup) run the same program: left alone they stay in phase, both
-    // queueing for the matrix pipe and then both leaving it idle.  Priority while in the MFMA burst makes one of them finish its
-    // burst first, after which the bursts of one overlap the epilogue / refill of the other.
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gk = 0; gk < NG; ++gk) {
@@ -237,7 +237,7 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&
 #pragma unroll
         for (int k = 0; k < GK; ++k)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], afr[rb][gk * GK + k], acc[rb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -246,16 +246,17 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[2], const bf16x8 (&
 
 template <int KC, int EPI>
 __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
+    constexpr int RB = rows_rb<EPI>(), ROWS = 128 * RB;
     constexpr int KS = KC / 16, LDB = KC + 8, TILE = 33 * LDB;   // 32 weight rows + 1 bias row
     constexpr int NLD = 32 * KC / 8 / R2_THREADS;                // 16-byte loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    uint16_t *stage = lsm + 2 * TILE + wave * r2_stage_elems<EPI>();
-    const int64_t row0 = (int64_t)blockIdx.x * R2_ROWS + wave * 64;
+    uint16_t *stage = lsm + 2 * TILE + wave * (32 * RB * R2_SLD);
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * (32 * RB);
 
-    bf16x8 afr[2][KS];
+    bf16x8 afr[RB][KS];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
         const int64_t m = row0 + rb * 32 + r < p.M ? row0 + rb * 32 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     const int rot = 2 * (blockIdx.x % (ntiles / 2));
     u32x4 breg[NLD];          // the next tile on its way from L2 to LDS (loaded one iteration before its LDS store)
     uint32_t biasreg = 0u;
+    u32x4 ureg[4 * RB];       // EPI_SWIGLU_BWD: the next tile's slice of the saved u (32 RB rows x 64 columns)
 #define VSDE_TILE_LOAD(t_)                                                                                    \
     do {                                                                                                      \
         const int tile_ = ((t_) + rot) % ntiles;                                                              \
@@ -276,19 +278,32 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         wtile_store<NLD, KC, LDB, R2_THREADS>(breg, (Bs_), tid);                                              \
         if (tid < 16) *(uint32_t *)((Bs_) + 32 * LDB + 2 * tid) = biasreg;                                    \
     } while (0)
-// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (register set 1 - PAR_) goes to the other buffer.
+#define VSDE_U_LOAD(t_)                                                                                       \
+    do {                                                                                                      \
+        if constexpr (EPI == EPI_SWIGLU_BWD) {                                                                \
+            const int n0_ = (((t_) + rot) % ntiles) * 32;                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4 * RB; ++i) {                                              \
+                const int row = (lane >> 3) + 8 * i, c = lane & 7;                                            \
+                const int64_t m_ = row0 + row < p.M ? row0 + row : p.M - 1;                                   \
+                ureg[i] = *(const u32x4 *)(p.U + m_ * p.ldu + 2 * n0_ + c * 8);                               \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (in breg) goes to the other buffer.
 // t and the tile index have the same parity (rot is even): PAR_ = 1 closes a pair of tiles.
 #define VSDE_ROWS_BODY(t_, PAR_)                                                                              \
     do {                                                                                                      \
         const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
-        f32x16 acc[2];                                                                                        \
-        rows_tile_mfma<KC>(acc, afr, Bs + r * LDB + 8 * h);                                                   \
-        rows_epilogue<EPI, PAR_>(p, acc, Bs + 32 * LDB, stage, row0, (((t_) + rot) % ntiles) * 32, lane);       \
+        f32x16 acc[RB];                                                                                       \
+        rows_tile_mfma<KC, RB>(acc, afr, Bs + r * LDB + 8 * h);                                               \
+        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (((t_) + rot) % ntiles) * 32, lane); \
         if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE);                                    \
         lds_barrier();                                                                                        \
         if ((t_) + 2 < ntiles) VSDE_TILE_LOAD((t_) + 2);                                                      \
+        if ((t_) + 1 < ntiles) VSDE_U_LOAD((t_) + 1);                                                         \
     } while (0)
     VSDE_TILE_LOAD(0);
+    VSDE_U_LOAD(0);
     VSDE_TILE_STORE(lsm);
     lds_barrier();
     VSDE_TILE_LOAD(1);
@@ -297,6 +312,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         VSDE_ROWS_BODY(nt + 1, 1);
     }
 #undef VSDE_ROWS_BODY
+#undef VSDE_U_LOAD
 #undef VSDE_TILE_LOAD
 #undef VSDE_TILE_STORE
 }
@@ -392,14 +408,15 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
     }
 }
 
-template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * r2_stage_elems<EPI>()) * sizeof(uint16_t); }
+template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI>() * R2_SLD) * sizeof(uint16_t); }
 template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * 72 + 8 * 32 * 72) * sizeof(uint16_t); }
 
 template <int KC, int EPI>
 static int launch_rows(const LinParams &p, hipStream_t s) {
     const size_t lds = rows_lds_bytes<KC, EPI>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)((p.M + R2_ROWS - 1) / R2_ROWS)), dim3(R2_THREADS), lds, s, p);
+    constexpr int rows = 128 * rows_rb<EPI>();
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)((p.M + rows - 1) / rows)), dim3(R2_THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
