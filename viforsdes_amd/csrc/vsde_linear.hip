@@ -9,8 +9,8 @@
 // tile, 32 v_mfma_f32_32x32x16_bf16 per wave and tile):
 //   * rows kernel ("A-stationary", K in {128, 256}): the wave's 32 x K slice of x sits in VGPRs for the whole stripe,
 //     the loop runs over 64-column tiles of W ([64][K]); x is read from HBM exactly once, y written once.
-//   * cols kernel ("C-stationary", N tile of 128 / 256, any K % 64 == 0): the wave's 32 x N accumulators stay in VGPRs, the
-//     loop runs over 64-deep K chunks of W ([N][64]) and of x (fragment loads straight to registers).
+//   * cols kernel ("C-stationary", 256- or 128-column output tiles, any K % 64 == 0): the waves' accumulators stay in VGPRs,
+//     the loop runs over 64-deep K chunks of W ([NT][64]) and of x (fragment loads straight to registers).
 // Products are computed swapped (D = W_tile . x_tile^T): the lane that owns activation row r keeps it through the whole
 // stripe, and each accumulator register quad is 4 consecutive output columns of that row -- bias, SwiGLU and its derivative
 // are then lane-local register math, and the tile leaves through a per-wave LDS staging buffer as full 128-byte row segments.
@@ -30,8 +30,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte register quad (native vector: stays in VGPRs)
 
 constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2;
-constexpr int LIN_ROWS = 256;   // rows per workgroup (8 waves x 32)
-constexpr int LIN_THREADS = 512;
 constexpr int R2_THREADS = 256, R2_SLD = 88;   // rows kernel: 4 waves, staging rows of 64 + 16 (+ 8 pad) elements
 
 struct LinParams {
@@ -317,14 +315,22 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #undef VSDE_TILE_STORE
 }
 
-// The 4 x NB (k-step, column block) products of one 64-deep chunk for the wave's 32 rows; the weight fragments of a group of
-// 4 are fetched while the MFMAs of the previous group run.  bsrc = tile + r * 72 + 8 h.
+// ------------------------------------------------------------------------------------------------ cols kernel
+// Deep reductions (any K % 64 == 0): workgroup = 4 waves x 32 rows x one output tile of NT = 32 NB columns (NB = 8: 256
+// columns, or 4), whose accumulator blocks stay in VGPRs while K streams in chunks of 64: the weight chunk [NT][64] through LDS
+// (double-buffered, one barrier per chunk, 4 NB MFMAs per wave and chunk), the activation fragments of the next chunk straight
+// into registers during the MFMAs of the current one.  With N <= 256 the activations -- the big operand -- are read from HBM
+// exactly once.  <= 74 KB of LDS, <= 256 VGPRs: two workgroups per CU whose phases overlap.
+constexpr int C2_THREADS = 256, C2_ROWS = 128, C2_LDB = 72;
+
 template <int NB>
-__device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (&afr)[4], const uint16_t *bsrc) {
-    constexpr int G = 4, NGRP = 4 * NB / G, LDB = 72;
+__device__ __forceinline__ void cols_chunk_mfma(f32x16 (&acc)[NB], const bf16x8 (&afr)[4], const uint16_t *bsrc) {
+    // the chunk's 4 (k-step) x NB (column block) weight fragments in order; a group of 4 is fetched while the previous group's
+    // MFMAs run
+    constexpr int G = 4, NGRP = 4 * NB / G;
     bf16x8 bq[2][G];
 #pragma unroll
-    for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * LDB + (i / NB) * 16);
+    for (int i = 0; i < G; ++i) bq[0][i] = *(const bf16x8 *)(bsrc + (i % NB) * 32 * C2_LDB + (i / NB) * 16);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
@@ -332,7 +338,7 @@ __device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int q = (g + 1) * G + i;
-                bq[(g + 1) & 1][i] = *(const bf16x8 *)(bsrc + (q % NB) * 32 * LDB + (q / NB) * 16);
+                bq[(g + 1) & 1][i] = *(const bf16x8 *)(bsrc + (q % NB) * 32 * C2_LDB + (q / NB) * 16);
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
@@ -345,27 +351,21 @@ __device__ __forceinline__ void cols_tile_mfma(f32x16 (&acc)[NB], const bf16x8 (
     __builtin_amdgcn_s_setprio(0);
 }
 
-// ------------------------------------------------------------------------------------------------ cols kernel
-// NB accumulator blocks of 32 columns (N tile = 32 NB in {128, 256}); blockIdx.y = N tile; K % 64 == 0.
 template <int NB>
-__global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
-    constexpr int NT = 32 * NB, LDB = 72, TILE = NT * LDB;      // weight tile [NT][64] with 144-byte rows
-    constexpr int NLD = NT * 64 / 8 / LIN_THREADS;               // 16-byte loads per thread and tile (2 or 4)
+__global__ void __launch_bounds__(C2_THREADS, 2) lin_cols_kernel(LinParams p) {
+    constexpr int NT = 32 * NB, TILE = NT * C2_LDB;
+    constexpr int NLD = NT * 64 / 8 / C2_THREADS;   // 16-byte loads per thread and chunk (8 or 4)
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    uint16_t *stage = lsm + 2 * TILE + wave * (32 * 72);
-    const int64_t row0 = (int64_t)blockIdx.x * LIN_ROWS + wave * 32;
-    const int nbase = blockIdx.y * NT;
-    const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one; they are never stored
+    const int ntn = p.N / NT, stripe = blockIdx.x / ntn, nbase = (blockIdx.x - stripe * ntn) * NT;
+    const int64_t row0 = (int64_t)stripe * C2_ROWS + wave * 32;
+    const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
     const uint16_t *asrc = p.A + m * p.lda + 8 * h;
     const int ktiles = p.K / 64;
-
-    // K chunks are visited in a rotated order (see the rows kernel); chunk t travels in breg[t & 1], loaded two iterations
-    // before its LDS store; the activation fragments of chunk t + 1 are fetched during the MFMAs of chunk t.
-    const int rot = blockIdx.x % ktiles;
-    u32x4 breg[2][NLD];
-    bf16x8 afr[2][4];
+    const int rot = stripe % ktiles;   // K chunks in a rotated order: concurrent workgroups pull different chunks of W out of L2
     const uint16_t *wsrc = p.W + (int64_t)nbase * p.K;
+    u32x4 breg[NLD];
+    bf16x8 afr[2][4];   // [set][k-step]
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -377,17 +377,16 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
 #define VSDE_COLS_BODY(t_, PAR_)                                                                              \
     do {                                                                                                      \
         if ((t_) + 1 < ktiles) { VSDE_A_LOAD((t_) + 1, 1 - (PAR_)) }                                          \
-        cols_tile_mfma<NB>(acc, afr[PAR_], lsm + (PAR_) * TILE + r * LDB + 8 * h);                            \
-        if ((t_) + 1 < ktiles) wtile_store<NLD, 64, LDB, LIN_THREADS>(breg[1 - (PAR_)], lsm + (1 - (PAR_)) * TILE, tid);   \
+        cols_chunk_mfma<NB>(acc, afr[PAR_], lsm + (PAR_) * TILE + r * C2_LDB + 8 * h);                        \
+        if ((t_) + 1 < ktiles) wtile_store<NLD, 64, C2_LDB, C2_THREADS>(breg, lsm + (1 - (PAR_)) * TILE, tid); \
         lds_barrier();                                                                                        \
-        if ((t_) + 3 < ktiles) wtile_load<NLD, 64, LIN_THREADS>(breg[1 - (PAR_)], wsrc + VSDE_CHUNK((t_) + 3), p.K, tid);  \
+        if ((t_) + 2 < ktiles) wtile_load<NLD, 64, C2_THREADS>(breg, wsrc + VSDE_CHUNK((t_) + 2), p.K, tid);  \
     } while (0)
-    wtile_load<NLD, 64, LIN_THREADS>(breg[0], wsrc + VSDE_CHUNK(0), p.K, tid);
+    wtile_load<NLD, 64, C2_THREADS>(breg, wsrc + VSDE_CHUNK(0), p.K, tid);
     VSDE_A_LOAD(0, 0)
-    wtile_store<NLD, 64, LDB, LIN_THREADS>(breg[0], lsm, tid);
+    wtile_store<NLD, 64, C2_LDB, C2_THREADS>(breg, lsm, tid);
     lds_barrier();
-    if (ktiles > 1) wtile_load<NLD, 64, LIN_THREADS>(breg[1], wsrc + VSDE_CHUNK(1), p.K, tid);
-    if (ktiles > 2) wtile_load<NLD, 64, LIN_THREADS>(breg[0], wsrc + VSDE_CHUNK(2), p.K, tid);
+    if (ktiles > 1) wtile_load<NLD, 64, C2_THREADS>(breg, wsrc + VSDE_CHUNK(1), p.K, tid);
     for (int kt = 0; kt < ktiles; kt += 2) {
         VSDE_COLS_BODY(kt, 0);
         if (kt + 1 < ktiles) VSDE_COLS_BODY(kt + 1, 1);
@@ -395,21 +394,22 @@ __global__ void __launch_bounds__(LIN_THREADS) lin_cols_kernel(LinParams p) {
 #undef VSDE_COLS_BODY
 #undef VSDE_A_LOAD
 #undef VSDE_CHUNK
-    // epilogue: 64 columns at a time through the wave's staging buffer; the bias row is staged in the (now free) tile buffer 0
-    if (tid < NT / 2) *(uint32_t *)(lsm + 2 * tid) = p.bias ? *(const uint32_t *)(p.bias + nbase + 2 * tid) : 0u;
+    // epilogue: the weight buffers are free now: bias row in front, then one 32-row staging area per wave
+    uint16_t *brow = lsm, *stage = lsm + NT + wave * (32 * C2_LDB);
+    if (tid < NT / 2) *(uint32_t *)(brow + 2 * tid) = p.bias ? *(const uint32_t *)(p.bias + nbase + 2 * tid) : 0u;
     lds_barrier();
 #pragma unroll
-    for (int q = 0; q < NB / 2; ++q) {
-        stage_block(acc[2 * q], lsm + 64 * q, stage + r * 72, h);
-        stage_block(acc[2 * q + 1], lsm + 64 * q + 32, stage + r * 72 + 32, h);
+    for (int q = 0; q < NB / 2; ++q) {   // 64 columns at a time
+        stage_block(acc[2 * q], brow + 64 * q, stage + r * C2_LDB, h);
+        stage_block(acc[2 * q + 1], brow + 64 * q + 32, stage + r * C2_LDB + 32, h);
         wave_lds_fence();
-        flush_rows64<72, 32>(stage, p.C + nbase + 64 * q, p.ldc, row0, p.M, lane);
+        flush_rows64<C2_LDB, 32>(stage, p.C + nbase + 64 * q, p.ldc, row0, p.M, lane);
         wave_lds_fence();
     }
 }
 
 template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI>() * R2_SLD) * sizeof(uint16_t); }
-template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * 72 + 8 * 32 * 72) * sizeof(uint16_t); }
+template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * C2_LDB) * sizeof(uint16_t); }   // two weight buffers (the epilogue reuses them)
 
 template <int KC, int EPI>
 static int launch_rows(const LinParams &p, hipStream_t s) {
@@ -430,7 +430,8 @@ template <int NB>
 static int launch_cols(const LinParams &p, hipStream_t s) {
     const size_t lds = cols_lds_bytes<NB>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_cols_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((lin_cols_kernel<NB>), dim3((unsigned)((p.M + LIN_ROWS - 1) / LIN_ROWS), p.N / (32 * NB)), dim3(LIN_THREADS), lds, s, p);
+    const int64_t stripes = (p.M + C2_ROWS - 1) / C2_ROWS;
+    hipLaunchKernelGGL((lin_cols_kernel<NB>), dim3((unsigned)(stripes * (p.N / (32 * NB)))), dim3(C2_THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
