@@ -71,20 +71,21 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
 
 
 def pmc_traffic_bytes(workload, batch):
-    """HBM bytes per launch of the serial forward kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE in KiB, separate passes, LV B=512; newest profiles/r*_pmc_head_lv*.txt).  The kernel reads with 4-byte
-    loads, for which the guide gives no FETCH_SIZE correction, so the raw counter is used; null for other workloads."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_head_lv*.txt")))
-    if workload != "lv" or batch != 512 or not files:
+    """HBM bytes per launch of the serial forward kernel (training variant) from the committed rocprofv3 --pmc passes
+    (profiles/r02_pmc_head_lv.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed
+    over the XCDs).  The kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
+    counter is used; null for other workloads."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_head_lv.txt")
+    if workload != "lv" or batch != 512 or not os.path.exists(path):
         return None
-    vals = {}
-    for line in open(files[-1]):
-        if "head_fwd_v2_kernel" in line or "head_fwd_" in line:
-            parts = line.split()
-            ctr = [p for p in parts if p in ("FETCH_SIZE", "WRITE_SIZE")]
-            if ctr and "mean=" in line:
-                vals[ctr[0]] = float(line.split("mean=")[1].split()[0])
+    vals, kernel = {}, ""
+    for line in open(path):
+        if not line.startswith(" ") and "dispatches=" in line:
+            kernel = line
+        elif "head_fwd_v2_kernel<2, true" in kernel and "mean=" in line:
+            name = line.split()[0]
+            if name in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[name] = float(line.split("mean=")[1])
     if len(vals) != 2:
         return None
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
