@@ -353,7 +353,7 @@ def main():
         allreduce_ms = e0.elapsed_time(e1) / 10
 
     # per-kernel timing of the hand-written head kernels (HIP events on the launch stream) -- eager steps
-    H, L, C = model.head.hidden_dim, model.head.num_layers, model.head.context_dim
+    H, L, C, P = model.head.hidden_dim, model.head.num_layers, model.head.context_dim, sde.sde_param_dim
     ntril = S * (S + 1) // 2
     _hip.profile_enable(True)
     slots = {k: [] for k in range(7)}
@@ -371,6 +371,8 @@ def main():
     steps_per_launch = args.batch * T
     gbs = lambda bytes_step, ms: bytes_step * steps_per_launch / (ms * 1e-3) / 1e9
     achieved = gbs(fwd_bytes_step, fwd_ms)
+    macs_step = 3 * H * (S + P + H) + (L - 1) * 3 * H * 2 * H + (S + ntril) * H   # context term excluded: hoisted into the GEMM
+    valu_floor_ms = steps_per_launch * (macs_step / 64.0) * 4.0 / (256 * 4) / 2.4e9 * 1e3
 
     # encoder alone: forward + backward of the context (bf16 autocast), for the MFMA utilisation figure
     enc_mod = model.encoder
@@ -417,6 +419,9 @@ def main():
                      "bytes_per_path_step": fwd_bytes_step, "path_steps_per_launch": steps_per_launch,
                      # the context read is done by the hoisted projection GEMM: the whole forward path priced with the same bytes
                      "projection_gemm_ms": avg[4], "forward_path_ms": avg[2],
+                     # what actually bounds the serial kernel: its fp32 MACs at 4 issue cycles per wave64 v_fma_f32 over all SIMDs
+                     # (256 CUs x 4) at the 2.4 GHz peak clock -- a floor no memory system changes
+                     "valu_floor_ms": valu_floor_ms, "frac_of_valu_floor": valu_floor_ms / fwd_ms,
                      "frac_incl_projection": gbs(fwd_bytes_step, avg[2]) / HBM_PEAK_GBS,
                      "backward": {"serial_kernel_ms": bwd_ms, "grad_context_gemm_ms": avg[5], "weight_grad_reduction_ms": avg[6],
                                   "backward_path_ms": avg[3], "bytes_per_path_step": bwd_bytes_step,
