@@ -353,7 +353,7 @@ def main():
         allreduce_ms = e0.elapsed_time(e1) / 10
 
     # per-kernel timing of the hand-written head kernels (HIP events on the launch stream) -- eager steps
-    H, L, C, P = model.head.hidden_dim, model.head.num_layers, model.head.context_dim, sde.sde_param_dim
+    H, L, C = model.head.hidden_dim, model.head.num_layers, model.head.context_dim
     ntril = S * (S + 1) // 2
     _hip.profile_enable(True)
     slots = {k: [] for k in range(7)}
@@ -371,7 +371,7 @@ def main():
     steps_per_launch = args.batch * T
     gbs = lambda bytes_step, ms: bytes_step * steps_per_launch / (ms * 1e-3) / 1e9
     achieved = gbs(fwd_bytes_step, fwd_ms)
-    macs_step = 3 * H * (S + P + H) + (L - 1) * 3 * H * 2 * H + (S + ntril) * H   # context term excluded: hoisted into the GEMM
+    macs_step = 3 * H * (S + H) + (L - 1) * 3 * H * 2 * H + (S + ntril) * H   # context / theta terms excluded: hoisted out of the loop
     valu_floor_ms = steps_per_launch * (macs_step / 64.0) * 4.0 / (256 * 4) / 2.4e9 * 1e3
 
     # encoder alone: forward + backward of the context (bf16 autocast), for the MFMA utilisation figure
