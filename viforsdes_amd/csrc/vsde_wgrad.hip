@@ -2,270 +2,301 @@
 //
 //   dW[n][k] = sum_m dY[m][n] * X[m][k]        db[n] = sum_m dY[m][n]          (M = B * tokens ~ 2e5)
 //
-// hipBLASLt runs these "reduce over a huge M into a small N x K" GEMMs at 15-270 TF/s (0.45-0.6 ms each
-// at the LV shapes whatever their size) and torch adds a separate bf16 column-sum kernel for the bias.
-// They are HBM-bound (read dY and X once): this kernel splits M over the grid, every workgroup keeps a
-// 128 x 128 fp32 output tile in MFMA accumulators (v_mfma_f32_32x32x16_bf16), stages 64 rows of both
-// operands per iteration through LDS with an in-register 8x8 bf16 transpose (the MFMA wants the reduction
-// index contiguous per lane, memory has it as the slow index), prefetches the next 64 rows into registers
-// during the MFMAs, accumulates the column sums of dY from the staging registers, and a second kernel sums
-// the split partials in a fixed order (deterministic; fp32 results, better than the bf16 outputs torch
-// produces under autocast).
+// hipBLASLt runs these "reduce over a huge M into a small N x K" GEMMs at 15-270 TF/s (0.45-0.6 ms each at the LV shapes
+// whatever their size) and torch adds a separate bf16 column-sum kernel for the bias.  They are memory-bound (dY and X are
+// read once from HBM, X once more per output tile row from L2), so the kernel is organised around the loads:
+//
+//   * M is split over the grid in interleaved 32-row blocks (split s owns blocks s, s + nsplit, ...), every workgroup keeps
+//     a TN x 256 fp32 output tile in MFMA accumulators (v_mfma_f32_32x32x16_bf16; a wave owns 64 x 128) and writes it as a
+//     partial; a second kernel sums the partials in a fixed order (deterministic; fp32 results).
+//   * dy and x rows are staged exactly as they sit in memory ([m][cols], 32 rows per step, two LDS buffers, one LDS-only barrier
+//     per step); the MFMA fragments -- which want the reduction index m contiguous per lane -- come out of LDS through
+//     ds_read_b64_tr_b16, so the transpose is free.  Row pitch = cols + 32 bf16 (64 bytes past a multiple of 256): the 4 rows
+//     x 2 column halves one transposing read touches per 32 lanes fall in 8 different 8-bank groups.
+//   * Loads are requested TWO steps ahead into two register sets, branch-free (clamped addresses, zeroing at the LDS store):
+//     a predicated load sits in its own exec branch and hipcc then drains vmcnt(0) around each of them.
+//   * The workgroups of one split (same rows, different output tiles) sit on one XCD, so the shared X rows are served by that
+//     XCD's L2.  TN = 128: 4 waves, two workgroups per CU; TN = 256: 8 waves, one workgroup per CU, half the X re-reads.
+//   * The column sums of dY (bias gradient) are accumulated from the staging registers on the way to LDS.
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t w2u4 __attribute__((ext_vector_type(4)));
+typedef short w2bf4 __attribute__((ext_vector_type(4)));
 
-constexpr int WG_BM = 64;          // rows of M per staging step
-constexpr int WG_LD = WG_BM + 8;   // LDS row stride in bf16 elements (144 B: conflict-free ds_read_b128)
+constexpr int W2_TK = 256, W2_BM = 32;
+constexpr int W2_LDB = W2_TK + 32;   // LDS row pitch of the x tile (bf16)
 
-struct WgradParams {
-    const uint16_t *dy;  // [M][N] bf16
-    const uint16_t *x;   // [M][K] bf16
-    int64_t M;
-    int N, K;
-    int tile;            // output tile edge: 128 (256 threads) or 256 (512 threads)
-    int tiles_k;         // ceil(K / tile)
-    int tiles;           // output tiles in total
-    int nsplit;
-    int64_t rows_per_split;  // multiple of WG_BM
-    float *partial;      // [tiles][nsplit][tile*tile + tile]
-    float *dW;           // [N][K]
-    float *db;           // [N] or nullptr
+template <int TN> struct W2 {
+    static constexpr int THREADS = 2 * TN;              // waves: (TN / 64) along n x 2 along k
+    static constexpr int LDA = TN + 32;                  // LDS row pitch of the dy tile
+    static constexpr int BUF = W2_BM * (LDA + W2_LDB);   // bf16 elements per buffer
+    static constexpr int PART = TN * W2_TK + TN;         // fp32 partial tile + bias row
+    static constexpr int YC = TN / 8;                    // 16-byte chunks per dy tile row
+    static constexpr int YR = THREADS / YC;              // dy rows per staging pass (16)
+    static constexpr int NY = W2_BM / YR;                // dy chunks per thread and step (2)
+    static constexpr int XR = THREADS / 32;              // x rows per staging pass (8 | 16)
+    static constexpr int NX = W2_BM / XR;                // x chunks per thread and step (4 | 2)
 };
 
-// T x T output tile per workgroup of 2T threads: T=128 -> 4 waves of 64x64, T=256 -> 8 waves of 64(n) x 128(k).
-// The larger tile halves the operand re-reads (dY is re-read K/T times, X N/T times).
-template <int T>
-__global__ void __launch_bounds__(2 * T) wgrad_bf16_kernel(WgradParams p) {
-    constexpr int WK = T == 128 ? 64 : 128;  // wave sub-tile width along k
-    constexpr int NB = WK / 32;               // MFMA tiles along k per wave
-    extern __shared__ __attribute__((aligned(16))) uint16_t wsm[];
-    uint16_t *At = wsm;                 // dY^T tile: [n][m]
-    uint16_t *Bt = wsm + T * WG_LD;     // X^T  tile: [k][m]
-    float *bred = (float *)(wsm + 2 * T * WG_LD);  // [8][T]
+struct Wgrad2Params {
+    const uint16_t *dy, *x;
+    int64_t M;
+    int N, K, tn, tiles_n, tiles_k, tiles, nsplit;
+    int64_t chunks;           // 32-row blocks of the reduction index
+    float *partial, *dW, *db;
+};
+
+__device__ __forceinline__ uint2 w2_read_tr(const uint16_t *ptr) {
+    w2bf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w2bf4 *)ptr);
+    return *(uint2 *)&r;
+}
+__device__ __forceinline__ void w2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// fragment "row index = column c0 + (lane & 31) of the tile, 8 reduction rows" for the 16-row half `mc` of a 32-row tile
+__device__ __forceinline__ bf16x8 w2_frag(const uint16_t *tile, int ld, int c0, int mc, int lane) {
+    const int h2 = lane >> 5, m = lane & 15;
+    const uint16_t *src = tile + (16 * mc + 4 * h2 + (m >> 2)) * ld + c0 + ((lane >> 4) & 1) * 16 + (m & 3) * 4;
+    const uint2 a0 = w2_read_tr(src), a1 = w2_read_tr(src + 8 * ld);
+    uint4 w = make_uint4(a0.x, a0.y, a1.x, a1.y);
+    return *(bf16x8 *)&w;
+}
+
+template <int TN>
+__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) {
+    using C = W2<TN>;
+    extern __shared__ __attribute__((aligned(16))) uint16_t w2s[];
+    __shared__ float bred[C::YR][TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, so id = 8*local + xcd.  The workgroups
-    // of one split (same rows of dY / X, different output tiles) are given consecutive `local` on ONE xcd: the operand
-    // rows they share are then served by that XCD's L2 instead of being fetched once per tile.
+    // consecutive workgroup ids go round-robin over the 8 XCDs, so id = 8 * local + xcd
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tile = local % p.tiles, split = (local / p.tiles) * 8 + xcd;
     if (split >= p.nsplit) return;
-    const int n_blk = (tile / p.tiles_k) * T, k_blk = (tile % p.tiles_k) * T;
+    const int n_blk = (tile / p.tiles_k) * TN, k_blk = (tile % p.tiles_k) * W2_TK;
     const bool want_bias = p.db != nullptr && k_blk == 0;
-    // staging role: first T threads load dY, the other T load X; each an 8(m) x 8(col) block
-    const bool is_a = tid < T;
-    // adjacent lanes take adjacent m-blocks of the same column chunk: their 16-byte LDS stores fall into one
-    // 128-byte row segment (conflict-free) and every global load instruction covers 8 rows x 128 contiguous bytes
-    const int st = is_a ? tid : tid - T, mblk = st & 7, cch = st >> 3;
-    const uint16_t *src = is_a ? p.dy : p.x;
-    const int ld = is_a ? p.N : p.K;
-    const int col0 = (is_a ? n_blk : k_blk) + cch * 8;
-    const bool col_ok = col0 < ld;  // N, K are multiples of 8
-    uint16_t *dst = (is_a ? At : Bt) + (cch * 8) * WG_LD + mblk * 8;
-
-    const int64_t m_begin = (int64_t)split * p.rows_per_split;
-    const int64_t m_end = m_begin + p.rows_per_split < p.M ? m_begin + p.rows_per_split : p.M;
-    uint4 rows[8];
-    auto fetch = [&](int64_t m0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int64_t m = m0 + mblk * 8 + i;
-            rows[i] = (col_ok && m < m_end) ? *(const uint4 *)(src + m * ld + col0) : make_uint4(0, 0, 0, 0);
-        }
-    };
+    // Split s owns the 32-row blocks s, s + nsplit, s + 2 nsplit, ...: at any moment the resident workgroups read one contiguous
+    // window of rows.
+    const int64_t m_end = p.M, m_last = p.M - 1;
+#define W2_ROW0(t_) (((int64_t)(t_) * p.nsplit + split) * W2_BM)
+    const int ya_c = tid % C::YC, ya_r = tid / C::YC;   // + YR rows per i
+    const int xb_c = tid & 31, xb_r = tid >> 5;         // + XR rows per i
+    const bool ya_ok = n_blk + ya_c * 8 < p.N, xb_ok = k_blk + xb_c * 8 < p.K;   // N, K multiples of 8
+    const uint16_t *ysrc = p.dy + (ya_ok ? n_blk + ya_c * 8 : 0), *xsrc = p.x + (xb_ok ? k_blk + xb_c * 8 : 0);
+    // two register sets: step t travels in set t & 1, requested two steps before its LDS store
+    w2u4 ry[2][C::NY], rx[2][C::NX];
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc[2][NB];
+#define W2_FETCH(set_, m0_)                                                                                              \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < C::NY; ++i) {                                                              \
+            int64_t m = (m0_) + ya_r + C::YR * i; m = m < m_last ? m : m_last; ry[set_][i] = *(const w2u4 *)(ysrc + m * p.N); }  \
+        _Pragma("unroll") for (int i = 0; i < C::NX; ++i) {                                                              \
+            int64_t m = (m0_) + xb_r + C::XR * i; m = m < m_last ? m : m_last; rx[set_][i] = *(const w2u4 *)(xsrc + m * p.K); }  \
+    } while (0)
+#define W2_COMMIT(set_, buf_, m0_)                                                                                       \
+    do {                                                                                                                 \
+        uint16_t *ay_ = (buf_), *bx_ = (buf_) + W2_BM * C::LDA;                                                          \
+        const w2u4 z = {0u, 0u, 0u, 0u};                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < C::NY; ++i) {                                                              \
+            if (!(ya_ok && (m0_) + ya_r + C::YR * i < m_end)) ry[set_][i] = z;                                           \
+            *(w2u4 *)(ay_ + (ya_r + C::YR * i) * C::LDA + ya_c * 8) = ry[set_][i]; }                                     \
+        _Pragma("unroll") for (int i = 0; i < C::NX; ++i) {                                                              \
+            if (!(xb_ok && (m0_) + xb_r + C::XR * i < m_end)) rx[set_][i] = z;                                           \
+            *(w2u4 *)(bx_ + (xb_r + C::XR * i) * W2_LDB + xb_c * 8) = rx[set_][i]; }                                     \
+        if (want_bias) {                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < C::NY; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+                    const uint32_t w = ry[set_][i][j];                                                                   \
+                    bsum[2 * j] += __uint_as_float(w << 16); bsum[2 * j + 1] += __uint_as_float(w & 0xffff0000u);        \
+                }                                                                                                        \
+        }                                                                                                                \
+    } while (0)
+    f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int wn = (T == 128 ? (wave >> 1) : (wave >> 1)) * 64, wk = (wave & 1) * WK;  // this wave's sub-tile
-    const int fr = lane & 31, fh = lane >> 5;
-
-    if (m_begin < m_end) fetch(m_begin);
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_BM) {
-        uint4 cols[8];
-        transpose8x8(rows, cols);
-        if (want_bias && is_a) {
-            const uint32_t *rr = (const uint32_t *)rows;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t w = rr[i * 4 + (j >> 1)];
-                    bsum[j] += __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
-                }
-        }
-        __syncthreads();  // previous tile consumed
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *(uint4 *)(dst + j * WG_LD) = cols[j];
-        __syncthreads();
-        if (m0 + WG_BM < m_end) fetch(m0 + WG_BM);  // in flight during the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < WG_BM / 16; ++ks) {
-            bf16x8 af[2], bf[NB];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *(const bf16x8 *)(At + (wn + 32 * a + fr) * WG_LD + ks * 16 + fh * 8);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) bf[b] = *(const bf16x8 *)(Bt + (wk + 32 * b + fr) * WG_LD + ks * 16 + fh * 8);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+    const int nsteps = (int)((p.chunks - split + p.nsplit - 1) / p.nsplit);
+// step s_: MFMAs out of LDS buffer PAR_, then step s + 1 (register set 1 - PAR_) goes to the other buffer and that set is
+// re-requested for step s + 3
+#define W2_BODY(s_, PAR_)                                                                                                \
+    do {                                                                                                                 \
+        const uint16_t *buf = w2s + (PAR_) * C::BUF, *ay = buf, *bx = buf + W2_BM * C::LDA;                              \
+        _Pragma("unroll") for (int mc = 0; mc < 2; ++mc) {                                                               \
+            bf16x8 af[2], bf[4];                                                                                         \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a) af[a] = w2_frag(ay, C::LDA, wn + 32 * a, mc, lane);            \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = w2_frag(bx, W2_LDB, wk + 32 * b, mc, lane);            \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                \
+                _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                            \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);               \
+        }                                                                                                                \
+        if ((s_) + 1 < nsteps) W2_COMMIT(1 - (PAR_), w2s + (1 - (PAR_)) * C::BUF, W2_ROW0((s_) + 1));                    \
+        w2_barrier();                                                                                                    \
+        W2_FETCH(1 - (PAR_), W2_ROW0((s_) + 3));                                                                         \
+    } while (0)
+    if (nsteps > 0) {
+        W2_FETCH(0, W2_ROW0(0));
+        W2_COMMIT(0, w2s, W2_ROW0(0));
+        w2_barrier();
+        W2_FETCH(1, W2_ROW0(1));
+        W2_FETCH(0, W2_ROW0(2));
     }
+    // no condition on the odd step inside the loop: a merge of "taken / not taken" makes hipcc's vmcnt bookkeeping fall back to a
+    // full drain at the even step
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        W2_BODY(s, 0);
+        W2_BODY(s + 1, 1);
+    }
+    if (s < nsteps) W2_BODY(s, 0);
+#undef W2_BODY
+#undef W2_COMMIT
+#undef W2_FETCH
+#undef W2_ROW0
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float *out = p.partial + ((int64_t)tile * p.nsplit + split) * (T * T + T);
+    float *out = p.partial + ((int64_t)tile * p.nsplit + split) * C::PART;
+    const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = wn + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * fh, col = wk + 32 * b + fr;
-                out[row * T + col] = acc[a][b][e];
+                out[row * W2_TK + col] = acc[a][b][e];
             }
-    if (want_bias) {
-        __syncthreads();
-        if (is_a)
+    if (want_bias) {   // YR threads share a column chunk
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bred[mblk * T + cch * 8 + j] = bsum[j];
+        for (int j = 0; j < 8; ++j) bred[ya_r][ya_c * 8 + j] = bsum[j];
         __syncthreads();
-        if (tid < T) {
-            float s = 0.f;
+        if (tid < TN) {
+            float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += bred[g * T + tid];
-            out[T * T + tid] = s;
+            for (int g = 0; g < C::YR; ++g) t += bred[g][tid];
+            out[TN * W2_TK + tid] = t;
         }
     }
 }
 
-// Sum of the nsplit partial tiles, in a fixed association (deterministic).  grid (T*T/4/VPB + 1, tiles), 256 threads:
-// a block owns VPB = 256/G float4 vectors of one tile; thread (v, g) adds the splits g, g+G, ... (8 loads in flight),
-// the G group sums are combined through LDS in order.  The extra block (last blockIdx.x) sums the tile's bias row.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradParams p, int G) {
-    __shared__ float4 red[256];
-    const int T = p.tile, PART = T * T + T;
+// Fixed-order sum of the split partials.  grid (TN * 256 / 4 / 64 + 1, tiles), 256 threads = 64 float4 columns x 4 groups of
+// splits: group g adds splits g, g + 4, ... with four loads in flight, the four group sums are combined through LDS in order.  (One
+// thread per float4 walking all splits leaves ~64 workgroups on the chip for a two-tile problem and is latency-bound: 57 us against
+// 50 us for the product itself.)  The extra block (last blockIdx.x) sums the tile's bias row.
+template <int TN>
+__global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) {
+    constexpr int PART = W2<TN>::PART;
+    __shared__ float4 comb[3][64];
+    __shared__ float bcomb[256];
     const int tile = blockIdx.y;
-    const int n_blk = (tile / p.tiles_k) * T, k_blk = (tile % p.tiles_k) * T;
+    const int n_blk = (tile / p.tiles_k) * TN, k_blk = (tile % p.tiles_k) * W2_TK;
     const float *src = p.partial + (int64_t)tile * p.nsplit * PART;
-    if (blockIdx.x == gridDim.x - 1) {  // bias row: column c, split group g
+    if (blockIdx.x == gridDim.x - 1) {
         if (p.db == nullptr || k_blk != 0) return;
-        const int GB = 256 / T, c = threadIdx.x % T, g = threadIdx.x / T;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sp = g;
-        for (; sp + 7 * GB < p.nsplit; sp += 8 * GB) {
-            float v[8];
+        constexpr int H = 256 / TN;   // groups of splits per column (2 | 1)
+        const int c = threadIdx.x % TN, h = threadIdx.x / TN;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        int sp = h;
+        for (; sp + 3 * H < p.nsplit; sp += 4 * H) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(sp + q * GB) * PART + T * T + c];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += v[q];
+            for (int q = 0; q < 4; ++q) t[q] += src[(int64_t)(sp + H * q) * PART + TN * W2_TK + c];
         }
-        for (; sp < p.nsplit; sp += GB) acc[0] += src[(int64_t)sp * PART + T * T + c];
-        float *r = (float *)red;
-        r[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (; sp < p.nsplit; sp += H) t[0] += src[(int64_t)sp * PART + TN * W2_TK + c];
+        const float sum = (t[0] + t[1]) + (t[2] + t[3]);
+        bcomb[threadIdx.x] = sum;
         __syncthreads();
-        if (g == 0 && n_blk + c < p.N) {
-            float t = r[c];
-            for (int gg = 1; gg < GB; ++gg) t += r[gg * T + c];
-            p.db[n_blk + c] = t;
-        }
+        if (h == 0 && n_blk + c < p.N) p.db[n_blk + c] = H == 2 ? sum + bcomb[(threadIdx.x + TN) & 255] : sum;
         return;
     }
-    const int VPB = 256 / G, vl = threadIdx.x % VPB, g = threadIdx.x / VPB;
-    const int e = (blockIdx.x * VPB + vl) * 4;  // first of 4 consecutive elements (same row of the tile)
-    float4 acc[8];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = (blockIdx.x * 64 + col) * 4;
+    const int n = n_blk + e / W2_TK, k = k_blk + e % W2_TK;
+    float4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     int sp = g;
-    for (; sp + 7 * G < p.nsplit; sp += 8 * G) {
-        float4 v[8];
+    for (; sp + 12 < p.nsplit; sp += 16) {   // 4 loads in flight, fixed association
+        float4 v[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *(const float4 *)(src + (int64_t)(sp + q * G) * PART + e);
+        for (int q = 0; q < 4; ++q) v[q] = *(const float4 *)(src + (int64_t)(sp + 4 * q) * PART + e);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { acc[q].x += v[q].x; acc[q].y += v[q].y; acc[q].z += v[q].z; acc[q].w += v[q].w; }
+        for (int q = 0; q < 4; ++q) { acc[q].x += v[q].x; acc[q].y += v[q].y; acc[q].z += v[q].z; acc[q].w += v[q].w; }
     }
-    for (; sp < p.nsplit; sp += G) {
+    for (; sp < p.nsplit; sp += 4) {
         const float4 v = *(const float4 *)(src + (int64_t)sp * PART + e);
         acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
     }
     float4 t;
-    t.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
-    t.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
-    t.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
-    t.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
-    red[threadIdx.x] = t;
+    t.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x); t.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    t.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z); t.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    if (g > 0) comb[g - 1][col] = t;
     __syncthreads();
     if (g == 0) {
-        for (int gg = 1; gg < G; ++gg) {
-            const float4 u = red[gg * VPB + vl];
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        const int n = n_blk + e / T, k = k_blk + e % T;
-        if (n < p.N && k < p.K) *(float4 *)(p.dW + (int64_t)n * p.K + k) = t;  // K % 8 == 0: all four or none
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float4 u = comb[q][col]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        if (n < p.N && k < p.K) *(float4 *)(p.dW + (int64_t)n * p.K + k) = t;   // K % 8 == 0: all four or none
     }
 }
 
-static void wgrad_plan(int64_t M, int N, int K, WgradParams &p, int &tiles) {
+// TN = 256 when the output has at least three 256 x 256 tiles (half the re-reads of X; measured 155 | 227 | 126 us against
+// 172 | 264 | 136 us for dW[832,256] | [1536,256] | [256,768] at M = 205k, and 94 against 77 us for the one-tile [256,256]:
+// VSDE_WGRAD_TN=128|256 forces one for such comparisons).  The grid is one round of resident
+// workgroups (512 four-wave or 256 eight-wave workgroups), whole splits per XCD.  Problems of one or two tiles run 256 workgroups:
+// their partial-tile traffic (131 KB per workgroup) is otherwise as large as the operands.
+static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
+    static int force_tn = -1;
+    if (force_tn < 0) { const char *e = getenv("VSDE_WGRAD_TN"); force_tn = e ? atoi(e) : 0; }
     p.M = M; p.N = N; p.K = K;
-    p.tile = (N > 128 && K > 128) ? 256 : 128;
-    p.tiles_k = (K + p.tile - 1) / p.tile;
-    tiles = ((N + p.tile - 1) / p.tile) * p.tiles_k;
-    const int64_t chunks = (M + WG_BM - 1) / WG_BM;
-    // one round of workgroups: the 256 tile runs one workgroup per CU (register-limited: 8 waves x ~200 VGPRs), the 128
-    // tile two (measured optimum on MI355X: 256 / 512 workgroups); a multiple of 8 so that every XCD gets whole splits
-    int64_t nsplit = ((p.tile == 256 ? 256 : 512) / tiles) & ~7;
+    p.tn = force_tn ? force_tn : (((N + 255) / 256) * ((K + W2_TK - 1) / W2_TK) >= 3 ? 256 : 128);
+    p.tiles_n = (N + p.tn - 1) / p.tn; p.tiles_k = (K + W2_TK - 1) / W2_TK; p.tiles = p.tiles_n * p.tiles_k;
+    const int64_t chunks = (M + W2_BM - 1) / W2_BM;
+    const int wgs = p.tn == 256 || p.tiles <= 2 ? 256 : 512;
+    int64_t nsplit = (wgs / p.tiles) & ~7;
     if (nsplit < 8) nsplit = 8;
     if (nsplit > 256) nsplit = 256;
     if (nsplit > chunks) nsplit = chunks;
-    const int64_t cps = (chunks + nsplit - 1) / nsplit;
-    p.rows_per_split = cps * WG_BM;
-    p.nsplit = (int)((chunks + cps - 1) / cps);
-    p.tiles = tiles;
+    p.nsplit = (int)nsplit; p.chunks = chunks;
+}
+static size_t wgrad2_workspace(const Wgrad2Params &p) {
+    return (size_t)p.tiles * p.nsplit * (p.tn == 256 ? W2<256>::PART : W2<128>::PART) * sizeof(float);
 }
 
-static size_t wgrad_lds_bytes(int T) { return (size_t)2 * T * WG_LD * sizeof(uint16_t) + (size_t)8 * T * sizeof(float); }
+template <int TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s) {
+    using C = W2<TN>;
+    const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_tr_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wgrad_tr_kernel<TN>, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(C::THREADS), lds, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_tr_reduce_kernel<TN>, dim3(TN * W2_TK / 4 / 64 + 1, p.tiles), dim3(256), 0, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 }  // namespace vsde
 
-using namespace vsde;
-
 extern "C" size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    WgradParams p; int tiles;
-    wgrad_plan(M, N, K, p, tiles);
-    return (size_t)tiles * p.nsplit * (p.tile * p.tile + p.tile) * sizeof(float);
+    vsde::Wgrad2Params p;
+    vsde::wgrad2_plan(M, N, K, p);
+    return vsde::wgrad2_workspace(p);
 }
 
-extern "C" int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    using namespace vsde;
     VSDE_CHECK_ARG(dy && x && dW && workspace && M > 0, VSDE_E_BADARG, "bad linear_wgrad arguments");
     VSDE_CHECK_ARG(N % 8 == 0 && K % 8 == 0, VSDE_E_BADARG, "linear_wgrad needs N %% 8 == 0 and K %% 8 == 0 (got %d, %d)", N, K);
     VSDE_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0, VSDE_E_BADARG, "linear_wgrad operands must be 16-byte aligned");
-    WgradParams p; int tiles;
-    wgrad_plan(M, N, K, p, tiles);
-    const size_t need = (size_t)tiles * p.nsplit * (p.tile * p.tile + p.tile) * sizeof(float);
+    Wgrad2Params p;
+    wgrad2_plan(M, N, K, p);
+    const size_t need = wgrad2_workspace(p);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "linear_wgrad workspace too small: %zu < %zu", workspace_bytes, need);
     p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t lds = wgrad_lds_bytes(p.tile);
-    const dim3 grid((unsigned)(((p.nsplit + 7) / 8) * 8 * tiles));
-    if (p.tile == 256) {
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_bf16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((wgrad_bf16_kernel<256>), grid, dim3(512), lds, s, p);
-    } else {
-        hipLaunchKernelGGL((wgrad_bf16_kernel<128>), grid, dim3(256), lds, s, p);
-    }
-    VSDE_CHECK_HIP(hipGetLastError());
-    const int64_t vecs = (int64_t)tiles * p.tile * p.tile / 4;
-    int G = 1;
-    while (G < 16 && vecs * G < 524288 && 2 * G <= p.nsplit) G *= 2;  // enough threads to cover the load latency
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(p.tile * p.tile / 4 / (256 / G) + 1, tiles), dim3(256), 0, s, p, G);
-    VSDE_CHECK_HIP(hipGetLastError());
-    return 0;
+    return p.tn == 256 ? wgrad2_launch<256>(p, (hipStream_t)stream) : wgrad2_launch<128>(p, (hipStream_t)stream);
 }
