@@ -263,6 +263,16 @@ int vsde_euler_maruyama_bwd(int kind, int B, int T, int S, int P, const float *t
                             const float *g_traj, double time_step, const uint8_t *positive_mask_host, float *g_x0,
                             float *g_theta, void *stream);
 
+/* Drift and diffusion factor of a built-in SDE on every grid point of a batch of paths -- what the ELBO evaluates through the
+ * user's Python callables on the flattened [(B T), S] states (inference/evidence_lower_bound.py:37-40) -- and the
+ * vector-Jacobian product its backward needs.  x[B][T+1][S] (rows 0..T-1 are read), theta[B][P] -> drift[B][T][S],
+ * diffusion[B][T][S][S].  _bwd: g_drift, g_diffusion -> g_x[B][T+1][S] (row T zero), g_theta[B][P] (sum over t in a fixed
+ * order).  torch.clamp(min=1e-6) semantics: the gradient passes where the clamped quantity is >= the bound. */
+int vsde_sde_coefficients_fwd(int kind, int B, int T, int S, int P, const float *x, const float *theta, float *drift,
+                              float *diffusion, void *stream);
+int vsde_sde_coefficients_bwd(int kind, int B, int T, int S, int P, const float *x, const float *theta, const float *g_drift,
+                              const float *g_diffusion, float *g_x, float *g_theta, void *stream);
+
 /* Measurement aid (no reference counterpart): when enabled, the launchers bracket their kernels with hipEvents on the
  * launch stream.  which: 0 = serial time-stepping forward kernel (training variant), 1 = serial backward kernel,
  * 2 = everything vsde_head_forward enqueues (training variant), 3 = everything vsde_head_backward enqueues,

@@ -341,3 +341,64 @@ def euler_maruyama_bwd(kind: str, theta, noise, traj, g_traj, dt: float, positiv
     fn(ctypes.c_int(EM_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S), ctypes.c_int(theta.shape[1]),
        _p(theta), _p(noise), _p(traj), _p(g_traj), ctypes.c_double(dt), _p(_mask(positive_dims, S)), _p(g_x0), _p(g_theta))
     return g_x0, g_theta
+
+
+def sde_coefficients(kind: str, x, theta):
+    """Drift [B,T,S] and diffusion factor [B,T,S,S] of the example SDEs on the first T points of x [B,T+1,S], float64:
+    examples/ornstein_uhlenbeck.py:18-30 (f = kappa (mu - x), G = sigma), examples/lotka_volterra.py:18-46 (analytic 2x2
+    Cholesky factor with three clamp(min=1e-6)); ``linear_diagonal`` is BASELINE config 5 (f = -a x, G = diag(softplus(b) + 1e-3)).
+    This is what inference/evidence_lower_bound.py:37-40 evaluates on the flattened [(B T), S] states."""
+    x = np.asarray(x, np.float64)[:, :-1]; th = np.asarray(theta, np.float64)[:, None, :]
+    B, T, S = x.shape
+    G = np.zeros((B, T, S, S))
+    if kind == "ou":
+        f = th[..., 0:1] * (th[..., 1:2] - x); G[..., 0, 0] = th[..., 2]
+    elif kind == "lv":
+        u, v = x[..., 0], x[..., 1]; t1, t2, t3 = th[..., 0], th[..., 1], th[..., 2]
+        uv = t2 * u * v
+        l00 = np.sqrt(np.maximum(t1 * u + uv, 1e-6)); l10 = -uv / np.maximum(l00, 1e-6)
+        l11 = np.sqrt(np.maximum(t3 * v + uv - l10 * l10, 1e-6))
+        f = np.stack([t1 * u - uv, uv - t3 * v], -1)
+        G[..., 0, 0], G[..., 1, 0], G[..., 1, 1] = l00, l10, l11
+    else:
+        a, b = th[..., :S], th[..., S:]
+        f = -a * x
+        d = np.arange(S)
+        G[..., d, d] = np.broadcast_to(np.logaddexp(0.0, b) + 1e-3, (B, T, S))
+    return f, G
+
+
+def sde_coefficients_bwd(kind: str, x, theta, g_drift, g_diffusion):
+    """What torch autograd returns for ``sde_coefficients``: (g_x [B,T+1,S] with a zero last row, g_theta [B,P]); clamp(min)
+    passes the gradient where its input is >= the bound (ATen clamp_backward)."""
+    xf = np.asarray(x, np.float64); x = xf[:, :-1]; th = np.asarray(theta, np.float64)[:, None, :]
+    gf = np.asarray(g_drift, np.float64); gG = np.asarray(g_diffusion, np.float64)
+    B, T, S = x.shape
+    gx = np.zeros_like(xf); gth = np.zeros((B, th.shape[-1]))
+    if kind == "ou":
+        gth[:, 0] = (gf[..., 0] * (th[..., 1] - x[..., 0])).sum(1); gth[:, 1] = (gf[..., 0] * th[..., 0]).sum(1)
+        gth[:, 2] = gG[..., 0, 0].sum(1)
+        gx[:, :-1, 0] = -gf[..., 0] * th[..., 0]
+    elif kind == "lv":
+        u, v = x[..., 0], x[..., 1]; t1, t2, t3 = th[..., 0], th[..., 1], th[..., 2]
+        uv = t2 * u * v
+        q00 = t1 * u + uv; l00 = np.sqrt(np.maximum(q00, 1e-6)); c = np.maximum(l00, 1e-6); l10 = -uv / c
+        q11 = t3 * v + uv - l10 * l10; l11 = np.sqrt(np.maximum(q11, 1e-6))
+        d_l00, d_l10, d_l11 = gG[..., 0, 0].copy(), gG[..., 1, 0].copy(), gG[..., 1, 1]
+        d_q11 = np.where(q11 >= 1e-6, d_l11 / (2 * l11), 0.0)
+        d_t3 = d_q11 * v; d_v = d_q11 * t3; d_uv = d_q11.copy(); d_l10 += -2 * l10 * d_q11
+        d_uv += -d_l10 / c
+        d_l00 += np.where(l00 >= 1e-6, d_l10 * uv / (c * c), 0.0)
+        d_q00 = np.where(q00 >= 1e-6, d_l00 / (2 * l00), 0.0)
+        d_t1 = d_q00 * u; d_u = d_q00 * t1; d_uv += d_q00
+        d_t1 += gf[..., 0] * u; d_u += gf[..., 0] * t1; d_uv -= gf[..., 0]
+        d_uv += gf[..., 1]; d_t3 -= gf[..., 1] * v; d_v -= gf[..., 1] * t3
+        gth[:, 0], gth[:, 1], gth[:, 2] = d_t1.sum(1), (d_uv * u * v).sum(1), d_t3.sum(1)
+        gx[:, :-1, 0] = d_u + d_uv * t2 * v; gx[:, :-1, 1] = d_v + d_uv * t2 * u
+    else:
+        a, b = th[..., :S], th[..., S:]
+        d = np.arange(S)
+        gth[:, :S] = -(gf * x).sum(1)
+        gth[:, S:] = gG[..., d, d].sum(1) / (1.0 + np.exp(-b[:, 0]))
+        gx[:, :-1] = -gf * a
+    return gx, gth

@@ -495,6 +495,35 @@ def make_em_cases():
     print("wrote euler_maruyama.npz")
 
 
+def make_sde_coeffs():
+    """Drift / diffusion of the example OU and LV SDEs on the grid points of a few paths, evaluated exactly like
+    inference/evidence_lower_bound.py:37-40 (flattened states, theta repeated over time), and torch autograd's gradients of
+    <drift, g_f> + <diffusion, g_G>.  The LV paths contain near-zero states so that all three clamp(min=1e-6) fire."""
+    ou, lv = example_sdes()
+    rec = {}
+    for name, sde, B, T in (("ou", ou, 4, 9), ("lv", lv, 6, 11)):
+        g = torch.Generator().manual_seed(900 + B + T)
+        S, P = sde.state_dim, sde.sde_param_dim
+        theta = (torch.rand(B, P, generator=g) * 0.8 + 0.1).requires_grad_(True)
+        x = torch.rand(B, T + 1, S, generator=g) * 3.0 + 0.2
+        if name == "lv":
+            x[0, :4] = torch.tensor([[1e-7, 2.0], [3.0, 1e-8], [1e-9, 1e-9], [1e-7, 1e-2]])
+            x[1, 2] = torch.tensor([0.0, 0.0])
+        x.requires_grad_(True)
+        x_flat = x[:, :-1].reshape(B * T, S)
+        theta_flat = theta.unsqueeze(1).expand(B, T, -1).reshape(B * T, -1)
+        drift = sde.drift(x_flat, theta_flat).reshape(B, T, S)
+        diffusion = sde.diffusion(x_flat, theta_flat).reshape(B, T, S, S)
+        gf = torch.randn(drift.shape, generator=g); gG = torch.randn(diffusion.shape, generator=g)
+        gx, gth = torch.autograd.grad((drift * gf).sum() + (diffusion * gG).sum(), [x, theta])
+        for k, v in dict(x=x, theta=theta, drift=drift, diffusion=diffusion, g_drift=gf, g_diffusion=gG, grad_x=gx,
+                         grad_theta=gth).items():
+            rec[f"{name}_{k}"] = v.detach().numpy().copy()
+        print(f"  sde_coeffs_{name}: B={B} T={T}, min diffusion diag {float(diffusion.diagonal(dim1=-2, dim2=-1).min()):.3g}")
+    np.savez_compressed(os.path.join(OUT, "sde_coefficients.npz"), **rec)
+    print("wrote sde_coefficients.npz")
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"head", "elbo", "encoder", "manifest", "trajectory"}
     if "head" in which:
@@ -531,3 +560,5 @@ if __name__ == "__main__":
         make_fused_dims()
     if "em" in which:
         make_em_cases()
+    if "sde_coeffs" in which:
+        make_sde_coeffs()

@@ -58,7 +58,7 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
-    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -306,6 +306,36 @@ def euler_maruyama_bwd(kind: str, theta, noise, traj, g_traj, time_step: float, 
               ctypes.c_int(theta.shape[1]), _ptr(theta), _ptr(noise), _ptr(traj), _ptr(g_traj), ctypes.c_double(time_step),
               _mask_bytes(positive_dims, S), _ptr(g_x0), _ptr(g_theta), _stream(dev))
     return g_x0, g_theta
+
+
+def sde_coefficients_fwd(kind: str, x, theta):
+    """(drift [B,T,S], diffusion [B,T,S,S]) of a built-in SDE on the first T points of every path x [B, T+1, S]."""
+    lib = load()
+    dev = _require_hip(x, theta)
+    x, theta = _f32c(x), _f32c(theta)
+    B, T1, S = x.shape
+    T = T1 - 1
+    with torch.cuda.device(dev):
+        drift = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+        diffusion = torch.empty(B, T, S, S, device=dev, dtype=torch.float32)
+        _call(lib.vsde_sde_coefficients_fwd, ctypes.c_int(SDE_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T), ctypes.c_int(S),
+              ctypes.c_int(theta.shape[1]), _ptr(x), _ptr(theta), _ptr(drift), _ptr(diffusion), _stream(dev))
+    return drift, diffusion
+
+
+def sde_coefficients_bwd(kind: str, x, theta, g_drift, g_diffusion):
+    """(g_x [B,T+1,S], g_theta [B,P]) of ``sde_coefficients_fwd``."""
+    lib = load()
+    dev = _require_hip(x, theta, g_drift, g_diffusion)
+    x, theta, g_drift, g_diffusion = _f32c(x), _f32c(theta), _f32c(g_drift), _f32c(g_diffusion)
+    B, T1, S = x.shape
+    with torch.cuda.device(dev):
+        g_x = torch.empty_like(x)
+        g_theta = torch.empty_like(theta)
+        _call(lib.vsde_sde_coefficients_bwd, ctypes.c_int(SDE_KINDS[kind]), ctypes.c_int(B), ctypes.c_int(T1 - 1), ctypes.c_int(S),
+              ctypes.c_int(theta.shape[1]), _ptr(x), _ptr(theta), _ptr(g_drift), _ptr(g_diffusion), _ptr(g_x), _ptr(g_theta),
+              _stream(dev))
+    return g_x, g_theta
 
 
 def profile_enable(on: bool) -> None:

@@ -209,6 +209,159 @@ __global__ void __launch_bounds__(256) em_diag_bwd_kernel(EmParams p) {
     p.g_theta[(int64_t)b * p.P + p.S + i] = gth[1];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Drift f(x_t, theta) and diffusion factor G(x_t, theta) of the built-in SDEs on every grid point of a batch of paths, and
+// the vector-Jacobian product the ELBO backward needs.  Replaces the ~35 (forward) + ~70 (autograd backward) tiny torch
+// kernels the Python drift / diffusion callables expand to on the flattened [(B T), S] states
+// (inference/evidence_lower_bound.py:37-40 of the reference evaluates them exactly there).
+//   x [B][T+1][S] (rows 0..T-1 used), theta [B][P]  ->  drift [B][T][S], diffusion [B][T][S][S]
+//   backward: g_drift, g_diff -> g_x [B][T+1][S] (row T = 0), g_theta [B][P] (sum over t, fixed order)
+// torch.clamp(min=1e-6) passes the gradient where the input is >= the bound.
+struct CoefParams {
+    int B, T, S, P;
+    const float *x, *theta, *g_drift, *g_diff;
+    float *drift, *diff, *g_x, *g_theta;
+};
+
+template <int KIND> __device__ __forceinline__ void coef_fwd(const float *x, const float *th, float *f, float *G) {
+    if constexpr (KIND == 1) {
+        f[0] = th[0] * (th[1] - x[0]); G[0] = th[2];
+    } else {
+        const float u = x[0], v = x[1], uv = th[1] * u * v;
+        const float l00 = sqrtf(fmaxf(th[0] * u + uv, kEmFloor));
+        const float l10 = -uv / fmaxf(l00, kEmFloor);
+        const float l11 = sqrtf(fmaxf(th[2] * v + uv - l10 * l10, kEmFloor));
+        f[0] = th[0] * u - uv; f[1] = uv - th[2] * v;
+        G[0] = l00; G[1] = 0.f; G[2] = l10; G[3] = l11;
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void coef_bwd(const float *x, const float *th, const float *gf, const float *gG, float *gx, float *gth) {
+    if constexpr (KIND == 1) {
+        gth[0] += gf[0] * (th[1] - x[0]); gth[1] += gf[0] * th[0]; gth[2] += gG[0];
+        gx[0] = -gf[0] * th[0];
+    } else {
+        const float u = x[0], v = x[1], t1 = th[0], t2 = th[1], t3 = th[2], uv = t2 * u * v;
+        const float q00r = t1 * u + uv, l00 = sqrtf(fmaxf(q00r, kEmFloor));
+        const float c = fmaxf(l00, kEmFloor), l10 = -uv / c;
+        const float q11r = t3 * v + uv - l10 * l10, l11 = sqrtf(fmaxf(q11r, kEmFloor));
+        float d_l00 = gG[0], d_l10 = gG[2];
+        float d_u = 0.f, d_v = 0.f, d_uv = 0.f, d_t1 = 0.f, d_t3 = 0.f;
+        const float d_q11 = q11r >= kEmFloor ? gG[3] / (2.f * l11) : 0.f;
+        d_t3 += d_q11 * v; d_v += d_q11 * t3; d_uv += d_q11; d_l10 += -2.f * l10 * d_q11;
+        d_uv += -d_l10 / c;
+        if (l00 >= kEmFloor) d_l00 += d_l10 * uv / (c * c);
+        const float d_q00 = q00r >= kEmFloor ? d_l00 / (2.f * l00) : 0.f;
+        d_t1 += d_q00 * u; d_u += d_q00 * t1; d_uv += d_q00;
+        d_t1 += gf[0] * u; d_u += gf[0] * t1; d_uv -= gf[0];
+        d_uv += gf[1]; d_t3 -= gf[1] * v; d_v -= gf[1] * t3;
+        gth[0] += d_t1; gth[1] += d_uv * u * v; gth[2] += d_t3;
+        gx[0] = d_u + d_uv * t2 * v; gx[1] = d_v + d_uv * t2 * u;
+    }
+}
+
+// thread = grid point (b, t)
+template <int KIND>
+__global__ void __launch_bounds__(256) coef_fwd_kernel(CoefParams p) {
+    constexpr int S = EmDims<KIND>::S, P = EmDims<KIND>::P;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)p.B * p.T) return;
+    const int b = (int)(q / p.T), t = (int)(q % p.T);
+    float x[S], th[P], f[S], G[S * S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = p.x[((int64_t)b * (p.T + 1) + t) * S + i];
+#pragma unroll
+    for (int i = 0; i < P; ++i) th[i] = p.theta[(int64_t)b * P + i];
+    coef_fwd<KIND>(x, th, f, G);
+#pragma unroll
+    for (int i = 0; i < S; ++i) p.drift[q * S + i] = f[i];
+#pragma unroll
+    for (int i = 0; i < S * S; ++i) p.diff[q * S * S + i] = G[i];
+}
+
+// workgroup = path: threads walk the time steps, the theta gradient is reduced through LDS in a fixed tree
+template <int KIND>
+__global__ void __launch_bounds__(256) coef_bwd_kernel(CoefParams p) {
+    constexpr int S = EmDims<KIND>::S, P = EmDims<KIND>::P;
+    __shared__ float red[256][P + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float th[P], gth[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) { th[i] = p.theta[(int64_t)b * P + i]; gth[i] = 0.f; }
+    for (int t = tid; t <= p.T; t += 256) {
+        float gx[S];
+        if (t < p.T) {
+            const int64_t q = (int64_t)b * p.T + t;
+            float x[S], gf[S], gG[S * S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) { x[i] = p.x[((int64_t)b * (p.T + 1) + t) * S + i]; gf[i] = p.g_drift[q * S + i]; }
+#pragma unroll
+            for (int i = 0; i < S * S; ++i) gG[i] = p.g_diff[q * S * S + i];
+            coef_bwd<KIND>(x, th, gf, gG, gx, gth);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) gx[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) p.g_x[((int64_t)b * (p.T + 1) + t) * S + i] = gx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) red[tid][i] = gth[i];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w)
+#pragma unroll
+            for (int i = 0; i < P; ++i) red[tid][i] += red[tid + w][i];
+        __syncthreads();
+    }
+    if (tid < P) p.g_theta[(int64_t)b * P + tid] = red[0][tid];
+}
+
+// kind 3 (f_i = -a_i x_i, G = diag(softplus(b_i) + 1e-3)): thread = (b, t, i) forward; workgroup = path backward with the threads
+// laid out as (time slot, i)
+__global__ void __launch_bounds__(256) coef_diag_fwd_kernel(CoefParams p) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)p.B * p.T * p.S) return;
+    const int i = (int)(q % p.S);
+    const int64_t bt = q / p.S;
+    const int b = (int)(bt / p.T), t = (int)(bt % p.T);
+    const float a = p.theta[(int64_t)b * p.P + i], g = softplus_f(p.theta[(int64_t)b * p.P + p.S + i]) + 1e-3f;
+    p.drift[q] = -a * p.x[((int64_t)b * (p.T + 1) + t) * p.S + i];
+    float *row = p.diff + q * p.S;
+    for (int j = 0; j < p.S; ++j) row[j] = j == i ? g : 0.f;
+}
+
+__global__ void __launch_bounds__(256) coef_diag_bwd_kernel(CoefParams p) {
+    __shared__ float red[256][2];
+    const int b = blockIdx.x, tid = threadIdx.x, S = p.S;
+    const int slots = 256 / S, slot = tid / S, i = tid % S;
+    float ga = 0.f, gb = 0.f;
+    if (slot < slots) {
+        const float a = p.theta[(int64_t)b * p.P + i];
+        for (int t = slot; t <= p.T; t += slots) {
+            float gx = 0.f;
+            if (t < p.T) {
+                const int64_t q = ((int64_t)b * p.T + t) * S + i;
+                const float gf = p.g_drift[q];
+                gx = -gf * a;
+                ga -= gf * p.x[((int64_t)b * (p.T + 1) + t) * S + i];
+                gb += p.g_diff[q * S + i];
+            }
+            p.g_x[((int64_t)b * (p.T + 1) + t) * S + i] = gx;
+        }
+    }
+    red[tid][0] = ga; red[tid][1] = gb;
+    __syncthreads();
+    if (tid < S) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < slots; ++k) { sa += red[k * S + tid][0]; sb += red[k * S + tid][1]; }
+        const float bb = p.theta[(int64_t)b * p.P + S + tid];
+        p.g_theta[(int64_t)b * p.P + tid] = sa;
+        p.g_theta[(int64_t)b * p.P + S + tid] = sb * (bb > 20.f ? 1.f : 1.f / (1.f + expf(-bb)));
+    }
+}
+
 static int em_check(int kind, int B, int T, int S, int P) {
     VSDE_CHECK_ARG(B > 0 && T > 0, VSDE_E_BADARG, "bad Euler-Maruyama dims B=%d T=%d", B, T);
     VSDE_CHECK_ARG(kind >= 1 && kind <= 3, VSDE_E_BADARG, "unknown built-in SDE kind %d", kind);
@@ -261,6 +414,38 @@ extern "C" int vsde_euler_maruyama_bwd(int kind, int B, int T, int S, int P, con
     if (kind == 1) hipLaunchKernelGGL(em_bwd_kernel<1>, dim3(grid), dim3(kEmPaths), 0, s, p);
     else if (kind == 2) hipLaunchKernelGGL(em_bwd_kernel<2>, dim3(grid), dim3(kEmPaths), 0, s, p);
     else hipLaunchKernelGGL(em_diag_bwd_kernel, dim3((unsigned)(((int64_t)B * S + 255) / 256)), dim3(256), 0, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_sde_coefficients_fwd(int kind, int B, int T, int S, int P, const float *x, const float *theta, float *drift,
+                                         float *diffusion, void *stream) {
+    int rc = em_check(kind, B, T, S, P);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(x && theta && drift && diffusion, VSDE_E_BADARG, "NULL argument");
+    CoefParams p = {};
+    p.B = B; p.T = T; p.S = S; p.P = P; p.x = x; p.theta = theta; p.drift = drift; p.diff = diffusion;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(((int64_t)B * T + 255) / 256);
+    if (kind == 1) hipLaunchKernelGGL(coef_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, p);
+    else if (kind == 2) hipLaunchKernelGGL(coef_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(coef_diag_fwd_kernel, dim3((unsigned)(((int64_t)B * T * S + 255) / 256)), dim3(256), 0, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_sde_coefficients_bwd(int kind, int B, int T, int S, int P, const float *x, const float *theta,
+                                         const float *g_drift, const float *g_diffusion, float *g_x, float *g_theta, void *stream) {
+    int rc = em_check(kind, B, T, S, P);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(x && theta && g_drift && g_diffusion && g_x && g_theta, VSDE_E_BADARG, "NULL argument");
+    CoefParams p = {};
+    p.B = B; p.T = T; p.S = S; p.P = P; p.x = x; p.theta = theta; p.g_drift = g_drift; p.g_diff = g_diffusion;
+    p.g_x = g_x; p.g_theta = g_theta;
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 1) hipLaunchKernelGGL(coef_bwd_kernel<1>, dim3(B), dim3(256), 0, s, p);
+    else if (kind == 2) hipLaunchKernelGGL(coef_bwd_kernel<2>, dim3(B), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(coef_diag_bwd_kernel, dim3(B), dim3(256), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -5,7 +5,9 @@
 The three B*T-sized terms (SDE transition log-density, generative/variational path log-density,
 softplus log-Jacobian) are one fused HIP kernel with an analytic backward
 (csrc/vsde_elbo.hip); drift and diffusion are the user's Python callables evaluated on the
-flattened ``[(B*T), S]`` states exactly like the reference does (lines 37-40)."""
+flattened ``[(B*T), S]`` states exactly like the reference does (lines 37-40) -- except for the SDEs
+built into the HIP library (``sde.builtin_kind``), whose coefficients and vector-Jacobian products are
+one kernel each (csrc/vsde_sde.hip)."""
 from __future__ import annotations
 
 import torch
@@ -40,6 +42,45 @@ class _PathTerms(torch.autograd.Function):
         return tuple(g.to(d) for g, d in zip(grads, dtypes)) + (None, None)
 
 
+HIP_COEFFICIENTS = True  # set False to evaluate built-in SDEs through their Python callables too (A/B tests)
+
+
+class _BuiltinCoefficients(torch.autograd.Function):
+    """(x [B,T+1,S], theta [B,P]) -> (drift [B,T,S], diffusion [B,T,S,S]) of a built-in SDE: one kernel forward, one backward
+    (csrc/vsde_sde.hip) instead of the ~100 tiny kernels the Python callables and their autograd graph expand to."""
+
+    @staticmethod
+    def forward(ctx, x, theta, kind):
+        from .. import _hip
+        xc, tc = x.detach().float().contiguous(), theta.detach().float().contiguous()
+        ctx.save_for_backward(xc, tc)
+        ctx.meta = (kind, x.dtype, theta.dtype)
+        return _hip.sde_coefficients_fwd(kind, xc, tc)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_drift, g_diffusion):
+        from .. import _hip
+        kind, xdtype, tdtype = ctx.meta
+        g_x, g_theta = _hip.sde_coefficients_bwd(kind, *ctx.saved_tensors, g_drift.float().contiguous(),
+                                                 g_diffusion.float().contiguous())
+        return g_x.to(xdtype), g_theta.to(tdtype), None
+
+
+def sde_coefficients(sde: SDE, x: Tensor, sde_parameters: Tensor) -> tuple[Tensor, Tensor]:
+    """Drift ``[B,T,S]`` and diffusion ``[B,T,S,S]`` on the first T grid points of ``x [B,T+1,S]`` (reference lines 37-40)."""
+    B, n_steps, S = x.shape[0], x.shape[1] - 1, x.shape[2]
+    kind = getattr(sde, "builtin_kind", None)
+    if kind is not None and HIP_COEFFICIENTS and x.is_cuda and x.dtype == torch.float32:
+        from .. import _hip
+        if kind in _hip.SDE_KINDS:
+            return _BuiltinCoefficients.apply(x, sde_parameters, kind)
+    x_flat = x[:, :-1].reshape(B * n_steps, S)
+    theta_flat = sde_parameters.unsqueeze(1).expand(B, n_steps, -1).reshape(B * n_steps, -1)
+    return (sde.drift(x_flat, theta_flat).reshape(B, n_steps, S),
+            sde.diffusion(x_flat, theta_flat).reshape(B, n_steps, S, S))
+
+
 def path_log_terms(sample: DiffusionPathSample, drift: Tensor, diffusion: Tensor, time_step: float
                    ) -> tuple[Tensor, Tensor, Tensor]:
     """Per-sample ``(sde_log_prob, generative_log_prob, log_jacobian)``, each ``[B]``."""
@@ -53,10 +94,7 @@ def compute_evidence_lower_bound(sde: SDE, observations: Observations, observati
     z = sample.z
     B, n_steps, S = z.shape[0], z.shape[1] - 1, z.shape[2]
     x = sample.x
-    x_flat = x[:, :-1].reshape(B * n_steps, S)
-    theta_flat = sde_parameters.unsqueeze(1).expand(B, n_steps, -1).reshape(B * n_steps, -1)
-    drift = sde.drift(x_flat, theta_flat).reshape(B, n_steps, S)
-    diffusion = sde.diffusion(x_flat, theta_flat).reshape(B, n_steps, S, S)
+    drift, diffusion = sde_coefficients(sde, x, sde_parameters)
 
     sde_lp, gen_lp, jac = _PathTerms.apply(z, x, sample.transition_means, sample.transition_cholesky, drift,
                                            diffusion, sample.state_space.positive_dims, time_step)
