@@ -263,6 +263,23 @@ int vsde_euler_maruyama_bwd(int kind, int B, int T, int S, int P, const float *t
                             const float *g_traj, double time_step, const uint8_t *positive_mask_host, float *g_x0,
                             float *g_theta, void *stream);
 
+/* The [B]-sized tail of the ELBO (inference/evidence_lower_bound.py:52-83): Gaussian observation log-density of the states at
+ * the K observed grid points x_obs[B][K][S] (core/observations.py:57-74; obs_matrix [O][S] or NULL = identity), iid prior
+ * (prior_type 0 Normal, 1 LogNormal; core/priors.py:46-60), mean-field posterior log q(theta)
+ * (models/sde_parameter_posterior.py:44-66; theta_positive_mask_host: P bytes), combined with the three path terms into
+ *   out6 = [mean_b(obs + sde - gen + jac + prior - post), mean obs, mean sde, mean gen, mean prior, mean post].
+ * _bwd: upstream gradient of out6 -> gradients of x_obs, theta, the posterior's mean / log_std [P] and the three path terms
+ * [B].  One single-workgroup kernel each; dims S, O, P <= 16. */
+int vsde_elbo_tail_fwd(int B, int K, int S, int O, int P, const float *x_obs, const float *obs_values, const float *obs_matrix,
+                       double variance, const float *theta, int prior_type, double prior_mean, double prior_std,
+                       const float *post_mean, const float *post_log_std, const uint8_t *theta_positive_mask_host,
+                       const float *sde_lp, const float *gen_lp, const float *log_jac, float *out6, void *stream);
+int vsde_elbo_tail_bwd(int B, int K, int S, int O, int P, const float *x_obs, const float *obs_values, const float *obs_matrix,
+                       double variance, const float *theta, int prior_type, double prior_mean, double prior_std,
+                       const float *post_mean, const float *post_log_std, const uint8_t *theta_positive_mask_host,
+                       const float *g_out6, float *g_x_obs, float *g_theta, float *g_post_mean, float *g_post_log_std,
+                       float *g_sde, float *g_gen, float *g_jac, void *stream);
+
 /* Drift and diffusion factor of a built-in SDE on every grid point of a batch of paths -- what the ELBO evaluates through the
  * user's Python callables on the flattened [(B T), S] states (inference/evidence_lower_bound.py:37-40) -- and the
  * vector-Jacobian product its backward needs.  x[B][T+1][S] (rows 0..T-1 are read), theta[B][P] -> drift[B][T][S],

@@ -51,7 +51,7 @@ EXPORTS = (
     "vsde_abi_version", "vsde_last_error",
     "vsde_head_forward_workspace_bytes", "vsde_head_forward",
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
-    "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd",
+    "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd", "vsde_elbo_tail_fwd", "vsde_elbo_tail_bwd",
     "vsde_profile_enable", "vsde_profile_elapsed_ms", "vsde_debug_force_v1",
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
@@ -306,6 +306,50 @@ def euler_maruyama_bwd(kind: str, theta, noise, traj, g_traj, time_step: float, 
               ctypes.c_int(theta.shape[1]), _ptr(theta), _ptr(noise), _ptr(traj), _ptr(g_traj), ctypes.c_double(time_step),
               _mask_bytes(positive_dims, S), _ptr(g_x0), _ptr(g_theta), _stream(dev))
     return g_x0, g_theta
+
+
+def _tail_args(x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std, post_mean, post_log_std, theta_positive_dims):
+    B, K, S = x_obs.shape
+    O, P = obs_values.shape[1], theta.shape[1]
+    return (ctypes.c_int(B), ctypes.c_int(K), ctypes.c_int(S), ctypes.c_int(O), ctypes.c_int(P), _ptr(x_obs), _ptr(obs_values),
+            _ptr(obs_matrix), ctypes.c_double(variance), _ptr(theta), ctypes.c_int(prior_type), ctypes.c_double(prior_mean),
+            ctypes.c_double(prior_std), _ptr(post_mean), _ptr(post_log_std), _mask_bytes(theta_positive_dims, P))
+
+
+def elbo_tail_fwd(x_obs, obs_values, obs_matrix, variance: float, theta, prior_type: int, prior_mean: float, prior_std: float,
+                  post_mean, post_log_std, theta_positive_dims, sde_lp, gen_lp, log_jac):
+    """[elbo, obs, sde, gen, prior, post] batch means (see include/vsde_hip.h: vsde_elbo_tail_fwd)."""
+    lib = load()
+    dev = _require_hip(x_obs, obs_values, theta, post_mean, post_log_std, sde_lp, gen_lp, log_jac)
+    x_obs, obs_values, theta, post_mean, post_log_std, sde_lp, gen_lp, log_jac = (
+        _f32c(t) for t in (x_obs, obs_values, theta, post_mean, post_log_std, sde_lp, gen_lp, log_jac))
+    obs_matrix = None if obs_matrix is None else _f32c(obs_matrix)
+    with torch.cuda.device(dev):
+        out = torch.empty(6, device=dev, dtype=torch.float32)
+        _call(lib.vsde_elbo_tail_fwd, *_tail_args(x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std,
+                                                  post_mean, post_log_std, theta_positive_dims),
+              _ptr(sde_lp), _ptr(gen_lp), _ptr(log_jac), _ptr(out), _stream(dev))
+    return out
+
+
+def elbo_tail_bwd(x_obs, obs_values, obs_matrix, variance: float, theta, prior_type: int, prior_mean: float, prior_std: float,
+                  post_mean, post_log_std, theta_positive_dims, g_out):
+    """Gradients of ``elbo_tail_fwd``: (g_x_obs, g_theta, g_post_mean, g_post_log_std, g_sde, g_gen, g_jac)."""
+    lib = load()
+    dev = _require_hip(x_obs, obs_values, theta, post_mean, post_log_std, g_out)
+    x_obs, obs_values, theta, post_mean, post_log_std, g_out = (
+        _f32c(t) for t in (x_obs, obs_values, theta, post_mean, post_log_std, g_out))
+    obs_matrix = None if obs_matrix is None else _f32c(obs_matrix)
+    B = theta.shape[0]
+    with torch.cuda.device(dev):
+        g_x = torch.empty_like(x_obs); g_theta = torch.empty_like(theta)
+        g_mean = torch.empty_like(post_mean); g_ls = torch.empty_like(post_log_std)
+        g_paths = torch.empty(3, B, device=dev, dtype=torch.float32)
+        _call(lib.vsde_elbo_tail_bwd, *_tail_args(x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std,
+                                                  post_mean, post_log_std, theta_positive_dims),
+              _ptr(g_out), _ptr(g_x), _ptr(g_theta), _ptr(g_mean), _ptr(g_ls), _ptr(g_paths[0]), _ptr(g_paths[1]), _ptr(g_paths[2]),
+              _stream(dev))
+    return g_x, g_theta, g_mean, g_ls, g_paths[0], g_paths[1], g_paths[2]
 
 
 def sde_coefficients_fwd(kind: str, x, theta):

@@ -179,6 +179,153 @@ static uint32_t mask_bits(const uint8_t *m, int S) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The [B]-sized tail of the ELBO (inference/evidence_lower_bound.py:52-83 of the reference): Gaussian observation log-density
+// at the observed grid points (core/observations.py:57-74), iid Normal / LogNormal prior (core/priors.py:46-60), mean-field
+// (Log)Normal posterior log q(theta) (models/sde_parameter_posterior.py:44-66), and the batch means
+//   out = [ mean_b(obs + sde - gen + jac + prior - post), mean obs, mean sde, mean gen, mean prior, mean post ].
+// ~50 tiny torch kernels forward and ~100 in autograd's backward become one single-workgroup kernel each (B is a few hundred to
+// a few thousand; the work is microseconds, the launches were not).  Sums over b in a fixed tree: deterministic.
+struct TailParams {
+    int B, K, S, O, P;
+    const float *x_obs;        // [B][K][S] states at the observed grid points
+    const float *obs_values;   // [K][O]
+    const float *obs_matrix;   // [O][S] or nullptr (identity, O == S)
+    float inv_var, log_norm;   // 1 / variance, -0.5 log(2 pi variance)
+    const float *theta;        // [B][P]
+    int prior_lognormal; float prior_mean, prior_inv_std, prior_const;   // const = -log(std) - 0.5 log(2 pi)
+    const float *post_mean, *post_log_std;   // [P]
+    uint32_t theta_pos;
+    const float *sde_lp, *gen_lp, *jac;      // [B]
+    float *out;                // [6]
+    const float *g_out;        // [6]
+    float *g_x_obs, *g_theta, *g_post_mean, *g_post_log_std, *g_sde, *g_gen, *g_jac;
+};
+
+constexpr int kTailMaxDim = 16;   // S, O, P <= 16 (P <= 32 for the mask; the per-thread arrays set the smaller bound)
+
+template <int N> __device__ __forceinline__ void tail_block_sum(float (*red)[N], float (&v)[N], int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[tid][i] = v[i];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w)
+#pragma unroll
+            for (int i = 0; i < N; ++i) red[tid][i] += red[tid + w][i];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = red[0][i];
+    __syncthreads();
+}
+
+// observation term of path b; when GX, also d obs_lp / d x_obs scaled by w
+template <bool GX> __device__ __forceinline__ float tail_obs(const TailParams &p, int b, float w) {
+    float lp = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+        const float *x = p.x_obs + ((int64_t)b * p.K + k) * p.S;
+        float *gx = GX ? p.g_x_obs + ((int64_t)b * p.K + k) * p.S : nullptr;
+        if (GX) for (int i = 0; i < p.S; ++i) gx[i] = 0.f;
+        for (int o = 0; o < p.O; ++o) {
+            float pred;
+            if (p.obs_matrix) {
+                pred = 0.f;
+                for (int i = 0; i < p.S; ++i) pred += p.obs_matrix[o * p.S + i] * x[i];
+            } else {
+                pred = x[o];
+            }
+            const float r = p.obs_values[k * p.O + o] - pred;
+            lp += -0.5f * r * r * p.inv_var + p.log_norm;
+            if (GX) {
+                const float gr = w * r * p.inv_var;   // d lp / d pred
+                if (p.obs_matrix) for (int i = 0; i < p.S; ++i) gx[i] += gr * p.obs_matrix[o * p.S + i];
+                else gx[o] += gr;
+            }
+        }
+    }
+    return lp;
+}
+
+__global__ void __launch_bounds__(256) elbo_tail_fwd_kernel(TailParams p) {
+    __shared__ float red[256][6];
+    const int tid = threadIdx.x;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < p.B; b += 256) {
+        const float obs = tail_obs<false>(p, b, 0.f);
+        float prior = 0.f, post = 0.f;
+        for (int i = 0; i < p.P; ++i) {
+            const float th = p.theta[(int64_t)b * p.P + i];
+            const bool pos = (p.theta_pos >> i) & 1u;
+            const float lg = (pos || p.prior_lognormal) ? logf(th) : 0.f;
+            const float zp = ((p.prior_lognormal ? lg : th) - p.prior_mean) * p.prior_inv_std;
+            prior += -0.5f * zp * zp + p.prior_const - (p.prior_lognormal ? lg : 0.f);
+            const float ls = p.post_log_std[i];
+            const float zq = ((pos ? lg : th) - p.post_mean[i]) * expf(-ls);
+            post += -0.5f * zq * zq - ls - 0.5f * kLog2Pi - (pos ? lg : 0.f);
+        }
+        const float s = p.sde_lp[b], g = p.gen_lp[b];
+        acc[0] += obs + s - g + p.jac[b] + prior - post;
+        acc[1] += obs; acc[2] += s; acc[3] += g; acc[4] += prior; acc[5] += post;
+    }
+    tail_block_sum<6>(red, acc, tid);
+    if (tid < 6) p.out[tid] = acc[tid] / (float)p.B;
+}
+
+__global__ void __launch_bounds__(256) elbo_tail_bwd_kernel(TailParams p) {
+    __shared__ float red[256][2 * kTailMaxDim];
+    const int tid = threadIdx.x;
+    const float ib = 1.f / (float)p.B, g0 = p.g_out[0];
+    const float w_obs = (g0 + p.g_out[1]) * ib, w_sde = (g0 + p.g_out[2]) * ib, w_gen = (p.g_out[3] - g0) * ib, w_jac = g0 * ib;
+    const float w_prior = (g0 + p.g_out[4]) * ib, w_post = (p.g_out[5] - g0) * ib;
+    float gq[2 * kTailMaxDim];
+#pragma unroll
+    for (int i = 0; i < 2 * kTailMaxDim; ++i) gq[i] = 0.f;
+    for (int b = tid; b < p.B; b += 256) {
+        tail_obs<true>(p, b, w_obs);
+        p.g_sde[b] = w_sde; p.g_gen[b] = w_gen; p.g_jac[b] = w_jac;
+#pragma unroll
+        for (int i = 0; i < kTailMaxDim; ++i) {
+            if (i < p.P) {
+                const float th = p.theta[(int64_t)b * p.P + i];
+                const bool pos = (p.theta_pos >> i) & 1u;
+                const float lg = (pos || p.prior_lognormal) ? logf(th) : 0.f;
+                const float zp = ((p.prior_lognormal ? lg : th) - p.prior_mean) * p.prior_inv_std;
+                // d prior / d theta
+                float gt = w_prior * (p.prior_lognormal ? (-zp * p.prior_inv_std - 1.f) / th : -zp * p.prior_inv_std);
+                const float ls = p.post_log_std[i], e = expf(-ls);
+                const float zq = ((pos ? lg : th) - p.post_mean[i]) * e;
+                // d post / d theta = d/du (-0.5 zq^2) du/dtheta - [pos] 1/theta
+                gt += w_post * (pos ? (-zq * e - 1.f) / th : -zq * e);
+                p.g_theta[(int64_t)b * p.P + i] = gt;
+                gq[i] += w_post * zq * e;                         // d post / d mean
+                gq[kTailMaxDim + i] += w_post * (zq * zq - 1.f);  // d post / d log_std
+            }
+        }
+    }
+    tail_block_sum<2 * kTailMaxDim>(red, gq, tid);
+    if (tid < p.P) { p.g_post_mean[tid] = gq[tid]; p.g_post_log_std[tid] = gq[kTailMaxDim + tid]; }
+}
+
+static int tail_fill(TailParams &p, int B, int K, int S, int O, int P, const float *x_obs, const float *obs_values,
+                     const float *obs_matrix, double variance, const float *theta, int prior_type, double prior_mean,
+                     double prior_std, const float *post_mean, const float *post_log_std, const uint8_t *theta_positive_mask_host,
+                     const float *sde_lp, const float *gen_lp, const float *jac) {
+    VSDE_CHECK_ARG(B > 0 && K >= 0 && S > 0 && O > 0 && P > 0, VSDE_E_BADARG, "bad ELBO tail dims B=%d K=%d S=%d O=%d P=%d", B, K, S, O, P);
+    VSDE_CHECK_ARG(S <= kTailMaxDim && O <= kTailMaxDim && P <= kTailMaxDim, VSDE_E_BADARG,
+                   "ELBO tail kernel supports state / observation / parameter dims <= %d (got %d, %d, %d)", kTailMaxDim, S, O, P);
+    VSDE_CHECK_ARG(obs_matrix || O == S, VSDE_E_BADARG, "without an observation matrix obs_dim must equal state_dim (%d vs %d)", O, S);
+    VSDE_CHECK_ARG(variance > 0 && prior_std > 0 && (prior_type == 0 || prior_type == 1), VSDE_E_BADARG, "bad variance / prior");
+    VSDE_CHECK_ARG((K == 0 || (x_obs && obs_values)) && theta && post_mean && post_log_std && sde_lp && gen_lp && jac, VSDE_E_BADARG,
+                   "NULL argument");
+    p.B = B; p.K = K; p.S = S; p.O = O; p.P = P; p.x_obs = x_obs; p.obs_values = obs_values; p.obs_matrix = obs_matrix;
+    p.inv_var = (float)(1.0 / variance); p.log_norm = (float)(-0.5 * log(2.0 * M_PI * variance));
+    p.theta = theta; p.prior_lognormal = prior_type; p.prior_mean = (float)prior_mean; p.prior_inv_std = (float)(1.0 / prior_std);
+    p.prior_const = (float)(-log(prior_std) - 0.5 * log(2.0 * M_PI));
+    p.post_mean = post_mean; p.post_log_std = post_log_std; p.theta_pos = mask_bits(theta_positive_mask_host, P);
+    p.sde_lp = sde_lp; p.gen_lp = gen_lp; p.jac = jac;
+    return 0;
+}
+
 }  // namespace vsde
 
 using namespace vsde;
@@ -211,4 +358,39 @@ extern "C" int vsde_elbo_path_terms_bwd(int B, int T, int S, const float *z, con
     p.g_sde = g_sde; p.g_gen = g_gen; p.g_jac = g_jac;
     p.g_z = g_z; p.g_x = g_x; p.g_means = g_means; p.g_chol = g_chol; p.g_drift = g_drift; p.g_diffusion = g_diffusion;
     return dispatch_elbo(S, p, true, (hipStream_t)stream);
+}
+
+extern "C" int vsde_elbo_tail_fwd(int B, int K, int S, int O, int P, const float *x_obs, const float *obs_values,
+                                  const float *obs_matrix, double variance, const float *theta, int prior_type, double prior_mean,
+                                  double prior_std, const float *post_mean, const float *post_log_std,
+                                  const uint8_t *theta_positive_mask_host, const float *sde_lp, const float *gen_lp,
+                                  const float *log_jac, float *out6, void *stream) {
+    TailParams p = {};
+    int rc = tail_fill(p, B, K, S, O, P, x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std, post_mean,
+                       post_log_std, theta_positive_mask_host, sde_lp, gen_lp, log_jac);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(out6, VSDE_E_BADARG, "NULL output");
+    p.out = out6;
+    hipLaunchKernelGGL(elbo_tail_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_elbo_tail_bwd(int B, int K, int S, int O, int P, const float *x_obs, const float *obs_values,
+                                  const float *obs_matrix, double variance, const float *theta, int prior_type, double prior_mean,
+                                  double prior_std, const float *post_mean, const float *post_log_std,
+                                  const uint8_t *theta_positive_mask_host, const float *g_out6, float *g_x_obs, float *g_theta,
+                                  float *g_post_mean, float *g_post_log_std, float *g_sde, float *g_gen, float *g_jac, void *stream) {
+    TailParams p = {};
+    // the path-term inputs are not read by the backward: any non-NULL pointer satisfies the shared argument check
+    int rc = tail_fill(p, B, K, S, O, P, x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std, post_mean,
+                       post_log_std, theta_positive_mask_host, theta, theta, theta);
+    if (rc) return rc;
+    VSDE_CHECK_ARG(g_out6 && (K == 0 || g_x_obs) && g_theta && g_post_mean && g_post_log_std && g_sde && g_gen && g_jac, VSDE_E_BADARG,
+                   "NULL argument");
+    p.g_out = g_out6; p.g_x_obs = g_x_obs; p.g_theta = g_theta; p.g_post_mean = g_post_mean; p.g_post_log_std = g_post_log_std;
+    p.g_sde = g_sde; p.g_gen = g_gen; p.g_jac = g_jac;
+    hipLaunchKernelGGL(elbo_tail_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
 }

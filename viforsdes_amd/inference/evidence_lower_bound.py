@@ -81,6 +81,56 @@ def sde_coefficients(sde: SDE, x: Tensor, sde_parameters: Tensor) -> tuple[Tenso
             sde.diffusion(x_flat, theta_flat).reshape(B, n_steps, S, S))
 
 
+HIP_TAIL = True  # set False to keep the [B]-sized tail of the ELBO in torch ops (A/B tests)
+
+
+class _ElboTail(torch.autograd.Function):
+    """Observation / prior / posterior log-densities and the batch means of the ELBO and its components as one kernel
+    (csrc/vsde_elbo.hip: elbo_tail_*_kernel) -> ``[elbo, obs, sde, gen, prior, post]``."""
+
+    @staticmethod
+    def forward(ctx, x_obs, theta, post_mean, post_log_std, sde_lp, gen_lp, jac, cfg):
+        from .. import _hip
+        obs_values, obs_matrix, variance, prior_type, prior_mean, prior_std, theta_pos = cfg
+        tens = tuple(t.detach().float().contiguous() for t in (x_obs, theta, post_mean, post_log_std))
+        ctx.save_for_backward(*tens)
+        ctx.cfg = cfg
+        ctx.dtypes = tuple(t.dtype for t in (x_obs, theta, post_mean, post_log_std, sde_lp, gen_lp, jac))
+        return _hip.elbo_tail_fwd(tens[0], obs_values, obs_matrix, variance, tens[1], prior_type, prior_mean, prior_std, tens[2],
+                                  tens[3], theta_pos, sde_lp.detach(), gen_lp.detach(), jac.detach())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        from .. import _hip
+        obs_values, obs_matrix, variance, prior_type, prior_mean, prior_std, theta_pos = ctx.cfg
+        x_obs, theta, post_mean, post_log_std = ctx.saved_tensors
+        grads = _hip.elbo_tail_bwd(x_obs, obs_values, obs_matrix, variance, theta, prior_type, prior_mean, prior_std, post_mean,
+                                   post_log_std, theta_pos, g_out.float().contiguous())
+        return tuple(g.to(d) for g, d in zip(grads, ctx.dtypes)) + (None,)
+
+
+def _fused_tail_config(observations: Observations, observation_likelihood, prior, sde_parameter_posterior, x: Tensor,
+                       sde_parameters: Tensor):
+    """Arguments of the fused tail kernel when every piece is one of the package's own closed forms, else None."""
+    from ..core.observations import GaussianObservationLikelihood
+    from ..core.priors import PriorType
+    if not (HIP_TAIL and x.is_cuda and x.dtype == torch.float32 and sde_parameters.dtype == torch.float32):
+        return None
+    if type(observation_likelihood) is not GaussianObservationLikelihood or type(prior) is not Prior \
+            or type(sde_parameter_posterior) is not SDEParameterPosterior:
+        return None
+    H = observation_likelihood.obs_matrix
+    S, O, P = x.shape[-1], observations.values.shape[-1], sde_parameters.shape[-1]
+    if max(S, O, P) > 16 or (H is None and O != S) or (H is not None and tuple(H.shape) != (O, S)) or prior.dim != P:
+        return None
+    theta_pos = getattr(sde_parameter_posterior, "_positive_dims", None)
+    if theta_pos is None:
+        return None
+    return (observations.values, None if H is None else H.to(x), float(observation_likelihood.variance),
+            1 if prior.type == PriorType.LOG_NORMAL else 0, float(prior.mean), float(prior.std), tuple(theta_pos))
+
+
 def path_log_terms(sample: DiffusionPathSample, drift: Tensor, diffusion: Tensor, time_step: float
                    ) -> tuple[Tensor, Tensor, Tensor]:
     """Per-sample ``(sde_log_prob, generative_log_prob, log_jacobian)``, each ``[B]``."""
@@ -100,6 +150,15 @@ def compute_evidence_lower_bound(sde: SDE, observations: Observations, observati
                                            diffusion, sample.state_space.positive_dims, time_step)
 
     obs_idx = torch.round(observations.times / time_step).long().clamp(max=n_steps)
+    cfg = _fused_tail_config(observations, observation_likelihood, prior, sde_parameter_posterior, x, sde_parameters)
+    if cfg is not None:
+        out = _ElboTail.apply(x[:, obs_idx], sde_parameters, sde_parameter_posterior.mean, sde_parameter_posterior.log_std,
+                              sde_lp, gen_lp, jac, cfg)
+        return EvidenceLowerBoundResult(
+            evidence_lower_bound=out[0],
+            components=EvidenceLowerBoundComponents(
+                observation_log_prob=out[1], sde_log_prob=out[2], generative_log_prob=out[3], prior_log_prob=out[4],
+                posterior_log_prob=out[5]))
     obs_lp = observation_likelihood.log_prob(observations.values.unsqueeze(0).expand(B, -1, -1), x[:, obs_idx]).sum(dim=-1)
     prior_lp = prior.log_prob(sde_parameters)
     if prior_lp.ndim > 1:

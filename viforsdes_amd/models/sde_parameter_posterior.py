@@ -24,6 +24,7 @@ class SDEParameterPosterior(nn.Module):
         if any(d < 0 or d >= sde_param_dim for d in sde_param_positive_dims):
             raise ValueError(f"sde_param_positive_dims must be in [0, {sde_param_dim})")
         self.sde_param_dim = sde_param_dim
+        self._positive_dims = tuple(sorted(set(int(d) for d in sde_param_positive_dims)))   # host copy of positive_mask
         self.mean = nn.Parameter(torch.zeros(sde_param_dim) if init_mean is None else init_mean.clone())
         self.log_std = nn.Parameter(torch.full((sde_param_dim,), math.log(init_std)))
         mask = torch.zeros(sde_param_dim, dtype=torch.bool)
