@@ -51,7 +51,7 @@ def main():
                                                       tr.time_horizon, cfg.time_step, tr.state_space), "head forward (+ noise)", top=6)
         res = count(lambda: compute_evidence_lower_bound(tr.sde, ctx.observations, tr.observation_likelihood, tr.prior,
                                                          model.sde_parameter_posterior, theta, sample, cfg.time_step), "ELBO forward", top=12)
-    count(lambda: ctx.scaler.scale(-res.evidence_lower_bound).backward(), "backward (all)", top=14)
+    count(lambda: ctx.scaler.scale(-res.evidence_lower_bound).backward(), "backward (all)", top=40)
     count(tr._optimizer_step, "optimizer step (+ weight refresh)", top=10)
     count(ctx.ema.update, "EMA", top=3)
 
