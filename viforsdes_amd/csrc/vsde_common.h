@@ -137,6 +137,10 @@ size_t tn_workspace_bytes(const TnProblem *probs, int nprob, int M);
 int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes,
                       hipStream_t stream);
 
+// fast path for hidden_dim 64 (vsde_tn_wide.hip): 0 = not applicable (use the generic kernel), 1 = done, < 0 = error
+size_t tn_wide_workspace_bytes(const TnProblem *probs, int nprob, int M);
+int launch_tn_wide(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes, hipStream_t stream);
+
 // ---- streamed attention kernels (vsde_attn_stream.hip): any N, head_dim 64 or 128 ------------
 int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
                                 double scale, hipStream_t s);

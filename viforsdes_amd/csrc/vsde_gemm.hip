@@ -10,6 +10,8 @@
 // Arithmetic is exact fp32 (v_mfma_f32_16x16x4_f32 == fmaf chain), no reduced precision.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -173,6 +175,7 @@ struct TnKernelArgs {
     int M;
     int rows_per_split;  // multiple of TN_BM
     int nsplit;
+    int ntiles;
     float *partial;      // [ntiles][nsplit][64*64 + 64]  (tile + column sums of X for the bias gradient)
 };
 constexpr int TN_PART = TN_T * TN_T + TN_T;
@@ -200,7 +203,12 @@ __global__ void __launch_bounds__(256) tn_grouped_kernel(TnKernelArgs a) {
     __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_LD];
     __shared__ __attribute__((aligned(16))) float Ys[TN_BM * TN_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.y, split = blockIdx.x;
+    // consecutive workgroup ids go round-robin over the 8 XCDs (id = 8 * local + xcd): the tiles of one split -- same rows of the
+    // operands, different column blocks -- get consecutive `local` on ONE XCD, so the rows they share come out of that XCD's L2
+    // instead of HBM once per tile (2.15 GB fetched per launch at LV before, against ~0.65 GB of distinct operand bytes)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile = local % a.ntiles, split = (local / a.ntiles) * 8 + xcd;
+    if (split >= a.nsplit) return;
     int pi = 0;
     while (pi + 1 < a.nprob && tile >= a.tile_begin[pi + 1]) ++pi;
     // copy the descriptor with static indices (a runtime-indexed kernarg array would live in scratch)
@@ -227,16 +235,24 @@ __global__ void __launch_bounds__(256) tn_grouped_kernel(TnKernelArgs a) {
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     float4 xv[4], yv[4];
+    // (batch, step) of this thread's four staging rows, advanced by 64 rows per chunk: no division in the loop.  Both views of a
+    // problem share rows_per_batch (every operand is a [b][t] record); the shifts differ.
+    int rb[4], rt[4];
+    const int rpb = P.X.rows_per_batch;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) { const int m = m_begin + srow + 16 * ps; rb[ps] = m / rpb; rt[ps] = m - rb[ps] * rpb; }
+    const int adv_b = TN_BM / rpb, adv_t = TN_BM - adv_b * rpb;
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int m = m0 + srow + 16 * ps;
-            const bool in = m < m_end;
-            bool vx = false, vy = false;
-            int64_t ox = 0, oy = 0;
-            if (in) { ox = rowview_offset(P.X, m, vx); oy = rowview_offset(P.Y, m, vy); }
-            xv[ps] = load_row4(P.X, ox, in && vx, n_blk + sc4, P.NX, x_vec);
-            yv[ps] = load_row4(P.Y, oy, in && vy, k_blk + sc4, P.NY, y_vec);
+            const bool in = m0 + srow + 16 * ps < m_end;
+            const int tx = rt[ps] + P.X.shift, ty = rt[ps] + P.Y.shift;
+            const int64_t ox = (int64_t)rb[ps] * P.X.batch_stride + (int64_t)tx * P.X.row_stride;
+            const int64_t oy = (int64_t)rb[ps] * P.Y.batch_stride + (int64_t)ty * P.Y.row_stride;
+            xv[ps] = load_row4(P.X, ox, in && tx >= 0, n_blk + sc4, P.NX, x_vec);
+            yv[ps] = load_row4(P.Y, oy, in && ty >= 0, k_blk + sc4, P.NY, y_vec);
+            rb[ps] += adv_b; rt[ps] += adv_t;
+            if (rt[ps] >= rpb) { rt[ps] -= rpb; ++rb[ps]; }
         }
     };
     if (m_begin < m_end) fetch(m_begin);
@@ -320,7 +336,11 @@ static int tn_plan(const TnProblem *probs, int nprob, int M, TnKernelArgs &a) {
     }
     for (int i = nprob; i <= kMaxTnProblems; ++i) a.tile_begin[i] = tiles;
     int chunks = (M + TN_BM - 1) / TN_BM;
-    int want = tiles > 0 ? (2048 + tiles - 1) / tiles : 1;
+    // Whole rounds of resident workgroups (4 per CU: 36 KB of LDS each): all workgroups take the same time, so 2072 of them on
+    // 1024 slots cost three rounds, 2044 cost two.
+    static int target = -1;
+    if (target < 0) { const char *e = getenv("VSDE_TN_WGS"); target = e ? atoi(e) : 2048; }
+    int want = tiles > 0 ? target / tiles : 1;
     int nsplit = want < 1 ? 1 : want;
     if (nsplit > chunks) nsplit = chunks;
     if (nsplit > 256) nsplit = 256;
@@ -333,19 +353,30 @@ static int tn_plan(const TnProblem *probs, int nprob, int M, TnKernelArgs &a) {
 size_t tn_workspace_bytes(const TnProblem *probs, int nprob, int M) {
     TnKernelArgs a;
     int tiles = tn_plan(probs, nprob, M, a);
-    return (size_t)tiles * a.nsplit * TN_PART * sizeof(float);
+    const size_t generic = (size_t)tiles * a.nsplit * TN_PART * sizeof(float), wide = tn_wide_workspace_bytes(probs, nprob, M);
+    return generic > wide ? generic : wide;   // the fast path can still decline at launch (operand alignment)
 }
 
 int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes,
                       hipStream_t stream) {
     if (nprob == 0 || M <= 0) return 0;
     VSDE_CHECK_ARG(nprob <= kMaxTnProblems, VSDE_E_BADARG, "too many grouped TN problems (%d)", nprob);
+    for (int i = 0; i < nprob; ++i)
+        VSDE_CHECK_ARG(probs[i].X.rows_per_batch == probs[i].Y.rows_per_batch && probs[i].X.rows_per_batch > 0, VSDE_E_BADARG,
+                       "grouped TN problem %d: both operands must share rows_per_batch", i);
+    {
+        static int generic_only = -1;   // VSDE_TN_GENERIC=1: A/B against the generic kernel
+        if (generic_only < 0) { const char *e = getenv("VSDE_TN_GENERIC"); generic_only = e ? atoi(e) : 0; }
+        const int rc = generic_only ? 0 : launch_tn_wide(probs, nprob, M, workspace, workspace_bytes, stream);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     TnKernelArgs a;
     int tiles = tn_plan(probs, nprob, M, a);
     size_t need = (size_t)tiles * a.nsplit * TN_PART * sizeof(float);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "TN workspace too small: %zu < %zu", workspace_bytes, need);
     a.partial = (float *)workspace;
-    hipLaunchKernelGGL(tn_grouped_kernel, dim3(a.nsplit, tiles), dim3(256), 0, stream, a);
+    a.ntiles = tiles;
+    hipLaunchKernelGGL(tn_grouped_kernel, dim3((unsigned)(((a.nsplit + 7) / 8) * 8 * tiles)), dim3(256), 0, stream, a);
     VSDE_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(tiles, TN_T * TN_T / 256), dim3(256), 0, stream, a);
     VSDE_CHECK_HIP(hipGetLastError());

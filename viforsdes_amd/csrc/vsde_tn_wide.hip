@@ -1,0 +1,403 @@
+// Weight / bias gradients of the fused head for hidden_dim = 64: the fast path of launch_tn_grouped (vsde_gemm.hip).
+//
+//   dW[n][k] = sum_m X(m, n) * Y(m, k)      m = (b, t) over all B*T path-steps, X = gate pre-activation gradients [.., 3H = 192]
+//
+// The generic grouped kernel cuts every problem into 64 x 64 output tiles (28 of them at the Lotka-Volterra shapes, 7 of which
+// are padding around the 2 / 3 / 5-wide state, theta and emission operands), re-reads the 192-wide X rows once per tile and
+// spends 4 vector-ALU instructions per MFMA on its general operand views.  Here
+//   * "wide" problems (NX = 192, NY a multiple of 64) run as 192 x 64 tiles: X rows are staged once per tile and shared by
+//     the 4 waves (a wave owns 48 x 64 = 3 x 4 accumulator blocks of v_mfma_f32_16x16x4_f32; exact fp32), operands go to LDS as
+//     they sit in memory ([m][cols], 16 rows per step, two buffers, one LDS-only barrier per step; 37 KB and 138 VGPRs: three
+//     workgroups per CU), loads are requested two steps ahead and branch-free, every load slot carries its element offset
+//     forward by constants (no division or 64-bit multiply in the loop), masked Y rows (h_{t-1} at t = 0) come from a zero buffer;
+//   * the narrow operands (the state / theta columns of W_ih0: NY <= 16; the emission rows of out_proj: NX <= 16, computed as
+//     out^T with the roles swapped) run in the same launch as 192 x 16 / 64 x 16 tiles with one column block of MFMAs;
+//   * the tiles of one row split sit on one XCD, so the X rows the four context tiles share come out of that XCD's L2.
+// Splits are summed in a fixed order by the reduce kernels (deterministic).  Reference: kernels/backward.py:108-139,575-590
+// (the global fp32 atomics these reductions replace).
+#include <stdlib.h>
+
+#include "vsde_common.h"
+
+namespace vsde {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t twu4 __attribute__((ext_vector_type(4)));
+typedef uint32_t twu2 __attribute__((ext_vector_type(2)));
+
+constexpr int TW_N = 192, TW_K = 64, TW_BM = 16;   // rows per step: 16 -> 37 KB of LDS, three workgroups per CU
+constexpr int TW_YI = TW_BM * 16 / 256;             // Y chunks per thread and step
+constexpr int TW_LDX = TW_N + 16, TW_LDY = TW_K + 16;   // row pitches (floats), 16 past a multiple of 32: the two 16-lane rows a
+                                                         // 32-lane ds_read_b32 group touches fall on disjoint banks
+constexpr int TW_BUF = TW_BM * (TW_LDX + TW_LDY);        // floats per buffer
+constexpr int TW_PART = TW_N * TW_K + TW_N;              // partial tile + bias row
+constexpr int TW_MAXTILES = 16;
+
+struct TwTile {
+    const float *x;          // X view base
+    const void *y;           // Y view base (+ k_blk columns)
+    int64_t xbs, xrs, ybs, yrs;   // batch / row strides in elements
+    int xshift, yshift, x_split, x_skip, y_bf16;
+    int kind;                // 0: 192 x 64,  1: 192 x (NY <= 16),  2: 64 x (NY <= 16) with the roles swapped (out^T is computed)
+    int ny;                  // valid Y columns (kinds 1, 2)
+    float *out; int64_t ldo; int col_off;   // destination of the reduced tile: out[n * ldo + col_off + k]
+    float *bias_out;         // column sums of X (kinds 0, 1) or of Y (kind 2)
+    int nsplit, local_begin;  // row splits of this tile (multiple of 8); first `local` workgroup index (id = 8 * local + xcd)
+    int64_t part_off;        // offset of its partials in floats
+};
+
+struct TwArgs {
+    TwTile tile[TW_MAXTILES];
+    int ntiles, nlocal, M, T;
+    int64_t chunks;
+    float *partial;
+};
+
+__device__ float tw_zeros[8];   // never written: the source of masked Y rows
+
+__device__ __forceinline__ void tw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// NB: 16-column blocks of X per wave (3: X is 192 wide, 1: 64 wide); NARROW: Y has at most 16 columns (one block, scalar loads)
+template <int NB, bool NARROW>
+__device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *tws, int split) {
+    constexpr int NX = 64 * NB, LDX = NX + 16, JB = NARROW ? 1 : 4, LDY = NARROW ? 48 : TW_LDY;
+    constexpr int XI = NX * TW_BM / 4 / 256;          // 16-byte X chunks per thread and step (6 | 2)
+    constexpr int XCH = NX / 4;                        // chunks per X row
+    constexpr int BUF = TW_BM * (LDX + LDY);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int xr[XI], xc[XI], yr[TW_YI], yc[TW_YI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int id = tid + 256 * i;
+        xr[i] = id / XCH; const int c = (id % XCH) * 4;
+        xc[i] = c < P.x_split ? c : c + P.x_skip;   // (dr, du | dc_n) views skip one 64-wide block
+    }
+#pragma unroll
+    for (int i = 0; i < TW_YI; ++i) { const int id = tid + 256 * i; yr[i] = id >> 4; yc[i] = NARROW ? (id & 15) : (id & 15) * 4; }
+    // Block k of this split covers rows (k * nsplit + split) * TW_BM ...  Every load slot keeps the time index of its row and the
+    // element offset of its 16 bytes; a step adds constants (+ a correction when the time index wraps into the next batch row):
+    // no division and no 64-bit multiply in the loop.  M is a multiple of TW_BM and X views have no time shift (launcher), so
+    // X needs no masking; a Y row with t + shift < 0 (h_{t-1} at t = 0) or a column past ny is fetched from a zero buffer.
+    const int nsteps = (int)((a.chunks - split + P.nsplit - 1) / P.nsplit);
+    const int64_t adv_rows = (int64_t)P.nsplit * TW_BM;
+    const int adv_b = (int)(adv_rows / a.T), adv_t = (int)(adv_rows % a.T);
+    const int64_t x_adv = (int64_t)adv_b * P.xbs + (int64_t)adv_t * P.xrs, x_wrap = P.xbs - (int64_t)a.T * P.xrs;
+    const int64_t y_adv = (int64_t)adv_b * P.ybs + (int64_t)adv_t * P.yrs, y_wrap = P.ybs - (int64_t)a.T * P.yrs;
+    int xt[XI], yt[TW_YI];
+    int64_t xo[XI], yo[TW_YI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int64_t m = (int64_t)split * TW_BM + xr[i];
+        const int bb = (int)(m / a.T); xt[i] = (int)(m % a.T);
+        xo[i] = (int64_t)bb * P.xbs + (int64_t)xt[i] * P.xrs + xc[i];
+    }
+    const bool ybf = P.y_bf16 != 0;
+    const int yesz = ybf ? 2 : 4, yhi = ybf ? 0 : 8;
+    bool ycol_ok[TW_YI];
+#pragma unroll
+    for (int i = 0; i < TW_YI; ++i) {
+        const int64_t m = (int64_t)split * TW_BM + yr[i];
+        const int bb = (int)(m / a.T); yt[i] = (int)(m % a.T);
+        yo[i] = ((int64_t)bb * P.ybs + (int64_t)(yt[i] + P.yshift) * P.yrs + yc[i]) * yesz;   // bytes
+        ycol_ok[i] = !NARROW || yc[i] < P.ny;
+    }
+    const int64_t y_adv_b = y_adv * yesz, y_wrap_b = y_wrap * yesz;
+    const char *ybase = (const char *)P.y;
+    const char *zeros = (const char *)tw_zeros;
+    twu4 rx[2][XI], ry[2][TW_YI];
+    int fetched = 0;   // blocks requested so far; the offsets only move on while another block of this split exists, so the two
+                       // requests past the end re-read the last block instead of running off the operands
+#define TW_FETCH(set_)                                                                                                  \
+    do {                                                                                                                \
+        ++fetched;                                                                                                      \
+        const bool go = fetched < nsteps;                                                                               \
+        const int at_ = go ? adv_t : 0;                                                                                 \
+        const int64_t xa_ = go ? x_adv : 0, ya_ = go ? y_adv_b : 0;                                                     \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                \
+            rx[set_][i] = *(const twu4 *)(P.x + xo[i]);                                                                 \
+            xt[i] += at_; const bool w = xt[i] >= a.T; xt[i] -= w ? a.T : 0; xo[i] += xa_ + (w ? x_wrap : 0);           \
+        }                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TW_YI; ++i) {                                                             \
+            const char *src = (ycol_ok[i] && yt[i] + P.yshift >= 0) ? ybase + yo[i] : zeros;                            \
+            if constexpr (NARROW) {                                                                                     \
+                ry[set_][i].x = *(const uint32_t *)src;                                                                 \
+            } else {   /* two 8-byte requests, no branch: the second one repeats the first when the row holds bf16 */   \
+                const twu2 lo = *(const twu2 *)src, hi = *(const twu2 *)(src + yhi);                                    \
+                ry[set_][i] = (twu4){lo.x, lo.y, hi.x, hi.y};                                                           \
+            }                                                                                                           \
+            yt[i] += at_; const bool w = yt[i] >= a.T; yt[i] -= w ? a.T : 0; yo[i] += ya_ + (w ? y_wrap_b : 0);         \
+        }                                                                                                               \
+    } while (0)
+#define TW_COMMIT(set_, buf_)                                                                                           \
+    do {                                                                                                                \
+        float *xs_ = (buf_), *ys_ = (buf_) + TW_BM * LDX;                                                               \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                                  \
+            *(twu4 *)(xs_ + xr[i] * LDX + (tid + 256 * i) % XCH * 4) = rx[set_][i];                                     \
+        _Pragma("unroll") for (int i = 0; i < TW_YI; ++i) {                                                             \
+            if constexpr (NARROW) {                                                                                     \
+                *(uint32_t *)(ys_ + yr[i] * LDY + yc[i]) = ry[set_][i].x;                                               \
+            } else {                                                                                                    \
+                const twu4 r = ry[set_][i];                                                                             \
+                *(twu4 *)(ys_ + yr[i] * LDY + yc[i]) =                                                                  \
+                    ybf ? (twu4){r.x << 16, r.x & 0xffff0000u, r.y << 16, r.y & 0xffff0000u} : r;                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+    f32x4 acc[NB][JB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NB], ysum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bsum[i] = 0.f;
+    const int fr = lane & 15, fq = lane >> 4;
+#define TW_BODY(s_, PAR_)                                                                                               \
+    do {                                                                                                                \
+        const float *xs = tws + (PAR_) * BUF, *ys = xs + TW_BM * LDX;                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < TW_BM / 4; ++ks) {                                                      \
+            float xa[NB], yb[JB];                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) xa[i] = xs[(4 * ks + fq) * LDX + 16 * NB * wave + 16 * i + fr]; \
+            _Pragma("unroll") for (int j = 0; j < JB; ++j) yb[j] = ys[(4 * ks + fq) * LDY + 16 * j + fr];               \
+            ysum += yb[0];                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                            \
+                bsum[i] += xa[i];                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < JB; ++j)                                                          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i], yb[j], acc[i][j], 0, 0, 0);                 \
+            }                                                                                                           \
+            if (ks & 1) __builtin_amdgcn_sched_barrier(0);                                                              \
+        }                                                                                                               \
+        if ((s_) + 1 < nsteps) TW_COMMIT(1 - (PAR_), tws + (1 - (PAR_)) * BUF);                                         \
+        tw_barrier();                                                                                                   \
+        TW_FETCH(1 - (PAR_));                                                                                           \
+    } while (0)
+    if (nsteps > 0) {
+        TW_FETCH(0);
+        TW_COMMIT(0, tws);
+        tw_barrier();
+        TW_FETCH(1);
+        TW_FETCH(0);
+    }
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        TW_BODY(s, 0);
+        TW_BODY(s + 1, 1);
+    }
+    if (s < nsteps) TW_BODY(s, 0);
+#undef TW_BODY
+#undef TW_COMMIT
+#undef TW_FETCH
+    // C/D layout of the 16x16 MFMA: column (k) = lane & 15, rows (n) 4 * (lane >> 4) + r.  Partial tile: [n][64] + bias row.
+    float *dst = a.partial + P.part_off + (int64_t)split * TW_PART;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(16 * NB * wave + 16 * i + 4 * fq + r) * TW_K + 16 * j + fr] = acc[i][j][r];
+    // column sums: lanes fr, fr + 16, fr + 32, fr + 48 hold disjoint rows of one column
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        float b = bsum[i];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (fq == 0 && P.kind != 2) dst[TW_N * TW_K + 16 * NB * wave + 16 * i + fr] = b;
+    }
+    ysum += __shfl_xor(ysum, 16, 64);
+    ysum += __shfl_xor(ysum, 32, 64);
+    if (P.kind == 2 && wave == 0 && fq == 0) dst[TW_N * TW_K + fr] = ysum;
+}
+
+__global__ void __launch_bounds__(256, 3) tn_wide_kernel(TwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tws[];
+    // id = 8 * local + xcd; a tile owns the locals [local_begin, local_begin + nsplit / 8), split = 8 * (local - begin) + xcd:
+    // split s of every tile runs on XCD s % 8, so tiles that read the same rows (the context tiles) share them through that L2
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    TwTile P = a.tile[0];
+#pragma unroll
+    for (int i = 1; i < TW_MAXTILES; ++i)
+        if (i < a.ntiles && local >= a.tile[i].local_begin) P = a.tile[i];
+    const int split = (local - P.local_begin) * 8 + xcd;
+    if (split >= P.nsplit) return;
+    if (P.kind == 0) tw_run<3, false>(a, P, tws, split);
+    else if (P.kind == 1) tw_run<3, true>(a, P, tws, split);
+    else tw_run<1, true>(a, P, tws, split);
+}
+
+// grid (TW_N * TW_K / 4 / 64 + 1, ntiles), 256 threads = 64 float4 columns x 4 groups of splits (see wgrad_tr_reduce_kernel)
+__global__ void __launch_bounds__(256) tn_wide_reduce_kernel(TwArgs a) {
+    __shared__ float4 comb[3][64];
+    const int tile = blockIdx.y;
+    TwTile P = a.tile[0];
+#pragma unroll
+    for (int i = 1; i < TW_MAXTILES; ++i)
+        if (tile == i) P = a.tile[i];
+    const float *src = a.partial + P.part_off;
+    const int nsplit = P.nsplit;
+    const int nrows = P.kind == 2 ? 64 : TW_N, ncols = P.kind == 0 ? TW_K : P.ny;
+    if (blockIdx.x == gridDim.x - 1) {
+        const int nb = P.kind == 2 ? P.ny : TW_N;
+        if (P.bias_out == nullptr || (int)threadIdx.x >= nb) return;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 3 < nsplit; sp += 4)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] += src[(int64_t)(sp + q) * TW_PART + TW_N * TW_K + threadIdx.x];
+        for (; sp < nsplit; ++sp) t[0] += src[(int64_t)sp * TW_PART + TW_N * TW_K + threadIdx.x];
+        P.bias_out[threadIdx.x] = (t[0] + t[1]) + (t[2] + t[3]);
+        return;
+    }
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = (blockIdx.x * 64 + col) * 4;
+    const int n = e / TW_K, k = e % TW_K;
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = n < nrows && k < ncols;
+    if (live) {
+        int sp = g;
+        for (; sp + 12 < nsplit; sp += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *(const float4 *)(src + (int64_t)(sp + 4 * q) * TW_PART + e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[q].x += v[q].x; acc[q].y += v[q].y; acc[q].z += v[q].z; acc[q].w += v[q].w; }
+        }
+        for (; sp < nsplit; sp += 4) {
+            const float4 v = *(const float4 *)(src + (int64_t)sp * TW_PART + e);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+    }
+    float4 t;
+    t.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x); t.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    t.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z); t.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    if (g > 0) comb[g - 1][col] = t;
+    __syncthreads();
+    if (g == 0 && live) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float4 u = comb[q][col]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k + c >= ncols) continue;
+            // kind 2 holds out^T: partial row = Y' ... = column of the destination
+            if (P.kind == 2) P.out[(int64_t)(k + c) * P.ldo + P.col_off + n] = tv[c];
+            else P.out[(int64_t)n * P.ldo + P.col_off + k + c] = tv[c];
+        }
+    }
+}
+
+// ---- planning -----------------------------------------------------------------------------------------------------------
+// kind of a problem by its shapes only (the same answer for the sizing call with dummy pointers and for the launch):
+//   0: NX = 192, NY % 64 == 0 (NY / 64 tiles)   1: NX = 192, NY <= 16   2: NX <= 16, NY = 64 (roles swapped)   -1: not ours
+static int tw_kind(const TnProblem &q) {
+    if (q.NX == TW_N && q.NY > 0 && q.NY % TW_K == 0) return 0;
+    if (q.NX == TW_N && q.NY > 0 && q.NY <= 16) return 1;
+    if (q.NX > 0 && q.NX <= 16 && q.NY == 64) return 2;
+    return -1;
+}
+static bool tw_plan_shapes(const TnProblem *probs, int nprob, int &tiles) {
+    tiles = 0;
+    bool any_wide = false;
+    for (int i = 0; i < nprob; ++i) {
+        const int k = tw_kind(probs[i]);
+        if (k < 0) return false;
+        tiles += k == 0 ? probs[i].NY / TW_K : 1;
+        any_wide |= k == 0;
+    }
+    return any_wide && tiles <= TW_MAXTILES;
+}
+// Row splits per tile: 1536 workgroups (two rounds of three per CU; measured 488 | 447 | 429 us for 768 | 1024 | 1536 at LV,
+// VSDE_TW_WGS overrides) shared out by MFMA work per row -- a 192 x 64 tile issues 4x the MFMAs of a 192 x 16 tile, the
+// swapped 64 x 16 tile a twelfth, all stage the same rows -- in multiples of 8 (one split per XCD and `local`).
+static void tw_splits(const int *kinds, int nt, int64_t chunks, int *nsplit) {
+    const float w[3] = {1.0f, 0.35f, 0.2f};
+    static int wgs = -1;
+    if (wgs < 0) { const char *e = getenv("VSDE_TW_WGS"); wgs = e ? atoi(e) : 1536; }
+    float tot = 0.f;
+    for (int i = 0; i < nt; ++i) tot += w[kinds[i]];
+    for (int i = 0; i < nt; ++i) {
+        int n = ((int)(wgs * w[kinds[i]] / tot + 4.f)) & ~7;
+        if (n < 8) n = 8;
+        if (n > chunks) n = (int)chunks;
+        nsplit[i] = n;
+    }
+}
+static int tw_tile_kinds(const TnProblem *probs, int nprob, int *kinds) {
+    int nt = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const int k = tw_kind(probs[i]);
+        for (int kt = 0; kt < (k == 0 ? probs[i].NY / TW_K : 1); ++kt) kinds[nt++] = k;
+    }
+    return nt;
+}
+
+size_t tn_wide_workspace_bytes(const TnProblem *probs, int nprob, int M) {
+    int tiles;
+    if (!tw_plan_shapes(probs, nprob, tiles)) return 0;
+    int kinds[TW_MAXTILES], nsplit[TW_MAXTILES];
+    const int nt = tw_tile_kinds(probs, nprob, kinds);
+    tw_splits(kinds, nt, ((int64_t)M + TW_BM - 1) / TW_BM, nsplit);
+    size_t tot = 0;
+    for (int i = 0; i < nt; ++i) tot += (size_t)nsplit[i];
+    return tot * TW_PART * sizeof(float);
+}
+
+static bool tw_vec_view(const RowView &V, int ncols, int align_bytes) {
+    return (uintptr_t)V.base % align_bytes == 0 && V.batch_stride % 4 == 0 && V.row_stride % 4 == 0 && V.col_split >= ncols;
+}
+
+// returns 1 when the fast path ran, 0 when the caller has to use the generic kernel, < 0 on error
+int launch_tn_wide(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    int tiles;
+    if (!tw_plan_shapes(probs, nprob, tiles)) return 0;
+    const int T = probs[0].X.rows_per_batch;
+    if (T < TW_BM || M % TW_BM != 0) return 0;   // a block must not span more than two batch rows; no partial blocks
+    TwArgs a = {};
+    int nt = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const TnProblem &q = probs[i];
+        if (q.X.rows_per_batch != T || q.Y.rows_per_batch != T) return 0;
+        const int kind = tw_kind(q);
+        // kind 2 computes out^T: the 64-wide operand plays X, the narrow one Y
+        const RowView &X = kind == 2 ? q.Y : q.X, &Y = kind == 2 ? q.X : q.Y;
+        const int nx = kind == 2 ? 64 : TW_N, ny = kind == 2 ? q.NX : q.NY;
+        // operand views the branch-free loads can take: X in 16-byte fp32 chunks (a (dr, du | dc_n) remap moves whole chunks)
+        if (X.dtype != 0 || (uintptr_t)X.base % 16 || X.batch_stride % 4 || X.row_stride % 4 || X.shift != 0 || Y.shift > 0) return 0;
+        if (X.col_split < nx && (X.col_split % 4 || X.col_skip % 4)) return 0;
+        if (kind == 0 ? !tw_vec_view(Y, ny, Y.dtype == 0 ? 16 : 8) : (Y.dtype != 0 || Y.col_split < ny)) return 0;
+        for (int kt = 0; kt < (kind == 0 ? q.NY / TW_K : 1); ++kt) {
+            TwTile &t = a.tile[nt++];
+            t.kind = kind; t.ny = ny;
+            t.x = (const float *)X.base; t.xbs = X.batch_stride; t.xrs = X.row_stride; t.xshift = X.shift;
+            t.x_split = X.col_split < nx ? X.col_split : nx; t.x_skip = X.col_split < nx ? X.col_skip : 0;
+            t.y_bf16 = Y.dtype != 0;
+            t.y = Y.dtype == 0 ? (const void *)((const float *)Y.base + kt * TW_K) : (const void *)((const uint16_t *)Y.base + kt * TW_K);
+            t.ybs = Y.batch_stride; t.yrs = Y.row_stride; t.yshift = Y.shift;
+            t.out = q.out; t.ldo = q.ldo; t.col_off = q.col_off + kt * TW_K; t.bias_out = kt == 0 ? q.bias_out : nullptr;
+        }
+    }
+    a.ntiles = nt; a.M = M; a.T = T; a.chunks = ((int64_t)M + TW_BM - 1) / TW_BM;
+    int kinds[TW_MAXTILES], nsplit[TW_MAXTILES];
+    tw_tile_kinds(probs, nprob, kinds);
+    tw_splits(kinds, nt, a.chunks, nsplit);
+    int local = 0;
+    int64_t part = 0;
+    for (int i = 0; i < nt; ++i) {
+        a.tile[i].nsplit = nsplit[i]; a.tile[i].local_begin = local; a.tile[i].part_off = part;
+        local += (nsplit[i] + 7) / 8; part += (int64_t)nsplit[i] * TW_PART;
+    }
+    a.nlocal = local;
+    const size_t need = (size_t)part * sizeof(float);
+    VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "TN workspace too small: %zu < %zu", workspace_bytes, need);
+    a.partial = (float *)workspace;
+    const size_t lds = (size_t)2 * TW_BUF * sizeof(float);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tn_wide_kernel, dim3((unsigned)(a.nlocal * 8)), dim3(256), lds, stream, a);
+    VSDE_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tn_wide_reduce_kernel, dim3(TW_N * TW_K / 4 / 64 + 1, nt), dim3(256), 0, stream, a);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 1;
+}
+
+}  // namespace vsde
