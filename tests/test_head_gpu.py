@@ -88,9 +88,12 @@ def test_bf16_context_is_read_directly():
     d2 = dict(d)
     d2["context_full"] = torch.from_numpy(d["context_full"]).to(torch.bfloat16).float().numpy()
     (p32, m32, c32, _, _), g32, _ = _run_case(d2)
-    assert torch.allclose(p16, p32, rtol=1e-6, atol=1e-6)
+    # the bf16 context takes the bf16-plane projection kernel (vsde_proj.hip: exact products, fp32 accumulation in a different
+    # order than the fp32-MFMA kernel the up-cast copy takes), so the two runs agree to fp32 round-off, not bit for bit
+    assert rel_err(p16.cpu().numpy(), p32.cpu().numpy()) < 2e-6
     for a, b_ in zip(g16, g32):
-        assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6)
+        if b_.numel():
+            assert rel_err(a.float().cpu().numpy(), b_.float().cpu().numpy()) < 1e-5
 
 
 def test_argument_errors_raise():
@@ -193,3 +196,33 @@ def test_full_size_ou_matches_oracle():
     for a, b_, n in zip(grads, gref, G_NAMES):
         if b_.size:
             assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, n
+
+
+def test_bf16_grad_context_matches_the_rounded_fp32_result():
+    """grad_context written as bf16 (the autocast encoder's dtype) comes from the two-plane bf16-MFMA kernel (vsde_proj.hip,
+    relative error 2^-16 before the final rounding): against the fp32 kernel's result rounded to bf16 it may differ by one
+    bf16 ulp on a few elements, never more."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(9)
+    B, T, S, C, P, H, L = 24, 40, 2, 256, 3, 64, 2
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(_dev())
+    ws = [rn(3 * H, S + C + P, sc=0.08), rn(3 * H, H, sc=0.12), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1),
+          rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1),
+          rn(S + 3, H, sc=0.1), rn(S + 3, sc=0.1)]
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C).to(torch.bfloat16), rn(B, P).abs(), rn(B, T, S)
+    gp, gm, gl = rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+    out = _hip.head_forward(x0, ctx[:, :-1], theta, eps, ws, 0.1, True)
+    g32 = _hip.head_backward(gp, gm, gl, ctx[:, :-1], theta, eps, out[0], out[3], out[4], ws, 0.1)
+    gctx = torch.zeros(B, T + 1, C, device=_dev(), dtype=torch.bfloat16)
+    g16 = _hip.head_backward(gp, gm, gl, ctx[:, :-1], theta, eps, out[0], out[3], out[4], ws, 0.1, context_grad_out=gctx)
+    want = g32[1].to(torch.bfloat16).float()
+    got = gctx[:, :-1].float()
+    # one bf16 ulp at |want|, plus the kernel's 2^-16 relative to the size of the summed terms (matters where they cancel)
+    tol = want.abs() * 2.0 ** -7 + float(want.abs().max()) * 2.0 ** -14
+    diff = (got - want).abs()
+    assert bool((diff <= tol).all()), float((diff / tol).max())
+    assert float(((got != want).float().mean())) < 0.02, "more than 2% of the elements moved by an ulp"
+    assert float(gctx[:, -1].abs().max()) == 0.0   # the extra context row receives no gradient
+    for a, b_ in zip(g16[:1] + g16[2:], g32[:1] + g32[2:]):   # every other gradient is untouched by the output dtype
+        if b_.numel():
+            assert torch.equal(a, b_)

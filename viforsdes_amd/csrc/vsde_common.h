@@ -141,6 +141,13 @@ int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace,
 size_t tn_wide_workspace_bytes(const TnProblem *probs, int nprob, int M);
 int launch_tn_wide(const TnProblem *probs, int nprob, int M, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+// ---- bf16-plane fast paths of the two head GEMMs (vsde_proj.hip): 1 = done, 0 = not applicable (use launch_gemm_nt), < 0 = error
+size_t proj_planes_bytes(int N, int K);
+int launch_proj_fwd_bf16(const RowView &A, int64_t M, int K, const float *W, int ldw, int N, const float *bias, float *G, int64_t ldc,
+                         void *scratch, size_t scratch_bytes, hipStream_t s);
+int launch_proj_bwd_bf16(const RowView &A, int64_t M, int K, const float *Wt, int ldw, int N, void *C, int64_t ldc, int out_rpb,
+                         int64_t out_bstride, void *scratch, size_t scratch_bytes, hipStream_t s);
+
 // ---- streamed attention kernels (vsde_attn_stream.hip): any N, head_dim 64 or 128 ------------
 int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
                                 double scale, hipStream_t s);

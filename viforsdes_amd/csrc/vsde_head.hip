@@ -1375,14 +1375,21 @@ static int check_dims(const vsde_head_dims *d) {
 }
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+// VSDE_PROJ_GENERIC=1: run the context projection / grad_context on the generic fp32-MFMA kernel (A/B against vsde_proj.hip)
+static bool proj_fast_path() {
+    static int generic = -1;
+    if (generic < 0) { const char *e = getenv("VSDE_PROJ_GENERIC"); generic = e ? atoi(e) : 0; }
+    return generic == 0;
+}
 
-struct FwdLayout { size_t packF, packO, Wc, G, total; };
+struct FwdLayout { size_t packF, packO, Wc, planes, G, total; };
 static FwdLayout fwd_layout(const vsde_head_dims *d) {
     const int NO = d->S + d->S * (d->S + 1) / 2;
     FwdLayout o; size_t off = 0;
     o.packF = off; off += align256((size_t)(2 * d->L - 1) * kMatF4 * sizeof(float4));
     o.packO = off; off += align256((size_t)kChunks * NO * sizeof(float4));
     o.Wc = off; off += align256((size_t)3 * d->H * d->C * sizeof(float));
+    o.planes = off; off += align256(proj_planes_bytes(3 * d->H, d->C));   // bf16 planes of W_c (vsde_proj.hip)
     o.G = off; off += align256((size_t)d->B * d->T * 3 * d->H * sizeof(float));
     o.total = off;
     return o;
@@ -1494,7 +1501,11 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
 
     float *G = (float *)(ws + lay.G);
     if (save) prof_mark(4, 0, s);
-    rc = launch_gemm_nt(ctx_rowview(ctx, d->T, d->C), d->B * d->T, d->C, pk.Wc, d->C, 3 * d->H, w->b_ih_l0, G, 3 * d->H, s);
+    rc = proj_fast_path() ? launch_proj_fwd_bf16(ctx_rowview(ctx, d->T, d->C), (int64_t)d->B * d->T, d->C, pk.Wc, d->C, 3 * d->H, w->b_ih_l0, G,
+                                                 3 * d->H, ws + lay.planes, proj_planes_bytes(3 * d->H, d->C), s) : 0;
+    if (rc < 0) return rc;
+    if (rc == 0) rc = launch_gemm_nt(ctx_rowview(ctx, d->T, d->C), d->B * d->T, d->C, pk.Wc, d->C, 3 * d->H, w->b_ih_l0, G, 3 * d->H, s);
+    else rc = 0;
     if (save) prof_mark(4, 1, s);
     if (rc) return rc;
 
@@ -1814,8 +1825,14 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     VSDE_CHECK_ARG(g->context_batch_stride == 0 || g->context_batch_stride >= (int64_t)d->T * d->C, VSDE_E_BADARG,
                    "grads->context_batch_stride smaller than T*C");
     prof_mark(5, 0, s);
-    rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s,
-                        g->context_batch_stride ? d->T : 0, g->context_batch_stride, g->context_dtype);
+    // the grouped weight-gradient reduction below runs after this GEMM on the same stream: its workspace doubles as plane scratch
+    rc = (proj_fast_path() && g->context_dtype == 1)
+             ? launch_proj_bwd_bf16(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, g->context, d->C, g->context_batch_stride ? d->T : 0,
+                                    g->context_batch_stride, ws + lay.tn, lay.total - lay.tn, s) : 0;
+    if (rc < 0) return rc;
+    if (rc == 0) rc = launch_gemm_nt(dv, M, 3 * d->H, pk.WcT, 3 * d->H, d->C, nullptr, g->context, d->C, s,
+                                     g->context_batch_stride ? d->T : 0, g->context_batch_stride, g->context_dtype);
+    else rc = 0;
     prof_mark(5, 1, s);
     if (rc) return rc;
 
