@@ -260,14 +260,15 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
     }
-    const int ntiles = p.N / 32;
+    // blockIdx.y = chunk of the output columns (small M: one stripe per workgroup would leave most CUs idle, see launch_rows)
+    const int ntiles = p.N / 32 / gridDim.y, tile0 = blockIdx.y * ntiles;
     const int rot = 2 * (blockIdx.x % (ntiles / 2));
     u32x4 breg[NLD];          // the next tile on its way from L2 to LDS (loaded one iteration before its LDS store)
     uint32_t biasreg = 0u;
     u32x4 ureg[4 * RB];       // EPI_SWIGLU_BWD: the next tile's slice of the saved u (32 RB rows x 64 columns)
 #define VSDE_TILE_LOAD(t_)                                                                                    \
     do {                                                                                                      \
-        const int tile_ = ((t_) + rot) % ntiles;                                                              \
+        const int tile_ = tile0 + ((t_) + rot) % ntiles;                                                      \
         wtile_load<NLD, KC, R2_THREADS>(breg, p.W + (int64_t)tile_ * 32 * KC, KC, tid);                       \
         if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * tid) : 0u;             \
     } while (0)
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #define VSDE_U_LOAD(t_)                                                                                       \
     do {                                                                                                      \
         if constexpr (EPI == EPI_SWIGLU_BWD) {                                                                \
-            const int n0_ = (((t_) + rot) % ntiles) * 32;                                                     \
+            const int n0_ = (tile0 + ((t_) + rot) % ntiles) * 32;                                             \
             _Pragma("unroll") for (int i = 0; i < 4 * RB; ++i) {                                              \
                 const int row = (lane >> 3) + 8 * i, c = lane & 7;                                            \
                 const int64_t m_ = row0 + row < p.M ? row0 + row : p.M - 1;                                   \
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
         f32x16 acc[RB];                                                                                       \
         rows_tile_mfma<KC, RB>(acc, afr, Bs + r * LDB + 8 * h);                                               \
-        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (((t_) + rot) % ntiles) * 32, lane); \
+        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane); \
         if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE);                                    \
         lds_barrier();                                                                                        \
         if ((t_) + 2 < ntiles) VSDE_TILE_LOAD((t_) + 2);                                                      \
@@ -416,7 +417,14 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     const size_t lds = rows_lds_bytes<KC, EPI>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int rows = 128 * rows_rb<EPI>();
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)((p.M + rows - 1) / rows)), dim3(R2_THREADS), lds, s, p);
+    // Few row stripes (M of a few thousand: the OU example has 12.9 k tokens = 51 stripes on 256 CUs): split the output columns
+    // over blockIdx.y so that about two workgroups per CU exist; a chunk is a whole number of tile pairs.  Each chunk re-reads its
+    // stripe's activation rows (L2 hits).
+    const int64_t stripes = (p.M + rows - 1) / rows;
+    const int pairs = p.N / 64;
+    int chunks = 1;
+    while (stripes * chunks < 512 && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)stripes, (unsigned)chunks), dim3(R2_THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
