@@ -30,6 +30,12 @@ WORKLOADS = {
     # name: (B launched, sub-batch scored, T, S, C, P, H, L, dt, bf16 context, free-running fwd tol, bwd tol)
     "lv": (512, 64, 400, 2, 256, 3, 64, 2, 0.1, True, 5e-5, 2e-4),
     "synthetic": (256, 32, 1000, 8, 512, 16, 64, 2, 0.01, True, 5e-5, 2e-4),
+    # small shapes that still take the hidden_dim-64 fast paths (192-wide weight-gradient tiles need B*T % 16 == 0 and T >= 16;
+    # bf16-plane projection needs a 256-wide bf16 context): narrow state / theta tiles, swapped emission tile, 1 and 3 GRU layers,
+    # fp32 context (generic projection + wide weight gradients), a context width that is a single 64-column tile
+    "ou_like_l1": (12, 4, 48, 1, 256, 3, 64, 1, 0.05, True, 5e-5, 2e-4),
+    "s3_l3_fp32ctx": (8, 4, 32, 3, 128, 5, 64, 3, 0.05, False, 5e-5, 2e-4),
+    "c64_t16": (6, 2, 16, 2, 64, 3, 64, 2, 0.1, False, 5e-5, 2e-4),
 }
 TF_FWD_TOL, TF_BWD_TOL = 2e-5, 2e-4
 

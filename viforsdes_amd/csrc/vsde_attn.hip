@@ -16,6 +16,8 @@
 //     bound is so loose that every term could underflow (scale |q||k| > 27, never the case behind the encoder's
 //     QK-RMS-norm) a first pass computes the true row maxima.
 // Token-major layout [B][N][H][64] for q, k, v, o (what qk_norm_rope writes and gate_merge reads).
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -468,6 +470,13 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
 
 using namespace vsde;
 
+// VSDE_ATTN_STREAM=1: take the streamed kernels for every shape (A/B runs)
+static bool force_stream() {
+    static int f = -1;
+    if (f < 0) { const char *e = getenv("VSDE_ATTN_STREAM"); f = e ? atoi(e) : 0; }
+    return f != 0;
+}
+
 extern "C" int vsde_attention_max_tokens(void) { return AT_MAXN; }
 
 extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
@@ -475,7 +484,7 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     VSDE_CHECK_ARG(q && k && v && o && lse && B > 0 && N > 0 && H > 0, VSDE_E_BADARG, "bad attention arguments");
     VSDE_CHECK_ARG(head_dim == 64 || head_dim == 128, VSDE_E_BADARG, "attention kernels are built for head_dim 64 and 128, got %d", head_dim);
     VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
-    if (head_dim != AT_D || N > AT_MAXN)   // does not fit the LDS-resident kernel: K / V stream through LDS (vsde_attn_stream.hip)
+    if (head_dim != AT_D || N > AT_MAXN || force_stream())   // does not fit the LDS-resident kernel: K / V stream through LDS (vsde_attn_stream.hip)
         return launch_attention_stream_fwd(q, k, v, o, lse, B, N, H, head_dim, scale, (hipStream_t)stream);
     AttnParams p;
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (uint16_t *)o; p.lse = lse;
@@ -495,7 +504,7 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
                    "bad attention_bwd arguments");
     VSDE_CHECK_ARG(head_dim == 64 || head_dim == 128, VSDE_E_BADARG, "attention kernels are built for head_dim 64 and 128, got %d", head_dim);
     VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
-    if (head_dim != AT_D || N > AT_MAXN)
+    if (head_dim != AT_D || N > AT_MAXN || force_stream())
         return launch_attention_stream_bwd(dout, q, k, v, o, lse, dq, dk, dv, delta, B, N, H, head_dim, scale, (hipStream_t)stream);
     AttnBwdParams p;
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o;
