@@ -1,0 +1,33 @@
+"""Kernels of one no-grad posterior-sampling call (theta ~ q -> encoder -> head, eval kernels) at the LV size (GPU only)."""
+import os, sys
+from collections import defaultdict
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from torch.profiler import profile, ProfilerActivity
+import bench
+from viforsdes_amd.examples.sdes import lv_problem
+from viforsdes_amd.inference.diffusion_path_sampler import sample_diffusion_paths
+
+dev = torch.device("cuda:0")
+tr = bench.build_trainer(lv_problem(), 512, dev, True, seed=1234)
+model, ctx, cfg = tr.ctx.model, tr.ctx, tr.config
+model.eval()
+
+@torch.no_grad()
+def step():
+    theta = model.sde_parameter_posterior.rsample(512)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        sample_diffusion_paths(model.encoder, model.head, ctx.observations, theta, ctx.x0_buffer, tr.time_horizon, cfg.time_step, tr.state_space)
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+kern = defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        k = kern[ev.name[:100]]; k[0] += 1; k[1] += ev.device_time
+print(f"kernels {sum(v[0] for v in kern.values())}, device time {sum(v[1] for v in kern.values()) / 1e3:.2f} ms")
+for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:22]:
+    print(f"{v[0]:4d} {v[1]:9.1f} us  {k}")

@@ -603,13 +603,15 @@ class _SwiGLUMLP(torch.autograd.Function):
     halves interleaved in blocks of 16 rows (``swiglu_packs(..., interleave=True)``)."""
 
     @staticmethod
-    def forward(ctx, x, pin, pout, *params):
+    def forward(ctx, x, pin, pout, train, *params):
         w1, b1 = pin.operands()
         w2, b2 = pout.operands()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        u, s_ = _hip.linear_swiglu_bf16(x2, w1, b1)
+        # the pre-activation u is only kept for the backward: a no-grad call (posterior sampling) skips its [M, 2*width] write
+        u, s_ = _hip.linear_swiglu_bf16(x2, w1, b1, want_u=train)
         y = _mm_nt(s_, w2, b2)
-        ctx.save_for_backward(x2, u, s_, w1)
+        if train:
+            ctx.save_for_backward(x2, u, s_, w1)
         ctx.packs = (pin, pout)
         ctx.xshape = x.shape
         return y.reshape(*x.shape[:-1], w2.shape[0])
@@ -627,7 +629,7 @@ class _SwiGLUMLP(torch.autograd.Function):
             dx = du @ w1
         dW1, db1 = _hip.linear_wgrad(du, x2, pin.bias is not None)
         dW2, db2 = _hip.linear_wgrad(dy2, s_, pout.bias is not None)
-        return (dx.reshape(ctx.xshape), None, None, *pin.split_grads(dW1, db1), *pout.split_grads(dW2, db2))
+        return (dx.reshape(ctx.xshape), None, None, None, *pin.split_grads(dW1, db1), *pout.split_grads(dW2, db2))
 
 
 def swiglu_mlp_usable(x: Tensor, width: int) -> bool:
@@ -637,7 +639,9 @@ def swiglu_mlp_usable(x: Tensor, width: int) -> bool:
 
 
 def swiglu_mlp(x: Tensor, pin: PackedWeight, pout: PackedWeight) -> Tensor:
-    return _SwiGLUMLP.apply(x, pin, pout, *pin.params, *pout.params)
+    # grad mode is always off inside Function.forward: whether a backward can follow is decided here
+    train = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in pin.params + pout.params))
+    return _SwiGLUMLP.apply(x, pin, pout, train, *pin.params, *pout.params)
 
 
 def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Optional[int] = None) -> PackedWeight:
