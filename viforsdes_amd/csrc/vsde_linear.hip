@@ -40,6 +40,7 @@ struct LinParams {
     uint16_t *S; int64_t lds_;         // EPI_SWIGLU: s [M][N/2]
     const uint16_t *U; int64_t ldu;    // EPI_SWIGLU_BWD: saved u [M][2N]
     int64_t M; int N, K;
+    int chunks;                        // rows kernel: column chunks per row stripe
     int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
 };
 
@@ -250,7 +251,13 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     uint16_t *stage = lsm + 2 * TILE + wave * (32 * RB * R2_SLD);
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS + wave * (32 * RB);
+    // Workgroup id = 8 * local + xcd (consecutive ids go round-robin over the XCDs); the column chunks of one row stripe take
+    // consecutive `local` on ONE XCD: they run together and share the stripe's activation rows through that XCD's L2.
+    const int nchunks = p.chunks, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int chunk = local % nchunks;
+    const int64_t stripe = (int64_t)(local / nchunks) * 8 + xcd;
+    if (stripe * ROWS >= p.M) return;
+    const int64_t row0 = stripe * ROWS + wave * (32 * RB);
 
     bf16x8 afr[RB][KS];
 #pragma unroll
@@ -260,9 +267,9 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
     }
-    // blockIdx.y = chunk of the output columns (small M: one stripe per workgroup would leave most CUs idle, see launch_rows)
-    const int ntiles = p.N / 32 / gridDim.y, tile0 = blockIdx.y * ntiles;
-    const int rot = 2 * (blockIdx.x % (ntiles / 2));
+    // a workgroup owns one chunk of the output columns of its stripe (see launch_rows)
+    const int ntiles = p.N / 32 / nchunks, tile0 = chunk * ntiles;
+    const int rot = 2 * ((int)stripe % (ntiles / 2));
     u32x4 breg[NLD];          // the next tile on its way from L2 to LDS (loaded one iteration before its LDS store)
     uint32_t biasreg = 0u;
     u32x4 ureg[4 * RB];       // EPI_SWIGLU_BWD: the next tile's slice of the saved u (32 RB rows x 64 columns)
@@ -417,14 +424,25 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     const size_t lds = rows_lds_bytes<KC, EPI>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int rows = 128 * rows_rb<EPI>();
-    // Few row stripes (M of a few thousand: the OU example has 12.9 k tokens = 51 stripes on 256 CUs): split the output columns
-    // over blockIdx.y so that about two workgroups per CU exist; a chunk is a whole number of tile pairs.  Each chunk re-reads its
-    // stripe's activation rows (L2 hits).
+    // Column chunks per row stripe (a chunk is a whole number of tile pairs; its workgroup re-reads the stripe's rows, L2 hits):
+    //  * few stripes (the OU example has 12.9 k tokens = 51 stripes on 256 CUs): enough chunks for about two workgroups per CU;
+    //  * many stripes: the grid is a non-integer number of rounds of the 512 resident workgroups (802 stripes = 1.57 rounds:
+    //    1.39 ns per row at M = 205 k against 1.22 at M = 393 k) -- finer workgroups round up less.
     const int64_t stripes = (p.M + rows - 1) / rows;
     const int pairs = p.N / 64;
     int chunks = 1;
     while (stripes * chunks < 512 && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)stripes, (unsigned)chunks), dim3(R2_THREADS), lds, s, p);
+    {
+        static int big = -1;   // VSDE_ROWS_CHUNKS: chunks at large M (A/B runs; 0 = the default below)
+        if (big < 0) { const char *e = getenv("VSDE_ROWS_CHUNKS"); big = e ? atoi(e) : 0; }
+        // measured at M = 205 k: SwiGLU forward 290 | 277 | 272 | 307 us and backward 303 | 287 | 295 | 305 us for 1 | 2 | 4 | 8
+        // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
+        const int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
+        if (stripes >= 512 && want > 1 && pairs % want == 0) chunks = want;
+    }
+    LinParams q = p;
+    q.chunks = chunks;
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(R2_THREADS), lds, s, q);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
