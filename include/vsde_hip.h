@@ -224,6 +224,11 @@ int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, cons
 size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* Same, with the rows of the product scattered: row n of dY^T X (and of the column sums) is stored at dW[row_map[n]] /
+ * db[row_map[n]] (int32 [N] on the device; negative = dropped).  Lets a weight packed in a permuted / padded row order (the
+ * 16-row-interleaved SwiGLU input projection) hand its gradient back in the parameter's own row order without a gather. */
+int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db,
+                                const int32_t *row_map, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Dense contractions of the encoder on bf16 MFMA ----------------------------------------------------------------
  * y[M][N] = x[M][K] w[N][K]^T + bias[N]   (x, w, bias, y bf16; fp32 accumulation).  Replaces the hipBLASLt GEMMs behind

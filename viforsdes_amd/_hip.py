@@ -56,7 +56,7 @@ EXPORTS = (
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
-    "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16",
+    "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16",
 )
@@ -661,18 +661,21 @@ def attention_bwd(dout, q, k, v, o, lse, scale: float):
     return dq, dk, dv
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
-    """dW[N,K] = dy^T x and db[N] = colsum(dy) in fp32 for bf16 dy [M,N], x [M,K]."""
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool, row_map: Optional[torch.Tensor] = None,
+                 out_rows: Optional[int] = None):
+    """dW[N,K] = dy^T x and db[N] = colsum(dy) in fp32 for bf16 dy [M,N], x [M,K].  ``row_map`` (int32 [N] on the device):
+    product row n is stored at output row ``row_map[n]`` (negative: dropped) of an ``[out_rows, K]`` result."""
     lib = load(); dev = _require_hip(dy, x)
     M, N = dy.shape
     K = x.shape[1]
-    dW = torch.empty(N, K, device=dev, dtype=torch.float32)
-    db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
+    rows = N if row_map is None else int(out_rows)
+    dW = torch.empty(rows, K, device=dev, dtype=torch.float32)
+    db = torch.empty(rows, device=dev, dtype=torch.float32) if want_bias else None
     nbytes = lib.vsde_linear_wgrad_workspace_bytes(_i64(M), ctypes.c_int(N), ctypes.c_int(K))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
-        _call(lib.vsde_linear_wgrad_bf16, _ptr(dy), _ptr(x), _i64(M), ctypes.c_int(N), ctypes.c_int(K), _ptr(dW), _ptr(db),
-              _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
+        _call(lib.vsde_linear_wgrad_bf16_rows, _ptr(dy), _ptr(x), _i64(M), ctypes.c_int(N), ctypes.c_int(K), _ptr(dW), _ptr(db),
+              _ptr(row_map), _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
     return dW, db
 
 

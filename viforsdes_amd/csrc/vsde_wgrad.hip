@@ -50,6 +50,7 @@ struct Wgrad2Params {
     int N, K, tn, tiles_n, tiles_k, tiles, nsplit;
     int64_t chunks;           // 32-row blocks of the reduction index
     float *partial, *dW, *db;
+    const int32_t *row_map;   // output row of product row n (dW[row_map[n]], db[row_map[n]]; < 0: dropped), or nullptr = identity
 };
 
 __device__ __forceinline__ uint2 w2_read_tr(const uint16_t *ptr) {
@@ -211,7 +212,10 @@ __global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) {
         const float sum = (t[0] + t[1]) + (t[2] + t[3]);
         bcomb[threadIdx.x] = sum;
         __syncthreads();
-        if (h == 0 && n_blk + c < p.N) p.db[n_blk + c] = H == 2 ? sum + bcomb[(threadIdx.x + TN) & 255] : sum;
+        if (h == 0 && n_blk + c < p.N) {
+            const int r = p.row_map ? p.row_map[n_blk + c] : n_blk + c;
+            if (r >= 0) p.db[r] = H == 2 ? sum + bcomb[(threadIdx.x + TN) & 255] : sum;
+        }
         return;
     }
     const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -240,7 +244,10 @@ __global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) {
     if (g == 0) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { const float4 u = comb[q][col]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        if (n < p.N && k < p.K) *(float4 *)(p.dW + (int64_t)n * p.K + k) = t;   // K % 8 == 0: all four or none
+        if (n < p.N && k < p.K) {   // K % 8 == 0: all four or none
+            const int r = p.row_map ? p.row_map[n] : n;
+            if (r >= 0) *(float4 *)(p.dW + (int64_t)r * p.K + k) = t;
+        }
     }
 }
 
@@ -287,8 +294,16 @@ extern "C" size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
     return vsde::wgrad2_workspace(p);
 }
 
+extern "C" int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db,
+                                           const int32_t *row_map, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db, void *workspace,
                                       size_t workspace_bytes, void *stream) {
+    return vsde_linear_wgrad_bf16_rows(dy, x, M, N, K, dW, db, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db,
+                                           const int32_t *row_map, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace vsde;
     VSDE_CHECK_ARG(dy && x && dW && workspace && M > 0, VSDE_E_BADARG, "bad linear_wgrad arguments");
     VSDE_CHECK_ARG(N % 8 == 0 && K % 8 == 0, VSDE_E_BADARG, "linear_wgrad needs N %% 8 == 0 and K %% 8 == 0 (got %d, %d)", N, K);
@@ -297,6 +312,6 @@ extern "C" int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, 
     wgrad2_plan(M, N, K, p);
     const size_t need = wgrad2_workspace(p);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "linear_wgrad workspace too small: %zu < %zu", workspace_bytes, need);
-    p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db;
+    p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db; p.row_map = row_map;
     return p.tn == 256 ? wgrad2_launch<256>(p, (hipStream_t)stream) : wgrad2_launch<128>(p, (hipStream_t)stream);
 }

@@ -415,6 +415,11 @@ class PackedWeight:
         self._t_versions: Optional[list[int]] = None
         # packs whose rows are a permutation of ONE parameter (interleaved SwiGLU halves): packed row of every parameter row
         self.grad_rows = grad_rows
+        # its inverse for the weight-gradient kernel: output (parameter) row of every packed row, -1 for padding rows
+        self.grad_row_map: Optional[Tensor] = None
+        if grad_rows is not None:
+            self.grad_row_map = torch.full((rows,), -1, device=device, dtype=torch.int32)
+            self.grad_row_map[grad_rows] = torch.arange(grad_rows.numel(), device=device, dtype=torch.int32)
         self.params: list[Tensor] = []
         for p, *_ in self.weight_pieces + self.bias_pieces:
             if not any(p is q for q in self.params):
@@ -455,10 +460,12 @@ class PackedWeight:
             self._t_versions = list(self._versions)
         return self.weight_t
 
-    def split_grads(self, dW: Tensor, db: Optional[Tensor]) -> list[Optional[Tensor]]:
+    def split_grads(self, dW: Tensor, db: Optional[Tensor], mapped: bool = False) -> list[Optional[Tensor]]:
         """fp32 gradient of the packed operand -> one gradient per entry of ``self.params`` (a view when the parameter is
         one whole row block, otherwise its row blocks concatenated; a row gather for permuted packs)."""
         if self.grad_rows is not None:   # params = [weight] or [weight, bias], rows permuted
+            if mapped:   # the kernel already stored the rows in parameter order (grad_row_map)
+                return [dW if q.ndim == 2 else db for q in self.params]
             return [dW.index_select(0, self.grad_rows) if q.ndim == 2 else db.index_select(0, self.grad_rows) for q in self.params]
         out: list[Optional[Tensor]] = []
         for q in self.params:
@@ -627,9 +634,10 @@ class _SwiGLUMLP(torch.autograd.Function):
             dx = _hip.linear_bf16(du, pin.transposed(), None)
         else:
             dx = du @ w1
-        dW1, db1 = _hip.linear_wgrad(du, x2, pin.bias is not None)
+        dW1, db1 = _hip.linear_wgrad(du, x2, pin.bias is not None, pin.grad_row_map,
+                                     None if pin.grad_rows is None else pin.grad_rows.numel())
         dW2, db2 = _hip.linear_wgrad(dy2, s_, pout.bias is not None)
-        return (dx.reshape(ctx.xshape), None, None, None, *pin.split_grads(dW1, db1), *pout.split_grads(dW2, db2))
+        return (dx.reshape(ctx.xshape), None, None, None, *pin.split_grads(dW1, db1, mapped=pin.grad_row_map is not None), *pout.split_grads(dW2, db2))
 
 
 def swiglu_mlp_usable(x: Tensor, width: int) -> bool:
