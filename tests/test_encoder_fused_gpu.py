@@ -314,3 +314,33 @@ def test_residual_norm_fused_op(C, dtype, tol):
 
     for name, a, b_ in zip(["xnew", "h", "dx", "dy", "dgate", "dscale", "dshift"], run(True), run(False)):
         assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < tol, name
+
+
+@pytest.mark.parametrize("residual_v", [False, True])
+@pytest.mark.parametrize("B,N", [(112, 37), (40, 130)])   # >= 4096 rows: below that the packed projection is not taken at all
+def test_nograd_projection_kernel_matches_the_training_path(residual_v, B, N):
+    """Posterior sampling (no grad) runs the [q | k | v | gate] projection with the QK-norm / RoPE / value-mix epilogue in ONE
+    kernel (vsde_linear_qknorm_bf16); the training path runs the same arithmetic with the same rounding points as GEMM ->
+    qk_norm_rope.  Same block, same inputs: outputs and value heads must agree to bf16 round-off (the RMS sums are formed in a
+    different order, so a few elements may move by one bf16 ulp)."""
+    from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis
+    from viforsdes_amd.primitives import fused
+    blk = _block(dim=256, heads=4, cond=32, residual_v=residual_v, seed=3)
+    att = blk.self_attn
+    g = torch.Generator().manual_seed(B * N)
+    x = torch.randn(B, N, 256, generator=g).to(DEV, torch.bfloat16)
+    rot = RotarySpec.from_freqs(precompute_freq_cis(64, end=256)[:N].to(DEV))
+    v0 = (torch.randn(B, N, 4, 64, generator=g).to(DEV, torch.bfloat16)).transpose(1, 2) if residual_v else None
+    assert att.fusable(x, rot)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_t, val_t = att.forward_fused(x, rotary=rot, v0=v0)          # grad mode: GEMM, then qk_norm_rope
+        with torch.no_grad():
+            pack = att._proj_pack
+            cos, sin = rot.cos_sin_tables(N)
+            assert fused.projection_split_nograd_usable(x, pack, 4, 64, att.q_norm.weight, cos)
+            out_n, val_n = att.forward_fused(x, rotary=rot, v0=v0)      # the fused-epilogue kernel
+    for a, b_ in ((out_n, out_t), (val_n, val_t)):
+        a, b_ = a.float(), b_.float()
+        assert torch.isfinite(a).all()
+        assert float((a - b_).abs().max()) <= 2.0 ** -6 * float(b_.abs().max())
+        assert float((a != b_).float().mean()) < 0.05

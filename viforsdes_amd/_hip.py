@@ -58,7 +58,7 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
-    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -723,6 +723,24 @@ def linear_swiglu_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
         _call(lib.vsde_linear_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _ptr(u), _i64(N), _i64(M), ctypes.c_int(N),
               ctypes.c_int(K), ctypes.c_int(EPI_SWIGLU), _ptr(s), _i64(N // 2), None, _i64(0), _stream(dev))
     return u, s
+
+
+def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, tokens: int, cos, sin, wq, wk,
+                       v0: Optional[torch.Tensor], lam: Optional[torch.Tensor], eps: float):
+    """No-grad attention projection: x [M,256] against the packed [q | k | v | gate] weight w [3*heads*64 + G, 256] with the
+    QK-RMS-norm + RoPE + value mix in the GEMM epilogue -> (q, k, v [M, heads*64] token-major, gate logits [M, G] or None)."""
+    lib = load(); dev = _require_hip(x, w, cos, sin, wq, wk)
+    x, ldx = _rows2d(x)
+    M, K = x.shape
+    C = heads * 64
+    G = w.shape[0] - 3 * C
+    q = torch.empty(M, C, device=dev, dtype=torch.bfloat16); k = torch.empty_like(q); v = torch.empty_like(q)
+    gate = torch.empty(M, G, device=dev, dtype=torch.bfloat16) if G > 0 else None
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_qknorm_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _i64(M), ctypes.c_int(K), ctypes.c_int(heads),
+              ctypes.c_int(G), ctypes.c_int(tokens), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
+              ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), _stream(dev))
+    return q, k, v, gate
 
 
 def linear_swiglu_bwd_bf16(dy: torch.Tensor, w_t: torch.Tensor, u: torch.Tensor):

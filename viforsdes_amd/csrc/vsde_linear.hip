@@ -19,6 +19,10 @@
 //   EPI_SWIGLU       u = acc + bias (kept for the backward), s = silu(a) * b   with [a | b] the two 16-column halves of a
 //                    32-column tile: the packed weight interleaves the SwiGLU halves in blocks of 16 rows (primitives/fused.py)
 //   EPI_SWIGLU_BWD   acc = ds (gradient of s); reads u, writes du = (da | db) in the same interleaved layout
+//   EPI_QKNORM       no-grad attention projection [q | k | v | gate]: a pair of tiles is one 64-wide head; q / k heads are
+//                    RMS-normalised and rotated (RoPE) in the wave's staging buffer, v is mixed with the residual values, and every
+//                    head leaves straight in the attention kernels' layout -- the [M, 3C + d] intermediate and the separate
+//                    qk_norm_rope pass of the training path do not exist here
 #include <stdlib.h>
 
 #include "vsde_common.h"
@@ -29,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte register quad (native vector: stays in VGPRs)
 
-constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2;
+constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2, EPI_QKNORM = 3;
 constexpr int R2_THREADS = 256, R2_SLD = 88;   // rows kernel: 4 waves, staging rows of 64 + 16 (+ 8 pad) elements
 
 struct LinParams {
@@ -41,6 +45,11 @@ struct LinParams {
     const uint16_t *U; int64_t ldu;    // EPI_SWIGLU_BWD: saved u [M][2N]
     int64_t M; int N, K;
     int chunks;                        // rows kernel: column chunks per row stripe
+    // EPI_QKNORM: N = 3 heads*64 + gate columns; a tile pair = one 64-wide head of q / k / v (or the gate block)
+    uint16_t *Qo, *Ko, *Vo, *Go; int64_t ldg;   // q, k, v [M][heads*64] token-major; gate logits [M][ldg]
+    const float *cosT, *sinT, *wq, *wk, *lam;   // rotary tables [tokens][32], RMS weights [64], value-mix weight [1]
+    const uint16_t *V0;                         // residual values [M][heads*64] or nullptr
+    int heads, tokens; float eps;
     int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
 };
 
@@ -133,12 +142,55 @@ __device__ __forceinline__ void swiglu_quads(const f32x16 &acc, const uint16_t *
     }
 }
 
+// EPI_QKNORM on the staged head (R = 32 rows x 64 columns of bf16 = the projection output after bias and rounding, exactly what
+// the unfused chain hands to qk_norm_rope): lane (r, h) owns the rotary pairs i in [16 h, 16 h + 16) of row r, i.e. columns i
+// and i + 32.  kind 0 / 1: x -> rnd(x rms w) rotated by the row's (cos, sin); kind 2 with residual values: lam v + (1 - lam) v0.
+__device__ __forceinline__ void qknorm_head(const LinParams &p, uint16_t *stage, int kind, int hh, int64_t row0, int lane,
+                                            const float (&cs)[16], const float (&sn)[16], const u32x4 (&v0r)[4], const float *wlds) {
+    const int r = lane & 31, h = lane >> 5;
+    uint16_t *px = stage + r * R2_SLD + 16 * h;
+    const u32x4 l0 = *(const u32x4 *)px, l1 = *(const u32x4 *)(px + 8), h0 = *(const u32x4 *)(px + 32), h1 = *(const u32x4 *)(px + 40);
+    const uint32_t lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, hw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float xl[16], xh[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xl[2 * e] = bf_lo(lw[e]); xl[2 * e + 1] = bf_hi(lw[e]); xh[2 * e] = bf_lo(hw[e]); xh[2 * e + 1] = bf_hi(hw[e]); }
+    uint32_t ol[8], oh[8];
+    if (kind <= 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ss = fmaf(xl[e], xl[e], fmaf(xh[e], xh[e], ss));
+        ss += __shfl_xor(ss, 32, 64);
+        const float rq = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+        const float *w = wlds + 64 * kind;   // [wq | wk] staged in LDS by the kernel prologue
+        float o0[16], o1[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float a0 = rbf(xl[e] * rq * w[16 * h + e]), a1 = rbf(xh[e] * rq * w[32 + 16 * h + e]);
+            o0[e] = a0 * cs[e] - a1 * sn[e]; o1[e] = a0 * sn[e] + a1 * cs[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ol[e] = pack_bf16x2(o0[2 * e], o0[2 * e + 1]); oh[e] = pack_bf16x2(o1[2 * e], o1[2 * e + 1]); }
+    } else {
+        const float l = p.lam[0];
+        const uint32_t vw[16] = {v0r[0].x, v0r[0].y, v0r[0].z, v0r[0].w, v0r[1].x, v0r[1].y, v0r[1].z, v0r[1].w,
+                                 v0r[2].x, v0r[2].y, v0r[2].z, v0r[2].w, v0r[3].x, v0r[3].y, v0r[3].z, v0r[3].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ol[e] = pack_bf16x2(l * xl[2 * e] + (1.0f - l) * bf_lo(vw[e]), l * xl[2 * e + 1] + (1.0f - l) * bf_hi(vw[e]));
+            oh[e] = pack_bf16x2(l * xh[2 * e] + (1.0f - l) * bf_lo(vw[8 + e]), l * xh[2 * e + 1] + (1.0f - l) * bf_hi(vw[8 + e]));
+        }
+    }
+    *(u32x4 *)px = (u32x4){ol[0], ol[1], ol[2], ol[3]}; *(u32x4 *)(px + 8) = (u32x4){ol[4], ol[5], ol[6], ol[7]};
+    *(u32x4 *)(px + 32) = (u32x4){oh[0], oh[1], oh[2], oh[3]}; *(u32x4 *)(px + 40) = (u32x4){oh[4], oh[5], oh[6], oh[7]};
+}
+
 template <int EPI, int PAR, int RB>
 __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[RB], const uint16_t *bias32, uint16_t *stage,
-                                              const u32x4 (&ureg)[4 * RB], int64_t row0, int n0, int lane) {
+                                              const u32x4 (&ureg)[4 * RB], int64_t row0, int n0, int lane,
+                                              const float (&cs)[16], const float (&sn)[16], const float *wlds) {
     const int r = lane & 31, h = lane >> 5;
     constexpr int SLD = R2_SLD, R = 32 * RB;
-    if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU) {
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_QKNORM) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
@@ -149,6 +201,20 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 64 + 8 * g + 4 * h) = make_uint2(s0[2 * g], s0[2 * g + 1]);
             }
         }
+        if constexpr (EPI == EPI_QKNORM && PAR == 1) {
+            // ureg[0..3] (RB = 1): this lane's 4 x 16 bytes of the residual values of the head, requested when the pair began
+            const int pp = (n0 - 32) >> 6, kind = pp / p.heads, hh = pp - kind * p.heads;
+            wave_lds_fence();
+            if (kind <= 1 || (kind == 2 && p.V0 != nullptr)) {
+                const u32x4 v0r[4] = {ureg[0], ureg[1], ureg[2], ureg[3]};
+                qknorm_head(p, stage, kind, hh, row0, lane, cs, sn, v0r, wlds);
+                wave_lds_fence();
+            }
+            uint16_t *dst = kind == 0 ? p.Qo : (kind == 1 ? p.Ko : (kind == 2 ? p.Vo : p.Go));
+            const int64_t ld = kind <= 2 ? (int64_t)p.heads * 64 : p.ldg;
+            flush_rows64<SLD, R>(stage, dst + (kind <= 2 ? hh * 64 : 0), ld, row0, p.M, lane);
+            wave_lds_fence();
+        } else
         if constexpr (PAR == 1) {
             wave_lds_fence();
             if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD, R>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
@@ -214,7 +280,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
 // Outputs leave in pairs of tiles (64 columns = 128-byte row segments, non-temporal) through the wave's staging buffer.
 // EPI_SWIGLU_BWD runs with RB = 1: the tile's slice of the saved u is requested a tile ahead into registers, so its HBM
 // latency is hidden behind the MFMAs (with RB = 2 there are no registers left for that and every tile waited for its u).
-template <int EPI> constexpr int rows_rb() { return EPI == EPI_SWIGLU_BWD ? 1 : 2; }
+template <int EPI> constexpr int rows_rb() { return (EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM) ? 1 : 2; }
 
 template <int KC, int RB>
 __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (&afr)[RB][KC / 16], const uint16_t *bsrc) {
@@ -267,6 +333,21 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
     }
+    __shared__ float wlds[128];   // EPI_QKNORM: [wq | wk]
+    if constexpr (EPI == EPI_QKNORM) { if (tid < 128) wlds[tid] = tid < 64 ? p.wq[tid] : p.wk[tid - 64]; }   // visible after the first barrier
+    float cs[16], sn[16];   // EPI_QKNORM: (cos, sin) of this lane's 16 rotary pairs of ITS row (token = row % tokens)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { cs[e] = 1.f; sn[e] = 0.f; }
+    if constexpr (EPI == EPI_QKNORM) {
+        const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
+        const int64_t tok = m % p.tokens;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 c4 = *(const float4 *)(p.cosT + tok * 32 + 16 * h + 4 * q), s4 = *(const float4 *)(p.sinT + tok * 32 + 16 * h + 4 * q);
+            cs[4 * q] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
+            sn[4 * q] = s4.x; sn[4 * q + 1] = s4.y; sn[4 * q + 2] = s4.z; sn[4 * q + 3] = s4.w;
+        }
+    }
     // a workgroup owns one chunk of the output columns of its stripe (see launch_rows)
     const int ntiles = p.N / 32 / nchunks, tile0 = chunk * ntiles;
     const int rot = 2 * ((int)stripe % (ntiles / 2));
@@ -286,6 +367,15 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     } while (0)
 #define VSDE_U_LOAD(t_)                                                                                       \
     do {                                                                                                      \
+        if constexpr (EPI == EPI_QKNORM) {   /* residual values of a v head: requested when its tile pair begins */ \
+            const int tl_ = tile0 + ((t_) + rot) % ntiles, pp_ = tl_ >> 1, kind_ = pp_ / p.heads;              \
+            if (p.V0 != nullptr && (tl_ & 1) == 0 && kind_ == 2) {                                            \
+                const int64_t m_ = row0 + r < p.M ? row0 + r : p.M - 1;                                       \
+                const uint16_t *v_ = p.V0 + m_ * ((int64_t)p.heads * 64) + (pp_ - 2 * p.heads) * 64 + 16 * h; \
+                ureg[0] = *(const u32x4 *)v_; ureg[1] = *(const u32x4 *)(v_ + 8);                             \
+                ureg[2] = *(const u32x4 *)(v_ + 32); ureg[3] = *(const u32x4 *)(v_ + 40);                     \
+            }                                                                                                 \
+        }                                                                                                     \
         if constexpr (EPI == EPI_SWIGLU_BWD) {                                                                \
             const int n0_ = (tile0 + ((t_) + rot) % ntiles) * 32;                                             \
             _Pragma("unroll") for (int i = 0; i < 4 * RB; ++i) {                                              \
@@ -302,7 +392,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
         f32x16 acc[RB];                                                                                       \
         rows_tile_mfma<KC, RB>(acc, afr, Bs + r * LDB + 8 * h);                                               \
-        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane); \
+        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds); \
         if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE);                                    \
         lds_barrier();                                                                                        \
         if ((t_) + 2 < ntiles) VSDE_TILE_LOAD((t_) + 2);                                                      \
@@ -462,6 +552,9 @@ static int launch_cols(const LinParams &p, hipStream_t s) {
     return 0;
 }
 
+// EPI_QKNORM is instantiated for K = 256 only (the encoder width it was written for)
+static int launch_qknorm(const LinParams &p, hipStream_t s) { return launch_rows<256, EPI_QKNORM>(p, s); }
+
 // 1 = rows kernel, 2 = cols kernel, 0 = shape not covered (the caller keeps its library GEMM)
 static int lin_variant(int N, int K, int epilogue) {
     const bool rows_ok = (K == 128 || K == 256) && N % 64 == 0;   // K = 512 would need 172 KB of LDS: cols kernel
@@ -508,4 +601,25 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
     VSDE_CHECK_ARG(y && u_in && ldy >= 2 * N && ldu >= 2 * N && ldy % 8 == 0 && ldu % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
                    ((uintptr_t)u_in % 16) == 0, VSDE_E_BADARG, "bad SwiGLU-backward epilogue buffers");
     return launch_rows_k<EPI_SWIGLU_BWD>(p, st);
+}
+
+extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads,
+                                       int gate_width, int tokens, const float *cosT, const float *sinT, const float *wq,
+                                       const float *wk, const void *v0, const float *lam, double eps, void *q, void *k, void *v,
+                                       void *gate, int64_t ldg, void *stream) {
+    VSDE_CHECK_ARG(x && w && q && k && v && cosT && sinT && wq && wk && M > 0 && heads > 0 && tokens > 0, VSDE_E_BADARG,
+                   "bad linear_qknorm arguments");
+    VSDE_CHECK_ARG(K == 256 && gate_width % 64 == 0 && gate_width >= 0 && (gate_width == 0 || (gate && ldg >= gate_width && ldg % 8 == 0)),
+                   VSDE_E_BADARG, "linear_qknorm is built for K = 256, head_dim 64 and a gate block that is a multiple of 64 wide");
+    VSDE_CHECK_ARG((!v0) == (!lam), VSDE_E_BADARG, "residual values and their mixing weight go together");
+    VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)q % 16) == 0 &&
+                   ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)cosT % 16) == 0 && ((uintptr_t)sinT % 16) == 0,
+                   VSDE_E_BADARG, "linear_qknorm operands must be 16-byte aligned");
+    LinParams p = {};
+    p.A = (const uint16_t *)x; p.lda = ldx; p.W = (const uint16_t *)w; p.bias = (const uint16_t *)bias;
+    p.M = M; p.N = 3 * heads * 64 + gate_width; p.K = K;
+    p.Qo = (uint16_t *)q; p.Ko = (uint16_t *)k; p.Vo = (uint16_t *)v; p.Go = (uint16_t *)gate; p.ldg = ldg;
+    p.cosT = cosT; p.sinT = sinT; p.wq = wq; p.wk = wk; p.lam = lam; p.V0 = (const uint16_t *)v0;
+    p.heads = heads; p.tokens = tokens; p.eps = (float)eps;
+    return launch_qknorm(p, (hipStream_t)stream);
 }

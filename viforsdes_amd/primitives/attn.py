@@ -78,6 +78,18 @@ class Attention(nn.Module):
                 pack = fused.row_pack([self.qkv_proj.weight, self.gate_proj.weight],
                                       [self.qkv_proj.bias, self.gate_proj.bias] if has_b else None)
                 object.__setattr__(self, "_proj_pack", pack)
+            if fused.projection_split_nograd_usable(hidden_states, pack, self.num_heads, self.head_dim, self.q_norm.weight, cos):
+                # posterior sampling: projection, QK-norm, RoPE, value mix and head layout in ONE kernel; no [B,N,3C+d] intermediate
+                q, k, v, glog = fused.projection_split_nograd(hidden_states, pack, cos, sin, self.q_norm.weight, self.k_norm.weight,
+                                                              v0.transpose(1, 2) if mix else None,
+                                                              self.v_residual_lambda if mix else None, self.num_heads,
+                                                              self.q_norm.eps)
+                if fused.attention_usable(q):
+                    out_tm = fused.attention(q, k, v, self.head_dim ** -0.5)
+                else:
+                    out_tm = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+                merged = fused._hip.gate_merge_fwd(out_tm.contiguous(), glog, True)
+                return lin(merged, self.out_proj.weight, self.out_proj.bias), v.transpose(1, 2)
             y = fused.packed_linear(hidden_states, pack)
         else:
             W = torch.cat([self.qkv_proj.weight, self.gate_proj.weight], dim=0)

@@ -324,6 +324,29 @@ def attention_projection_split(y: Tensor, cos: Tensor, sin: Tensor, wq: Tensor, 
     return _QkNormRopeJoint.apply(y.contiguous(), cos, sin, wq, wk, v0, lam, heads, eps, token_major, 3 * heads * d, link, v0link)
 
 
+def projection_split_nograd_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, cos: Tensor) -> bool:
+    """The no-grad form of [qkv | gate] projection + attention_projection_split as ONE kernel (GEMM with the QK-norm / RoPE /
+    value-mix epilogue): K = 256, head_dim 64, a gate block that is a multiple of 64 wide, fp32 norm weights and tables."""
+    rows = x.numel() // x.shape[-1]
+    return (OWN_GEMM and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and d == 64
+            and pack.weight.shape[0] >= 3 * heads * 64 and (pack.weight.shape[0] - 3 * heads * 64) % 64 == 0 and rows > 0
+            and wq.dtype == torch.float32 and cos.dtype == torch.float32 and cos.shape[-1] == 32)
+
+
+@torch.no_grad()
+def projection_split_nograd(x: Tensor, pack: "PackedWeight", cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor,
+                            v0: Optional[Tensor], lam: Optional[Tensor], heads: int, eps: float):
+    """(q, k, v [B,N,heads,64], gate logits [B,N,G]) for x [B,N,256]; v0 token-major [B,N,heads,64] or None."""
+    B, N, K = x.shape
+    w, b = pack.operands()
+    v0c = v0.to(torch.bfloat16).contiguous() if v0 is not None else None
+    lamc = lam.detach().float().reshape(1).contiguous() if lam is not None and v0 is not None else None
+    q, k, v, g = _hip.linear_qknorm_bf16(x.reshape(B * N, K), w, b, heads, N, cos.contiguous(), sin.contiguous(), wq.contiguous(),
+                                         wk.contiguous(), v0c, lamc, eps)
+    shape = (B, N, heads, 64)
+    return q.view(shape), k.view(shape), v.view(shape), (g.view(B, N, -1) if g is not None else None)
+
+
 def gate_merge_joint(attn: Tensor, y: Tensor, heads: int, token_major: bool, link: GradLink) -> Tensor:
     """gate_merge with the gate logits taken from the last d columns of ``y`` (see attention_projection_split)."""
     d = y.shape[-1] // (3 * heads + 1)
