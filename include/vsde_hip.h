@@ -257,6 +257,11 @@ int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias
 int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads, int gate_width,
                             int tokens, const float *cosT, const float *sinT, const float *wq, const float *wk, const void *v0,
                             const float *lam, double eps, void *q, void *k, void *v, void *gate, int64_t ldg, void *stream);
+/* No-grad attention output projection with gate_merge folded into the operand load (primitives/attn.py:107-110):
+ * y = (attn * sigmoid(gate[:, k % 64])) W^T + b for attn [M][K] (token-major heads of 64), gate logits [M][ldgate].
+ * Rows kernel shapes only (K in {128, 256}, N % 64 == 0). */
+int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int64_t ldgate, const void *w, const void *bias, void *y,
+                           int64_t ldy, int64_t M, int N, int K, void *stream);
 
 /* ---- Batched Euler-Maruyama simulator of the MODEL SDE (parameter pre-training stage) --------------------------------
  * Replaces the T-step Python loop of core/euler_maruyama.py:11-45 (called from trainer.py:246-259 with 4096 paths) for

@@ -58,7 +58,7 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
-    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -741,6 +741,19 @@ def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
               ctypes.c_int(G), ctypes.c_int(tokens), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
               ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), _stream(dev))
     return q, k, v, gate
+
+
+def linear_gated_bf16(attn: torch.Tensor, gate: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """y [M,N] = (attn [M,K] * sigmoid(gate [M,64] broadcast over the heads)) w^T + bias: gate_merge folded into the GEMM."""
+    lib = load(); dev = _require_hip(attn, gate, w)
+    attn, ldx = _rows2d(attn); gate, ldg = _rows2d(gate)
+    M, K = attn.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_gated_bf16, _ptr(attn), _i64(ldx), _ptr(gate), _i64(ldg), _ptr(w), _ptr(bias), _ptr(y), _i64(N), _i64(M),
+              ctypes.c_int(N), ctypes.c_int(K), _stream(dev))
+    return y
 
 
 def linear_swiglu_bwd_bf16(dy: torch.Tensor, w_t: torch.Tensor, u: torch.Tensor):

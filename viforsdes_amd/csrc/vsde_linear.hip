@@ -50,6 +50,8 @@ struct LinParams {
     const float *cosT, *sinT, *wq, *wk, *lam;   // rotary tables [tokens][32], RMS weights [64], value-mix weight [1]
     const uint16_t *V0;                         // residual values [M][heads*64] or nullptr
     int heads, tokens; float eps;
+    // gated A operand (no-grad out projection): row m of A is multiplied by sigmoid(Gate[m][k % 64]) on its way into the registers
+    const uint16_t *Gate; int64_t ldgate;
     int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
 };
 
@@ -332,6 +334,18 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
+        if (EPI == EPI_PLAIN && p.Gate != nullptr) {   // workgroup-uniform: gate_merge (primitives/attn.py:107-109) folded into the load:
+            const uint16_t *gsrc = p.Gate + m * p.ldgate + 8 * h;   // a[k] * rnd(sigmoid(g[k % 64])), rounded to bf16 like the kernel's output
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 a = __builtin_bit_cast(u32x4, afr[rb][ks]), g = *(const u32x4 *)(gsrc + (ks & 3) * 16);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf16x2(bf_lo(a[e]) * rbf(sigm_f(bf_lo(g[e]))), bf_hi(a[e]) * rbf(sigm_f(bf_hi(g[e]))));
+                afr[rb][ks] = __builtin_bit_cast(bf16x8, o);
+            }
+        }
     }
     __shared__ float wlds[128];   // EPI_QKNORM: [wq | wk]
     if constexpr (EPI == EPI_QKNORM) { if (tid < 128) wlds[tid] = tid < 64 ? p.wq[tid] : p.wk[tid - 64]; }   // visible after the first barrier
@@ -622,4 +636,17 @@ extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w
     p.cosT = cosT; p.sinT = sinT; p.wq = wq; p.wk = wk; p.lam = lam; p.V0 = (const uint16_t *)v0;
     p.heads = heads; p.tokens = tokens; p.eps = (float)eps;
     return launch_qknorm(p, (hipStream_t)stream);
+}
+
+extern "C" int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int64_t ldgate, const void *w, const void *bias,
+                                      void *y, int64_t ldy, int64_t M, int N, int K, void *stream) {
+    VSDE_CHECK_ARG(attn && gate && w && y && M > 0 && N > 0, VSDE_E_BADARG, "bad linear_gated arguments");
+    VSDE_CHECK_ARG((K == 128 || K == 256) && N % 64 == 0, VSDE_E_BADARG, "linear_gated runs on the rows kernel: K in {128, 256}, N %% 64 == 0");
+    VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ldgate >= 64 && ldgate % 8 == 0 && ldy >= N && ldy % 8 == 0 && ((uintptr_t)attn % 16) == 0 &&
+                   ((uintptr_t)gate % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, VSDE_E_BADARG,
+                   "linear_gated operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    LinParams p = {};
+    p.A = (const uint16_t *)attn; p.lda = ldx; p.W = (const uint16_t *)w; p.bias = (const uint16_t *)bias;
+    p.C = (uint16_t *)y; p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.Gate = (const uint16_t *)gate; p.ldgate = ldgate;
+    return launch_rows_k<EPI_PLAIN>(p, (hipStream_t)stream);
 }

@@ -88,6 +88,13 @@ class Attention(nn.Module):
                     out_tm = fused.attention(q, k, v, self.head_dim ** -0.5)
                 else:
                     out_tm = _sdpa(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+                B_, N_ = hidden_states.shape[0], hidden_states.shape[1]
+                if glog.shape[-1] == 64 and self.head_dim == 64 and self.out_proj.weight.shape[0] % 64 == 0:
+                    # gate_merge folded into the out projection's operand load (one kernel instead of two)
+                    po = fused.plain_pack(self.out_proj.weight, self.out_proj.bias)
+                    wo, bo = po.operands()
+                    y_out = fused._hip.linear_gated_bf16(out_tm.contiguous().view(B_ * N_, self.embed_dim), glog.reshape(B_ * N_, 64), wo, bo)
+                    return y_out.view(B_, N_, -1), v.transpose(1, 2)
                 merged = fused._hip.gate_merge_fwd(out_tm.contiguous(), glog, True)
                 return lin(merged, self.out_proj.weight, self.out_proj.bias), v.transpose(1, 2)
             y = fused.packed_linear(hidden_states, pack)
