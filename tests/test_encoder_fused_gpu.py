@@ -344,3 +344,24 @@ def test_nograd_projection_kernel_matches_the_training_path(residual_v, B, N):
         assert torch.isfinite(a).all()
         assert float((a - b_).abs().max()) <= 2.0 ** -6 * float(b_.abs().max())
         assert float((a != b_).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("M,N,K", [(31, 832, 256), (1, 64, 8), (20000, 832, 256), (3000, 264, 520)])
+def test_linear_wgrad_edge_shapes_and_row_map(M, N, K):
+    """Fewer rows than one 32-row block, one row, the [q|k|v|gate] width (6.5 tiles of 128), sizes that are no multiple of the
+    tile edges; and the row-mapped form: product row n stored at row_map[n] (negative = dropped), bias likewise."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    ref_w = (dy.double().t() @ x.double()).cpu().numpy()
+    ref_b = dy.double().sum(0).cpu().numpy()
+    dW, db = _hip.linear_wgrad(dy, x, True)
+    assert rel_err(dW.cpu().numpy(), ref_w) < 2e-5 and rel_err(db.cpu().numpy(), ref_b) < 2e-5
+    perm = torch.randperm(N, generator=g)
+    keep = perm[: N - N // 8]                      # one eighth of the rows is dropped
+    row_map = torch.full((N,), -1, dtype=torch.int32)
+    row_map[keep] = torch.arange(keep.numel(), dtype=torch.int32)
+    dWm, dbm = _hip.linear_wgrad(dy, x, True, row_map.to(DEV), keep.numel())
+    assert dWm.shape == (keep.numel(), K)
+    assert torch.equal(dWm, dW[keep.to(DEV)]) and torch.equal(dbm, db[keep.to(DEV)])
