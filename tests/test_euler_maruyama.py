@@ -116,3 +116,40 @@ def test_hip_simulator_linear_diagonal_matches_torch_loop():
             em.HIP_SIMULATOR = True
     for a, b in zip(*outs):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_simulator_propagates_nan_like_the_torch_loop():
+    """A path whose theta draw is NaN (or overflows to inf - inf) must come out NaN on the positive dims too, exactly as
+    ``torch.maximum`` / ``clamp`` do in the reference loop (core/euler_maruyama.py:38-42): ``fmaxf(NaN, 1e-6)`` would hide it
+    from the non-finite-loss guard of the pre-training loop (trainer.py:240-247)."""
+    from viforsdes_amd.core import euler_maruyama as em
+    from viforsdes_amd.examples.sdes import LotkaVolterra, OrnsteinUhlenbeck
+    from viforsdes_amd.inference.evidence_lower_bound import sde_coefficients
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    for sde, S, pos in ((LotkaVolterra(), 2, [0, 1]), (OrnsteinUhlenbeck(), 1, [0])):
+        B, T = 6, 12
+        theta = (0.1 + torch.rand(B, 3, generator=g)).to(dev)
+        theta[1, 0] = float("nan")
+        theta[4, 2] = float("inf")
+        x0 = (1.0 + torch.rand(B, S, generator=g)).to(dev)
+        noise = torch.randn(B, T, S, generator=g).to(dev)
+        outs = []
+        for hip in (True, False):
+            em.HIP_SIMULATOR = hip
+            try:
+                outs.append(em.euler_maruyama(sde, x0, theta, T * 0.1, 0.1, pos, noise=noise))
+            finally:
+                em.HIP_SIMULATOR = True
+        k, t = outs
+        assert torch.equal(torch.isnan(k), torch.isnan(t)) and bool(torch.isnan(k[1, 1:]).all())
+        ok = ~torch.isnan(t) & ~torch.isinf(t)
+        assert rel_err(k[ok].cpu().numpy(), t[ok].cpu().numpy()) < 2e-5
+        # the ELBO's coefficient kernel: NaN state or parameter -> NaN coefficients, as the Python callables give
+        xs = k.clone()
+        drift, diff = sde_coefficients(sde, xs, theta)
+        xf = xs[:, :-1].reshape(B * T, S)
+        tf = theta.unsqueeze(1).expand(B, T, -1).reshape(B * T, -1)
+        assert torch.equal(torch.isnan(drift.reshape(B * T, S)), torch.isnan(sde.drift(xf, tf)))
+        assert torch.equal(torch.isnan(diff.reshape(B * T, S, S)), torch.isnan(sde.diffusion(xf, tf)))

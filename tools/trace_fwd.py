@@ -5,7 +5,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/libvsde_trace.so"
-src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in ("vsde_gemm.hip", "vsde_head.hip", "vsde_elbo.hip", "vsde_encoder.hip", "vsde_wgrad.hip", "vsde_attn.hip")]
+sys.path.insert(0, ROOT)
+from viforsdes_amd.build import SOURCES
+src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in SOURCES]
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
 import viforsdes_amd.build as b
 b.LIB_PATH = so
@@ -18,7 +20,7 @@ rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
 NO = S + S * (S + 1) // 2
 ws = [rn(3*H, S+C+P, sc=.08), rn(3*H, H, sc=.12), rn(3*H, sc=.1), rn(3*H, sc=.1), rn(L-1, 3*H, H, sc=.12), rn(L-1, 3*H, H, sc=.12),
       rn(L-1, 3*H, sc=.1), rn(L-1, 3*H, sc=.1), rn(NO, H, sc=.1), torch.ones(NO).to(dev)]
-x0, ctx, theta, eps = rn(B, S), rn(B, T+1, C)[:, :-1], rn(B, P).abs(), rn(B, T, S)
+x0, ctx, theta, eps = rn(B, S), rn(B, T+1, C).to(torch.bfloat16)[:, :-1], rn(B, P).abs(), rn(B, T, S)
 for save in (False, True):
     _hip.head_forward(x0, ctx, theta, eps, ws, 0.1, save)
     torch.cuda.synchronize()

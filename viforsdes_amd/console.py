@@ -44,12 +44,12 @@ class TrainingProgress:
                 self.iter_per_sec = instant if self.iter_per_sec == 0.0 else 0.9 * self.iter_per_sec + 0.1 * instant
             self._last_step, self._last_time = step, now
         emit = self.console.enabled and ((step + 1) % self.update_interval == 0 or step + 1 == self.total)
-        self.last = dict(step=step, loss=loss, elbo=elbo, best_elbo=best_elbo, grad_norm=_scalar(grad_norm),
+        self.last = dict(step=step, loss=loss, elbo=elbo, best_elbo=best_elbo, grad_norm=grad_norm,
                          iter_per_sec=self.iter_per_sec, elapsed_s=now - self._start_time)
         if not emit:
             return
         m = self.metrics(components, param_means)
-        msg = (f"[{step + 1}/{self.total}] loss {loss:.4f} elbo {elbo:.4f} best {best_elbo:.4f} "
+        msg = (f"[{step + 1}/{self.total}] loss {m['loss']:.4f} elbo {m['elbo']:.4f} best {m['best_elbo']:.4f} "
                f"{m['iter_per_sec']:.2f} it/s eta {m['eta_s']:.0f}s")
         if m["grad_norm"] is not None:
             msg += f" |g| {m['grad_norm']:.3g}"
@@ -66,6 +66,9 @@ class TrainingProgress:
         """Everything the reference's panel shows, as plain numbers (device scalars are synchronised here, i.e. only
         when a line is actually emitted)."""
         m = dict(self.last)
+        for key in ("loss", "elbo", "best_elbo", "grad_norm"):   # device scalars: the only place they are synchronised
+            if m.get(key) is not None:
+                m[key] = _scalar(m[key])
         step = m.get("step", -1)
         m["eta_s"] = (self.total - step - 1) / max(self.iter_per_sec, 0.01)
         if components is not None:

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from .sde import SDE
+from .sde import SDE, builtin_sde_kind
 
 
 def euler_maruyama(sde: SDE, x0: Tensor, theta: Tensor, time_horizon: float, dt: float,
@@ -28,7 +28,7 @@ def euler_maruyama(sde: SDE, x0: Tensor, theta: Tensor, time_horizon: float, dt:
     if noise is None:
         noise = torch.randn(batch, n_steps, state_dim, device=x0.device, dtype=x0.dtype)
     pos = list(positive_dims)
-    kind = getattr(sde, "builtin_kind", None)
+    kind = builtin_sde_kind(sde)
     if kind is not None and x0.is_cuda and x0.dtype == torch.float32 and HIP_SIMULATOR:
         from .. import _hip
         if kind in _hip.SDE_KINDS and noise.shape == (batch, n_steps, state_dim):

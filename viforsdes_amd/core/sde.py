@@ -39,3 +39,24 @@ class FunctionalSDE:
 
 def make_sde(drift: TensorFn, diffusion: TensorFn, state_dim: int, sde_param_dim: int) -> SDE:
     return FunctionalSDE(drift, diffusion, state_dim, sde_param_dim)
+
+
+def builtin_sde_kind(sde: object) -> str | None:
+    """The HIP library's name for ``sde`` when -- and only when -- its drift and diffusion are exactly the closed forms the
+    library implements (csrc/vsde_sde.hip), else None (the Python callables are then used).
+
+    ``builtin_kind`` is a class attribute of the example SDEs and is therefore inherited: a subclass that overrides
+    ``drift`` or ``diffusion`` (or an instance that shadows them) must NOT be routed to the built-in kernels, which would
+    silently ignore the override.  The dispatch holds only if both callables still resolve to the functions of the class
+    that declared ``builtin_kind``, and the dimensions are inside what the kernels accept (linear-diagonal: state_dim <= 32)."""
+    cls = type(sde)
+    owner = next((c for c in cls.__mro__ if "builtin_kind" in vars(c)), None)
+    if owner is None or "builtin_kind" in getattr(sde, "__dict__", {}):
+        return None
+    kind = vars(owner)["builtin_kind"]
+    for name in ("drift", "diffusion"):
+        if name in getattr(sde, "__dict__", {}) or getattr(cls, name, None) is not vars(owner).get(name):
+            return None
+    if kind == "linear_diagonal" and not (1 <= int(getattr(sde, "state_dim", 0)) <= 32):
+        return None
+    return kind

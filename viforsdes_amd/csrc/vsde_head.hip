@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(512) head_fwd_kernel(FwdParams p) {
             wave_lds_fence();  // hbuf is rewritten by the next layer
         }
         // ---- emission (forward.py:314-375): lane k < S holds mu_k, lane S+q holds tril entry q
-        float lval = is_diag ? fmaxf(o, p.diag_min) : o;
+        float lval = (is_diag && o < p.diag_min) ? p.diag_min : o;  // NaN propagates (torch.max semantics)
         obuf[lane] = lane < S ? o : lval;
         if (lane < S) ebuf[lane] = ecur;
         wave_lds_fence();
@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
             VSDE_TP(10);
             if (SMALL) {
                 // o of row r sits on lanes 4r..4r+3 of EVERY wave: no LDS exchange, no barrier
-                const float oc = is_diag ? fmaxf(o, p.diag_min) : o;
+                const float oc = (is_diag && o < p.diag_min) ? p.diag_min : o;  // NaN propagates (torch.max semantics)
                 if (wave == 0 && kq == 0 && is_tril) {
                     s_chol[tt * S * S + trow * S + tcol] = oc;  // strict upper triangle stays 0 (zeroed once)
                     if (SAVE) s_raw[tt * p.ntril + (orow - S)] = o;
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                 VSDE_TP(11);
             } else {
                 if (kq == 0 && row_ok) {
-                    obuf[j] = is_diag ? fmaxf(o, p.diag_min) : o;
+                    obuf[j] = (is_diag && o < p.diag_min) ? p.diag_min : o;
                     if (SAVE && j >= S) s_raw[tt * p.ntril + (j - S)] = o;
                 }
                 __syncthreads();
@@ -1217,7 +1217,7 @@ __global__ void head_fwd_wide_kernel(FwdParams p, int L) {
             if (r >= S) {
                 int q = r - S, rr = 0;
                 while ((rr + 1) * (rr + 2) / 2 <= q) ++rr;
-                if (q - rr * (rr + 1) / 2 == rr) acc = fmaxf(acc, p.diag_min);
+                if (q - rr * (rr + 1) / 2 == rr && acc < p.diag_min) acc = p.diag_min;
             }
             obuf[r] = acc;
         }

@@ -16,6 +16,9 @@ namespace vsde {
 constexpr int kEmPaths = 64;   // paths per workgroup (one wavefront)
 constexpr int kEmChunk = 32;   // time steps staged per LDS round
 constexpr float kEmFloor = 1e-6f;
+// clamp(min = 1e-6) that propagates NaN like torch.clamp / torch.maximum do (fmaxf(NaN, floor) would return the floor and hide a
+// diverged path from the non-finite-loss guards of the pre-training loop and the ELBO)
+__device__ __forceinline__ float floor_nan(float y) { return y < kEmFloor ? kEmFloor : y; }
 
 struct EmParams {
     int B, T, S, P;
@@ -36,9 +39,9 @@ __device__ __forceinline__ void em_step(const float *x, const float *th, const f
         y[0] = x[0] + th[0] * (th[1] - x[0]) * dt + th[2] * e[0] * sqdt;
     } else if constexpr (KIND == 2) {
         const float u = x[0], v = x[1], uv = th[1] * u * v;
-        const float l00 = sqrtf(fmaxf(th[0] * u + uv, kEmFloor));
-        const float l10 = -uv / fmaxf(l00, kEmFloor);
-        const float l11 = sqrtf(fmaxf(th[2] * v + uv - l10 * l10, kEmFloor));
+        const float l00 = sqrtf(floor_nan(th[0] * u + uv));
+        const float l10 = -uv / floor_nan(l00);
+        const float l11 = sqrtf(floor_nan(th[2] * v + uv - l10 * l10));
         y[0] = u + (th[0] * u - uv) * dt + (l00 * e[0]) * sqdt;
         y[1] = v + (uv - th[2] * v) * dt + (l10 * e[0] + l11 * e[1]) * sqdt;
     } else {
@@ -55,9 +58,9 @@ __device__ __forceinline__ void em_step_bwd(const float *x, const float *th, con
         ax[0] = a[0] * (1.f - th[0] * dt);
     } else if constexpr (KIND == 2) {
         const float u = x[0], v = x[1], t1 = th[0], t2 = th[1], t3 = th[2], uv = t2 * u * v;
-        const float q00r = t1 * u + uv, l00 = sqrtf(fmaxf(q00r, kEmFloor));
-        const float c = fmaxf(l00, kEmFloor), l10 = -uv / c;
-        const float q11r = t3 * v + uv - l10 * l10, l11 = sqrtf(fmaxf(q11r, kEmFloor));
+        const float q00r = t1 * u + uv, l00 = sqrtf(floor_nan(q00r));
+        const float c = floor_nan(l00), l10 = -uv / c;
+        const float q11r = t3 * v + uv - l10 * l10, l11 = sqrtf(floor_nan(q11r));
         const float d_f0 = a[0] * dt, d_f1 = a[1] * dt, d_l11 = a[1] * e[1] * sqdt;
         float d_l00 = a[0] * e[0] * sqdt, d_l10 = a[1] * e[0] * sqdt;
         float d_u = a[0], d_v = a[1], d_uv = 0.f, d_t1 = 0.f, d_t3 = 0.f;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(kEmPaths) em_fwd_kernel(EmParams p) {
             em_step<KIND>(x, th, noise_s + lane * RS + k * S, p.dt, p.sqdt, y);
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                x[i] = ((p.pos_mask >> i) & 1u) ? fmaxf(y[i], kEmFloor) : y[i];
+                x[i] = ((p.pos_mask >> i) & 1u) ? floor_nan(y[i]) : y[i];
                 traj_s[lane * RS + k * S + i] = x[i];
             }
         }
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(256) em_diag_fwd_kernel(EmParams p) {
     for (int t = 0; t < p.T; ++t) {
         float y;
         em_step<3>(&x, th, nz + (int64_t)t * p.S, p.dt, p.sqdt, &y);
-        x = pos ? fmaxf(y, kEmFloor) : y;
+        x = pos ? floor_nan(y) : y;
         tr[(int64_t)(t + 1) * p.S] = x;
     }
 }
@@ -228,9 +231,9 @@ template <int KIND> __device__ __forceinline__ void coef_fwd(const float *x, con
         f[0] = th[0] * (th[1] - x[0]); G[0] = th[2];
     } else {
         const float u = x[0], v = x[1], uv = th[1] * u * v;
-        const float l00 = sqrtf(fmaxf(th[0] * u + uv, kEmFloor));
-        const float l10 = -uv / fmaxf(l00, kEmFloor);
-        const float l11 = sqrtf(fmaxf(th[2] * v + uv - l10 * l10, kEmFloor));
+        const float l00 = sqrtf(floor_nan(th[0] * u + uv));
+        const float l10 = -uv / floor_nan(l00);
+        const float l11 = sqrtf(floor_nan(th[2] * v + uv - l10 * l10));
         f[0] = th[0] * u - uv; f[1] = uv - th[2] * v;
         G[0] = l00; G[1] = 0.f; G[2] = l10; G[3] = l11;
     }
@@ -243,9 +246,9 @@ __device__ __forceinline__ void coef_bwd(const float *x, const float *th, const 
         gx[0] = -gf[0] * th[0];
     } else {
         const float u = x[0], v = x[1], t1 = th[0], t2 = th[1], t3 = th[2], uv = t2 * u * v;
-        const float q00r = t1 * u + uv, l00 = sqrtf(fmaxf(q00r, kEmFloor));
-        const float c = fmaxf(l00, kEmFloor), l10 = -uv / c;
-        const float q11r = t3 * v + uv - l10 * l10, l11 = sqrtf(fmaxf(q11r, kEmFloor));
+        const float q00r = t1 * u + uv, l00 = sqrtf(floor_nan(q00r));
+        const float c = floor_nan(l00), l10 = -uv / c;
+        const float q11r = t3 * v + uv - l10 * l10, l11 = sqrtf(floor_nan(q11r));
         float d_l00 = gG[0], d_l10 = gG[2];
         float d_u = 0.f, d_v = 0.f, d_uv = 0.f, d_t1 = 0.f, d_t3 = 0.f;
         const float d_q11 = q11r >= kEmFloor ? gG[3] / (2.f * l11) : 0.f;

@@ -16,7 +16,7 @@ from torch.autograd.function import once_differentiable
 
 from ..core.observations import ObservationLikelihood, Observations
 from ..core.priors import Prior
-from ..core.sde import SDE
+from ..core.sde import SDE, builtin_sde_kind
 from ..kernels.backend import get_backend
 from ..models.sde_parameter_posterior import SDEParameterPosterior
 from .types import DiffusionPathSample, EvidenceLowerBoundComponents, EvidenceLowerBoundResult
@@ -70,7 +70,7 @@ class _BuiltinCoefficients(torch.autograd.Function):
 def sde_coefficients(sde: SDE, x: Tensor, sde_parameters: Tensor) -> tuple[Tensor, Tensor]:
     """Drift ``[B,T,S]`` and diffusion ``[B,T,S,S]`` on the first T grid points of ``x [B,T+1,S]`` (reference lines 37-40)."""
     B, n_steps, S = x.shape[0], x.shape[1] - 1, x.shape[2]
-    kind = getattr(sde, "builtin_kind", None)
+    kind = builtin_sde_kind(sde)
     if kind is not None and HIP_COEFFICIENTS and x.is_cuda and x.dtype == torch.float32:
         from .. import _hip
         if kind in _hip.SDE_KINDS:

@@ -24,12 +24,22 @@ class SDEParameterPosterior(nn.Module):
         if any(d < 0 or d >= sde_param_dim for d in sde_param_positive_dims):
             raise ValueError(f"sde_param_positive_dims must be in [0, {sde_param_dim})")
         self.sde_param_dim = sde_param_dim
-        self._positive_dims = tuple(sorted(set(int(d) for d in sde_param_positive_dims)))   # host copy of positive_mask
+        self._positive_cache: tuple[int, tuple[int, ...]] | None = None
         self.mean = nn.Parameter(torch.zeros(sde_param_dim) if init_mean is None else init_mean.clone())
         self.log_std = nn.Parameter(torch.full((sde_param_dim,), math.log(init_std)))
         mask = torch.zeros(sde_param_dim, dtype=torch.bool)
         mask[list(sde_param_positive_dims)] = True
         self.register_buffer("positive_mask", mask)
+
+    @property
+    def _positive_dims(self) -> tuple[int, ...]:
+        """Host copy of ``positive_mask`` for the fused ELBO tail, re-derived whenever the buffer changes (``load_state_dict``
+        or an in-place edit bump its version counter), so the kernel's mask is always the one ``rsample`` drew with."""
+        mask = self.positive_mask
+        key = (mask._version, id(mask))
+        if self._positive_cache is None or self._positive_cache[0] != key:
+            self._positive_cache = (key, tuple(int(i) for i in torch.nonzero(mask.detach().cpu()).flatten().tolist()))
+        return self._positive_cache[1]
 
     def transform(self, unconstrained: Tensor) -> Tensor:
         return torch.where(self.positive_mask, unconstrained.exp(), unconstrained)

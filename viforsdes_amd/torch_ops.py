@@ -22,8 +22,8 @@ def sde_fwd(x0: Tensor, context: Tensor, sde_parameters: Tensor, eps: Tensor, we
     two are empty tensors unless ``save_activations``."""
     paths, means, chol, raw, acts = _hip.head_forward(x0, context, sde_parameters, eps, list(weights), float(time_step),
                                                       bool(save_activations))
-    empty = x0.new_empty(0)
-    return paths, means, chol, raw if raw is not None else empty, acts if acts is not None else empty
+    # custom-op outputs must not alias each other: two separate empty tensors
+    return (paths, means, chol, raw if raw is not None else x0.new_empty(0), acts if acts is not None else x0.new_empty(0))
 
 
 @sde_fwd.register_fake
