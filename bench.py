@@ -70,12 +70,15 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
     return tr
 
 
+PMC_FILE = "profiles/r02_pmc_head_lv.txt"
+
+
 def pmc_traffic_bytes(workload, batch):
     """HBM bytes per launch of the serial forward kernel (training variant) from the committed rocprofv3 --pmc passes
     (profiles/r02_pmc_head_lv.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed
     over the XCDs).  The kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
     counter is used; null for other workloads."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_head_lv.txt")
+    path = os.path.join(ROOT, PMC_FILE)
     if workload != "lv" or batch != 512 or not os.path.exists(path):
         return None
     vals, kernel = {}, ""
@@ -152,9 +155,11 @@ def cpu_baseline(lv, ou, lv_micro_batch, enc):
                    "sample": "OU T=100 S=1 full ELBO step, B=128 (the whole batch), fp32"}}
 
 
-def parity_gate(problem, enc, device, batch=16, steps=3):
+def parity_gate(problem, enc, device, batch=16, steps=3, name="LV"):
     """ELBO per step and theta ``expected_value`` after ``steps`` optimizer steps: GPU (fp32 and bf16-autocast encoder) vs
-    the CPU oracle path, same initial state, identical injected theta-eps and path noise."""
+    the CPU oracle path, same initial state, identical injected theta-eps and path noise.
+    BASELINE config 2 asks for exactly this on OU at its full batch (B=128, T=100); LV runs a 16-path batch of the T=400
+    problem (the host autograd footprint of more does not fit the time budget of a default run)."""
     from viforsdes_amd.kernels.backend import set_backend
     sde, obs, like, prior, horizon, dt, *_ = problem
     T, S, P = int(round(horizon / dt)), sde.state_dim, sde.sde_param_dim
@@ -175,7 +180,7 @@ def parity_gate(problem, enc, device, batch=16, steps=3):
         e_cpu, ev_cpu = run(cpu_tr, torch.device("cpu"))
     finally:
         set_backend(None)
-    res = {"workload": f"LV T={T} batch {batch}, {steps} optimizer steps from one initial state, injected noise",
+    res = {"workload": f"{name} T={T} batch {batch}, {steps} optimizer steps from one initial state, injected noise",
            "reference": "CPU oracle path (torch-CPU encoder + C oracle head/ELBO, fp32)",
            "elbo_cpu": e_cpu, "expected_value_cpu": ev_cpu}
     rel = lambda a, b: max(abs(x - y) / max(abs(y), 1e-12) for x, y in zip(a, b))
@@ -210,6 +215,12 @@ def self_launch(n, argv, script=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is drained while the ranks run: a full 64 KB pipe (RCCL with NCCL_DEBUG=INFO logs to stdout) would block
+    # rank 0 in write() and hang every rank in its next collective
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     pending = set(range(n))
     while pending:
@@ -223,8 +234,8 @@ def self_launch(n, argv, script=None):
                 for q in pending:  # a failed rank would leave the others hanging in a collective
                     procs[q].terminate()
         time.sleep(0.2)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
-    sys.stdout.write(out)
+    reader.join(timeout=30)
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     raise SystemExit(rc if rc else 0)
 
@@ -374,6 +385,30 @@ def main():
     macs_step = 3 * H * (S + H) + (L - 1) * 3 * H * 2 * H + (S + ntril) * H   # context / theta terms excluded: hoisted out of the loop
     valu_floor_ms = steps_per_launch * (macs_step / 64.0) * 4.0 / (256 * 4) / 2.4e9 * 1e3
 
+    # head-only sampling ("report head-only and encoder+head"): the no-grad eval launch of the path sampler on a
+    # resident bf16 context [B, T+1, C] sliced to [:, :-1], fresh N(0,1) noise per call; its serial kernel (the "fused GRU
+    # path-sampling kernel" of north_star, SAVE = false) is timed with HIP events on the launch stream (profile slot 0)
+    model.eval()
+    hctx = torch.randn(args.batch, T + 1, C, device=device, dtype=torch.bfloat16)
+    htheta = model.sde_parameter_posterior.rsample(args.batch).detach()
+    hx0 = tr.state_space.to_latent(ctx.x0_buffer).contiguous()
+
+    @torch.no_grad()
+    def head_sample_step():
+        eps = torch.randn(args.batch, T, S, device=device)
+        model.head.sample_diffusion_paths(hx0, hctx, htheta, eps, dt, context_has_extra_step=True)
+    h_elapsed = timed(head_sample_step, args.steps, max(2, args.warmup // 2), device, distributed)
+    _hip.profile_enable(True)
+    ev = []
+    for _ in range(5):
+        head_sample_step()
+        ev.append(_hip.profile_elapsed_ms(0))
+    _hip.profile_enable(False)
+    eval_ms = sum(ev) / len(ev)
+    model.train()
+    # SURVEY 8(d) eval bytes per path-step, bf16 context: 4 * [C/2 + S + 2S + S^2]
+    eval_bytes_step = 4 * (C // 2 + S + 2 * S + S * S)
+
     # encoder alone: forward + backward of the context (bf16 autocast), for the MFMA utilisation figure
     enc_mod = model.encoder
     mlp_hidden = enc_mod.sit.blocks[0].mlp.hidden_dim
@@ -400,6 +435,7 @@ def main():
     for p in model.parameters():
         p.grad = None
 
+    traffic = pmc_traffic_bytes(args.workload, args.batch)
     out = {
         "metric": "sampled-paths/sec + ELBO-iters/sec (full ELBO gradient step; value = global_batch * ELBO-iters/s)",
         "value": global_batch * iters_per_sec, "unit": "paths/s", "n_gpus": world, "steps": args.steps,
@@ -410,11 +446,14 @@ def main():
                    "global_batch": global_batch, "parallelism": f"dp{world}", "hip_graph": graph_mode},
         "elbo_iters_per_sec": iters_per_sec,
         "sampled_paths_per_sec": global_batch * args.steps / s_elapsed,
+        "sampled_paths_per_sec_head_only": global_batch * args.steps / h_elapsed,
         "rccl_ranks": dist.get_world_size() if distributed else 1,
         "allreduce_ms_per_step": allreduce_ms,
         "roofline": {"kernel": f"vsde head forward, serial GRU time-stepping kernel (training variant, L={L})",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(args.workload, args.batch),
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, "
+                                       "separate --pmc runs of tools/pmc_head.sh), not measured in this run",
                      "avg_ms": fwd_ms, "algorithmic_bytes": fwd_bytes_step * steps_per_launch,
                      "bytes_per_path_step": fwd_bytes_step, "path_steps_per_launch": steps_per_launch,
                      # the context read is done by the hoisted projection GEMM: the whole forward path priced with the same bytes
@@ -427,6 +466,12 @@ def main():
                                   "backward_path_ms": avg[3], "bytes_per_path_step": bwd_bytes_step,
                                   "achieved": gbs(bwd_bytes_step, bwd_ms), "frac": gbs(bwd_bytes_step, bwd_ms) / HBM_PEAK_GBS,
                                   "frac_whole_path": gbs(bwd_bytes_step, avg[3]) / HBM_PEAK_GBS}},
+        "roofline_eval": {"kernel": f"vsde head forward, serial GRU time-stepping kernel (no-grad sampling variant, L={L})",
+                          "bound": "hbm", "achieved": gbs(eval_bytes_step, eval_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs(eval_bytes_step, eval_ms) / HBM_PEAK_GBS, "traffic": None, "avg_ms": eval_ms,
+                          "algorithmic_bytes": eval_bytes_step * steps_per_launch, "bytes_per_path_step": eval_bytes_step,
+                          "path_steps_per_launch": steps_per_launch, "valu_floor_ms": valu_floor_ms,
+                          "frac_of_valu_floor": valu_floor_ms / eval_ms},
         "mfma_util": {"encoder_flops_per_step": enc_flops, "encoder_fwd_bwd_ms": enc_ms,
                       "achieved_tflops": enc_flops / (enc_ms * 1e-3) / 1e12, "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
                       "frac": enc_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -436,6 +481,9 @@ def main():
         del tr, model, ctx
         torch.cuda.empty_cache()
         out["parity"] = parity_gate(problem, enc, device)
+        # BASELINE config 2: OU (B=128, T=100) fused HIP GRU + ELBO, fp32 and bf16, vs the CPU path, with the tolerance
+        out["parity"]["ou"] = parity_gate(ou_problem(), dict(enc_hidden=256, enc_depth=8), device, batch=128, steps=3, name="OU")
+        out["parity"]["pass"] = bool(out["parity"]["pass"] and out["parity"]["ou"]["pass"])
         out["cpu_baseline"] = cpu_baseline(problem, ou_problem(), args.cpu_micro_batch, enc)
     elif rank == 0:
         out["parity"] = None
@@ -445,6 +493,8 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and out.get("parity") and not out["parity"]["pass"]:
+        raise SystemExit("parity gate failed: the GPU ELBO / posterior means left the stated tolerance of the CPU oracle path")
 
 
 if __name__ == "__main__":

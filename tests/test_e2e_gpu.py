@@ -229,3 +229,54 @@ def test_resume_reproduces_the_run_on_gpu():
     # (zero-initialised gates / modulators) shows up as an O(lr) difference: compare with an absolute bound of a few lr
     lr = tr.config.sde_param_lr
     assert all(float((a - b).abs().max()) <= 3 * 3 * lr for a, b in zip(p1, p2))
+
+
+def test_bf16_fused_trajectory_tracks_the_bf16_torch_chain():
+    """The benchmark's route (bf16 autocast, fused encoder operators, own MFMA GEMMs with cached bf16 operands, fused AdamW)
+    against the SAME arithmetic spelled with torch ops (autocast chain, fused operators off) from one initial state on
+    identical injected draws, at the OU example's size (B=128, T=100 => 12,928 token rows: every packed-operand path is
+    active).  Tight tolerance: both sides round to bf16 at almost the same points, so the ELBO trajectory over 6 optimizer
+    steps must agree to a few 1e-3 -- a stale weight cache, a wrong gradient piece or a bf16-only kernel bug of a few % all
+    fail here (the comparison with the fp32 reference has to allow for bf16 itself and would let them through).
+    Reference: trainer.py:166-206 (one step), primitives/mlp.py:50-54 / attn.py:46-54 (Linears under autocast)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_trainer
+    from viforsdes_amd.examples.sdes import ou_problem
+    from viforsdes_amd.primitives import fused
+    problem = ou_problem()
+    B, T, steps = 128, 100, 6
+    g = torch.Generator().manual_seed(5)
+    teps = [torch.randn(B, 3, generator=g).to(DEV) for _ in range(steps)]
+    noise = [torch.randn(B, T, 1, generator=g).to(DEV) for _ in range(steps)]
+    enc = dict(enc_hidden=128, enc_depth=2, heads=2)
+    ref = build_trainer(problem, B, torch.device(DEV), True, seed=31, **enc)
+    init = {k: v.clone() for k, v in ref.ctx.model.state_dict().items()}
+    del ref
+
+    def run(fused_on):
+        fused.ENABLED = fused_on
+        try:
+            tr = build_trainer(problem, B, torch.device(DEV), True, seed=31, **enc)
+            tr.ctx.model.load_state_dict(init)
+            tr.ctx.ema._init_shadow()
+            elbos = []
+            for k in range(steps):
+                r = tr._train_step(tr.ctx.model, theta_eps=teps[k], path_noise=noise[k])
+                elbos.append(float(r.elbo_result.evidence_lower_bound))
+            worst = 0.0
+            for pk in list(fused.PackedWeight._live):   # cached bf16 operands == their parameters after the last step
+                if any(any(q is p for p in tr.ctx.model.parameters()) for q in pk.params):
+                    for d, s in zip(*pk._copy_lists()):
+                        worst = max(worst, float((d.float() - s.to(torch.bfloat16).float()).abs().max()))
+                    if pk.weight_t is not None:
+                        worst = max(worst, float((pk.weight_t.float() - pk.weight.t().float()).abs().max()))
+            return elbos, tr.ctx.model.sde_parameter_posterior.expected_value.detach().cpu().numpy(), worst
+        finally:
+            fused.ENABLED = True
+    e_f, ev_f, stale = run(True)
+    e_t, ev_t, _ = run(False)
+    rel = max(abs(a - b) / abs(b) for a, b in zip(e_f, e_t))
+    print("\nbf16 fused vs bf16 torch chain: ELBO", e_f, e_t, "max rel", rel, "E[theta] rel", rel_err(ev_f, ev_t), "stale", stale)
+    assert stale == 0.0, "a cached bf16 GEMM operand no longer matches its parameter after the optimizer step"
+    assert rel < 5e-3 and rel_err(ev_f, ev_t) < 1e-3

@@ -117,3 +117,30 @@ def test_disabled_console_emits_nothing(tmp_path):
         for step in range(3):
             prog.update(step, 1.0, -1.0, -1.0, grad_norm=_CountingScalar(1.0))
     assert not path.exists()
+
+
+def test_packed_operands_follow_a_fused_optimizer_step():
+    """The cached bf16 GEMM operands must follow the parameters through the optimizer step the trainer uses.  The fused
+    (multi-tensor) AdamW kernel updates the parameters in place WITHOUT bumping ``Tensor._version``, so the version check of
+    ``PackedWeight`` alone would keep serving the first step's weights: ``refresh_all(force=True)`` is what the trainer
+    calls (reference semantics: ``nn.Linear`` under autocast re-casts its weight every forward, primitives/mlp.py:50-54)."""
+    from viforsdes_amd.primitives.fused import PackedWeight, plain_pack
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(16, 8))
+    b = torch.nn.Parameter(torch.randn(16))
+    pack = plain_pack(w, b)
+    wb, bb = pack.operands()
+    assert torch.equal(wb, w.detach().to(torch.bfloat16))
+    opt = torch.optim.AdamW([w, b], lr=0.1, fused=True)
+    w.grad, b.grad = torch.randn_like(w), torch.randn_like(b)
+    opt.step()
+    moved = not torch.equal(wb, w.detach().to(torch.bfloat16))
+    assert moved, "the step must have changed the bf16 image of the weight for this test to mean anything"
+    PackedWeight.refresh_all(force=True)
+    wb2, bb2 = pack.operands()
+    assert torch.equal(wb2, w.detach().to(torch.bfloat16)) and torch.equal(bb2, b.detach().to(torch.bfloat16))
+    tr = pack.transposed()
+    w.grad = torch.randn_like(w)
+    opt.step()
+    PackedWeight.refresh_all(force=True)
+    assert torch.equal(pack.transposed(), w.detach().to(torch.bfloat16).t()) and tr is pack.transposed()

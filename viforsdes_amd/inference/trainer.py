@@ -104,7 +104,8 @@ class VariationalInferenceTrainer:
         ctx.scaler.step(ctx.optimizer)
         ctx.scaler.update()
         if ctx.device.type == "cuda":
-            fused.PackedWeight.refresh_all()  # bf16 GEMM operands of the encoder follow the updated parameters
+            # bf16 GEMM operands of the encoder follow the updated parameters (forced: fused AdamW does not bump Tensor._version)
+            fused.PackedWeight.refresh_all(force=True)
         return grad_norm.detach()
 
     def _train_step(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,

@@ -421,8 +421,8 @@ class PackedWeight:
     The encoder's Linears need their weights in bf16 (autocast), some of them concatenated ([qkv | gate]) or zero-padded
     (SwiGLU width 682 -> 768).  With torch ops that is a cat/pad plus a cast per operand per step and their autograd nodes.
     A pack owns the assembled bf16 tensors, re-fills them only when a source parameter changed (``Tensor._version``), and
-    hands the fp32 gradient of the packed operand back to the parameters as views.  ``refresh_all()`` (called by the trainer
-    right after the optimizer step) re-fills every live pack with one multi-tensor copy.
+    hands the fp32 gradient of the packed operand back to the parameters as views.  ``refresh_all(force=True)`` (called by the
+    trainer right after the optimizer step) re-fills every live pack with one multi-tensor copy.
 
     ``weight_pieces`` / ``bias_pieces``: lists of ``(param, src_row, n, dst_row)``: rows ``src_row:src_row+n`` of the 2-D
     (1-D) parameter land in rows ``dst_row:dst_row+n`` of the packed weight (bias), columns ``:param.shape[1]``; everything
@@ -500,10 +500,13 @@ class PackedWeight:
 
     @staticmethod
     @torch.no_grad()
-    def refresh_all() -> None:
+    def refresh_all(force: bool = False) -> None:
+        """Re-fill every live pack whose sources changed.  ``force``: re-fill all of them regardless of the version counters --
+        what the trainer does right after the optimizer step: the fused (multi-tensor) AdamW kernel updates the parameters
+        WITHOUT bumping ``Tensor._version``, so a version check alone would keep the first step's operands forever."""
         dst, src, packs = [], [], []
         for pk in list(PackedWeight._live):
-            if pk.stale():
+            if force or pk.stale():
                 d, s_ = pk._copy_lists()
                 dst += d; src += s_; packs.append(pk)
         if dst:
