@@ -263,6 +263,17 @@ int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const voi
 int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int64_t ldgate, const void *w, const void *bias, void *y,
                            int64_t ldy, int64_t M, int N, int K, void *stream);
 
+/* ---- Refresh of the cached bf16 GEMM operands after an optimizer step -------------------------------------------------
+ * The reference re-casts each nn.Linear weight to bf16 in every forward under autocast (primitives/attn.py:46-54,
+ * primitives/mlp.py:41-54); this build keeps the bf16 operands (concatenated / padded / interleaved packs and their
+ * transposes) as persistent buffers and re-fills ALL of them with one launch after the optimizer step.
+ * tiles: device array of n_tiles records of vsde_pack_tile_bytes() = 64 bytes each:
+ *   { const float *src; uint16_t *dst; uint16_t *dst_t; int64_t src_pitch, dst_pitch, pitch_t; int32_t rows, cols; int64_t reserved; }
+ * = up to 16 rows x cols of one fp32 parameter row block -> bf16 at dst (row pitch dst_pitch) and, when dst_t != NULL, the
+ * same values transposed: dst_t[col * pitch_t + row]. */
+int vsde_pack_tile_bytes(void);
+int vsde_pack_refresh(const void *tiles, int n_tiles, void *stream);
+
 /* ---- Batched Euler-Maruyama simulator of the MODEL SDE (parameter pre-training stage) --------------------------------
  * Replaces the T-step Python loop of core/euler_maruyama.py:11-45 (called from trainer.py:246-259 with 4096 paths) for
  * SDEs whose drift / diffusion are built in:

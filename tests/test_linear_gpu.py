@@ -77,3 +77,44 @@ def test_swiglu_epilogues(M, H, K):
     da, db = ds * ub * sg * (1 + ua * (1 - sg)), ds * ua * sg
     du_ref = _interleave(da.t(), db.t()).t()
     assert _rel(du, du_ref) < 2e-2
+
+
+@pytest.mark.gpu
+def test_pack_refresh_kernel_refills_every_pack_kind():
+    """vsde_pack_refresh (one launch over a tile table) against the torch piece copies: plain, row-stacked ([qkv | gate]),
+    zero-padded and 16-row interleaved SwiGLU packs with odd widths (682 -> 768), biases, and the transposed copies the
+    input-gradient GEMMs read.  Reference semantics: the bf16 cast of each Linear weight under autocast
+    (primitives/attn.py:46-54, primitives/mlp.py:41-54)."""
+    import torch
+    from viforsdes_amd.primitives import fused
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(1)
+    P = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g).to(dev))
+    qkv_w, qkv_b, gate_w, gate_b = P(768, 256), P(768), P(64, 256), P(64)
+    w_in, b_in, w_out, b_out = P(2 * 682, 256), P(2 * 682), P(256, 682), P(256)
+    odd_w, odd_b = P(40, 24), P(40)
+    packs = [fused.row_pack([qkv_w, gate_w], [qkv_b, gate_b]), fused.plain_pack(odd_w, odd_b)]
+    packs += list(fused.swiglu_packs(w_in, b_in, w_out, b_out, 768, interleave=True))
+    packs += list(fused.swiglu_packs(w_in, None, w_out, None, 768, interleave=False))
+    for pk in packs:
+        pk.operands()
+        pk.transposed()
+    with torch.no_grad():   # an update that does not bump Tensor._version, like the fused AdamW kernel
+        for p in (qkv_w, qkv_b, gate_w, gate_b, w_in, b_in, w_out, b_out, odd_w, odd_b):
+            torch._foreach_add_([p.data], 0.37)
+    expect = []
+    for pk in packs:
+        w = torch.zeros_like(pk.weight)
+        b = None if pk.bias is None else torch.zeros_like(pk.bias)
+        for p, s0, n, d0 in pk.weight_pieces:
+            w[d0:d0 + n, :p.shape[1]] = p.detach()[s0:s0 + n].to(torch.bfloat16)
+        for p, s0, n, d0 in pk.bias_pieces:
+            b[d0:d0 + n] = p.detach()[s0:s0 + n].to(torch.bfloat16)
+        expect.append((w, b))
+    assert not torch.equal(packs[0].weight, expect[0][0])
+    fused.PackedWeight.refresh_all(force=True)
+    torch.cuda.synchronize()
+    for pk, (w, b) in zip(packs, expect):
+        assert torch.equal(pk.weight, w) and (b is None or torch.equal(pk.bias, b))
+        assert torch.equal(pk.weight_t, w.t().contiguous()) and torch.equal(pk.transposed(), w.t().contiguous())
+        assert not pk.stale()

@@ -59,6 +59,7 @@ EXPORTS = (
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16",
+    "vsde_pack_tile_bytes", "vsde_pack_refresh",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -380,6 +381,17 @@ def sde_coefficients_bwd(kind: str, x, theta, g_drift, g_diffusion):
               ctypes.c_int(theta.shape[1]), _ptr(x), _ptr(theta), _ptr(g_drift), _ptr(g_diffusion), _ptr(g_x), _ptr(g_theta),
               _stream(dev))
     return g_x, g_theta
+
+
+def pack_refresh(table: torch.Tensor) -> None:
+    """One launch that re-fills the cached bf16 GEMM operands (and their transposes) from the fp32 parameters; ``table`` is
+    the int64 [n_tiles, 8] device tensor built by ``primitives.fused.PackedWeight.refresh_all``."""
+    lib = load()
+    dev = _require_hip(table)
+    if table.dtype != torch.int64 or table.ndim != 2 or table.shape[1] * 8 != lib.vsde_pack_tile_bytes() or not table.is_contiguous():
+        raise ValueError("pack-refresh table must be a contiguous int64 [n_tiles, 8] tensor")
+    with torch.cuda.device(dev):
+        _call(lib.vsde_pack_refresh, _ptr(table), ctypes.c_int(table.shape[0]), _stream(dev))
 
 
 def profile_enable(on: bool) -> None:

@@ -498,14 +498,66 @@ class PackedWeight:
             out.append(None if not blocks else blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0))
         return out
 
+    _tables: dict = {}      # key (device, pack identities, buffer addresses) -> device table of refresh tiles (kept alive: a
+                            # captured HIP graph replays the launch with the table it was captured with)
+
+    def _refresh_tiles(self) -> list[tuple]:
+        """(src, dst, dst_t, src_pitch, dst_pitch, pitch_t, rows, cols) per tile of <= 16 rows: csrc/vsde_pack.hip."""
+        out = []
+        wt = self.weight_t
+        for p, s0, n, d0 in self.weight_pieces:
+            if p.dtype != torch.float32 or p.stride(1) != 1:
+                return []
+            for r0 in range(0, n, 16):
+                out.append((p.data_ptr() + 4 * (s0 + r0) * p.stride(0), self.weight.data_ptr() + 2 * (d0 + r0) * self.weight.stride(0),
+                            0 if wt is None else wt.data_ptr() + 2 * (d0 + r0), p.stride(0), self.weight.stride(0),
+                            0 if wt is None else wt.stride(0), min(16, n - r0), p.shape[1]))
+        for p, s0, n, d0 in self.bias_pieces:
+            if p.dtype != torch.float32:
+                return []
+            out.append((p.data_ptr() + 4 * s0, self.bias.data_ptr() + 2 * d0, 0, n, n, 0, 1, n))
+        return out
+
     @staticmethod
     @torch.no_grad()
     def refresh_all(force: bool = False) -> None:
         """Re-fill every live pack whose sources changed.  ``force``: re-fill all of them regardless of the version counters --
         what the trainer does right after the optimizer step: the fused (multi-tensor) AdamW kernel updates the parameters
-        WITHOUT bumping ``Tensor._version``, so a version check alone would keep the first step's operands forever."""
+        WITHOUT bumping ``Tensor._version``, so a version check alone would keep the first step's operands forever.
+        On the GPU a forced refresh is ONE kernel over a cached table of tiles (fp32 parameters -> bf16 packs and their
+        transposes, csrc/vsde_pack.hip); otherwise one multi-tensor copy."""
+        live = sorted(PackedWeight._live, key=id)
+        if force and live and all(pk.weight.is_cuda for pk in live):
+            by_dev: dict = {}
+            for pk in live:
+                by_dev.setdefault(pk.weight.device, []).append(pk)
+            ok = True
+            for dev, packs in by_dev.items():
+                key = (dev, tuple((id(pk), pk.weight.data_ptr(), 0 if pk.weight_t is None else pk.weight_t.data_ptr(),
+                                   tuple(q.data_ptr() for q in pk.params)) for pk in packs))
+                table = PackedWeight._tables.get(key)
+                if table is None:
+                    rows = []
+                    for pk in packs:
+                        tiles = pk._refresh_tiles()
+                        if not tiles:
+                            ok = False
+                            break
+                        rows += [(a, b, c, d, e, f, r | (cl << 32), 0) for a, b, c, d, e, f, r, cl in tiles]
+                    if not ok:
+                        break
+                    if len(PackedWeight._tables) > 64:   # a long-lived process that keeps building models: drop old tables
+                        PackedWeight._tables.clear()
+                    table = PackedWeight._tables[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+                _hip.pack_refresh(table)
+            if ok:
+                for pk in live:
+                    pk.mark_fresh()
+                    if pk.weight_t is not None:
+                        pk._t_versions = list(pk._versions)
+                return
         dst, src, packs = [], [], []
-        for pk in list(PackedWeight._live):
+        for pk in live:
             if force or pk.stale():
                 d, s_ = pk._copy_lists()
                 dst += d; src += s_; packs.append(pk)
