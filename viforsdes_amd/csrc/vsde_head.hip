@@ -507,19 +507,30 @@ __device__ __forceinline__ float quad_bcast(float v, int q) {
 // LDS carve of the v2 forward kernel (floats); CH = time steps staged per chunk.
 constexpr int kWoStride = 68;
 struct FwdV2Lds {
-    int hb, obuf, wx, wo, gbuf, ebuf, s_paths, s_means, s_chol, s_raw, s_acts, total;
+    int hb, obuf, wx, wo, gth, gbuf, ebuf, s_paths, s_means, s_chol, s_raw, s_acts, dummy, total;
 };
 __host__ __device__ inline FwdV2Lds fwd_v2_lds(int H, int S, int L, int CH, bool save) {
     const int ntril = S * (S + 1) / 2;
     FwdV2Lds o; int off = 0;
     auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
     o.hb = take(L * 64); o.obuf = take(64); o.wx = take(S * 3 * 64);
-    o.wo = take((S + ntril) * kWoStride);  // emission rows, row stride 68 floats: conflict-free ds_read_b128
+    o.wo = take((S + ntril + 1) * kWoStride);  // emission rows (+ one all-zero row), row stride 68 floats: conflict-free ds_read_b128
+    o.gth = take(3 * 64);                      // hoisted theta projection [gate][unit]
     o.gbuf = take(2 * CH * 3 * H); o.ebuf = take(2 * CH * S);
     o.s_paths = take(CH * S); o.s_means = take(CH * S); o.s_chol = take(CH * S * S);
-    o.s_raw = take(save ? CH * ntril : 0); o.s_acts = take(save ? CH * L * 5 * H : 0);
+    o.s_raw = take(save ? CH * ntril : 0);
+    o.s_acts = take(save ? CH * L * 5 * 64 : 0);   // staged activation records, unit stride padded to 64: compile-time offsets
+    o.dummy = take(save ? L * 5 * 64 : 0);         // where the lanes of units >= hidden_dim park their (unused) stores
     o.total = off;
     return o;
+}
+
+// LDS byte address of a pointer into the dynamic shared segment (generic -> local = the low 32 bits)
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)p; }
+// ds_write_b32 with an immediate byte offset, issued in program order among its kind: hipcc neither reorders, merges
+// (ds_write2) nor counts these, which is what the counted s_waitcnt in front of the per-layer barrier relies on
+template <int OFF> __device__ __forceinline__ void lds_store(uint32_t addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr), "v"(v), "i"(OFF) : "memory");
 }
 
 // All global traffic of the v2 kernels happens at chunk boundaries as wide coalesced bursts
@@ -527,11 +538,25 @@ __host__ __device__ inline FwdV2Lds fwd_v2_lds(int H, int S, int L, int CH, bool
 // only touches LDS, so no s_waitcnt vmcnt ever sits on the recurrence's critical path.
 // MODE: 1, 2 = state_dim known at compile time (z_t kept as wave-uniform registers, no LDS on the
 // emission -> Euler update -> next-step-input path); 3 = generic state_dim with NO <= 16; 4 = generic.
+//
+// Round 3 (what the cycle stamps of one wave asked for -- a step is a serial chain, ~40 % FMA issue, the rest latency):
+//  * gate pre-activations live in the exp2 domain: W_r, W_z, their biases, the state / theta / context terms are scaled by
+//    -log2(e) and the n-gate terms by 2 log2(e) when they are loaded, so sigmoid / tanh are exp2 -> +1 -> rcp with no multiply;
+//  * biases ride in the accumulators (lane kq == 0 of a quad starts from the bias, the others from 0): no adds after the quad sums;
+//    the hoisted theta projection is added (and the context record scaled) once per chunk when the record goes to LDS;
+//  * one accumulator per dot product (a wave cannot issue faster than one VALU per ~4.6 cycles, dependent or not);
+//  * the exchanged h^l is stored FIRST, the five saved-activation stores behind it, and the barrier waits with a COUNTED
+//    s_waitcnt lgkmcnt(5): the recurrence never waits for the staging stores (the stores are inline asm so that their
+//    number and order are exactly what the count assumes);
+//  * eps of the step is fetched a step ahead;
+//  * workgroups start with first chunks of different lengths: their flush bursts (41 KB of activations per chunk) are spread
+//    over time instead of all 512 workgroups hitting HBM in the same microsecond while the memory system idles in between.
 template <int L, bool SAVE, int CH, int MODE>
 __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
     constexpr bool SMALL = MODE <= 3;
     constexpr int SS = MODE <= 2 ? MODE : 0;   // compile-time state_dim (0 = runtime)
     constexpr int SSN = SS > 0 ? SS : 1;
+    constexpr float kSr = -1.4426950408889634f, kSn = 2.8853900817779268f, kInvSn = 1.0f / kSn;
     static_assert(L >= 1 && L <= 2, "v2 keeps at most three 64x192 matrices in registers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, u = lane >> 2, kq = lane & 3;
@@ -544,58 +569,61 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
     const int orow = SMALL ? u : j;
     const bool unit_ok = j < H, row_ok = orow < NO;
     const FwdV2Lds lay = fwd_v2_lds(H, S, L, CH, SAVE);
-    float *hb = smem + lay.hb, *obuf = smem + lay.obuf, *wxl = smem + lay.wx, *wol = smem + lay.wo;
+    float *hb = smem + lay.hb, *obuf = smem + lay.obuf, *wxl = smem + lay.wx, *wol = smem + lay.wo, *gthl = smem + lay.gth;
     float *gbuf = smem + lay.gbuf, *ebuf = smem + lay.ebuf;
     float *s_paths = smem + lay.s_paths, *s_means = smem + lay.s_means, *s_chol = smem + lay.s_chol;
     float *s_raw = smem + lay.s_raw, *s_acts = smem + lay.s_acts;
     for (int e = tid; e < lay.total; e += 256) smem[e] = 0.f;  // finite data everywhere (see head_bwd_v2_kernel)
     __syncthreads();
 
-    // ---- register-resident weights ---------------------------------------------------------
+    // ---- register-resident weights (gate rows pre-scaled into the exp2 domain) -------------
+    const float gsc[3] = {kSr, kSr, kSn};
     float wh[L][3][16], wi[L][3][16];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const bool ok = unit_ok && (k0 + i) < H;
-            wh[0][g][i] = ok ? p.W_hh0[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+            wh[0][g][i] = ok ? gsc[g] * p.W_hh0[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
             wi[0][g][i] = 0.f;
             if (L > 1) {
-                wh[L - 1][g][i] = ok ? p.W_hh_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
-                wi[L - 1][g][i] = ok ? p.W_ih_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+                wh[L - 1][g][i] = ok ? gsc[g] * p.W_hh_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
+                wi[L - 1][g][i] = ok ? gsc[g] * p.W_ih_st[(int64_t)(g * H + j) * H + k0 + i] : 0.f;
             }
         }
-    for (int e = tid; e < NO * 64; e += 256) {  // emission rows -> LDS (kept out of the VGPR budget)
+    for (int e = tid; e < NO * 64; e += 256) {  // emission rows -> LDS (kept out of the VGPR budget); row NO stays zero
         int kk = e & 63, r = e >> 6;
         wol[r * kWoStride + kk] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
     }
-    const float *wop = wol + (row_ok ? orow : 0) * kWoStride + k0;
-    float bhh[L][3], bih[L][3], gth[3];
+    const float *wop = wol + (row_ok ? orow : NO) * kWoStride + k0;
+    // biases enter through the accumulators: only lane kq == 0 of a quad carries them into the quad sum
+    float bhh[L][3], bih[L][3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        bhh[0][g] = unit_ok ? p.b_hh0[g * H + j] : 0.f;
+        const bool lead = unit_ok && kq == 0;
+        bhh[0][g] = lead ? gsc[g] * p.b_hh0[g * H + j] : 0.f;
         bih[0][g] = 0.f;
         if (L > 1) {
-            bhh[L - 1][g] = unit_ok ? p.b_hh_st[g * H + j] : 0.f;
-            bih[L - 1][g] = unit_ok ? p.b_ih_st[g * H + j] : 0.f;
+            bhh[L - 1][g] = lead ? gsc[g] * p.b_hh_st[g * H + j] : 0.f;
+            bih[L - 1][g] = lead ? gsc[g] * p.b_ih_st[g * H + j] : 0.f;
         }
-        float acc = 0.f;  // hoisted theta projection (forward.py:157-175)
+        float acc = 0.f;  // hoisted theta projection (forward.py:157-175) -> LDS, added to the context record at staging time
         if (unit_ok)
             for (int q = 0; q < p.P; ++q) acc = fmaf(p.theta[(int64_t)b * p.P + q], p.W_ih0[(int64_t)(g * H + j) * I + S + p.C + q], acc);
-        gth[g] = acc;
+        if (lead) gthl[g * H + j] = gsc[g] * acc;
     }
     for (int e = tid; e < S * 3 * 64; e += 256) {  // state rows of W_ih_l0: wxl[i][g][unit]
         int un = e & 63, g = (e >> 6) % 3, i = e / 192;
-        wxl[e] = un < H ? p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
+        wxl[e] = un < H ? gsc[g] * p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
     }
     float wxr[SSN][3], xu[SSN];  // SS > 0: state rows of W_ih_l0 and z_t as wave-uniform values
 #pragma unroll
     for (int i = 0; i < SSN; ++i) {
         xu[i] = (SS > 0) ? p.x0[(int64_t)b * S + i] : 0.f;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) wxr[i][g] = (SS > 0 && unit_ok) ? p.W_ih0[(int64_t)(g * H + j) * I + i] : 0.f;
+        for (int g = 0; g < 3; ++g) wxr[i][g] = (SS > 0 && unit_ok) ? gsc[g] * p.W_ih0[(int64_t)(g * H + j) * I + i] : 0.f;
     }
-    const float outb = row_ok ? p.out_b[orow] : 0.f;
+    const float outb = (row_ok && kq == 0) ? p.out_b[orow] : 0.f;
     int trow = 0, tcol = 0;
     if (orow >= S && orow < NO) {
         int q = orow - S, r = 0;
@@ -610,46 +638,66 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
     for (int l = 0; l < L; ++l) {
         h[l] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) cc[l][g] = bhh[l][g];
+        for (int g = 0; g < 3; ++g) cc[l][g] = quad_sum(bhh[l][g]);   // W_hh h_{-1} + b_hh with h_{-1} = 0
     }
     float xreg = lane < S ? p.x0[(int64_t)b * S + lane] : 0.f;  // every wave keeps z_t[i] on its lane i
     if (wave == 0 && lane < S) p.paths[(int64_t)b * (T + 1) * S + lane] = xreg;
+    __syncthreads();   // gthl complete
 
     // ---- chunked staging of the projected context record G[b, t, 3H] and eps ---------------
     const float *Gb = p.G + (int64_t)b * T * G3;
     const float *eb = p.eps + (int64_t)b * T * S;
     constexpr int PF = (CH * 3 * 64 + 255) / 256;  // floats of G per thread and chunk (H <= 64)
     float pf[PF], pe = 0.f;
-    auto issue_loads = [&](int t0) {
-        const int nG = min(CH, T - t0) * G3, nE = min(CH, T - t0) * S;
+    auto issue_loads = [&](int t0, int n) {
+        const int nG = n * G3, nE = n * S;
 #pragma unroll
-        for (int r = 0; r < PF; ++r) { int e = tid + 256 * r; pf[r] = (t0 < T && e < nG) ? Gb[(int64_t)t0 * G3 + e] : 0.f; }
-        pe = (t0 < T && tid < nE) ? eb[(int64_t)t0 * S + tid] : 0.f;
+        for (int r = 0; r < PF; ++r) { int e = tid + 256 * r; pf[r] = (e < nG) ? Gb[(int64_t)t0 * G3 + e] : 0.f; }
+        pe = (tid < nE) ? eb[(int64_t)t0 * S + tid] : 0.f;
     };
-    auto commit_loads = [&](int buf) {
+    auto commit_loads = [&](int buf) {   // record -> exp2 domain, + theta term
 #pragma unroll
-        for (int r = 0; r < PF; ++r) { int e = tid + 256 * r; if (e < CH * G3) gbuf[buf * CH * G3 + e] = pf[r]; }
+        for (int r = 0; r < PF; ++r) {
+            int e = tid + 256 * r;
+            if (e < CH * G3) {
+                int c = tid + 64 * (r % 3);            // e mod 192 when hidden_dim is 64
+                if (G3 == 192) { if (c >= 192) c -= 192; } else c = e % G3;
+                gbuf[buf * CH * G3 + e] = fmaf(pf[r], c < 2 * H ? kSr : kSn, gthl[c]);
+            }
+        }
         if (tid < CH * S) ebuf[buf * CH * S + tid] = pe;
     };
     for (int e = tid; e < CH * S * S; e += 256) s_chol[e] = 0.f;
-    issue_loads(0);
+    // first chunk of 1..CH steps: the workgroups' chunk boundaries (bursts of staged outputs) are spread over time; the two
+    // workgroups that share a CU (b and b + 256 in dispatch order) sit half a chunk apart
+    int t0 = 0, nsteps = min(CH - (b * 5 + (b >> 8) * (CH / 2)) % CH, T), cur = 0;
+    issue_loads(0, nsteps);
     commit_loads(0);
     __syncthreads();
 
-    const int nchunks = (T + CH - 1) / CH;
-    for (int c = 0; c < nchunks; ++c) {
-        const int t0 = c * CH, nsteps = min(CH, T - t0), cur = c & 1;
+    const uint32_t hb_a = lds_addr(hb + j);
+    const uint32_t act_a0 = lds_addr(SAVE ? (unit_ok ? s_acts + j : smem + lay.dummy) : smem);
+    const uint32_t act_step = unit_ok ? (uint32_t)(L * 5 * 64 * sizeof(float)) : 0u;
+    for (int c = 0; t0 < T; ++c) {   // c: chunk counter (trace builds)
         const float *gch = gbuf + cur * CH * G3, *ech = ebuf + cur * CH * S;
-        float gcur[3];
+        float gcur[3], ev[SSN];
         gcur[0] = unit_ok ? gch[j] : 0.f; gcur[1] = unit_ok ? gch[H + j] : 0.f; gcur[2] = unit_ok ? gch[2 * H + j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SSN; ++i) ev[i] = SS > 0 ? ech[i] : 0.f;
+        uint32_t act_a = act_a0;
         for (int tt = 0; tt < nsteps; ++tt) {
             VSDE_TP(0);
-            float a[3];
+            float a[3], evc[SSN];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) a[g] = gcur[g] + gth[g];
-            {   // prefetch the next step's projected record from LDS (off the critical path)
-                const float *gr = gch + min(tt + 1, nsteps - 1) * G3 + j;
+            for (int g = 0; g < 3; ++g) a[g] = gcur[g];
+#pragma unroll
+            for (int i = 0; i < SSN; ++i) evc[i] = ev[i];
+            {   // prefetch the next step's projected record and eps from LDS (off the critical path)
+                const int tn = min(tt + 1, nsteps - 1);
+                const float *gr = gch + tn * G3 + j;
                 gcur[0] = unit_ok ? gr[0] : 0.f; gcur[1] = unit_ok ? gr[H] : 0.f; gcur[2] = unit_ok ? gr[2 * H] : 0.f;
+#pragma unroll
+                for (int i = 0; i < SSN; ++i) ev[i] = SS > 0 ? ech[tn * SS + i] : 0.f;
             }
             if (SS > 0) {
 #pragma unroll
@@ -667,27 +715,39 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
             float o = 0.f;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                float r = fast_sigmoid(a[0] + cc[l][0]);
-                float uu = fast_sigmoid(a[1] + cc[l][1]);
-                float n = fast_tanh(a[2] + r * cc[l][2]);
-                float hn = (1.0f - uu) * n + uu * h[l];
-                if (kq == 0) hb[l * 64 + j] = hn;
-                if (SAVE && unit_ok) {  // quad lane kq stages slot kq (h, r, z, n); lane 0 also n_hh
-                    float *A = s_acts + ((tt * L + l) * 5) * H + j;
-                    float v = kq == 0 ? hn : (kq == 1 ? r : (kq == 2 ? uu : n));
-                    A[kq * H] = v;
-                    if (kq == 0) A[4 * H] = cc[l][2];
-                }
+                // exp2-domain gates: r = 1 / (1 + 2^(a_r + c_r)), n = 1 - 2 / (1 + 2^(a_n + r c_n))
+                const float r = fast_rcp(1.0f + fast_exp2(a[0] + cc[l][0]));
+                const float uu = fast_rcp(1.0f + fast_exp2(a[1] + cc[l][1]));
+                const float n = fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(r, cc[l][2], a[2]))), 1.0f);
+                const float hn = fmaf(uu, h[l] - n, n);   // (1 - u) n + u h
                 h[l] = hn;
                 VSDE_TP(2 + 4 * l);
-                __syncthreads();
+                // h^l first, the saved activations (h, r, z, n, n_hh of unit j: lane kq == 0) behind it; the barrier waits for
+                // everything but the five staging stores
+                asm volatile("" ::: "memory");
+                if (kq == 0) {
+                    if (l == 0) lds_store<0>(hb_a, hn); else lds_store<256>(hb_a, hn);
+                    if (SAVE) {
+                        const float nhh = cc[l][2] * kInvSn;
+                        if (l == 0) {
+                            lds_store<0>(act_a, hn); lds_store<256>(act_a, r); lds_store<512>(act_a, uu); lds_store<768>(act_a, n);
+                            lds_store<1024>(act_a, nhh);
+                        } else {
+                            lds_store<1280>(act_a, hn); lds_store<1536>(act_a, r); lds_store<1792>(act_a, uu); lds_store<2048>(act_a, n);
+                            lds_store<2304>(act_a, nhh);
+                        }
+                    }
+                }
+                if (SAVE) asm volatile("s_waitcnt lgkmcnt(5)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 VSDE_TP(3 + 4 * l);
-                // Plain v_fma_f32 chains (a wave64 v_pk_fma_f32 issues in 8 cycles = two v_fma_f32, and its broadcast operand
-                // costs an extra v_mov per h value): even/odd k accumulate separately and are summed at the end.  The 16
-                // staged h values (and the emission-row weights) are consumed 8 at a time: with three matrices in registers
-                // there is no room for more.
-                float eh[3] = {0.f, 0.f, 0.f}, oh[3] = {0.f, 0.f, 0.f};  // W_hh^l h^l: gate g, even / odd k
-                float ei[3] = {0.f, 0.f, 0.f}, oi[3] = {0.f, 0.f, 0.f};  // W_ih^{l+1} h^l, or [2] = emission row (last layer)
+                // Plain v_fma_f32 chains, one accumulator per dot product, started from the (lane-masked) bias.  The 16 staged h
+                // values (and the emission-row weights) are consumed 8 at a time: with three matrices in registers there is no
+                // room for more.
+                float eh[3] = {bhh[l][0], bhh[l][1], bhh[l][2]};             // W_hh^l h^l + b_hh^l
+                float ei[3];                                                   // W_ih^{l+1} h^l + b_ih^{l+1}, or [2] = emission row
+                if (l < L - 1) { constexpr int ln = (L > 1) ? 1 : 0; ei[0] = bih[ln][0]; ei[1] = bih[ln][1]; ei[2] = bih[ln][2]; }
+                else { ei[0] = 0.f; ei[1] = 0.f; ei[2] = outb; }
                 VSDE_TP(4 + 4 * l);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
@@ -696,41 +756,35 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                     if (l < L - 1) {
                         constexpr int ln = (L > 1) ? 1 : 0;
 #pragma unroll
-                        for (int i8 = 0; i8 < 8; i8 += 2) {
+                        for (int i8 = 0; i8 < 8; ++i8) {
                             const int i = 8 * hf + i8;
 #pragma unroll
-                            for (int g = 0; g < 3; ++g) {
-                                eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]); ei[g] = fmaf(hs[i8], wi[ln][g][i], ei[g]);
-                                oh[g] = fmaf(hs[i8 + 1], wh[l][g][i + 1], oh[g]); oi[g] = fmaf(hs[i8 + 1], wi[ln][g][i + 1], oi[g]);
-                            }
+                            for (int g = 0; g < 3; ++g) { ei[g] = fmaf(hs[i8], wi[ln][g][i], ei[g]); eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]); }
                         }
                     } else {
                         const float4 wa = *(const float4 *)(wop + 8 * hf), wc = *(const float4 *)(wop + 8 * hf + 4);
                         const float wo[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
-                        for (int i8 = 0; i8 < 8; i8 += 2) {
+                        for (int i8 = 0; i8 < 8; ++i8) {
                             const int i = 8 * hf + i8;
+                            ei[2] = fmaf(hs[i8], wo[i8], ei[2]);
 #pragma unroll
-                            for (int g = 0; g < 3; ++g) {
-                                eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]);
-                                oh[g] = fmaf(hs[i8 + 1], wh[l][g][i + 1], oh[g]);
-                            }
-                            ei[2] = fmaf(hs[i8], wo[i8], ei[2]); oi[2] = fmaf(hs[i8 + 1], wo[i8 + 1], oi[2]);
+                            for (int g = 0; g < 3; ++g) eh[g] = fmaf(hs[i8], wh[l][g][i], eh[g]);
                         }
                     }
                     if (hf == 0) __builtin_amdgcn_sched_barrier(0);  // second half's LDS reads stay behind the first half's FMAs
-                }
+                        }
                 if (l < L - 1) {
-                    constexpr int ln = (L > 1) ? 1 : 0;
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) a[g] = bih[ln][g] + quad_sum(ei[g] + oi[g]);
+                    for (int g = 0; g < 3; ++g) a[g] = quad_sum(ei[g]);
                 } else {
-                    o = outb + quad_sum(row_ok ? ei[2] + oi[2] : 0.f);
+                    o = quad_sum(ei[2]);
                 }
 #pragma unroll
-                for (int g = 0; g < 3; ++g) cc[l][g] = bhh[l][g] + quad_sum(eh[g] + oh[g]);
+                for (int g = 0; g < 3; ++g) cc[l][g] = quad_sum(eh[g]);
                 VSDE_TP(5 + 4 * l);
             }
+            act_a += act_step;
             // ---- emission (forward.py:314-375)
             VSDE_TP(10);
             if (SMALL) {
@@ -741,16 +795,13 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                     if (SAVE) s_raw[tt * p.ntril + (orow - S)] = o;
                 }
                 if (SS > 0) {
-                    float ev[SSN];
-#pragma unroll
-                    for (int i = 0; i < SSN; ++i) ev[i] = ech[tt * SS + i];
 #pragma unroll
                     for (int i = 0; i < SSN; ++i) {
                         const float mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * i));
                         float acc = 0.f;
 #pragma unroll
                         for (int q = 0; q <= i; ++q)
-                            acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * (SS + i * (i + 1) / 2 + q))), ev[q], acc);
+                            acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(oc), 4 * (SS + i * (i + 1) / 2 + q))), evc[q], acc);
                         xu[i] = xu[i] + mu * p.dt + acc * p.sqdt;
                         if (tid == 0) { s_means[tt * SS + i] = mu; s_paths[tt * SS + i] = xu[i]; }
                     }
@@ -791,8 +842,10 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
             }
             VSDE_TP(12);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last steps' staging stores
         __syncthreads();                 // chunk complete: staging buffers final
-        issue_loads(t0 + CH);            // next chunk's records; their latency hides behind the flush below
+        const int tnext = t0 + nsteps, nnext = min(CH, T - tnext);
+        issue_loads(tnext, nnext > 0 ? nnext : 0);   // next chunk's records; their latency hides behind the flush below
         // ---- flush the staged outputs (contiguous runs in the [b][t][...] layouts)
         {
             const int64_t bt = (int64_t)b * T + t0;
@@ -806,19 +859,21 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
             if (SAVE) {
 #pragma unroll 1
                 for (int e = tid; e < nsteps * p.ntril; e += 256) p.chol_raw[bt * p.ntril + e] = s_raw[e];
-                const int nA = nsteps * L * 5 * H;
                 float *dst = p.acts + bt * L * 5 * H;
-                if ((H & 3) == 0) {
+                if (H == 64) {
+                    const int nA = nsteps * L * 5 * 64;
 #pragma unroll 1
                     for (int e = tid; e < nA / 4; e += 256) ((float4 *)dst)[e] = ((const float4 *)s_acts)[e];
-                } else {
+                } else {   // staged with a unit stride of 64
+                    const int nA = nsteps * L * 5 * H;
 #pragma unroll 1
-                    for (int e = tid; e < nA; e += 256) dst[e] = s_acts[e];
+                    for (int e = tid; e < nA; e += 256) dst[e] = s_acts[(e / H) * 64 + e % H];
                 }
             }
         }
         commit_loads(cur ^ 1);
         __syncthreads();                 // staging reusable, gbuf[next] visible
+        t0 = tnext; nsteps = nnext; cur ^= 1;
     }
 }
 
