@@ -22,7 +22,8 @@ def _rel(a, b):
 # (M, N, K): the LV encoder's forward and input-gradient shapes, the C=128 fixture's, the synthetic C=512 ones, ragged M
 SHAPES = [(4264, 448, 128), (4264, 128, 128), (4264, 128, 384), (4264, 128, 448), (4264, 128, 768),
           (20000, 832, 256), (20000, 256, 256), (20000, 256, 768), (20000, 256, 832), (20000, 256, 1536),
-          (3000, 1664 + 128, 512), (3000, 512, 1408), (3000, 512, 1664), (257, 256, 256), (31, 128, 64)]
+          (3000, 1664 + 128, 512), (3000, 512, 512), (9000, 1664, 512), (3000, 512, 1408), (3000, 512, 1664), (3000, 512, 2816),
+          (257, 256, 256), (31, 128, 64)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -48,7 +49,7 @@ def _interleave(w_a, w_b):
     return torch.stack([w_a.reshape(H // 16, 16, -1), w_b.reshape(H // 16, 16, -1)], dim=1).reshape(2 * H, -1)
 
 
-@pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128)])
+@pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128), (9000, 1408, 512), (200, 128, 512)])
 def test_swiglu_epilogues(M, H, K):
     from viforsdes_amd import _hip
     x = _rand(M, K, seed=5)

@@ -974,7 +974,12 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     float dxreg = 0.f;  // lane i < S of every wave carries d z_t[i]
 
     const int64_t bt0 = (int64_t)b * T;
-    const int nchunks = (T + CH - 1) / CH;
+    // Chunk c covers the steps [max(0, c CH - phase), min(T, (c + 1) CH - phase)): the workgroups' chunk boundaries (bursts of
+    // D4 stores and activation loads) are spread over time; the two workgroups that share a CU sit half a chunk apart.
+    const int phase = (b * 5 + (b >> 8) * (CH / 2)) % CH;
+    const int nchunks = (T + phase + CH - 1) / CH;
+    auto chunk_t0 = [&](int c) { return max(0, c * CH - phase); };
+    auto chunk_n = [&](int c) { return min(T, (c + 1) * CH - phase) - max(0, c * CH - phase); };
     const int ABUF = (CH + 1) * REC;  // floats of one activation buffer
     // activation records t0-1 .. t0+n-1 (record -1 of the path is all zero)
     auto load_acts_sync = [&](int t0, int n, float *dst) {
@@ -1032,20 +1037,21 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
         }
     };
     {
-        const int t0 = (nchunks - 1) * CH;
+        const int t0 = chunk_t0(nchunks - 1), n = chunk_n(nchunks - 1);
         s_acts = acts_buf0 + (DMA ? ((nchunks - 1) & 1) * ABUF : 0);
-        if (DMA) load_acts_dma(t0, T - t0, s_acts); else load_acts_sync(t0, T - t0, s_acts);
-        small_issue(t0, T - t0);
-        small_commit(T - t0);
+        if (DMA) load_acts_dma(t0, n, s_acts); else load_acts_sync(t0, n, s_acts);
+        small_issue(t0, n);
+        small_commit(n);
         if (DMA) __builtin_amdgcn_s_waitcnt(0);
     }
     __syncthreads();
 
     for (int c = nchunks - 1; c >= 0; --c) {
-        const int t0 = c * CH, nsteps = min(CH, T - t0);
+        const int t0 = chunk_t0(c), nsteps = chunk_n(c);
+        const int tprev = c > 0 ? chunk_t0(c - 1) : 0, nprev = c > 0 ? chunk_n(c - 1) : 0;
         if (c > 0) {  // the next (earlier) chunk: its loads fly during this chunk's time steps
-            if (DMA) load_acts_dma(t0 - CH, CH, acts_buf0 + ((c - 1) & 1) * ABUF);
-            small_issue(t0 - CH, CH);
+            if (DMA) load_acts_dma(tprev, nprev, acts_buf0 + ((c - 1) & 1) * ABUF);
+            small_issue(tprev, nprev);
         }
         for (int tt = nsteps - 1; tt >= 0; --tt) {
             VSDE_TPB(tt == 5 ? 20 : 31);
@@ -1182,9 +1188,9 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
             for (int e = tid; e < nsteps * NO; e += 256) p.DO[(bt0 + t0) * NO + e] = s_dO[e];
         }
         if (c > 0) {
-            small_commit(CH);
+            small_commit(nprev);
             if (DMA) { s_acts = acts_buf0 + ((c - 1) & 1) * ABUF; __builtin_amdgcn_s_waitcnt(0); }
-            else load_acts_sync(t0 - CH, CH, s_acts);
+            else load_acts_sync(tprev, nprev, s_acts);
         }
         __syncthreads();
     }

@@ -282,15 +282,19 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
 // Outputs leave in pairs of tiles (64 columns = 128-byte row segments, non-temporal) through the wave's staging buffer.
 // EPI_SWIGLU_BWD runs with RB = 1: the tile's slice of the saved u is requested a tile ahead into registers, so its HBM
 // latency is hidden behind the MFMAs (with RB = 2 there are no registers left for that and every tile waited for its u).
-template <int EPI> constexpr int rows_rb() { return (EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM) ? 1 : 2; }
+template <int EPI, int NKH = 1> constexpr int rows_rb() { return (EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || NKH > 1) ? 1 : 2; }
 
-template <int KC, int RB>
-__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (&afr)[RB][KC / 16], const uint16_t *bsrc) {
+// KC: depth of the LDS weight tile; the wave's resident operand holds KSTOT = NKH * KC / 16 fragments per row block and this call
+// multiplies the slice [K0, K0 + KC / 16) of them (K = 512 runs as two k-halves of 256 through the same 17 KB tile buffers).
+template <int KC, int RB, int KSTOT, int K0, bool ZERO>
+__device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (&afr)[RB][KSTOT], const uint16_t *bsrc) {
     constexpr int KS = KC / 16, GK = RB == 1 ? 4 : 2, NG = KS / GK;
+    if constexpr (ZERO) {
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+    }
     bf16x8 bq[2][GK];
 #pragma unroll
     for (int k = 0; k < GK; ++k) bq[0][k] = *(const bf16x8 *)(bsrc + k * 16);
@@ -305,16 +309,16 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (
         for (int k = 0; k < GK; ++k)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], afr[rb][gk * GK + k], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], afr[rb][K0 + gk * GK + k], acc[rb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
 }
 
-template <int KC, int EPI>
+template <int KC, int EPI, int NKH>
 __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
-    constexpr int RB = rows_rb<EPI>(), ROWS = 128 * RB;
-    constexpr int KS = KC / 16, LDB = KC + 8, TILE = 33 * LDB;   // 32 weight rows + 1 bias row
+    constexpr int RB = rows_rb<EPI, NKH>(), ROWS = 128 * RB;
+    constexpr int KS = NKH * KC / 16, KT = NKH * KC, LDB = KC + 8, TILE = 33 * LDB;   // 32 weight rows + 1 bias row
     constexpr int NLD = 32 * KC / 8 / R2_THREADS;                // 16-byte loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(src + ks * 16);
-        if (EPI == EPI_PLAIN && p.Gate != nullptr) {   // workgroup-uniform: gate_merge (primitives/attn.py:107-109) folded into the load:
+        if (EPI == EPI_PLAIN && NKH == 1 && p.Gate != nullptr) {   // workgroup-uniform: gate_merge (primitives/attn.py:107-109) folded into the load:
             const uint16_t *gsrc = p.Gate + m * p.ldgate + 8 * h;   // a[k] * rnd(sigmoid(g[k % 64])), rounded to bf16 like the kernel's output
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -365,13 +369,15 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     // a workgroup owns one chunk of the output columns of its stripe (see launch_rows)
     const int ntiles = p.N / 32 / nchunks, tile0 = chunk * ntiles;
     const int rot = 2 * ((int)stripe % (ntiles / 2));
-    u32x4 breg[NLD];          // the next tile on its way from L2 to LDS (loaded one iteration before its LDS store)
+    u32x4 breg[NLD];          // the next sub-tile on its way from L2 to LDS (loaded one iteration before its LDS store)
     uint32_t biasreg = 0u;
     u32x4 ureg[4 * RB];       // EPI_SWIGLU_BWD: the next tile's slice of the saved u (32 RB rows x 64 columns)
-#define VSDE_TILE_LOAD(t_)                                                                                    \
+    // Sub-tile q = NKH * t + kh: k-half kh of the t-th visited tile, i.e. W[32 tile .. 32 tile + 32][KC kh .. KC kh + KC] (row pitch KT);
+    // the LDS buffers alternate with q.
+#define VSDE_TILE_LOAD(q_)                                                                                    \
     do {                                                                                                      \
-        const int tile_ = tile0 + ((t_) + rot) % ntiles;                                                      \
-        wtile_load<NLD, KC, R2_THREADS>(breg, p.W + (int64_t)tile_ * 32 * KC, KC, tid);                       \
+        const int tile_ = tile0 + ((q_) / NKH + rot) % ntiles;                                                \
+        wtile_load<NLD, KC, R2_THREADS>(breg, p.W + (int64_t)tile_ * 32 * KT + ((q_) % NKH) * KC, KT, tid);   \
         if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * tid) : 0u;             \
     } while (0)
 #define VSDE_TILE_STORE(Bs_)                                                                                  \
@@ -399,27 +405,37 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
             }                                                                                                 \
         }                                                                                                     \
     } while (0)
-// one tile: MFMAs out of LDS buffer PAR_, epilogue, then tile t + 1 (in breg) goes to the other buffer.
-// t and the tile index have the same parity (rot is even): PAR_ = 1 closes a pair of tiles.
-#define VSDE_ROWS_BODY(t_, PAR_)                                                                              \
+// one sub-tile: MFMAs out of LDS buffer q & 1 into the tile's accumulators; after the last k-half the epilogue; then sub-tile
+// q + 1 (in breg) goes to the other buffer.  t and the tile index have the same parity (rot is even): TPAR_ = 1 closes a pair of tiles.
+#define VSDE_ROWS_BODY(t_, TPAR_, KH_)                                                                        \
     do {                                                                                                      \
-        const uint16_t *Bs = lsm + (PAR_) * TILE;                                                             \
-        f32x16 acc[RB];                                                                                       \
-        rows_tile_mfma<KC, RB>(acc, afr, Bs + r * LDB + 8 * h);                                               \
-        rows_epilogue<EPI, PAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds); \
-        if ((t_) + 1 < ntiles) VSDE_TILE_STORE(lsm + (1 - (PAR_)) * TILE);                                    \
+        constexpr int q_par = (NKH * (TPAR_) + (KH_)) & 1;                                                    \
+        const int q_ = NKH * (t_) + (KH_);                                                                    \
+        const uint16_t *Bs = lsm + q_par * TILE;                                                              \
+        rows_tile_mfma<KC, RB, KS, (KH_) * (KC / 16), (KH_) == 0>(acc, afr, Bs + r * LDB + 8 * h);            \
+        if constexpr ((KH_) == NKH - 1)                                                                       \
+            rows_epilogue<EPI, TPAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds); \
+        if (q_ + 1 < NKH * ntiles) VSDE_TILE_STORE(lsm + (1 - q_par) * TILE);                                 \
         lds_barrier();                                                                                        \
-        if ((t_) + 2 < ntiles) VSDE_TILE_LOAD((t_) + 2);                                                      \
-        if ((t_) + 1 < ntiles) VSDE_U_LOAD((t_) + 1);                                                         \
+        if (q_ + 2 < NKH * ntiles) VSDE_TILE_LOAD(q_ + 2);                                                    \
+        if constexpr ((KH_) == NKH - 1) { if ((t_) + 1 < ntiles) VSDE_U_LOAD((t_) + 1); }                     \
     } while (0)
     VSDE_TILE_LOAD(0);
     VSDE_U_LOAD(0);
     VSDE_TILE_STORE(lsm);
     lds_barrier();
     VSDE_TILE_LOAD(1);
+    f32x16 acc[RB];
     for (int nt = 0; nt < ntiles; nt += 2) {
-        VSDE_ROWS_BODY(nt, 0);
-        VSDE_ROWS_BODY(nt + 1, 1);
+        if constexpr (NKH == 1) {
+            VSDE_ROWS_BODY(nt, 0, 0);
+            VSDE_ROWS_BODY(nt + 1, 1, 0);
+        } else {
+            VSDE_ROWS_BODY(nt, 0, 0);
+            VSDE_ROWS_BODY(nt, 0, 1);
+            VSDE_ROWS_BODY(nt + 1, 1, 0);
+            VSDE_ROWS_BODY(nt + 1, 1, 1);
+        }
     }
 #undef VSDE_ROWS_BODY
 #undef VSDE_U_LOAD
@@ -520,14 +536,14 @@ __global__ void __launch_bounds__(C2_THREADS, 2) lin_cols_kernel(LinParams p) {
     }
 }
 
-template <int KC, int EPI> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI>() * R2_SLD) * sizeof(uint16_t); }
+template <int KC, int EPI, int NKH> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t); }
 template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * C2_LDB) * sizeof(uint16_t); }   // two weight buffers (the epilogue reuses them)
 
-template <int KC, int EPI>
+template <int KC, int EPI, int NKH = 1>
 static int launch_rows(const LinParams &p, hipStream_t s) {
-    const size_t lds = rows_lds_bytes<KC, EPI>();
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int rows = 128 * rows_rb<EPI>();
+    const size_t lds = rows_lds_bytes<KC, EPI, NKH>();
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI, NKH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int rows = 128 * rows_rb<EPI, NKH>();
     // Column chunks per row stripe (a chunk is a whole number of tile pairs; its workgroup re-reads the stripe's rows, L2 hits):
     //  * few stripes (the OU example has 12.9 k tokens = 51 stripes on 256 CUs): enough chunks for about two workgroups per CU;
     //  * many stripes: the grid is a non-integer number of rounds of the 512 resident workgroups (802 stripes = 1.57 rounds:
@@ -546,13 +562,14 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     }
     LinParams q = p;
     q.chunks = chunks;
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(R2_THREADS), lds, s, q);
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(R2_THREADS), lds, s, q);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 template <int EPI>
 static int launch_rows_k(const LinParams &p, hipStream_t s) {
+    if (p.K == 512) return launch_rows<256, EPI, 2>(p, s);   // two k-halves through the K = 256 tile buffers
     return p.K == 128 ? launch_rows<128, EPI>(p, s) : launch_rows<256, EPI>(p, s);
 }
 
@@ -571,7 +588,7 @@ static int launch_qknorm(const LinParams &p, hipStream_t s) { return launch_rows
 
 // 1 = rows kernel, 2 = cols kernel, 0 = shape not covered (the caller keeps its library GEMM)
 static int lin_variant(int N, int K, int epilogue) {
-    const bool rows_ok = (K == 128 || K == 256) && N % 64 == 0;   // K = 512 would need 172 KB of LDS: cols kernel
+    const bool rows_ok = (K == 128 || K == 256 || K == 512) && N % 64 == 0;   // K = 512: two k-halves per output tile
     const bool cols_ok = K % 64 == 0 && N % 128 == 0 && epilogue == EPI_PLAIN;
     if (epilogue != EPI_PLAIN) return rows_ok ? 1 : 0;
     // both fit: the rows kernel reads the activations once and suits wide outputs; the cols kernel suits deep reductions
