@@ -21,6 +21,7 @@ What is recorded (inputs and expected outputs only -- no reference source text):
 * state_dict_manifest.json  key -> [shape, dtype] of ``VariationalSDEPosterior.state_dict()``.
 * fused_dims.npz   encoder forward/gradients and a K=20-step trainer trajectory from one initial state at dims
                   where the build's fused encoder route is active (hidden 128, 2 heads, depth 2, batch 104).
+* encoder_d128.npz  ``ObservationContextEncoder`` forward + gradients at head_dim 128 (hidden 128, one head, depth 2, batch 104).
 * euler_maruyama.npz  ``euler_maruyama`` trajectories + gradients for the example OU / LV SDEs with injected noise.
 * trajectory_tiny.npz  a K-step ``VariationalInferenceTrainer`` run on CPU with the head's
                   kernel call replaced by O1 and every ``torch.randn`` draw recorded.
@@ -465,6 +466,40 @@ def make_fused_dims():
     print("wrote fused_dims.npz; elbo[0], elbo[-1] =", elbos[0], elbos[-1], "grad_norm", gnorms[0], gnorms[-1])
 
 
+def make_encoder_d128():
+    """``ObservationContextEncoder`` forward + gradients at head_dim 128 (hidden 128 / ONE head / depth 2, cond 16; 41 grid
+    tokens x batch 104 = 4264 token rows): the dims at which the build's streamed attention kernels (D = 128), the QK-norm /
+    RoPE kernels with 64 rotary pairs, the 128-wide gate and the packed Linears run -- the head_dim of BASELINE config 5
+    (encoder 512 / 4 heads).  Depth 2 so that block 1 mixes the residual values of block 0.  The upstream context gradient is
+    ``RandomState(seed).randn`` (a frozen stream), regenerated by the test instead of being stored."""
+    g = torch.Generator().manual_seed(128)
+    torch.manual_seed(128)
+    cfg = EncoderConfig(hidden_dim=128, cond_dim=16, num_heads=1, depth=2)
+    enc = ObservationContextEncoder(observation_dim=2, sde_param_dim=3, config=cfg)
+    randomize_(enc, g, 0.1)
+    B, dt, horizon = 104, 0.05, 2.0
+    obs_t = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0])
+    obs_v = torch.tensor([[1.2, 0.7], [0.9, 1.1], [0.6, 1.4], [0.8, 1.0], [1.1, 0.8]])
+    theta = (torch.randn(B, 3, generator=g).abs() + 0.2).requires_grad_(True)
+    ctx = enc(obs_v, obs_t, theta, horizon, dt)
+    seed_g = 271828
+    gout = torch.from_numpy(np.random.RandomState(seed_g).randn(*ctx.shape).astype(np.float32))
+    names = [n for n, p in enc.named_parameters() if p.requires_grad]
+    params = [p for n, p in enc.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad((ctx * gout).sum(), [theta] + params)
+    rec = {"obs_times": obs_t.numpy(), "obs_values": obs_v.numpy(), "theta": theta.detach().numpy(),
+           "time_horizon": np.array(horizon), "time_step": np.array(dt),
+           "context_rows": np.arange(0, B, 13), "context": ctx.detach().numpy()[::13].copy(),
+           "g_context_seed": np.array(seed_g), "grad_theta": grads[0].numpy(),
+           "cfg": np.array([cfg.hidden_dim, cfg.cond_dim, cfg.num_heads, cfg.depth, B])}
+    for k, v in enc.state_dict().items():
+        rec["sd::" + k] = torch.view_as_real(v).numpy() if v.is_complex() else v.numpy()
+    for n, gr in zip(names, grads[1:]):
+        rec["grad::" + n] = gr.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder_d128.npz"), **rec)
+    print("wrote encoder_d128.npz", tuple(ctx.shape))
+
+
 # ------------------------------------------------------------------- Euler-Maruyama simulator of the model SDE
 def make_em_cases():
     """``euler_maruyama`` (core/euler_maruyama.py:11-45) with the example OU / LV SDEs, injected noise: trajectory and the
@@ -558,6 +593,8 @@ if __name__ == "__main__":
         make_trajectory()
     if "fused_dims" in which:
         make_fused_dims()
+    if "encoder_d128" in which:
+        make_encoder_d128()
     if "em" in which:
         make_em_cases()
     if "sde_coeffs" in which:
