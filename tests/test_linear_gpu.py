@@ -24,6 +24,9 @@ SHAPES = [(4264, 448, 128), (4264, 128, 128), (4264, 128, 384), (4264, 128, 448)
           (20000, 832, 256), (20000, 256, 256), (20000, 256, 768), (20000, 256, 832), (20000, 256, 1536),
           (3000, 1664 + 128, 512), (3000, 512, 512), (9000, 1664, 512), (3000, 512, 1408), (3000, 512, 1664), (3000, 512, 2816),
           (257, 256, 256), (31, 128, 64)]
+# the persistent deep-reduction kernel (opt-in: VSDE_DEEP_GEMM=1, M >= 32768): LV and config-5 shapes, ragged M, a row range that
+# is not a multiple of the 256-row tile, M just past a tile boundary
+DEEP_SHAPES = [(40000, 256, 768), (33001, 256, 832), (65536 + 32, 256, 1536), (35001, 512, 1408), (32768, 512, 512), (70000, 256, 1664)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -119,3 +122,34 @@ def test_pack_refresh_kernel_refills_every_pack_kind():
         assert torch.equal(pk.weight, w) and (b is None or torch.equal(pk.bias, b))
         assert torch.equal(pk.weight_t, w.t().contiguous()) and torch.equal(pk.transposed(), w.t().contiguous())
         assert not pk.stale()
+
+
+@pytest.mark.gpu
+def test_persistent_deep_reduction_kernel():
+    """lin_deep_kernel (persistent workgroups, both operands through LDS by global_load_lds, counted waits) is opt-in
+    (VSDE_DEEP_GEMM=1, read once per process): its shapes run in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from viforsdes_amd import _hip\n"
+        "for M, N, K in %r:\n"
+        "    assert _hip.linear_variant(M, N, K) == 3, (M, N, K)\n"
+        "    g = torch.Generator().manual_seed(M)\n"
+        "    x = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)\n"
+        "    w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().to(torch.bfloat16)\n"
+        "    b = torch.randn(N, generator=g).cuda().to(torch.bfloat16)\n"
+        "    ref = x.float() @ w.float().t() + b.float()\n"
+        "    y = _hip.linear_bf16(x, w, b)\n"
+        "    err = float((y.float() - ref).abs().max() / ref.abs().max())\n"
+        "    assert err < 1e-2, (M, N, K, err)\n"
+        "    wide = torch.randn(M, K + 64, generator=g).cuda().to(torch.bfloat16)\n"
+        "    out = torch.zeros(M, N + 8, device='cuda', dtype=torch.bfloat16)\n"
+        "    _hip.linear_bf16(wide[:, 32:32 + K], w, None, out=out[:, :N])\n"
+        "    ref2 = wide[:, 32:32 + K].float() @ w.float().t()\n"
+        "    assert float((out[:, :N].float() - ref2).abs().max() / ref2.abs().max()) < 1e-2 and float(out[:, N:].abs().max()) == 0.0\n"
+        "print('deep ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), DEEP_SHAPES)
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VSDE_DEEP_GEMM="1"), capture_output=True, text=True)
+    assert res.returncode == 0 and "deep ok" in res.stdout, res.stdout + res.stderr

@@ -53,3 +53,15 @@ t_b = timeit(lambda: _hip.swiglu_bwd(u, dy @ w2t.t()))
 t_bo = timeit(lambda: _hip.linear_swiglu_bwd_bf16(dy, w2t, u))
 print(f"mlp.in + SwiGLU fwd: hipBLASLt + swiglu kernel {t_f:7.1f} us | fused {t_fo:7.1f} us")
 print(f"mlp.out dgrad + SwiGLU bwd: hipBLASLt + swiglu_bwd kernel {t_b:7.1f} us | fused {t_bo:7.1f} us")
+# config-5 shapes (encoder 512, M = 256 x 1001)
+M5 = 256 * 1001
+print(f"config 5: M = {M5}")
+for name, N, K in (("qkv+gate fwd", 1664, 512), ("out_proj fwd/dgrad", 512, 512), ("mlp.out fwd", 512, 1408), ("qkv dgrad", 512, 1664),
+                   ("mlp.in dgrad", 512, 2816)):
+    x = torch.randn(M5, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev).to(torch.bfloat16)
+    t_lib = timeit(lambda: torch.nn.functional.linear(x, w, b))
+    t_own = timeit(lambda: _hip.linear_bf16(x, w, b))
+    fl, by = 2.0 * M5 * N * K, 2.0 * (M5 * K + M5 * N)
+    print(f"{name:24s} N={N:5d} K={K:5d}: hipBLASLt {t_lib:7.1f} us | own {t_own:7.1f} us = {fl / t_own / 1e6:6.0f} TF/s, {by / t_own / 1e3:6.0f} GB/s")

@@ -695,7 +695,8 @@ EPI_PLAIN, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2
 
 
 def linear_variant(M: int, N: int, K: int, epilogue: int = EPI_PLAIN) -> int:
-    """0 = shape not covered, 1 = rows kernel (K in {128, 256}), 2 = cols kernel (deep reductions)."""
+    """0 = shape not covered, 1 = rows kernel (K in {128, 256, 512}), 2 = cols kernel, 3 = persistent deep-reduction kernel
+    (K >= 512, N % 256 == 0, N <= K, M >= 32768)."""
     return int(load().vsde_linear_bf16_supported(_i64(M), ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(epilogue)))
 
 

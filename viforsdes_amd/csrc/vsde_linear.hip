@@ -536,6 +536,147 @@ __global__ void __launch_bounds__(C2_THREADS, 2) lin_cols_kernel(LinParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ deep kernel
+// Deep reductions with a narrow output (K = 768 / 832 / 1536 -> N = 256 at the LV encoder: SwiGLU output projection and the
+// input gradients of the wide projections; K = 1408 / 1664 / 2816 -> N = 512 at the 512-wide encoder): 2 K flops per activation
+// byte, i.e. right at the MFMA / HBM balance point, and an operand slice too deep to stay in registers.
+//   * persistent workgroups, one per CU (8 waves = 2 per SIMD, 96 KB of LDS): workgroup i owns the CONTIGUOUS row range
+//     [i R, (i + 1) R) with R = M / #CUs rounded up to 32 rows and walks it in 256 x 256 output tiles; the last tile of a
+//     range is partial and waves without valid rows skip their MFMAs -- 802 row tiles on 256 CUs cost ~3.2 tile times instead
+//     of the 4 rounds of a tile-per-workgroup grid;
+//   * both operands stream through LDS in 32-deep K chunks (activations [256][32] + weights [256][32] = 32 KB per stage, three
+//     stages -> FOUR since the ablation below) filled by global_load_lds_dwordx4 in full 64-byte row segments: no staging registers, no fragment-shaped global
+//     loads (which cost the texture path 4 requests per 128-byte line); a row's four 16-byte chunks are stored XOR-swizzled by
+//     (row >> 2) & 3 -- applied to the SOURCE address, the LDS image of a DMA is lane-linear -- so that the ds_read_b128 of a
+//     32-row MFMA fragment touches every bank group once;
+//   * counted waits: chunk t + 2 is requested right after the barrier that publishes chunk t, `s_waitcnt vmcnt(4)` (the four
+//     DMA instructions of chunk t + 1 may stay in flight) + a raw s_barrier per chunk -- __syncthreads() would drain the queue;
+//   * waves are laid out 4 (rows) x 2 (columns): a wave owns 64 rows x 128 columns = 2 x 4 accumulator blocks, 6 fragment reads
+//     per 8 MFMAs; products are swapped (D = W_tile x^T) like in the rows kernel, so the epilogue (bias, bf16, 128-byte row
+//     segments through the wave's staging buffer) is shared with it.
+constexpr int DP_THREADS = 512, DP_BK = 32, DP_STAGES = 4, DP_STAGE_BYTES = 2 * 256 * DP_BK * 2, DP_SLD = 72;
+
+__global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char dlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int64_t range0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t range1 = range0 + rows_per_wg < p.M ? range0 + rows_per_wg : p.M;
+    if (range0 >= p.M) return;
+    const int nk = p.K / DP_BK, ncol = p.N / 256;
+    // ---- this lane's part of the DMA pattern: instruction q of wave w fills LDS bytes [(4 w + q) 1024, + 1024) of a stage; waves
+    // 0..3 the activation half (rows 16 (4 w + q) + lane / 4), waves 4..7 the weight half; chunk c of a row sits at c ^ ((row >> 2) & 3)
+    const int cswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;   // element offset of the 16-byte chunk this lane fetches
+    const int lrow = lane >> 2;
+    // ---- fragment addresses (bytes inside a stage): row block base + r * 64 + ((h + 2 ks) ^ swz) * 16
+    const int swz = (r >> 2) & 3;
+    const int fo0 = r * 64 + ((h ^ swz) << 4), fo1 = r * 64 + (((h + 2) ^ swz) << 4);
+    const int a_base = (wm * 64) * 64, w_base = 256 * 64 + (wn * 128) * 64;
+    uint16_t *stage = (uint16_t *)dlds + (DP_STAGES * DP_STAGE_BYTES) / 2 - 0;   // epilogue staging: placed BEHIND the stages
+    (void)stage;
+
+    for (int64_t trow = range0; trow < range1; trow += 256) {
+        const bool active = trow + wm * 64 < range1;     // wave-uniform: rows of this wave inside the range
+        const int64_t bound = range1;                    // rows >= bound belong to the next workgroup (or do not exist)
+        for (int ct = 0; ct < ncol; ++ct) {
+            // source pointers of this lane's four DMA instructions (chunk 0 of K)
+            const uint16_t *src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gi = (wave & 3) * 4 + q;
+                if (wave < 4) {
+                    int64_t m = trow + gi * 16 + lrow;
+                    m = m < p.M ? m : p.M - 1;            // rows past the end repeat the last one (never stored)
+                    src[q] = p.A + m * p.lda + cswz;
+                } else {
+                    src[q] = p.W + (int64_t)(ct * 256 + gi * 16 + lrow) * p.K + cswz;
+                }
+            }
+            auto issue = [&](int kt) {
+                char *dst = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES + wave * 4096;
+                if (p.dbg && kt > 0 && ((p.dbg == 2 && wave < 4) || (p.dbg == 3 && wave >= 4) || p.dbg == 4)) return;   // ablation only
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_global_load_lds((const void *)(src[q] + kt * DP_BK), (__attribute__((address_space(3))) void *)(dst + q * 1024),
+                                                     16, 0, 0);
+            };
+            f32x16 acc[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[rb][nb][e] = 0.f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's output stores
+#pragma unroll
+            for (int q = 0; q < DP_STAGES - 1; ++q)
+                if (q < nk) issue(q);
+            for (int kt = 0; kt < nk; ++kt) {
+                // chunk kt has landed once at most the younger chunks' DMA instructions (4 each) are still in flight
+                const int younger = nk - 1 - kt < DP_STAGES - 2 ? nk - 1 - kt : DP_STAGES - 2;
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");    // chunk kt is in LDS for everyone; everyone is done with chunk kt - 1
+                if (kt + DP_STAGES - 1 < nk) issue(kt + DP_STAGES - 1);
+                if (active && p.dbg != 5) {
+                    const char *sb = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES;
+                    bf16x8 fa[2][2], fw[4][2];
+                    // the fragments of k-step 0 first: the second k-step's reads land behind the first k-step's MFMAs.  The reads are
+                    // inline asm with hand-counted waits: with scalar loads in flight hipcc only ever emits lgkmcnt(0) here
+                    const uint32_t sa = (uint32_t)(uintptr_t)(sb + a_base), sw = (uint32_t)(uintptr_t)(sb + w_base);
+#define VSDE_FRAG(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+                    {
+                        const uint32_t a0 = sa + fo0, w0 = sw + fo0, a1 = sa + fo1, w1 = sw + fo1;
+                        VSDE_FRAG(fa[0][0], a0, 0); VSDE_FRAG(fw[0][0], w0, 0); VSDE_FRAG(fw[1][0], w0, 2048); VSDE_FRAG(fa[1][0], a0, 2048);
+                        VSDE_FRAG(fw[2][0], w0, 4096); VSDE_FRAG(fw[3][0], w0, 6144);
+                        VSDE_FRAG(fa[0][1], a1, 0); VSDE_FRAG(fw[0][1], w1, 0); VSDE_FRAG(fw[1][1], w1, 2048); VSDE_FRAG(fa[1][1], a1, 2048);
+                        VSDE_FRAG(fw[2][1], w1, 4096); VSDE_FRAG(fw[3][1], w1, 6144);
+                    }
+#undef VSDE_FRAG
+                    __builtin_amdgcn_s_setprio(1);
+                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb][0], fa[rb][0], acc[rb][nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // the first k-step's MFMAs stay ABOVE the wait for the second k-step's fragments
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb][1], fa[rb][1], acc[rb][nb], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            // ---- epilogue: stage buffers are free once everyone has left the K loop
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            uint16_t *brow = (uint16_t *)dlds;                                   // 256 bias values
+            uint16_t *stg = (uint16_t *)dlds + 256 + wave * (32 * DP_SLD);      // 32 rows x 64 columns per wave
+            if (tid < 128) *(uint32_t *)(brow + 2 * tid) = p.bias ? *(const uint32_t *)(p.bias + ct * 256 + 2 * tid) : 0u;
+            lds_barrier();
+            if (active) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {   // 64 columns at a time
+                        const int n0 = wn * 128 + pr * 64;
+                        stage_block(acc[rb][2 * pr], brow + n0, stg + r * DP_SLD, h);
+                        stage_block(acc[rb][2 * pr + 1], brow + n0 + 32, stg + r * DP_SLD + 32, h);
+                        wave_lds_fence();
+                        flush_rows64<DP_SLD, 32>(stg, p.C + ct * 256 + n0, p.ldc, trow + wm * 64 + rb * 32, bound, lane);
+                        wave_lds_fence();
+                    }
+            }
+            lds_barrier();   // staging area is stage 0 again
+        }
+    }
+}
+
 template <int KC, int EPI, int NKH> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t); }
 template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * C2_LDB) * sizeof(uint16_t); }   // two weight buffers (the epilogue reuses them)
 
@@ -583,11 +724,40 @@ static int launch_cols(const LinParams &p, hipStream_t s) {
     return 0;
 }
 
+static int launch_deep(const LinParams &p, hipStream_t s) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        VSDE_CHECK_HIP(hipGetDevice(&dev));
+        VSDE_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t lds = (size_t)DP_STAGES * DP_STAGE_BYTES;
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t rows = (p.M + cus - 1) / cus;
+    rows = (rows + 31) / 32 * 32;                      // contiguous row range per workgroup, whole 32-row blocks
+    if (rows < 64) rows = 64;
+    const int64_t wgs = (p.M + rows - 1) / rows;
+    hipLaunchKernelGGL(lin_deep_kernel, dim3((unsigned)wgs), dim3(DP_THREADS), lds, s, p, (int)rows);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // EPI_QKNORM is instantiated for K = 256 only (the encoder width it was written for)
 static int launch_qknorm(const LinParams &p, hipStream_t s) { return launch_rows<256, EPI_QKNORM>(p, s); }
 
-// 1 = rows kernel, 2 = cols kernel, 0 = shape not covered (the caller keeps its library GEMM)
-static int lin_variant(int N, int K, int epilogue) {
+static bool deep_enabled() {
+    static int v = -1;
+    // off by default: 137 / 260 us at K = 768 / 1536 (M = 205 k) against 102 / 179 us of the tuned library solutions
+    // (profiles/r03_deep_gemm_ablation.txt); VSDE_DEEP_GEMM=1 routes the deep reductions here (tests, A/B runs)
+    if (v < 0) { const char *e = getenv("VSDE_DEEP_GEMM"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
+// 1 = rows kernel, 2 = cols kernel, 3 = deep kernel (persistent, both operands through LDS), 0 = shape not covered
+static int lin_variant(int64_t M, int N, int K, int epilogue) {
+    // deep reductions with a narrow output at sizes that fill the chip (>= 128 rows per CU): the persistent kernel
+    if (epilogue == EPI_PLAIN && deep_enabled() && K >= 512 && K % 32 == 0 && N % 256 == 0 && N <= K && M >= 32768) return 3;
     const bool rows_ok = (K == 128 || K == 256 || K == 512) && N % 64 == 0;   // K = 512: two k-halves per output tile
     const bool cols_ok = K % 64 == 0 && N % 128 == 0 && epilogue == EPI_PLAIN;
     if (epilogue != EPI_PLAIN) return rows_ok ? 1 : 0;
@@ -602,14 +772,14 @@ using namespace vsde;
 
 extern "C" int vsde_linear_bf16_supported(int64_t M, int N, int K, int epilogue) {
     if (M <= 0 || N <= 0 || K <= 0 || epilogue < 0 || epilogue > 2) return 0;
-    return lin_variant(N, K, epilogue);
+    return lin_variant(M, N, K, epilogue);
 }
 
 extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias, void *y, int64_t ldy, int64_t M, int N,
                                 int K, int epilogue, void *s_out, int64_t lds, const void *u_in, int64_t ldu, void *stream) {
     VSDE_CHECK_ARG(x && w && M > 0 && N > 0 && K > 0, VSDE_E_BADARG, "bad linear arguments");
     VSDE_CHECK_ARG(epilogue >= 0 && epilogue <= 2, VSDE_E_BADARG, "unknown linear epilogue %d", epilogue);
-    const int variant = lin_variant(N, K, epilogue);
+    const int variant = lin_variant(M, N, K, epilogue);
     VSDE_CHECK_ARG(variant != 0, VSDE_E_BADARG, "linear shape N=%d K=%d epilogue=%d is not covered by the gfx950 kernels", N, K, epilogue);
     VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, VSDE_E_BADARG,
                    "linear operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
@@ -622,6 +792,7 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
     if (epilogue == EPI_PLAIN) {
         VSDE_CHECK_ARG(y && ldy >= N && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0, VSDE_E_BADARG, "bad linear output");
         if (variant == 1) return launch_rows_k<EPI_PLAIN>(p, st);
+        if (variant == 3) return launch_deep(p, st);
         return N % 256 == 0 ? launch_cols<8>(p, st) : launch_cols<4>(p, st);
     }
     if (epilogue == EPI_SWIGLU) {

@@ -572,7 +572,7 @@ class PackedWeight:
 
 # the MFMA GEMM kernels of csrc/vsde_linear.hip for the shapes they cover (VSDE_OWN_GEMM=0: library GEMMs everywhere, for A/B runs)
 OWN_GEMM = os.environ.get("VSDE_OWN_GEMM", "1") != "0"
-# also their deep-reduction variant (K > 256), currently slower than the tuned hipBLASLt solutions
+# also the older non-persistent deep-reduction (cols) variant for shapes the persistent deep kernel does not take
 OWN_GEMM_COLS = os.environ.get("VSDE_OWN_GEMM_COLS", "0") == "1"
 
 
@@ -581,7 +581,7 @@ def own_gemm(M: int, N: int, K: int, epilogue: int = 0) -> bool:
     if not (ENABLED and OWN_GEMM) or M < 4096:
         return False
     variant = _hip.linear_variant(M, N, K, epilogue)
-    return variant == 1 or (variant == 2 and OWN_GEMM_COLS)
+    return variant in (1, 3) or (variant == 2 and OWN_GEMM_COLS)
 
 
 def _mm_nt(x2: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
