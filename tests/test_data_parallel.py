@@ -181,3 +181,61 @@ def _pretrain_worker(rank, world, port, out_dir):
 @pytest.mark.timeout(600)
 def test_two_rank_pretrain_keeps_replicas_identical(tmp_path):
     mp.spawn(_pretrain_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _split_worker(rank, world, port, out_dir):
+    """The step in the order the GPU's two-graph replay runs it -- [forward/backward + pack] | all-reduce | [attach is fixed at
+    capture: p.grad ARE the flat views] optimizer -- against the plain ``_train_step`` on a twin trainer with the same draws."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle.torch_backend import OracleBackend
+    from viforsdes_amd.kernels.backend import set_backend
+    set_backend(OracleBackend())
+    ref, two = _make_trainer(seed=31), _make_trainer(seed=31)
+    assert ref.ctx.grad_sync.active and two.ctx.grad_sync.active
+    g = torch.Generator().manual_seed(1000 + rank)
+    draws = [(torch.randn(4, 3, generator=g), torch.randn(4, 20, 1, generator=g)) for _ in range(3)]
+    for k, (eps, noise) in enumerate(draws):
+        ref._train_step(ref.ctx.model, theta_eps=eps, path_noise=noise)
+        ref.ctx.ema.update()
+        # --- phase 1 (graph 1 on the GPU): forward/backward, gradients packed into the flat buffer
+        two._forward_backward(two.ctx.model, eps, noise)
+        gs = two.ctx.grad_sync
+        gs.pack()
+        # --- between the graphs: the eager all-reduce of the flat buffer
+        gs.reduce()
+        if k == 0:
+            gs.attach()          # captured once: from here on p.grad are the flat buffer's views and STAY so across replays
+        else:
+            # a replay does not run Python: the optimizer graph keeps reading the views attached at capture time
+            for p, v in zip(gs.params, gs._views):
+                p.grad = v
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(gs.params, gs._views))
+        # --- phase 2 (graph 2): unscale, clip, AdamW, EMA
+        two._optimizer_step()
+        two.ctx.ema.update()
+        for a, b in zip(ref.ctx.model.parameters(), two.ctx.model.parameters()):
+            assert torch.equal(a, b), "split two-phase step diverged from the plain step"
+    flat = torch.cat([p.detach().reshape(-1) for p in two.ctx.model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], g_) for g_ in gathered), "parameters diverged across ranks"
+    shadow = torch.cat([v.reshape(-1) for v in two.ctx.ema.shadow.values()])
+    sh = [torch.zeros_like(shadow) for _ in range(world)]
+    dist.all_gather(sh, shadow)
+    assert all(torch.equal(sh[0], s_) for s_ in sh), "EMA shadows diverged across ranks"
+    torch.save({"ok": True}, os.path.join(out_dir, f"split{rank}.pt"))
+    ref.ctx.cleanup()
+
+
+@pytest.mark.timeout(600)
+def test_split_two_phase_step_matches_plain_step_on_two_ranks(tmp_path):
+    """pack -> all-reduce -> (attach) -> optimizer as separate phases (the ordering of the two-HIP-graph replay under data
+    parallelism, trainer.capture_step_graph) gives bit-identical parameters to ``_train_step`` on both ranks, and the ranks stay
+    identical (reference semantics: one gradient average per optimizer step before unscale / clip, trainer.py:128-131,
+    training_context.py:59-68)."""
+    world, port = 2, _free_port()
+    mp.spawn(_split_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"split{r}.pt").exists() for r in range(world))
