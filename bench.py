@@ -235,7 +235,9 @@ def self_launch(n, argv, script=None):
                     procs[q].terminate()
         time.sleep(0.2)
     reader.join(timeout=30)
-    sys.stdout.write("".join(chunks))
+    # stdout carries the JSON line only: anything else a library printed there (gloo / RCCL connection banners) goes to stderr
+    for ln in "".join(chunks).splitlines():
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     raise SystemExit(rc if rc else 0)
 
