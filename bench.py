@@ -70,7 +70,7 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
     return tr
 
 
-PMC_FILE = "profiles/r02_pmc_head_lv.txt"
+PMC_FILE = "profiles/r03_pmc_head_lv.txt"
 
 
 def pmc_traffic_bytes(workload, batch):
