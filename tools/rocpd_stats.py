@@ -76,3 +76,34 @@ if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--busy":
     busy(sys.argv[1])
 elif __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--categories":
     categories(sys.argv[1])
+
+
+def busy(path, marker="head_fwd_v2_kernel<2, true", first=8, last=28):
+    """GPU busy fraction between the `first`-th and `last`-th launch of the marker kernel (one per training step): sum of kernel
+    durations / wall span, plus the per-step wall time and the number of launches per step."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if len(marks) <= last:
+        print("not enough marker launches:", len(marks)); return
+    a, b = marks[first], marks[last]
+    t0, t1 = rows[a][1], rows[b][1]
+    dur = sum(r[2] - r[1] for r in rows[a:b])
+    # union of busy intervals (kernels may overlap)
+    busy_ns, cur_end = 0, t0
+    for _, s, e in rows[a:b]:
+        if e > cur_end:
+            busy_ns += e - max(s, cur_end); cur_end = e
+    steps = last - first
+    print(f"steps {steps}: wall {1e-6 * (t1 - t0) / steps:.3f} ms/step, sum of kernel durations {1e-6 * dur / steps:.3f} ms/step, "
+          f"GPU busy (union) {100.0 * busy_ns / (t1 - t0):.1f} %, launches/step {(b - a) / steps:.0f}")
+    gaps = sorted(((rows[i + 1][1] - rows[i][2]) for i in range(a, b - 1)), reverse=True)
+    print("idle gaps: total %.3f ms/step; gaps > 5 us: %d per step; largest (us): %s" % (
+        1e-6 * sum(g for g in gaps if g > 0) / steps, sum(1 for g in gaps if g > 5000) / steps, [round(g / 1e3, 1) for g in gaps[:8]]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "busy":
+    busy(sys.argv[1])
