@@ -26,3 +26,6 @@ print(f"ln_bwd (+dres)    {t(lambda: _hip.ln_modulate_bwd(x, sc, dy, mean, rstd,
 print(f"ln_bwd            {t(lambda: _hip.ln_modulate_bwd(x, sc, dy, mean, rstd)):7.1f} us  ({3*mb:.0f} MB)")
 print(f"gres_fwd          {t(lambda: _hip.gated_residual_fwd(x, y, gate)):7.1f} us  ({3*mb:.0f} MB)")
 print(f"gres_bwd          {t(lambda: _hip.gated_residual_bwd(y, gate, dy)):7.1f} us  ({3*mb:.0f} MB)")
+xn, h, *_ = _hip.residual_ln_fwd(x, y, gate, sc, sh, 1e-5) if hasattr(_hip, "residual_ln_fwd") else (None, None)
+if hasattr(_hip, "residual_ln_fwd"):
+    print(f"residual_ln_fwd   {t(lambda: _hip.residual_ln_fwd(x, y, gate, sc, sh, 1e-5)):7.1f} us  ({4*mb:.0f} MB)")

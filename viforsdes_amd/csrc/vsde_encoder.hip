@@ -12,6 +12,8 @@
 // Memory-bound streaming kernels: 8 (bf16) / 4 (f32) contiguous elements per lane, math in fp32.
 // T = float (mixed_precision off; parity tests) or bf16 (autocast).  Per-batch-row conditioning
 // vectors are [B, C]; reductions over the tokens of a batch row are deterministic (no atomics).
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -99,48 +101,65 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
                                                          int N, int C, float eps, const T *__restrict__ res_y,
                                                          const T *__restrict__ res_gate, T *__restrict__ xnew, int64_t mp) {
     // res_y != nullptr: the input of the norm is the gated residual x + gate * res_y, which is also written to xnew
-    // (same rounding points as gated_residual followed by ln_modulate)
+    // (same rounding points as gated_residual followed by ln_modulate).
+    // Grid-stride over the tokens with the next token's x / res_y rows requested before the current one is normalised: a capped
+    // grid of resident workgroups keeps more bytes in flight per CU than one tiny workgroup per 8 tokens (round 3).
     const int lane = threadIdx.x & (LPR - 1);
-    const int64_t m = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-    if (m >= M) return;
-    const int64_t b = m / N;
     constexpr int nslab = NSLAB;  // C == NSLAB * LPR * V
-    float v[NSLAB][V];
-    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPR);
+    int64_t m = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    float v[NSLAB][V], ry[NSLAB][V], nv[NSLAB][V], nry[NSLAB][V];
+    auto fetch = [&](int64_t mm, float (&vx)[NSLAB][V], float (&vy)[NSLAB][V]) {
 #pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl)
-        if (sl < nslab) {
-            Pack<T, V>::load(x + m * C + (sl * LPR + lane) * V, v[sl]);
-            if (res_y) {
-                float ry[V], rg[V];
-                Pack<T, V>::load(res_y + m * C + (sl * LPR + lane) * V, ry);
-                Pack<T, V>::load(res_gate + b * mp + (sl * LPR + lane) * V, rg);
+        for (int sl = 0; sl < NSLAB; ++sl)
+            if (sl < nslab) {
+                Pack<T, V>::load(x + mm * C + (sl * LPR + lane) * V, vx[sl]);
+                if (res_y) Pack<T, V>::load(res_y + mm * C + (sl * LPR + lane) * V, vy[sl]);
+            }
+    };
+    if (m < M) fetch(m, v, ry);
+    for (; m < M; m += stride) {
+        const int64_t mn = m + stride;
+        if (mn < M) fetch(mn, nv, nry);
+        const int64_t b = m / N;
+        float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < V; ++e) v[sl][e] = rnd<T>(v[sl][e] + rnd<T>(rg[e] * ry[e]));
-                Pack<T, V>::store(xnew + m * C + (sl * LPR + lane) * V, v[sl]);
+        for (int sl = 0; sl < NSLAB; ++sl)
+            if (sl < nslab) {
+                if (res_y) {
+                    float rg[V];
+                    Pack<T, V>::load(res_gate + b * mp + (sl * LPR + lane) * V, rg);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[sl][e] = rnd<T>(v[sl][e] + rnd<T>(rg[e] * ry[sl][e]));
+                    Pack<T, V>::store(xnew + m * C + (sl * LPR + lane) * V, v[sl]);
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) s += v[sl][e];
+            }
+        const float mu = seg_sum(s, LPR) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSLAB; ++sl)
+            if (sl < nslab)
+#pragma unroll
+                for (int e = 0; e < V; ++e) { const float d = v[sl][e] - mu; q += d * d; }
+        const float rs = rsqrtf(seg_sum(q, LPR) / C + eps);
+        if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+#pragma unroll
+        for (int sl = 0; sl < NSLAB; ++sl)
+            if (sl < nslab) {
+                const int c = (sl * LPR + lane) * V;
+                float sc[V], sh[V], o[V];
+                Pack<T, V>::load(scale + b * mp + c, sc); Pack<T, V>::load(shift + b * mp + c, sh);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = (v[sl][e] - mu) * rs * (1.0f + sc[e]) + sh[e];
+                Pack<T, V>::store(y + m * C + c, o);
             }
 #pragma unroll
-            for (int e = 0; e < V; ++e) s += v[sl][e];
-        }
-    const float mu = seg_sum(s, LPR) / C;
-    float q = 0.f;
+        for (int sl = 0; sl < NSLAB; ++sl)
 #pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl)
-        if (sl < nslab)
-#pragma unroll
-            for (int e = 0; e < V; ++e) { const float d = v[sl][e] - mu; q += d * d; }
-    const float rs = rsqrtf(seg_sum(q, LPR) / C + eps);
-    if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
-#pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl)
-        if (sl < nslab) {
-            const int c = (sl * LPR + lane) * V;
-            float sc[V], sh[V], o[V];
-            Pack<T, V>::load(scale + b * mp + c, sc); Pack<T, V>::load(shift + b * mp + c, sh);
-#pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = (v[sl][e] - mu) * rs * (1.0f + sc[e]) + sh[e];
-            Pack<T, V>::store(y + m * C + c, o);
-        }
+            for (int e = 0; e < V; ++e) { v[sl][e] = nv[sl][e]; ry[sl][e] = nry[sl][e]; }
+    }
 }
 
 // Backward passes that also need a per-(batch row, channel) sum over the N tokens.  Grid (nchunk, B): a block
@@ -583,6 +602,12 @@ static inline int ew_grid(int64_t total, int per_block) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+static int64_t ln_fwd_grid_cap() {   // resident workgroups of the grid-stride forward (VSDE_LN_GRID overrides, A/B runs)
+    static int64_t v = 0;
+    if (!v) { const char *e = getenv("VSDE_LN_GRID"); v = e && atoll(e) > 0 ? atoll(e) : 4096; }
+    return v;
+}
+
 struct LnResidual {  // optional gated residual fused in front of the norm (forward) / behind its backward
     const void *y = nullptr;     // residual branch [B][N][C]
     const void *gate = nullptr;  // [B][C]
@@ -601,7 +626,9 @@ static int ln_mod_dispatch(int which, const void *x, const void *scale, const vo
 #define LNM_N(V, LPR, NS)                                                                                                     \
     do {                                                                                                                      \
         if (which == 0) {                                                                                                     \
-            dim3 grid((unsigned)((M + 256 / LPR - 1) / (256 / LPR)));                                                         \
+            int64_t nblk = (M + 256 / LPR - 1) / (256 / LPR);                                                                 \
+            const int64_t cap = ln_fwd_grid_cap();                                                                            \
+            dim3 grid((unsigned)(nblk < cap ? nblk : cap));                                                                   \
             hipLaunchKernelGGL((ln_mod_fwd_kernel<T, V, LPR, NS>), grid, block, 0, s, (const T *)x, (const T *)scale,         \
                                (const T *)shift_or_dy, (T *)out, mean, rstd, M, N, C, eps, (const T *)res.y,                  \
                                (const T *)res.gate, (T *)res.out, res.mp ? res.mp : (int64_t)C);                              \
