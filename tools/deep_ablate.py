@@ -19,5 +19,5 @@ for N, K in ((256, 768), (256, 1536)):
     out.append(f"K={K}: {timeit(lambda: _hip.linear_bf16(x, w, None)):.1f} us")
 print("VSDE_LIN_DEBUG=" + os.environ.get("VSDE_LIN_DEBUG", "0"), " | ".join(out))
 '''
-for dbg in ("0", "2", "3", "4", "5"):
-    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VSDE_LIN_DEBUG=dbg))
+for dbg in ("0", "2", "3", "4", "5", "6", "7"):   # 6: activation DMA only, 7: weight DMA only (no MFMAs)
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VSDE_LIN_DEBUG=dbg, VSDE_DEEP_GEMM="1"))

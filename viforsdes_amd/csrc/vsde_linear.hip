@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
             }
             auto issue = [&](int kt) {
                 char *dst = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES + wave * 4096;
-                if (p.dbg && kt > 0 && ((p.dbg == 2 && wave < 4) || (p.dbg == 3 && wave >= 4) || p.dbg == 4)) return;   // ablation only
+                if (p.dbg && kt > 0 && (((p.dbg == 2 || p.dbg == 7) && wave < 4) || ((p.dbg == 3 || p.dbg == 6) && wave >= 4) || p.dbg == 4)) return;   // ablation only
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     __builtin_amdgcn_global_load_lds((const void *)(src[q] + kt * DP_BK), (__attribute__((address_space(3))) void *)(dst + q * 1024),
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");    // chunk kt is in LDS for everyone; everyone is done with chunk kt - 1
                 if (kt + DP_STAGES - 1 < nk) issue(kt + DP_STAGES - 1);
-                if (active && p.dbg != 5) {
+                if (active && p.dbg < 5) {
                     const char *sb = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES;
                     bf16x8 fa[2][2], fw[4][2];
                     // the fragments of k-step 0 first: the second k-step's reads land behind the first k-step's MFMAs.  The reads are
