@@ -53,6 +53,7 @@ struct LinParams {
     // gated A operand (no-grad out projection): row m of A is multiplied by sigmoid(Gate[m][k % 64]) on its way into the registers
     const uint16_t *Gate; int64_t ldgate;
     int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
+    int xstage;                        // rows kernel: 1 = activations loaded as full row segments and redistributed through LDS
 };
 
 typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -332,8 +333,40 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     const int64_t row0 = stripe * ROWS + wave * (32 * RB);
 
     bf16x8 afr[RB][KS];
+    // Two ways to fill the resident operand.  (a) fragment-shaped: lane (r, h) loads its 16 bytes of every k-step straight from
+    // global memory -- 32 rows x 32 bytes per instruction, i.e. every 128-byte line of x is requested by four instructions.
+    // (b) `xstage` (K <= 256, round 3): the wave loads its 32 rows as WHOLE row segments (a row = KT / 8 lanes x 16 bytes, full
+    // lines), parks them in its own 32 x KT slice of LDS (16-byte chunks XOR-swizzled by row & 15: conflict-free both ways) and
+    // reads the fragments back; no workgroup barrier is involved until the slices are handed over to the weight tiles.
+    const bool xst = NKH == 1 && p.xstage && !(EPI == EPI_PLAIN && p.Gate != nullptr);
+    if (xst) {
+        constexpr int CPR = KT / 8, RPI = 64 / CPR;          // 16-byte chunks per row, rows per load instruction
+        char *xs = (char *)lsm + wave * (32 * KT * 2);
+        const int lrow = lane / CPR, lc = lane % CPR;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            u32x4 t[KS];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int rl = i * RPI + lrow;
+                const int64_t m = row0 + rb * 32 + rl < p.M ? row0 + rb * 32 + rl : p.M - 1;
+                t[i] = *(const u32x4 *)(p.A + m * p.lda + lc * 8);
+            }
+            if (rb > 0) wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const int rl = i * RPI + lrow;
+                *(u32x4 *)(xs + rl * (KT * 2) + ((lc ^ (rl & 15)) << 4)) = t[i];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) afr[rb][ks] = *(const bf16x8 *)(xs + r * (KT * 2) + (((h + 2 * ks) ^ (r & 15)) << 4));
+        }
+        lds_barrier();   // every wave has its fragments: the slices become the weight-tile buffers / staging rows
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
+        if (xst) break;
         const int64_t m = row0 + rb * 32 + r < p.M ? row0 + rb * 32 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const uint16_t *src = p.A + m * p.lda + 8 * h;
 #pragma unroll
@@ -677,7 +710,17 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
     }
 }
 
-template <int KC, int EPI, int NKH> static size_t rows_lds_bytes() { return (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t); }
+static int rows_xstage() {   // VSDE_ROWS_XSTAGE=0: fragment-shaped activation loads in the rows kernel (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VSDE_ROWS_XSTAGE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+template <int KC, int EPI, int NKH> static size_t rows_lds_bytes() {
+    const size_t need = (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t);
+    const size_t xstage = NKH == 1 ? (size_t)4 * 32 * KC * 2 : 0;   // the waves' activation slices of the prologue
+    return need > xstage ? need : xstage;
+}
 template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * C2_LDB) * sizeof(uint16_t); }   // two weight buffers (the epilogue reuses them)
 
 template <int KC, int EPI, int NKH = 1>
@@ -703,6 +746,7 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     }
     LinParams q = p;
     q.chunks = chunks;
+    q.xstage = rows_xstage();
     hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(R2_THREADS), lds, s, q);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
