@@ -226,3 +226,38 @@ def test_bf16_grad_context_matches_the_rounded_fp32_result():
     for a, b_ in zip(g16[:1] + g16[2:], g32[:1] + g32[2:]):   # every other gradient is untouched by the output dtype
         if b_.numel():
             assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("S,L,T", [(2, 2, 1), (2, 2, 15), (2, 2, 17), (2, 2, 33), (1, 2, 48), (1, 1, 19), (3, 2, 21), (2, 2, 400)])
+def test_ragged_step_counts_with_staggered_chunks(S, L, T):
+    """Every path starts with a first chunk of a different length (the workgroups' chunk grids are staggered, forward and
+    backward): step counts around the chunk size, a single step, and the full LV length, B = 37 paths (all 16 phases), against
+    the float64 oracle (forward.py:137-375, backward.py:208-624 restated in oracle/vsde_oracle_impl.h)."""
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    dev = _dev()
+    B, C, P, H = 37, 32, 3, 64
+    NO = S + S * (S + 1) // 2
+    g = np.random.default_rng(1000 * S + 10 * L + T)
+    rn = lambda *s, sc=1.0: (g.standard_normal(s) * sc).astype(np.float32)
+    ws = [rn(3 * H, S + C + P, sc=.15), rn(3 * H, H, sc=.15), rn(3 * H, sc=.1), rn(3 * H, sc=.1), rn(L - 1, 3 * H, H, sc=.15),
+          rn(L - 1, 3 * H, H, sc=.15), rn(L - 1, 3 * H, sc=.1), rn(L - 1, 3 * H, sc=.1), rn(NO, H, sc=.2), rn(NO, sc=.3)]
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C), np.abs(rn(B, P)), rn(B, T, S)
+    gp, gm, gl = rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tws = [t(w) for w in ws]
+    out = _hip.head_forward(t(x0), t(ctx)[:, :-1], t(theta), t(eps), tws, 0.05, True)
+    grads = _hip.head_backward(t(gp), t(gm), t(gl), t(ctx)[:, :-1], t(theta), t(eps), out[0], out[3], out[4], tws, 0.05)
+    ev = _hip.head_forward(t(x0), t(ctx)[:, :-1], t(theta), t(eps), tws, 0.05, False)
+    w64 = vo.HeadWeights(*[w.astype(np.float64) for w in ws])
+    f64 = lambda a: a.astype(np.float64)
+    f = vo.head_forward(f64(x0), f64(ctx)[:, :-1], f64(theta), f64(eps), w64, 0.05, True, dtype=np.float64)
+    for a, b_ in zip(out[:3], (f.paths, f.means, f.chol)):
+        assert rel_err(a.cpu().numpy(), b_) < FWD_TOL
+    assert rel_err(out[4].cpu().numpy(), f.acts) < FWD_TOL and rel_err(out[3].cpu().numpy(), f.chol_raw) < FWD_TOL
+    for a, b_ in zip(ev[:3], out[:3]):
+        assert torch.equal(a, b_)
+    gref = vo.head_backward(f64(gp), f64(gm), f64(gl), f64(ctx)[:, :-1], f64(theta), f64(eps), f, w64, 0.05, dtype=np.float64)
+    for name, a, b_ in zip(G_NAMES, grads, gref):
+        if b_.size:
+            assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, name
