@@ -32,7 +32,8 @@ def timeit(fn, n=20):
 
 print(f"M = {M}")
 for name, N, K in (("qkv+gate fwd", 832, 256), ("out_proj fwd/dgrad", 256, 256), ("mlp.out fwd", 256, 768),
-                   ("qkv dgrad", 256, 832), ("mlp.in dgrad", 256, 1536), ("mlp.in fwd (plain)", 1536, 256), ("mlp.out dgrad (plain)", 768, 256)):
+                   ("qkv dgrad", 256, 832), ("mlp.in dgrad", 256, 1536), ("mlp.in fwd (plain)", 1536, 256), ("mlp.out dgrad (plain)", 768, 256),
+                   ("mlp.out fwd 704", 256, 704), ("mlp.in dgrad 1408", 256, 1408)):
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, device=dev).to(torch.bfloat16)

@@ -12,7 +12,10 @@ dev = torch.device("cuda:0")
 M = 512 * 401
 bf = torch.bfloat16
 shapes = [  # (name, kind, N, K): fwd = F.linear(x[M,K], W[N,K], b) ; dgrad = dy[M,N] @ W[N,K]
-    ("proj", 832, 256), ("out", 256, 256), ("mlp_in", 1536, 256), ("mlp_out", 256, 768)]
+    ("proj", 832, 256), ("out", 256, 256), ("mlp_in", 1536, 256), ("mlp_out", 256, 768),
+    ("mlp_in704", 1408, 256), ("mlp_out704", 256, 704)]   # SwiGLU width 682 padded to 704 (round 3)
+if len(sys.argv) > 2:   # only the named shapes
+    shapes = [s_ for s_ in shapes if s_[0] in sys.argv[2:]]
 
 def bench(fn, n=20):
     for _ in range(3): fn()
@@ -38,7 +41,7 @@ for n, f in ops:
     f(); torch.cuda.synchronize()
 print(f"tuning took {time.time() - t0:.1f} s")
 tuned = {n: bench(f) for n, f in ops}
-tn.write_file(out)
+(tn.write_file(out) if hasattr(tn, "write_file") else None)
 for n, _ in ops:
     print(f"{n:14s} default {base[n]:7.1f} us   tuned {tuned[n]:7.1f} us   ({base[n]/tuned[n]:.2f}x)")
 print(f"sum default {sum(base.values()):.0f} us  tuned {sum(tuned.values()):.0f} us")
