@@ -42,7 +42,7 @@ for name, N, K in (("qkv+gate fwd", 832, 256), ("out_proj fwd/dgrad", 256, 256),
     fl, by = 2.0 * M * N * K, 2.0 * (M * K + M * N)
     print(f"{name:24s} N={N:5d} K={K:5d}: hipBLASLt {t_lib:7.1f} us | own {t_own:7.1f} us = {fl / t_own / 1e6:6.0f} TF/s, {by / t_own / 1e3:6.0f} GB/s")
 # fused SwiGLU pair vs the unfused chain
-K, H = 256, 768
+K, H = 256, 704   # the padded SwiGLU width of the LV encoder (682 -> 704)
 x = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w1 = (torch.randn(2 * H, K, device=dev) * K ** -0.5).to(torch.bfloat16); b1 = torch.randn(2 * H, device=dev).to(torch.bfloat16)
 w2t = (torch.randn(H, K, device=dev) * H ** -0.5).to(torch.bfloat16)

@@ -400,7 +400,10 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         }
     }
     // a workgroup owns one chunk of the output columns of its stripe (see launch_rows)
-    const int ntiles = p.N / 32 / nchunks, tile0 = chunk * ntiles;
+    // column chunks in whole tile pairs; the last chunk may be shorter (N = 704: 11 pairs = 6 + 5)
+    const int pairs_all = p.N / 64, ppc = (pairs_all + nchunks - 1) / nchunks, pair0 = chunk * ppc;
+    const int ntiles = 2 * (ppc < pairs_all - pair0 ? ppc : pairs_all - pair0), tile0 = 2 * pair0;
+    if (ntiles <= 0) return;   // workgroup-uniform: an empty trailing chunk
     const int rot = 2 * ((int)stripe % (ntiles / 2));
     u32x4 breg[NLD];          // the next sub-tile on its way from L2 to LDS (loaded one iteration before its LDS store)
     uint32_t biasreg = 0u;
@@ -742,7 +745,8 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
         // measured at M = 205 k: SwiGLU forward 290 | 277 | 272 | 307 us and backward 303 | 287 | 295 | 305 us for 1 | 2 | 4 | 8
         // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
         const int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
-        if (stripes >= 512 && want > 1 && pairs % want == 0) chunks = want;
+        const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
+        if (stripes >= 512 && want > 1 && (pairs % want == 0 || (uneven_ok && pairs >= 2 * want))) chunks = want;
     }
     LinParams q = p;
     q.chunks = chunks;
