@@ -217,6 +217,29 @@ int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, cons
                             void *dq, void *dk, void *dv, float *delta, int64_t B, int N, int H, int head_dim, double scale,
                             void *stream);
 
+/* ---- Training step with the projection-side elementwise work folded into the attention kernels ------------------------
+ * (primitives/attn.py:80-113 between the [q | k | v | gate] projection and the output projection; head_dim 64 and
+ * N <= vsde_attention_max_tokens(): vsde_attention_fused_supported != 0.)  The forward is vsde_linear_qknorm_bf16 (with its
+ * rinv / vdiff outputs) + vsde_attention_fwd_gated_bf16; the backward is vsde_gate_bwd_delta + vsde_attention_bwd_fused_bf16,
+ * which leaves the gradient dy [M][ldy] of the projection output ready for its input- and weight-gradient GEMMs.  Replaces
+ * the separate qk_norm_rope fwd / bwd and gate_merge fwd passes of the unfused training chain.
+ *   vsde_attention_fwd_gated_bf16   o[b,n,h,:] = softmax(..) v * rnd(sigmoid(gate[b n][0..64)))   (the merged [B,N,(h d)] rows)
+ *   vsde_gate_bwd_delta             dattn = dout * s, dgate[m][0..64) = (1 - s) sum_h dout * og, delta[b,h,n] = <dout, og>
+ *   vsde_attention_bwd_fused_bf16   dattn, the forward's q, k, v, lse and that delta -> dy columns [dq_raw | dk_raw | dv_raw]:
+ *       the RoPE / RMS-norm backward from the saved rotated rows and rinv [M][2H] (weights wq / wk all non-zero), the value mix
+ *       from vdiff = v_raw - v0 (NULL: no mixing): dv_raw = lam dv, dv0 (+)= (1 - lam) dv, dlam_partial[B H ceil(N/32)] partial
+ *       sums of <dv, vdiff> (vsde_attention_bwd_fused_partials entries); dv_extra (NULL or [M][64H]) is added to dv first. */
+int vsde_attention_fused_supported(int N, int head_dim);
+int vsde_attention_fwd_gated_bf16(const void *q, const void *k, const void *v, const void *gate, int64_t ldg, void *o, float *lse,
+                                  int64_t B, int N, int H, double scale, void *stream);
+int vsde_gate_bwd_delta(const void *dout, const void *og, const void *gate, int64_t ldg, void *dattn, void *dgate, int64_t ldd,
+                        float *delta, int64_t B, int N, int H, void *stream);
+int64_t vsde_attention_bwd_fused_partials(int64_t B, int N, int H);
+int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, const void *k, const void *v, const float *lse, const float *delta,
+                                  const float *rinv, const float *cosT, const float *sinT, const float *wq, const float *wk,
+                                  const void *vdiff, const float *lam, void *dv0, int dv0_accumulate, const void *dv_extra, void *dy,
+                                  int64_t ldy, float *dlam_partial, int64_t B, int N, int H, double scale, void *stream);
+
 /* Weight and bias gradient of y = x W^T + b for bf16 activations:  dW[N][K] = dy^T x,  db[N] = colsum(dy)
  * (db may be NULL).  dy [M][N], x [M][K] bf16 contiguous, N % 8 == K % 8 == 0; results fp32, deterministic.
  * Replaces torch's hipBLASLt "wgrad" GEMM + bf16 column-sum kernel of every encoder nn.Linear
@@ -249,14 +272,17 @@ int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_t M, int N,
 int vsde_linear_bf16_supported(int64_t M, int N, int K, int epilogue);
 int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias, void *y, int64_t ldy, int64_t M, int N, int K,
                      int epilogue, void *s_out, int64_t lds, const void *u_in, int64_t ldu, void *stream);
-/* No-grad attention projection (primitives/attn.py:80-103 in one kernel): y = x W^T + b with W = [q | k | v | gate] rows
+/* Attention projection (primitives/attn.py:80-103 in one kernel): y = x W^T + b with W = [q | k | v | gate] rows
  * (N = 3 heads*64 + gate_width, K = 256), and in the epilogue RMS-norm (weights wq / wk [64], eps) + RoPE (cos / sin tables
  * [tokens][32], row m is token m % tokens, rotary pairs (i, i + 32)) on every q / k head, v = lam v + (1 - lam) v0 when residual
  * values are given, everything written straight in the attention layout: q, k, v [M][heads*64] (token-major [B,N,h,64]),
- * gate logits [M][ldg].  Same rounding points as vsde_linear_bf16 followed by vsde_qk_norm_rope_fwd. */
+ * gate logits [M][ldg].  Same rounding points as vsde_linear_bf16 followed by vsde_qk_norm_rope_fwd.  For the training step
+ * (both may be NULL): rinv [M][2 heads] fp32 receives the inverse RMS of every q / k head row and vdiff [M][heads*64] bf16
+ * v_raw - v0 -- all the backward needs, the raw projection is never written. */
 int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads, int gate_width,
                             int tokens, const float *cosT, const float *sinT, const float *wq, const float *wk, const void *v0,
-                            const float *lam, double eps, void *q, void *k, void *v, void *gate, int64_t ldg, void *stream);
+                            const float *lam, double eps, void *q, void *k, void *v, void *gate, int64_t ldg, float *rinv,
+                            void *vdiff, void *stream);
 /* No-grad attention output projection with gate_merge folded into the operand load (primitives/attn.py:107-110):
  * y = (attn * sigmoid(gate[:, k % 64])) W^T + b for attn [M][K] (token-major heads of 64), gate logits [M][ldgate].
  * Rows kernel shapes only (K in {128, 256}, N % 64 == 0). */

@@ -1,0 +1,185 @@
+"""GPU: the training-step form of the attention block's core (primitives/fused.py::_AttentionCore; reference
+primitives/attn.py:80-113): the QK-RMS-norm / RoPE / value mix in the projection GEMM's epilogue, the sigmoid gate + head merge
+in the attention store, and a backward whose attention kernels' epilogues undo RoPE / RMS-norm / the value mix and write the
+projection's gradient buffer -- against
+
+  (a) the same block with the separate qk_norm_rope / gate_merge passes (``fused.ATTN_FUSED_TRAIN = False``): both bf16, same
+      GEMM and attention kernels, different rounding points only -> relative L2 error 6e-3 forward / 1.5e-2 gradients,
+      max-norm 3e-2 / 6e-2;
+  (b) the unfused fp32 torch chain of the module (the specification): max-norm 3e-2 forward, 8e-2 gradients (bf16 activations;
+      the scalar value-mix weight 0.3), as tests/test_fused_dims.py.
+
+Covered: with and without the value residual (incl. the gradient of v0 and of the mixing weight), a gradient arriving at the
+returned values, ragged token counts (N not a multiple of 32), a non-unit RMS weight, the v0 link chain of a three-block
+encoder (accumulate + fold-in paths), and the building blocks one at a time (gated attention store, gate backward + delta)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def _attention(residual_v, seed=0, wscale=None):
+    from viforsdes_amd.primitives.attn import Attention
+    torch.manual_seed(seed)
+    att = Attention(256, 4, residual_v=residual_v).to(DEV)
+    with torch.no_grad():
+        att.gate_proj.weight.add_(torch.randn_like(att.gate_proj.weight) * 0.05)
+        att.gate_proj.bias.add_(torch.randn_like(att.gate_proj.bias) * 0.5)
+        if residual_v:
+            att.v_residual_lambda.fill_(0.37)
+        if wscale is not None:   # frozen, but a loaded state dict may carry any values
+            att.q_norm.weight.copy_(1.0 + wscale * torch.randn(64, device=DEV))
+            att.k_norm.weight.copy_(1.0 - wscale * torch.randn(64, device=DEV))
+    return att
+
+
+def _run(att, x, rot, v0, go, gv, mode):
+    """mode: 'core' (fused training core), 'split' (separate passes), 'fp32' (unfused torch chain in fp32)."""
+    from viforsdes_amd.primitives import fused
+    xs = x.clone().requires_grad_(True)
+    v0s = v0.clone().requires_grad_(True) if v0 is not None else None
+    params = [p for p in att.parameters() if p.requires_grad]
+    fused.ATTN_FUSED_TRAIN = mode == "core"
+    try:
+        if mode == "fp32":
+            out, val = att(xs.float(), rotary=rot, v0=v0s.float() if v0s is not None else None, return_value=True)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert att.fusable(xs.to(torch.bfloat16), rot)
+                out, val = att.forward_fused(xs.to(torch.bfloat16), rotary=rot, v0=v0s.to(torch.bfloat16) if v0s is not None else None)
+        loss = (out.float() * go).sum() + ((val.float() * gv).sum() if gv is not None else 0.0)
+        grads = torch.autograd.grad(loss, [xs] + ([v0s] if v0s is not None else []) + params)
+    finally:
+        fused.ATTN_FUSED_TRAIN = True
+    names = ["x"] + (["v0"] if v0s is not None else []) + [n for n, p in att.named_parameters() if p.requires_grad]
+    return out.detach().float().cpu().numpy(), val.detach().float().cpu().numpy(), {n: g.float().cpu().numpy() for n, g in zip(names, grads)}
+
+
+@pytest.mark.parametrize("residual_v,value_grad", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3)])
+def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
+    from viforsdes_amd.primitives import fused
+    from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis
+    att = _attention(residual_v, seed=B + N, wscale=wscale)
+    g = torch.Generator().manual_seed(B * N)
+    x = torch.randn(B, N, 256, generator=g).to(DEV)
+    rot = RotarySpec.from_freqs(precompute_freq_cis(64, end=512)[:N].to(DEV))
+    v0 = torch.randn(B, 4, N, 64, generator=g).to(DEV) if residual_v else None
+    go = torch.randn(B, N, 256, generator=g).to(DEV)
+    gv = torch.randn(B, 4, N, 64, generator=g).to(DEV) if value_grad else None
+    cos, _ = rot.cos_sin_tables(N)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        att.forward_fused(x.to(torch.bfloat16), rotary=rot, v0=None)   # builds the pack
+    assert fused.attention_core_usable(x.to(torch.bfloat16), att._proj_pack, 4, 64, att.q_norm.weight, att.k_norm.weight, cos)
+    o_c, v_c, g_c = _run(att, x, rot, v0, go, gv, "core")
+    o_s, v_s, g_s = _run(att, x, rot, v0, go, gv, "split")
+    o_f, v_f, g_f = _run(att, x, rot, v0, go, gv, "fp32")
+    assert np.isfinite(o_c).all() and all(np.isfinite(a).all() for a in g_c.values())
+    assert _l2(o_c, o_s) < 6e-3 and _l2(v_c, v_s) < 6e-3 and rel_err(o_c, o_s) < 3e-2, (_l2(o_c, o_s), rel_err(o_c, o_s))
+    assert rel_err(o_c, o_f) < 3e-2 and rel_err(v_c, v_f) < 3e-2
+    worst = {}
+    for n in g_c:
+        scalar = g_f[n].size == 1
+        worst[n] = (_l2(g_c[n], g_s[n]), rel_err(g_c[n], g_f[n]))
+        if not scalar:
+            assert _l2(g_c[n], g_s[n]) < 1.5e-2 and rel_err(g_c[n], g_s[n]) < 6e-2, (n, worst[n], rel_err(g_c[n], g_s[n]))
+        assert rel_err(g_c[n], g_f[n]) < (0.3 if scalar else 8e-2), (n, worst[n])
+        # the fused route must not be further from the fp32 specification than the separate passes are (+ slack for noise)
+        assert rel_err(g_c[n], g_f[n]) < 1.5 * rel_err(g_s[n], g_f[n]) + 1e-2, (n, rel_err(g_c[n], g_f[n]), rel_err(g_s[n], g_f[n]))
+    print("\nworst (L2 vs separate passes, max-norm vs fp32):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()})
+
+
+def test_three_block_encoder_with_the_value_link():
+    """hidden 256 / 4 heads / depth 3: block 0 produces the residual values, blocks 1 and 2 mix them in and accumulate their
+    gradient into ONE buffer inside the dk/dv kernels, block 0 folds it into its own dv.  Fused core on vs off."""
+    from viforsdes_amd import EncoderConfig
+    from viforsdes_amd.models.encoder import ObservationContextEncoder
+    from viforsdes_amd.primitives import fused
+    torch.manual_seed(7)
+    enc = ObservationContextEncoder(2, 3, EncoderConfig(hidden_dim=256, num_heads=4, depth=3)).to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.requires_grad and (float(p.abs().sum()) == 0.0 or "v_residual_lambda" in n):
+                p.add_((torch.randn(p.shape, generator=g) * 0.1).to(DEV))
+    B = 104   # x 41 tokens = 4264 rows
+    obs_t = torch.tensor([0.0, 0.7, 1.4, 2.0], device=DEV)
+    obs_v = torch.randn(4, 2, generator=g).to(DEV)
+    theta = (torch.rand(B, 3, generator=g) + 0.2).to(DEV)
+    gout = torch.randn(B, 41, 256, generator=g).to(DEV)
+    names = [n for n, p in enc.named_parameters() if p.requires_grad]
+    params = [p for n, p in enc.named_parameters() if p.requires_grad]
+
+    def run(core, autocast=True):
+        fused.ATTN_FUSED_TRAIN = core
+        try:
+            th = theta.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                ctx = enc(obs_v, obs_t, th, 2.0, 0.05)
+            grads = torch.autograd.grad((ctx.float() * gout).sum(), [th] + params)
+        finally:
+            fused.ATTN_FUSED_TRAIN = True
+        return ctx.detach().float().cpu().numpy(), {n: t.float().cpu().numpy() for n, t in zip(["theta"] + names, grads)}
+
+    c1, g1 = run(True)
+    c0, g0 = run(False)
+    fused.ENABLED = False
+    try:
+        cf, gf = run(False, autocast=False)
+    finally:
+        fused.ENABLED = True
+    assert _l2(c1, c0) < 6e-3 and rel_err(c1, cf) < 3e-2
+    for n in g1:
+        scalar = gf[n].size == 1 and n != "theta"
+        assert _l2(g1[n], g0[n]) < (0.1 if scalar else 1.5e-2), (n, _l2(g1[n], g0[n]))
+        assert rel_err(g1[n], gf[n]) < (0.3 if scalar else 8e-2), (n, rel_err(g1[n], gf[n]))
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 37, 4), (2, 401, 4), (1, 544, 2)])
+def test_gated_attention_store_and_gate_backward(B, N, H):
+    """attention_fwd_gated = attention_fwd followed by the gate product (one bf16 rounding less); gate_bwd_delta against the
+    closed forms dattn = dout s, dgate = (1 - s) sum_h dout og, delta = <dout, og> = <dattn, o>."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
+    wide = torch.randn(B * N, 96, generator=g).to(DEV, torch.bfloat16)
+    gate = wide[:, 16:80]                                  # a column range of a wider buffer
+    o, lse = _hip.attention_fwd(q, k, v, 0.125)
+    og, lse2 = _hip.attention_fwd_gated(q, k, v, gate, 0.125)
+    s = torch.sigmoid(gate.float()).to(torch.bfloat16).float().view(B, N, 1, 64)
+    assert torch.equal(lse, lse2)
+    assert rel_err(og.float().cpu().numpy(), (o.float() * s).cpu().numpy()) < 1e-2
+    dout = torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.zeros(B * N, 3 * H * 64 + 64 + 8, device=DEV, dtype=torch.bfloat16)
+    dattn, delta = _hip.gate_bwd_delta(dout, og, gate, dy[:, 3 * H * 64:3 * H * 64 + 64])
+    assert rel_err(dattn.float().cpu().numpy(), (dout.float() * s).cpu().numpy()) < 1e-2
+    dg = ((dout.float() * og.float()).sum(2) * (1 - s[:, :, 0])).view(B * N, 64)
+    assert rel_err(dy[:, 3 * H * 64:3 * H * 64 + 64].float().cpu().numpy(), dg.cpu().numpy()) < 1e-2
+    assert float(dy[:, :3 * H * 64].abs().max()) == 0.0 and float(dy[:, 3 * H * 64 + 64:].abs().max()) == 0.0
+    dl = (dout.float() * og.float()).sum(-1).permute(0, 2, 1)
+    assert rel_err(delta.cpu().numpy(), dl.cpu().numpy()) < 1e-5
+
+
+def test_zero_norm_weight_takes_the_separate_passes():
+    """The fused backward divides by the frozen RMS weights; a weight vector with a zero entry must not take that route."""
+    from viforsdes_amd.primitives import fused
+    from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis
+    att = _attention(False, seed=1)
+    with torch.no_grad():
+        att.q_norm.weight[5] = 0.0
+    x = torch.randn(112, 37, 256, device=DEV).to(torch.bfloat16)
+    rot = RotarySpec.from_freqs(precompute_freq_cis(64, end=64)[:37].to(DEV))
+    cos, _ = rot.cos_sin_tables(37)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out, _ = att.forward_fused(x, rotary=rot, v0=None)
+    assert not fused.attention_core_usable(x, att._proj_pack, 4, 64, att.q_norm.weight, att.k_norm.weight, cos)
+    assert torch.isfinite(out.float()).all()

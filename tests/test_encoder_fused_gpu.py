@@ -333,7 +333,11 @@ def test_nograd_projection_kernel_matches_the_training_path(residual_v, B, N):
     v0 = (torch.randn(B, N, 4, 64, generator=g).to(DEV, torch.bfloat16)).transpose(1, 2) if residual_v else None
     assert att.fusable(x, rot)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        out_t, val_t = att.forward_fused(x, rotary=rot, v0=v0)          # grad mode: GEMM, then qk_norm_rope
+        fused.ATTN_FUSED_TRAIN = False   # the separate-pass training chain (the fused training core has its own tests: test_attention_core_gpu.py)
+        try:
+            out_t, val_t = att.forward_fused(x, rotary=rot, v0=v0)      # grad mode: GEMM, then qk_norm_rope
+        finally:
+            fused.ATTN_FUSED_TRAIN = True
         with torch.no_grad():
             pack = att._proj_pack
             cos, sin = rot.cos_sin_tables(N)

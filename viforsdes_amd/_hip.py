@@ -58,6 +58,8 @@ EXPORTS = (
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
     "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
+    "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
+    "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh",
 )
@@ -91,6 +93,7 @@ def load() -> ctypes.CDLL:
     for f in (lib.vsde_head_forward, lib.vsde_head_backward, lib.vsde_elbo_path_terms, lib.vsde_elbo_path_terms_bwd):
         f.restype = ctypes.c_int
     lib.vsde_qk_norm_rope_bwd_partials.restype = ctypes.c_int64
+    lib.vsde_attention_bwd_fused_partials.restype = ctypes.c_int64
     lib.vsde_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.vsde_colsum_workspace_bytes.restype = ctypes.c_size_t
     _lib = lib
@@ -739,9 +742,10 @@ def linear_swiglu_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
 
 
 def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], heads: int, tokens: int, cos, sin, wq, wk,
-                       v0: Optional[torch.Tensor], lam: Optional[torch.Tensor], eps: float):
-    """No-grad attention projection: x [M,256] against the packed [q | k | v | gate] weight w [3*heads*64 + G, 256] with the
-    QK-RMS-norm + RoPE + value mix in the GEMM epilogue -> (q, k, v [M, heads*64] token-major, gate logits [M, G] or None)."""
+                       v0: Optional[torch.Tensor], lam: Optional[torch.Tensor], eps: float, save: bool = False):
+    """Attention projection: x [M,256] against the packed [q | k | v | gate] weight w [3*heads*64 + G, 256] with the
+    QK-RMS-norm + RoPE + value mix in the GEMM epilogue -> (q, k, v [M, heads*64] token-major, gate logits [M, G] or None).
+    ``save`` (training): also returns (rinv [M, 2*heads] fp32, vdiff [M, heads*64] bf16 or None) for the fused backward."""
     lib = load(); dev = _require_hip(x, w, cos, sin, wq, wk)
     x, ldx = _rows2d(x)
     M, K = x.shape
@@ -749,11 +753,73 @@ def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
     G = w.shape[0] - 3 * C
     q = torch.empty(M, C, device=dev, dtype=torch.bfloat16); k = torch.empty_like(q); v = torch.empty_like(q)
     gate = torch.empty(M, G, device=dev, dtype=torch.bfloat16) if G > 0 else None
+    rinv = torch.empty(M, 2 * heads, device=dev, dtype=torch.float32) if save else None
+    vdiff = torch.empty(M, C, device=dev, dtype=torch.bfloat16) if (save and v0 is not None) else None
     with torch.cuda.device(dev):
         _call(lib.vsde_linear_qknorm_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _i64(M), ctypes.c_int(K), ctypes.c_int(heads),
               ctypes.c_int(G), ctypes.c_int(tokens), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
-              ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), _stream(dev))
+              ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), _ptr(rinv), _ptr(vdiff), _stream(dev))
+    if save:
+        return q, k, v, gate, rinv, vdiff
     return q, k, v, gate
+
+
+def attention_fused_supported(N: int, head_dim: int) -> bool:
+    return bool(load().vsde_attention_fused_supported(ctypes.c_int(N), ctypes.c_int(head_dim)))
+
+
+def attention_fwd_gated(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, gate: torch.Tensor, scale: float):
+    """softmax(scale q k^T) v * sigmoid(gate) for token-major bf16 heads [B,N,H,64] and gate logits [B*N, >=64] (row-pitched):
+    returns (the merged rows og [B,N,H,64], lse [B,H,N] fp32)."""
+    lib = load(); dev = _require_hip(q, k, v, gate)
+    B, N, H, d = q.shape
+    if q.dtype != torch.bfloat16 or d != 64 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise ValueError("attention_fwd_gated needs contiguous bf16 [B,N,H,64] tensors")
+    gate, ldg = _rows2d(gate)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_attention_fwd_gated_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(ldg), _ptr(o), _ptr(lse), _i64(B),
+              ctypes.c_int(N), ctypes.c_int(H), ctypes.c_double(scale), _stream(dev))
+    return o, lse
+
+
+def gate_bwd_delta(dout: torch.Tensor, og: torch.Tensor, gate: torch.Tensor, dgate: torch.Tensor):
+    """Backward of the gate folded into ``attention_fwd_gated``: dout, og [B,N,H,64] bf16, gate logits [B*N, >=64]; ``dgate``
+    (row-pitched [B*N, 64], e.g. the gate columns of the projection's gradient buffer) is filled in place.
+    Returns (dattn [B,N,H,64] = the gradient of the ungated attention output, delta [B,H,N] fp32 = <dattn, o>)."""
+    lib = load(); dev = _require_hip(dout, og, gate, dgate)
+    B, N, H, d = og.shape
+    if d != 64 or not (dout.is_contiguous() and og.is_contiguous()) or dout.dtype != torch.bfloat16:
+        raise ValueError("gate_bwd_delta needs contiguous bf16 [B,N,H,64] tensors")
+    gate, ldg = _rows2d(gate); dgate, ldd = _rows2d(dgate)
+    dattn = torch.empty_like(og)
+    delta = torch.empty(B, H, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_gate_bwd_delta, _ptr(dout), _ptr(og), _ptr(gate), _i64(ldg), _ptr(dattn), _ptr(dgate), _i64(ldd), _ptr(delta),
+              _i64(B), ctypes.c_int(N), ctypes.c_int(H), _stream(dev))
+    return dattn, delta
+
+
+def attention_bwd_fused(dattn, q, k, v, lse, delta, rinv, cos, sin, wq, wk, vdiff, lam, dv0, dv_extra, dy, scale: float):
+    """Attention backward whose epilogues apply the RoPE / RMS-norm / value-mix backward and write the q, k, v columns of ``dy``
+    ([B*N, >= 192 H] bf16, the gradient of the [q | k | v | gate] projection).  ``dv0``: existing buffer to accumulate the
+    residual-value gradient into (a new one is made when ``vdiff`` is given and ``dv0`` is None).  Returns (dv0, dlam)."""
+    lib = load(); dev = _require_hip(dattn, q, k, v, lse, delta, rinv, dy)
+    B, N, H, d = q.shape
+    dy2, ldy = _rows2d(dy)
+    accumulate = dv0 is not None
+    parts = None
+    if vdiff is not None:
+        if dv0 is None:
+            dv0 = torch.empty_like(v)
+        parts = torch.empty(int(lib.vsde_attention_bwd_fused_partials(_i64(B), ctypes.c_int(N), ctypes.c_int(H))), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_attention_bwd_fused_bf16, _ptr(dattn), _ptr(q), _ptr(k), _ptr(v), _ptr(lse), _ptr(delta), _ptr(rinv), _ptr(cos),
+              _ptr(sin), _ptr(wq), _ptr(wk), _ptr(vdiff), _ptr(lam if vdiff is not None else None),
+              _ptr(dv0 if vdiff is not None else None), ctypes.c_int(int(accumulate)), _ptr(dv_extra), _ptr(dy2), _i64(ldy), _ptr(parts),
+              _i64(B), ctypes.c_int(N), ctypes.c_int(H), ctypes.c_double(scale), _stream(dev))
+    return (dv0 if vdiff is not None else None), (parts.sum() if parts is not None else None)
 
 
 def linear_gated_bf16(attn: torch.Tensor, gate: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):

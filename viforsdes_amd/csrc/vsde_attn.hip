@@ -40,6 +40,8 @@ struct AttnParams {
     int npad;                   // N rounded up to 32
     int vld;                    // LDS row stride of V^T in bf16: npad + 4 (stride/2 dwords = 2*odd mod 64: conflict-free b64)
     float scale, scale_log2e;
+    const uint16_t *gate;       // optional output gate logits [B*N][ldg] (64 per token, shared by the heads): o *= sigmoid(gate)
+    int64_t ldg;
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -47,6 +49,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     bf16v2 r = __builtin_convertvector(f, bf16v2);  // v_cvt_pk_bf16_f32
     return *(uint32_t *)&r;
 }
+
+__device__ __forceinline__ float bfl(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfh(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// sigmoid of a bf16 gate logit, rounded to bf16 like the unfused chain's sigmoid output under autocast (primitives/attn.py:108)
+__device__ __forceinline__ float gate_of(float x) { return (float)(__bf16)fast_rcp(1.0f + __expf(-x)); }
 
 __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
@@ -218,6 +225,18 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
         if (qok) {
             const float inv = 1.0f / lsum;
             uint16_t *orow = p.o + base + query * ts;
+            if (p.gate != nullptr) {   // sigmoid output gate + head merge (primitives/attn.py:107-113) folded into the store: o is the merged [B,N,(h d)] row
+                const uint16_t *grow = p.gate + ((int64_t)b * N + query) * p.ldg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 8 * g + 4 * h2;
+                    const uint2 ga = *(const uint2 *)(grow + d0), gb = *(const uint2 *)(grow + 32 + d0);
+                    const float sa[4] = {gate_of(bfl(ga.x)), gate_of(bfh(ga.x)), gate_of(bfl(ga.y)), gate_of(bfh(ga.y))};
+                    const float sb[4] = {gate_of(bfl(gb.x)), gate_of(bfh(gb.x)), gate_of(bfl(gb.y)), gate_of(bfh(gb.y))};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o0[4 * g + i] *= sa[i]; o1[4 * g + i] *= sb[i]; }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 = rows d = 8g + 4h2 + 0..3 (o0) and 32 + ... (o1)
                 const int d0 = 8 * g + 4 * h2;
@@ -241,13 +260,33 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
 // transposed operands (K^T, Q^T, dO^T) are never materialised: ds_read_b64_tr_b16 reads them out of the row-major tiles.
 // No atomics: every output element is owned by exactly one lane (deterministic).
 
+// Fused projection-side backward (training step, round 3): the attention's q, k are RoPE(rnd(RMS(x) w)) of the projection
+// output x (primitives/attn.py:80-95) and v = lam v_raw + (1 - lam) v0.  The dq / dkv kernels own whole 64-wide head rows of
+// dq^, dk^, dv, so the RoPE + RMS-norm + value-mix backward is lane-local epilogue math and the gradients leave straight as
+// columns of dy, the gradient of the [q | k | v | gate] projection -- the separate qk_norm_rope_bwd pass (a full read of the raw
+// projection + dq, dk, dv and a write of dy) does not exist.  The raw projection is not kept at all: with a = R^T y^ (= n w, n
+// the normalised row) and c = mean(dy^ . y^) (rotations preserve the dot product),
+//     dx = rinv (w R^T dy^  -  (a / w) c),            rinv = the row's inverse RMS saved by the projection kernel's epilogue.
+struct QkBwd {
+    uint16_t *dy; int64_t ldy;       // [M][ldy]: columns [0, 64 H) dq_raw, [64 H, 128 H) dk_raw, [128 H, 192 H) dv_raw
+    const float *rinv;               // [M][2 H]: inverse RMS of the q heads, then of the k heads
+    const float *cosT, *sinT;        // rotary tables [N][32]
+    const float *wq, *wk;            // frozen RMS weights [64] (all non-zero: checked by the host)
+    const float *lam;                // value-mix weight [1] (blocks that mix)
+    const uint16_t *vdiff;           // [M][64 H] v_raw - v0 saved by the projection epilogue, or nullptr (no mixing in this block)
+    uint16_t *dv0; int dv0_accumulate;   // [M][64 H] gradient of the residual values: = or += (1 - lam) dv
+    const uint16_t *dv_extra;        // [M][64 H] added to dv first (the block that produced v0), or nullptr
+    float *dlam_partial;             // [B H ntile] per (head, key block) partial sums of <dv, v_raw - v0>
+};
+
 struct AttnBwdParams {
     const uint16_t *q, *k, *v, *o, *dout;  // [B][N][H][64] bf16
     const float *lse;                      // [B][H][N]
-    float *delta;                          // [B][H][N]  D_i = <dO_i, O_i>   (written by the dq kernel, read by dk/dv)
+    float *delta;                          // [B][H][N]  D_i = <dO_i, O_i>   (written by the dq kernel, read by dk/dv; FUSED: given)
     uint16_t *dq, *dk, *dv;                // [B][N][H][64] bf16
     int N, H, ntile;                       // ntile = ceil(N / 32)
     float scale, scale_log2e;
+    QkBwd f;                               // FUSED kernels only
 };
 
 __device__ __forceinline__ f32x16 tile_product(const uint16_t *arow, const bf16x8 (&bfrag)[4]) {
@@ -313,6 +352,104 @@ __device__ __forceinline__ void store_transposed(uint16_t *row, int h2, const f3
     }
 }
 
+// B-operand fragments (lane (fr, h2): channels 16 ks + 8 h2 + e of token fr) -> the accumulator's channel set of the same
+// token (lo[4 g + i] = channel 8 g + 4 h2 + i, hi = + 32): each half-wave hands the other 4 of every 8 channels,
+// v_permlane32_swap moves two dwords per instruction.  All 64 lanes must execute this.
+__device__ __forceinline__ void frag_to_acc_layout(const bf16x8 (&f)[4], float (&lo)[16], float (&hi)[16]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 w = *(const uint4 *)&f[ks];
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);   // [0]: channels (i = 0, 1) of g, [1]: of g + 1
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);   // (i = 2, 3)
+        float *dst = ks < 2 ? lo : hi;
+        const int g0 = 2 * (ks & 1);
+        dst[4 * g0] = bfl(s0[0]); dst[4 * g0 + 1] = bfh(s0[0]); dst[4 * g0 + 2] = bfl(s1[0]); dst[4 * g0 + 3] = bfh(s1[0]);
+        dst[4 * g0 + 4] = bfl(s0[1]); dst[4 * g0 + 5] = bfh(s0[1]); dst[4 * g0 + 6] = bfl(s1[1]); dst[4 * g0 + 7] = bfh(s1[1]);
+    }
+}
+
+// Epilogue of a q (KIND 0) or k (KIND 1) head row: a0 / a1 x mul = gradient of the rotated, normalised row y^ (fragments yf) of
+// token m (position n) -> gradient of the raw projection row, stored as bf16 into dy.  Called by all lanes (cross-lane ops).
+template <int KIND>
+__device__ __forceinline__ void norm_rope_bwd_store(const QkBwd &f, const f32x16 &a0, const f32x16 &a1, float mul, const bf16x8 (&yf)[4],
+                                                    int64_t m, int n, int hh, int H, int lane, bool ok) {
+    const int h2 = lane >> 5;
+    float yl[16], yh[16];
+    frag_to_acc_layout(yf, yl, yh);
+    float c = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c = fmaf(a0[r], yl[r], fmaf(a1[r], yh[r], c));
+    c += __shfl_xor(c, 32, 64);
+    c *= mul * (1.0f / 64.0f);
+    if (!ok) return;
+    const float rr = f.rinv[m * (2 * H) + KIND * H + hh];
+    const float *w = KIND ? f.wk : f.wq;
+    uint16_t *dst = f.dy + m * f.ldy + (KIND * H + hh) * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * h2;
+        const float4 c4 = *(const float4 *)(f.cosT + n * 32 + d0), s4 = *(const float4 *)(f.sinT + n * 32 + d0);
+        const float4 wl4 = *(const float4 *)(w + d0), wh4 = *(const float4 *)(w + 32 + d0);
+        const float cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+        const float wl[4] = {wl4.x, wl4.y, wl4.z, wl4.w}, wh[4] = {wh4.x, wh4.y, wh4.z, wh4.w};
+        float ol[4], oh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            const float gl = a0[r] * mul, gh = a1[r] * mul;
+            const float ul = gl * cs[i] + gh * sn[i], uh = gh * cs[i] - gl * sn[i];            // R^T dy^
+            const float al = yl[r] * cs[i] + yh[r] * sn[i], ah = yh[r] * cs[i] - yl[r] * sn[i];  // R^T y^ = n w
+            ol[i] = rr * (wl[i] * ul - al * (c / wl[i]));
+            oh[i] = rr * (wh[i] * uh - ah * (c / wh[i]));
+        }
+        *(uint2 *)(dst + d0) = make_uint2(pack_bf16(ol[0], ol[1]), pack_bf16(ol[2], ol[3]));
+        *(uint2 *)(dst + 32 + d0) = make_uint2(pack_bf16(oh[0], oh[1]), pack_bf16(oh[2], oh[3]));
+        __builtin_amdgcn_sched_barrier(0);   // one group's table loads at a time (hoisting all four costs 48 VGPRs: spills)
+    }
+}
+
+// Epilogue of a v head row: a0 / a1 = gradient of the (mixed) values of token m.  Returns this lane's share of <dv, v_raw - v0>.
+__device__ __forceinline__ float value_bwd_store(const QkBwd &f, const f32x16 &a0, const f32x16 &a1, int64_t m, int hh, int H, int lane) {
+    const int h2 = lane >> 5;
+    const int64_t vo = m * ((int64_t)H * 64) + hh * 64;
+    uint16_t *dst = f.dy + m * f.ldy + (2 * H + hh) * 64;
+    const bool mix = f.vdiff != nullptr;
+    const float l = mix ? f.lam[0] : 1.0f;
+    float dl = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * h2;
+        float gl[4] = {a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]}, gh[4] = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
+        if (f.dv_extra != nullptr) {
+            const uint2 ea = *(const uint2 *)(f.dv_extra + vo + d0), eb = *(const uint2 *)(f.dv_extra + vo + 32 + d0);
+            gl[0] += bfl(ea.x); gl[1] += bfh(ea.x); gl[2] += bfl(ea.y); gl[3] += bfh(ea.y);
+            gh[0] += bfl(eb.x); gh[1] += bfh(eb.x); gh[2] += bfl(eb.y); gh[3] += bfh(eb.y);
+        }
+        if (mix) {
+            const uint2 da = *(const uint2 *)(f.vdiff + vo + d0), db = *(const uint2 *)(f.vdiff + vo + 32 + d0);
+            const float dfl[4] = {bfl(da.x), bfh(da.x), bfl(da.y), bfh(da.y)}, dfh[4] = {bfl(db.x), bfh(db.x), bfl(db.y), bfh(db.y)};
+            float zl[4], zh[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dl = fmaf(gl[i], dfl[i], fmaf(gh[i], dfh[i], dl));
+                zl[i] = (1.0f - l) * gl[i]; zh[i] = (1.0f - l) * gh[i];
+                gl[i] *= l; gh[i] *= l;
+            }
+            if (f.dv0_accumulate) {
+                const uint2 ya = *(const uint2 *)(f.dv0 + vo + d0), yb = *(const uint2 *)(f.dv0 + vo + 32 + d0);
+                zl[0] += bfl(ya.x); zl[1] += bfh(ya.x); zl[2] += bfl(ya.y); zl[3] += bfh(ya.y);
+                zh[0] += bfl(yb.x); zh[1] += bfh(yb.x); zh[2] += bfl(yb.y); zh[3] += bfh(yb.y);
+            }
+            *(uint2 *)(f.dv0 + vo + d0) = make_uint2(pack_bf16(zl[0], zl[1]), pack_bf16(zl[2], zl[3]));
+            *(uint2 *)(f.dv0 + vo + 32 + d0) = make_uint2(pack_bf16(zh[0], zh[1]), pack_bf16(zh[2], zh[3]));
+        }
+        *(uint2 *)(dst + d0) = make_uint2(pack_bf16(gl[0], gl[1]), pack_bf16(gl[2], gl[3]));
+        *(uint2 *)(dst + 32 + d0) = make_uint2(pack_bf16(gh[0], gh[1]), pack_bf16(gh[2], gh[3]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return dl;
+}
+
 // ---- staging of whole row-major operands [npad][64] -> LDS [npad][AT_KLD]; all global loads issued before first use ---
 constexpr int AT_BT = 768;                                 // threads of a backward workgroup (12 waves: 3 per SIMD)
 constexpr int AT_SIT = (AT_MAXN * 8 + AT_BT - 1) / AT_BT;  // 16-byte chunks per thread and operand
@@ -343,6 +480,9 @@ __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2,
 // first round's before the operand staging, the next round's before the tile loop -- and only waited for at use.
 
 // dq: one workgroup per (batch, head); K and V resident in LDS, a wavefront owns 32 queries at a time.
+// FUSED: delta = <dO, O> is given (the gate backward computes it from the gated output), o is not read, and the result leaves
+// through norm_rope_bwd_store as the q columns of dy.
+template <bool FUSED>
 __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
@@ -351,13 +491,14 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
     const int64_t srow = ((int64_t)b * p.H + hh) * N;
     bf16x8 qn[4], don[4], on[4];  // fragments of the NEXT round
-    float lsen;
+    float lsen, deln = 0.f;
     auto request = [&](int qblk) {
         const int query = qblk * 32 + fr;
         const bool ok = qblk < p.ntile && query < N;
         load_bfrag(p.q + base, ts, query, ok, h2, qn);
         load_bfrag(p.dout + base, ts, query, ok, h2, don);
-        load_bfrag(p.o + base, ts, query, ok, h2, on);
+        if constexpr (!FUSED) load_bfrag(p.o + base, ts, query, ok, h2, on);
+        else deln = ok ? p.delta[srow + query] : 0.f;
         lsen = ok ? p.lse[srow + query] : INFINITY;  // padded queries: P = 0
     };
     request(wave);
@@ -374,13 +515,16 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks] = qn[ks]; dof[ks] = don[ks];
+            if constexpr (!FUSED) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)don[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)on[ks][e]) << 16), dsum);
+                for (int e = 0; e < 8; ++e)
+                    dsum = fmaf(__uint_as_float(((uint32_t)(uint16_t)don[ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)on[ks][e]) << 16), dsum);
+            }
         }
-        dsum += __shfl_xor(dsum, 32, 64);
+        if constexpr (FUSED) dsum = deln;
+        else dsum += __shfl_xor(dsum, 32, 64);
         const float lse2 = lsen * 1.4426950408889634f;
-        if (qok && h2 == 0) p.delta[srow + query] = dsum;
+        if constexpr (!FUSED) { if (qok && h2 == 0) p.delta[srow + query] = dsum; }
         f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
 #pragma unroll 1
         for (int kt = 0; kt < p.ntile; ++kt) {
@@ -399,11 +543,14 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
             pack_tile(ds, b0, b1);
             accumulate_transposed(kt_, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
         }
-        if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
+        if constexpr (FUSED) asm volatile("" ::: "memory");
+        if constexpr (FUSED) norm_rope_bwd_store<0>(p.f, acc0, acc1, p.scale, qf, (int64_t)b * N + query, query, hh, p.H, lane, qok);
+        else if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
     }
 }
 
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
+template <bool FUSED>
 __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
@@ -459,11 +606,62 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
             accumulate_transposed(dot_, lane, p0, p1, dv0, dv1);  // dV^T += dO^T P
             accumulate_transposed(qt_, lane, s0, s1, dk0, dk1);   // dK^T += Q^T dS
         }
-        if (kok) {
+        if constexpr (FUSED) {
+            asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
+            const int64_t m = (int64_t)b * N + key;
+            float dl = kok ? value_bwd_store(p.f, dv0, dv1, m, hh, p.H, lane) : 0.f;   // values first: their accumulators die here
+            if (p.f.dlam_partial != nullptr) {   // every key block is owned by exactly one wave: deterministic partials
+                dl = wave_sum(dl);
+                if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + kblk] = dl;
+            }
+            norm_rope_bwd_store<1>(p.f, dk0, dk1, p.scale, kf, m, key, hh, p.H, lane, kok);
+        } else if (kok) {
             store_transposed(p.dk + base + key * ts, h2, dk0, dk1, p.scale);
             store_transposed(p.dv + base + key * ts, h2, dv0, dv1, 1.0f);
         }
     }
+}
+
+// Backward of the sigmoid output gate that the forward folded into the attention store (og = o sigmoid(gate), one gate row per
+// token shared by the heads; primitives/attn.py:107-113): dO = dout s, dgate = (1 - s) sum_h dout og, and the attention
+// backward's D = <dO, O> = <dout, og> per (token, head).  8 threads per token, 8 channels each.
+__global__ void __launch_bounds__(256) gate_bwd_delta_kernel(const uint16_t *__restrict__ dout, const uint16_t *__restrict__ og,
+                                                             const uint16_t *__restrict__ gate, int64_t ldg, uint16_t *__restrict__ dattn,
+                                                             uint16_t *__restrict__ dgate, int64_t ldd, float *__restrict__ delta,
+                                                             int64_t M, int N, int H) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = gid < M * 8;
+    const int64_t m = ok ? gid >> 3 : M - 1;
+    const int k = (int)(gid & 7) * 8;
+    const int64_t b = m / N, n = m - b * N;
+    const uint4 g4 = *(const uint4 *)(gate + m * ldg + k);
+    const uint32_t gw[4] = {g4.x, g4.y, g4.z, g4.w};
+    float s[8], acc[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] = gate_of(bfl(gw[e])); s[2 * e + 1] = gate_of(bfh(gw[e])); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int hh = 0; hh < H; ++hh) {
+        const int64_t off = (m * H + hh) * 64 + k;
+        const uint4 d4 = *(const uint4 *)(dout + off), o4 = *(const uint4 *)(og + off);
+        const uint32_t dw[4] = {d4.x, d4.y, d4.z, d4.w}, ow[4] = {o4.x, o4.y, o4.z, o4.w};
+        uint32_t r[4];
+        float dsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d0 = bfl(dw[e]), d1 = bfh(dw[e]), p0 = d0 * bfl(ow[e]), p1 = d1 * bfh(ow[e]);
+            acc[2 * e] += p0; acc[2 * e + 1] += p1; dsum += p0 + p1;
+            r[e] = pack_bf16(d0 * s[2 * e], d1 * s[2 * e + 1]);
+        }
+        dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+        if (ok) {
+            *(uint4 *)(dattn + off) = make_uint4(r[0], r[1], r[2], r[3]);
+            if (k == 0) delta[(b * H + hh) * N + n] = dsum;
+        }
+    }
+    if (ok)
+        *(uint4 *)(dgate + m * ldd + k) = make_uint4(pack_bf16(acc[0] * (1.0f - s[0]), acc[1] * (1.0f - s[1])), pack_bf16(acc[2] * (1.0f - s[2]), acc[3] * (1.0f - s[3])),
+                                                     pack_bf16(acc[4] * (1.0f - s[4]), acc[5] * (1.0f - s[5])), pack_bf16(acc[6] * (1.0f - s[6]), acc[7] * (1.0f - s[7])));
 }
 
 }  // namespace vsde
@@ -490,6 +688,7 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (uint16_t *)o; p.lse = lse;
     p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    p.gate = nullptr; p.ldg = 0;
     const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(768), lds, (hipStream_t)stream, p);
@@ -506,18 +705,84 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
     VSDE_CHECK_ARG(B * H < (1LL << 31), VSDE_E_BADARG, "too many (batch, head) pairs");
     if (head_dim != AT_D || N > AT_MAXN || force_stream())
         return launch_attention_stream_bwd(dout, q, k, v, o, lse, dq, dk, dv, delta, B, N, H, head_dim, scale, (hipStream_t)stream);
-    AttnBwdParams p;
+    AttnBwdParams p = {};
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o;
     p.dout = (const uint16_t *)dout; p.lse = lse; p.delta = delta;
     p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32;
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     const size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);   // also writes delta, read by the next kernel
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);   // also writes delta, read by the next kernel
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- training step with the projection-side elementwise work folded into the attention kernels (head_dim 64, N <= AT_MAXN) ----
+extern "C" int vsde_attention_fused_supported(int N, int head_dim) { return head_dim == AT_D && N > 0 && N <= AT_MAXN && !force_stream(); }
+
+extern "C" int vsde_attention_fwd_gated_bf16(const void *q, const void *k, const void *v, const void *gate, int64_t ldg, void *o,
+                                             float *lse, int64_t B, int N, int H, double scale, void *stream) {
+    VSDE_CHECK_ARG(q && k && v && gate && o && lse && B > 0 && N > 0 && H > 0, VSDE_E_BADARG, "bad gated attention arguments");
+    VSDE_CHECK_ARG(vsde_attention_fused_supported(N, AT_D), VSDE_E_BADARG, "gated attention runs the LDS-resident kernel: N <= %d", AT_MAXN);
+    VSDE_CHECK_ARG(ldg >= 64 && ldg % 4 == 0 && ((uintptr_t)gate % 8) == 0 && B * H < (1LL << 31), VSDE_E_BADARG, "bad gate rows");
+    AttnParams p;
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (uint16_t *)o; p.lse = lse;
+    p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
+    p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    p.gate = (const uint16_t *)gate; p.ldg = ldg;
+    const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(768), lds, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vsde_gate_bwd_delta(const void *dout, const void *og, const void *gate, int64_t ldg, void *dattn, void *dgate, int64_t ldd,
+                                   float *delta, int64_t B, int N, int H, void *stream) {
+    VSDE_CHECK_ARG(dout && og && gate && dattn && dgate && delta && B > 0 && N > 0 && H > 0, VSDE_E_BADARG, "bad gate_bwd_delta arguments");
+    VSDE_CHECK_ARG(ldg >= 64 && ldg % 8 == 0 && ldd >= 64 && ldd % 8 == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)dgate % 16) == 0 &&
+                   ((uintptr_t)dout % 16) == 0 && ((uintptr_t)og % 16) == 0 && ((uintptr_t)dattn % 16) == 0, VSDE_E_BADARG,
+                   "gate_bwd_delta operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    const int64_t M = B * N, blocks = (M * 8 + 255) / 256;
+    VSDE_CHECK_ARG(blocks < (1LL << 31), VSDE_E_BADARG, "too many rows");
+    hipLaunchKernelGGL(gate_bwd_delta_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dout,
+                       (const uint16_t *)og, (const uint16_t *)gate, ldg, (uint16_t *)dattn, (uint16_t *)dgate, ldd, delta, M, N, H);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t vsde_attention_bwd_fused_partials(int64_t B, int N, int H) { return B * H * ((N + 31) / 32); }
+
+extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, const void *k, const void *v, const float *lse,
+                                             const float *delta, const float *rinv, const float *cosT, const float *sinT,
+                                             const float *wq, const float *wk, const void *vdiff, const float *lam, void *dv0,
+                                             int dv0_accumulate, const void *dv_extra, void *dy, int64_t ldy, float *dlam_partial,
+                                             int64_t B, int N, int H, double scale, void *stream) {
+    VSDE_CHECK_ARG(dattn && q && k && v && lse && delta && rinv && cosT && sinT && wq && wk && dy && B > 0 && N > 0 && H > 0, VSDE_E_BADARG,
+                   "bad attention_bwd_fused arguments");
+    VSDE_CHECK_ARG(vsde_attention_fused_supported(N, AT_D), VSDE_E_BADARG, "attention_bwd_fused runs the LDS-resident kernels: N <= %d", AT_MAXN);
+    VSDE_CHECK_ARG((!vdiff) == (!lam) && (!vdiff) == (!dv0) && (!vdiff) == (!dlam_partial), VSDE_E_BADARG,
+                   "value mixing needs vdiff, lam, dv0 and dlam_partial together");
+    VSDE_CHECK_ARG(ldy >= 3 * H * 64 && ldy % 4 == 0 && ((uintptr_t)dy % 8) == 0 && ((uintptr_t)cosT % 16) == 0 && ((uintptr_t)sinT % 16) == 0 &&
+                   ((uintptr_t)wq % 16) == 0 && ((uintptr_t)wk % 16) == 0 && B * H < (1LL << 31), VSDE_E_BADARG, "bad attention_bwd_fused buffers");
+    AttnBwdParams p = {};
+    p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = nullptr;
+    p.dout = (const uint16_t *)dattn; p.lse = lse; p.delta = (float *)delta;
+    p.N = N; p.H = H; p.ntile = (N + 31) / 32;
+    p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
+    p.f.dy = (uint16_t *)dy; p.f.ldy = ldy; p.f.rinv = rinv; p.f.cosT = cosT; p.f.sinT = sinT; p.f.wq = wq; p.f.wk = wk; p.f.lam = lam;
+    p.f.vdiff = (const uint16_t *)vdiff; p.f.dv0 = (uint16_t *)dv0; p.f.dv0_accumulate = dv0_accumulate;
+    p.f.dv_extra = (const uint16_t *)dv_extra; p.f.dlam_partial = dlam_partial;
+    const size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }

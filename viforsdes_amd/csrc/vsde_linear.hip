@@ -50,6 +50,8 @@ struct LinParams {
     const float *cosT, *sinT, *wq, *wk, *lam;   // rotary tables [tokens][32], RMS weights [64], value-mix weight [1]
     const uint16_t *V0;                         // residual values [M][heads*64] or nullptr
     int heads, tokens; float eps;
+    float *Rinv;                                // training: inverse RMS of every q / k head row [M][2 heads], or nullptr
+    uint16_t *Vdiff;                            // training: v_raw - v0 [M][heads*64] (what the value-mix weight's gradient needs), or nullptr
     // gated A operand (no-grad out projection): row m of A is multiplied by sigmoid(Gate[m][k % 64]) on its way into the registers
     const uint16_t *Gate; int64_t ldgate;
     int dbg;                           // ablation (VSDE_LIN_DEBUG): 1 = skip the output stores
@@ -164,6 +166,7 @@ __device__ __forceinline__ void qknorm_head(const LinParams &p, uint16_t *stage,
         for (int e = 0; e < 16; ++e) ss = fmaf(xl[e], xl[e], fmaf(xh[e], xh[e], ss));
         ss += __shfl_xor(ss, 32, 64);
         const float rq = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+        if (p.Rinv != nullptr && h == 0 && row0 + r < p.M) p.Rinv[(row0 + r) * (2 * p.heads) + kind * p.heads + hh] = rq;
         const float *w = wlds + 64 * kind;   // [wq | wk] staged in LDS by the kernel prologue
         float o0[16], o1[16];
 #pragma unroll
@@ -177,6 +180,19 @@ __device__ __forceinline__ void qknorm_head(const LinParams &p, uint16_t *stage,
         const float l = p.lam[0];
         const uint32_t vw[16] = {v0r[0].x, v0r[0].y, v0r[0].z, v0r[0].w, v0r[1].x, v0r[1].y, v0r[1].z, v0r[1].w,
                                  v0r[2].x, v0r[2].y, v0r[2].z, v0r[2].w, v0r[3].x, v0r[3].y, v0r[3].z, v0r[3].w};
+        if (p.Vdiff != nullptr) {   // wave-uniform: v_raw - v0 leaves through the staging rows first, then the mixed values below
+            uint32_t dl[8], dh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dl[e] = pack_bf16x2(xl[2 * e] - bf_lo(vw[e]), xl[2 * e + 1] - bf_hi(vw[e]));
+                dh[e] = pack_bf16x2(xh[2 * e] - bf_lo(vw[8 + e]), xh[2 * e + 1] - bf_hi(vw[8 + e]));
+            }
+            *(u32x4 *)px = (u32x4){dl[0], dl[1], dl[2], dl[3]}; *(u32x4 *)(px + 8) = (u32x4){dl[4], dl[5], dl[6], dl[7]};
+            *(u32x4 *)(px + 32) = (u32x4){dh[0], dh[1], dh[2], dh[3]}; *(u32x4 *)(px + 40) = (u32x4){dh[4], dh[5], dh[6], dh[7]};
+            wave_lds_fence();
+            flush_rows64<R2_SLD, 32>(stage, p.Vdiff + hh * 64, (int64_t)p.heads * 64, row0, p.M, lane);
+            wave_lds_fence();
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             ol[e] = pack_bf16x2(l * xl[2 * e] + (1.0f - l) * bf_lo(vw[e]), l * xl[2 * e + 1] + (1.0f - l) * bf_hi(vw[e]));
@@ -856,7 +872,7 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
 extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads,
                                        int gate_width, int tokens, const float *cosT, const float *sinT, const float *wq,
                                        const float *wk, const void *v0, const float *lam, double eps, void *q, void *k, void *v,
-                                       void *gate, int64_t ldg, void *stream) {
+                                       void *gate, int64_t ldg, float *rinv, void *vdiff, void *stream) {
     VSDE_CHECK_ARG(x && w && q && k && v && cosT && sinT && wq && wk && M > 0 && heads > 0 && tokens > 0, VSDE_E_BADARG,
                    "bad linear_qknorm arguments");
     VSDE_CHECK_ARG(K == 256 && gate_width % 64 == 0 && gate_width >= 0 && (gate_width == 0 || (gate && ldg >= gate_width && ldg % 8 == 0)),
@@ -871,6 +887,8 @@ extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w
     p.Qo = (uint16_t *)q; p.Ko = (uint16_t *)k; p.Vo = (uint16_t *)v; p.Go = (uint16_t *)gate; p.ldg = ldg;
     p.cosT = cosT; p.sinT = sinT; p.wq = wq; p.wk = wk; p.lam = lam; p.V0 = (const uint16_t *)v0;
     p.heads = heads; p.tokens = tokens; p.eps = (float)eps;
+    VSDE_CHECK_ARG(!vdiff || (v0 && ((uintptr_t)vdiff % 16) == 0), VSDE_E_BADARG, "vdiff needs residual values (and 16-byte alignment)");
+    p.Rinv = rinv; p.Vdiff = (uint16_t *)vdiff;
     return launch_qknorm(p, (hipStream_t)stream);
 }
 

@@ -730,6 +730,97 @@ def swiglu_mlp(x: Tensor, pin: PackedWeight, pout: PackedWeight) -> Tensor:
     return _SwiGLUMLP.apply(x, pin, pout, train, *pin.params, *pout.params)
 
 
+# VSDE_ATTN_FUSED_TRAIN=0: keep the separate qk_norm_rope / gate_merge passes in the training step (A/B runs)
+ATTN_FUSED_TRAIN = os.environ.get("VSDE_ATTN_FUSED_TRAIN", "1") != "0"
+_NONZERO: dict[int, tuple] = {}   # id(weight) -> (weakref, version, all entries non-zero)
+
+
+def _all_nonzero(w: Tensor) -> bool:
+    """The fused backward divides by the (frozen) RMS weights: checked once per weight version (one host sync)."""
+    hit = _NONZERO.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    ok = bool((w.detach() != 0).all())
+    _NONZERO[id(w)] = (weakref.ref(w), w._version, ok)
+    return ok
+
+
+class _AttentionCore(torch.autograd.Function):
+    """x -> [q | k | v | gate] projection -> QK-RMS-norm, RoPE, value mix -> softmax(q k^T) v -> sigmoid gate, head merge
+    (reference primitives/attn.py:80-113) as TWO kernels forward (``vsde_linear_qknorm_bf16``: everything up to the attention
+    inputs in the GEMM epilogue; ``vsde_attention_fwd_gated_bf16``: the gate in the attention store) and three + the projection's
+    two GEMMs backward (``vsde_gate_bwd_delta``, the dq and dk/dv attention kernels whose epilogues undo RoPE / RMS-norm / the
+    value mix and write the projection's gradient buffer directly).  The raw projection [B,N,3C+d] is never materialised; the
+    backward works from the attention inputs, one inverse RMS per (token, head) and v_raw - v0.
+
+    Value-residual gradient: as in ``_QkNormRopeJoint`` -- consumer blocks accumulate into ``v0link`` inside their dk/dv kernel,
+    the producing block (``v0 is None``) folds that buffer into its own dv."""
+
+    @staticmethod
+    def forward(ctx, x, pack, cos, sin, wq, wk, v0, lam, heads, eps, scale, v0link, *params):
+        B, N, K = x.shape
+        w, b = pack.operands()
+        mix = v0 is not None
+        v0c = v0.to(torch.bfloat16).contiguous() if mix else None
+        lamc = lam.detach().float().reshape(1).contiguous() if mix else None
+        x2 = x.reshape(B * N, K)
+        q, k, v, glog, rinv, vdiff = _hip.linear_qknorm_bf16(x2, w, b, heads, N, cos, sin, wq, wk, v0c, lamc, eps, save=True)
+        shape = (B, N, heads, 64)
+        og, lse = _hip.attention_fwd_gated(q.view(shape), k.view(shape), v.view(shape), glog, scale)
+        ctx.save_for_backward(x2, q, k, v, glog, og, lse, rinv, vdiff, cos, sin, wq, wk, lamc)
+        ctx.meta = (pack, heads, scale, lam.dtype if mix else None, v0link, (B, N, K))
+        ctx.set_materialize_grads(False)
+        return og.view(B, N, heads * 64), v.view(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmerged, dv_out):
+        x2, q, k, v, glog, og, lse, rinv, vdiff, cos, sin, wq, wk, lamc = ctx.saved_tensors
+        pack, heads, scale, lam_dtype, v0link, (B, N, K) = ctx.meta
+        M, C3, G = B * N, 3 * heads * 64, glog.shape[1]
+        shape = (B, N, heads, 64)
+        mix = vdiff is not None
+        dy = torch.empty(M, C3 + G, device=x2.device, dtype=torch.bfloat16)
+        if dmerged is None:
+            dmerged = torch.zeros(B, N, heads * 64, device=x2.device, dtype=torch.bfloat16)
+        dattn, delta = _hip.gate_bwd_delta(dmerged.to(torch.bfloat16).contiguous().view(shape), og, glog, dy[:, C3:])
+        acc = v0link.value if (v0link is not None and mix) else None
+        extra = v0link.take() if (v0link is not None and not mix) else None
+        if dv_out is not None:   # the values were consumed outside the link protocol (a direct use of the returned tensor)
+            dv_out = dv_out.to(torch.bfloat16).contiguous()
+            extra = dv_out if extra is None else (extra + dv_out)
+        dv0, dlam = _hip.attention_bwd_fused(dattn, q.view(shape), k.view(shape), v.view(shape), lse, delta, rinv, cos, sin, wq, wk,
+                                             vdiff, lamc, acc, extra, dy, scale)
+        if v0link is not None and mix:
+            v0link.value, dv0 = dv0, None
+        if dlam is not None:
+            dlam = dlam.to(lam_dtype).reshape(())
+        wb = pack.weight
+        if own_gemm(M, wb.shape[1], wb.shape[0]):
+            dx = _hip.linear_bf16(dy, pack.transposed(), None)
+        else:
+            dx = dy @ wb
+        dW, db = _hip.linear_wgrad(dy, x2.contiguous(), pack.bias is not None)
+        return (dx.view(B, N, K), None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db))
+
+
+def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, wk: Tensor, cos: Tensor) -> bool:
+    """Training-step form of the attention block's core (see ``_AttentionCore``): K = 256, head_dim 64, a 64-wide gate block,
+    a sequence the LDS-resident attention kernels take, fp32 non-zero norm weights and fp32 rotary tables."""
+    rows = x.numel() // x.shape[-1]
+    return (ENABLED and OWN_GEMM and ATTN_FUSED_TRAIN and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+            and x.ndim == 3 and x.shape[-1] == 256 and d == 64 and pack.weight.shape[0] == 3 * heads * 64 + 64 and rows >= 4096
+            and wq.dtype == torch.float32 and wk.dtype == torch.float32 and cos.dtype == torch.float32 and cos.shape[-1] == 32
+            and _hip.attention_fused_supported(x.shape[1], d) and _all_nonzero(wq) and _all_nonzero(wk))
+
+
+def attention_core(x: Tensor, pack: "PackedWeight", cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor],
+                   lam: Optional[Tensor], heads: int, eps: float, scale: float, v0link: Optional[GradLink]):
+    """(merged gated attention output [B,N,heads*64], values [B,N,heads,64]) for x [B,N,256]; v0 token-major or None."""
+    return _AttentionCore.apply(x, pack, cos.contiguous(), sin.contiguous(), wq.contiguous(), wk.contiguous(), v0,
+                                lam if v0 is not None else None, heads, eps, scale, v0link, *pack.params)
+
+
 def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Optional[int] = None) -> PackedWeight:
     """Pack of several Linears that share their input, stacked along the output rows ([qkv | gate])."""
     rows = sum(w.shape[0] for w in weights)
