@@ -223,8 +223,10 @@ int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, cons
  * rinv / vdiff outputs) + vsde_attention_fwd_gated_bf16; the backward is vsde_gate_bwd_delta + vsde_attention_bwd_fused_bf16,
  * which leaves the gradient dy [M][ldy] of the projection output ready for its input- and weight-gradient GEMMs.  Replaces
  * the separate qk_norm_rope fwd / bwd and gate_merge fwd passes of the unfused training chain.
- *   vsde_attention_fwd_gated_bf16   o[b,n,h,:] = softmax(..) v * rnd(sigmoid(gate[b n][0..64)))   (the merged [B,N,(h d)] rows)
- *   vsde_gate_bwd_delta             dattn = dout * s, dgate[m][0..64) = (1 - s) sum_h dout * og, delta[b,h,n] = <dout, og>
+ *   vsde_attention_fwd_gated_bf16   o[b,n,h,:] = softmax(..) v * s[b n][0..64), s = rnd(sigmoid(gate logit)) as written by
+ *                                   vsde_linear_qknorm_bf16(gate_sigmoid = 1)          (the merged [B,N,(h d)] rows)
+ *   vsde_gate_bwd_delta             dattn = dout * s, dgate[m][0..64) = (1 - s) sum_h dout * og (the gradient of the LOGITS),
+ *                                   delta[b,h,n] = <dout, og>
  *   vsde_attention_bwd_fused_bf16   dattn, the forward's q, k, v, lse and that delta -> dy columns [dq_raw | dk_raw | dv_raw]:
  *       the RoPE / RMS-norm backward from the saved rotated rows and rinv [M][2H] (weights wq / wk all non-zero), the value mix
  *       from vdiff = v_raw - v0 (NULL: no mixing): dv_raw = lam dv, dv0 (+)= (1 - lam) dv, dlam_partial[B H ceil(N/32)] partial
@@ -278,11 +280,12 @@ int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias
  * values are given, everything written straight in the attention layout: q, k, v [M][heads*64] (token-major [B,N,h,64]),
  * gate logits [M][ldg].  Same rounding points as vsde_linear_bf16 followed by vsde_qk_norm_rope_fwd.  For the training step
  * (both may be NULL): rinv [M][2 heads] fp32 receives the inverse RMS of every q / k head row and vdiff [M][heads*64] bf16
- * v_raw - v0 -- all the backward needs, the raw projection is never written. */
+ * v_raw - v0 -- all the backward needs, the raw projection is never written; gate_sigmoid != 0: the gate block is written as
+ * rnd(sigmoid(logit)), the factor vsde_attention_fwd_gated_bf16 multiplies by (one sigmoid per token and channel, not per head). */
 int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads, int gate_width,
                             int tokens, const float *cosT, const float *sinT, const float *wq, const float *wk, const void *v0,
-                            const float *lam, double eps, void *q, void *k, void *v, void *gate, int64_t ldg, float *rinv,
-                            void *vdiff, void *stream);
+                            const float *lam, double eps, void *q, void *k, void *v, void *gate, int64_t ldg, int gate_sigmoid,
+                            float *rinv, void *vdiff, void *stream);
 /* No-grad attention output projection with gate_merge folded into the operand load (primitives/attn.py:107-110):
  * y = (attn * sigmoid(gate[:, k % 64])) W^T + b for attn [M][K] (token-major heads of 64), gate logits [M][ldgate].
  * Rows kernel shapes only (K in {128, 256}, N % 64 == 0). */

@@ -147,15 +147,15 @@ def test_three_block_encoder_with_the_value_link():
 @pytest.mark.parametrize("B,N,H", [(3, 37, 4), (2, 401, 4), (1, 544, 2)])
 def test_gated_attention_store_and_gate_backward(B, N, H):
     """attention_fwd_gated = attention_fwd followed by the gate product (one bf16 rounding less); gate_bwd_delta against the
-    closed forms dattn = dout s, dgate = (1 - s) sum_h dout og, delta = <dout, og> = <dattn, o>."""
+    closed forms dattn = dout s, dgate (gradient of the logits) = (1 - s) sum_h dout og, delta = <dout, og> = <dattn, o>."""
     from viforsdes_amd import _hip
     g = torch.Generator().manual_seed(N)
     q, k, v = (torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
-    wide = torch.randn(B * N, 96, generator=g).to(DEV, torch.bfloat16)
-    gate = wide[:, 16:80]                                  # a column range of a wider buffer
+    wide = torch.sigmoid(torch.randn(B * N, 96, generator=g)).to(DEV, torch.bfloat16)
+    gate = wide[:, 16:80]                                  # the gate factors s = sigmoid(logits): a column range of a wider buffer
     o, lse = _hip.attention_fwd(q, k, v, 0.125)
     og, lse2 = _hip.attention_fwd_gated(q, k, v, gate, 0.125)
-    s = torch.sigmoid(gate.float()).to(torch.bfloat16).float().view(B, N, 1, 64)
+    s = gate.float().view(B, N, 1, 64)
     assert torch.equal(lse, lse2)
     assert rel_err(og.float().cpu().numpy(), (o.float() * s).cpu().numpy()) < 1e-2
     dout = torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16)

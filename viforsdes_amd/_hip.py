@@ -745,7 +745,8 @@ def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
                        v0: Optional[torch.Tensor], lam: Optional[torch.Tensor], eps: float, save: bool = False):
     """Attention projection: x [M,256] against the packed [q | k | v | gate] weight w [3*heads*64 + G, 256] with the
     QK-RMS-norm + RoPE + value mix in the GEMM epilogue -> (q, k, v [M, heads*64] token-major, gate logits [M, G] or None).
-    ``save`` (training): also returns (rinv [M, 2*heads] fp32, vdiff [M, heads*64] bf16 or None) for the fused backward."""
+    ``save`` (training): the gate block is returned as sigmoid(logits) and (rinv [M, 2*heads] fp32, vdiff [M, heads*64] bf16 or
+    None) are returned for the fused backward."""
     lib = load(); dev = _require_hip(x, w, cos, sin, wq, wk)
     x, ldx = _rows2d(x)
     M, K = x.shape
@@ -758,7 +759,8 @@ def linear_qknorm_bf16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Te
     with torch.cuda.device(dev):
         _call(lib.vsde_linear_qknorm_bf16, _ptr(x), _i64(ldx), _ptr(w), _ptr(bias), _i64(M), ctypes.c_int(K), ctypes.c_int(heads),
               ctypes.c_int(G), ctypes.c_int(tokens), _ptr(cos), _ptr(sin), _ptr(wq), _ptr(wk), _ptr(v0), _ptr(lam),
-              ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), _ptr(rinv), _ptr(vdiff), _stream(dev))
+              ctypes.c_double(eps), _ptr(q), _ptr(k), _ptr(v), _ptr(gate), _i64(G), ctypes.c_int(int(save)), _ptr(rinv), _ptr(vdiff),
+              _stream(dev))
     if save:
         return q, k, v, gate, rinv, vdiff
     return q, k, v, gate
@@ -769,8 +771,8 @@ def attention_fused_supported(N: int, head_dim: int) -> bool:
 
 
 def attention_fwd_gated(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, gate: torch.Tensor, scale: float):
-    """softmax(scale q k^T) v * sigmoid(gate) for token-major bf16 heads [B,N,H,64] and gate logits [B*N, >=64] (row-pitched):
-    returns (the merged rows og [B,N,H,64], lse [B,H,N] fp32)."""
+    """softmax(scale q k^T) v * gate for token-major bf16 heads [B,N,H,64] and the gate factors s = sigmoid(logits) [B*N, >=64]
+    (row-pitched; ``linear_qknorm_bf16(save=True)`` produces them): returns (the merged rows og [B,N,H,64], lse [B,H,N] fp32)."""
     lib = load(); dev = _require_hip(q, k, v, gate)
     B, N, H, d = q.shape
     if q.dtype != torch.bfloat16 or d != 64 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
@@ -785,8 +787,8 @@ def attention_fwd_gated(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, gate:
 
 
 def gate_bwd_delta(dout: torch.Tensor, og: torch.Tensor, gate: torch.Tensor, dgate: torch.Tensor):
-    """Backward of the gate folded into ``attention_fwd_gated``: dout, og [B,N,H,64] bf16, gate logits [B*N, >=64]; ``dgate``
-    (row-pitched [B*N, 64], e.g. the gate columns of the projection's gradient buffer) is filled in place.
+    """Backward of the gate folded into ``attention_fwd_gated``: dout, og [B,N,H,64] bf16, gate factors s [B*N, >=64]; ``dgate``
+    (row-pitched [B*N, 64], e.g. the gate columns of the projection's gradient buffer) receives the gradient of the LOGITS.
     Returns (dattn [B,N,H,64] = the gradient of the ungated attention output, delta [B,H,N] fp32 = <dattn, o>)."""
     lib = load(); dev = _require_hip(dout, og, gate, dgate)
     B, N, H, d = og.shape

@@ -40,7 +40,7 @@ struct AttnParams {
     int npad;                   // N rounded up to 32
     int vld;                    // LDS row stride of V^T in bf16: npad + 4 (stride/2 dwords = 2*odd mod 64: conflict-free b64)
     float scale, scale_log2e;
-    const uint16_t *gate;       // optional output gate logits [B*N][ldg] (64 per token, shared by the heads): o *= sigmoid(gate)
+    const uint16_t *gate;       // optional output gate [B*N][ldg] (64 factors per token, shared by the heads, = rnd(sigmoid(logit))): o *= gate
     int64_t ldg;
 };
 
@@ -52,8 +52,6 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 
 __device__ __forceinline__ float bfl(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfh(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-// sigmoid of a bf16 gate logit, rounded to bf16 like the unfused chain's sigmoid output under autocast (primitives/attn.py:108)
-__device__ __forceinline__ float gate_of(float x) { return (float)(__bf16)fast_rcp(1.0f + __expf(-x)); }
 
 __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
@@ -127,6 +125,10 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int query = qblk * 32 + fr;
         const bool qok = query < N;
+        // the first 8 bytes of this lane's share of the token's gate row, requested a whole round before the epilogue needs the
+        // row: the 128-byte line is in the cache by then (the tile loop itself issues no global loads)
+        uint2 gate0 = make_uint2(0u, 0u);
+        if (p.gate != nullptr && qok) gate0 = *(const uint2 *)(p.gate + ((int64_t)b * N + query) * p.ldg + 4 * h2);
         bf16x8 qf[4];  // B operand of S^T = K Q^T: column = query, k = d
         float qss = 0.f;
 #pragma unroll
@@ -230,9 +232,9 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 8 * g + 4 * h2;
-                    const uint2 ga = *(const uint2 *)(grow + d0), gb = *(const uint2 *)(grow + 32 + d0);
-                    const float sa[4] = {gate_of(bfl(ga.x)), gate_of(bfh(ga.x)), gate_of(bfl(ga.y)), gate_of(bfh(ga.y))};
-                    const float sb[4] = {gate_of(bfl(gb.x)), gate_of(bfh(gb.x)), gate_of(bfl(gb.y)), gate_of(bfh(gb.y))};
+                    const uint2 ga = g == 0 ? gate0 : *(const uint2 *)(grow + d0), gb = *(const uint2 *)(grow + 32 + d0);
+                    const float sa[4] = {bfl(ga.x), bfh(ga.x), bfl(ga.y), bfh(ga.y)};   // the sigmoid was applied where the gate was produced
+                    const float sb[4] = {bfl(gb.x), bfh(gb.x), bfl(gb.y), bfh(gb.y)};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { o0[4 * g + i] *= sa[i]; o1[4 * g + i] *= sb[i]; }
                 }
@@ -277,6 +279,7 @@ struct QkBwd {
     uint16_t *dv0; int dv0_accumulate;   // [M][64 H] gradient of the residual values: = or += (1 - lam) dv
     const uint16_t *dv_extra;        // [M][64 H] added to dv first (the block that produced v0), or nullptr
     float *dlam_partial;             // [B H ntile] per (head, key block) partial sums of <dv, v_raw - v0>
+    int dbg;                         // ablation (VSDE_ATTN_DEBUG): 1 / 2 / 4 = k / v / q rows of the direct epilogues stored without their math, 8 = every round takes the direct epilogues
 };
 
 struct AttnBwdParams {
@@ -409,43 +412,173 @@ __device__ __forceinline__ void norm_rope_bwd_store(const QkBwd &f, const f32x16
 }
 
 // Epilogue of a v head row: a0 / a1 = gradient of the (mixed) values of token m.  Returns this lane's share of <dv, v_raw - v0>.
+// All of the row's loads (v_raw - v0, the residual-gradient accumulator, the extra gradient: streamed data, HBM latency) are
+// issued before the first use -- per-group loads cost four serialized memory round trips per wave (+200 us per launch).
 __device__ __forceinline__ float value_bwd_store(const QkBwd &f, const f32x16 &a0, const f32x16 &a1, int64_t m, int hh, int H, int lane) {
     const int h2 = lane >> 5;
-    const int64_t vo = m * ((int64_t)H * 64) + hh * 64;
-    uint16_t *dst = f.dy + m * f.ldy + (2 * H + hh) * 64;
+    const int64_t vo = m * ((int64_t)H * 64) + hh * 64 + 4 * h2;
+    uint16_t *dst = f.dy + m * f.ldy + (2 * H + hh) * 64 + 4 * h2;
+    const bool mix = f.vdiff != nullptr, acc = mix && f.dv0_accumulate, ext = f.dv_extra != nullptr;
+    const float l = mix ? f.lam[0] : 1.0f;
+    uint2 df[8], ya[8], ex[8];   // index 2 g + (0: channels 8 g + 4 h2 .., 1: + 32)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int off = 8 * (j >> 1) + 32 * (j & 1);
+        df[j] = mix ? *(const uint2 *)(f.vdiff + vo + off) : make_uint2(0u, 0u);
+        ya[j] = acc ? *(const uint2 *)(f.dv0 + vo + off) : make_uint2(0u, 0u);
+        ex[j] = ext ? *(const uint2 *)(f.dv_extra + vo + off) : make_uint2(0u, 0u);
+    }
+    float dl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int off = 8 * (j >> 1) + 32 * (j & 1), g = j >> 1;
+        const f32x16 &a = (j & 1) ? a1 : a0;
+        float gv[4] = {a[4 * g] + bfl(ex[j].x), a[4 * g + 1] + bfh(ex[j].x), a[4 * g + 2] + bfl(ex[j].y), a[4 * g + 3] + bfh(ex[j].y)};
+        if (mix) {
+            const float d[4] = {bfl(df[j].x), bfh(df[j].x), bfl(df[j].y), bfh(df[j].y)};
+            const float y[4] = {bfl(ya[j].x), bfh(ya[j].x), bfl(ya[j].y), bfh(ya[j].y)};
+            float z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dl = fmaf(gv[i], d[i], dl);
+                z[i] = (1.0f - l) * gv[i] + y[i];
+                gv[i] *= l;
+            }
+            *(uint2 *)(f.dv0 + vo + off) = make_uint2(pack_bf16(z[0], z[1]), pack_bf16(z[2], z[3]));
+        }
+        *(uint2 *)(dst + off) = make_uint2(pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]));
+    }
+    return dl;
+}
+
+// ---- the same epilogues through LDS (the last round of every wave, after the workgroup is done with its resident operands) ----
+// In the accumulator layout a lane owns 4 consecutive channels of one token: every global access of the direct epilogues above
+// is 64 lanes x 8 bytes in 32 different rows, i.e. one tag lookup per lane for 8 bytes -- the epilogues were bound by the
+// texture-address unit (+100 us per launch without, +270 us with the value mix).  Staged through a per-wave LDS slice the tile
+// is re-read as rows: 8 lanes x 16 bytes = one full 128-byte head row, 8 rows per instruction, and the row's loads (saved
+// y^, tables, v_raw - v0, the residual accumulator) and stores have the same shape.
+constexpr int AT_ELD = 68;                   // floats per staged row (64 channels + 4: conflict-free b128 writes and reads)
+constexpr int AT_ESLICE = 32 * AT_ELD;       // floats per wave (8.5 KB)
+
+__device__ __forceinline__ void stage_acc_tile(float *slice, const f32x16 &a0, const f32x16 &a1, float mul, int lane) {
+    float *row = slice + (lane & 31) * AT_ELD + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *(float4 *)(row + 8 * g) = make_float4(a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul);
+        *(float4 *)(row + 32 + 8 * g) = make_float4(a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul);
+    }
+}
+
+__device__ __forceinline__ void unpack8(const uint4 &w, float (&x)[8]) {
+    x[0] = bfl(w.x); x[1] = bfh(w.x); x[2] = bfl(w.y); x[3] = bfh(w.y); x[4] = bfl(w.z); x[5] = bfh(w.z); x[6] = bfl(w.w); x[7] = bfh(w.w);
+}
+__device__ __forceinline__ void load8f(const float *p, float (&x)[8]) {
+    const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+
+// The rows' streamed inputs are requested BEFORE the workgroup barrier that frees the LDS (waves 1..11 wait there for the
+// wave that owns the 13th block): by the time the tile is staged they have arrived.  Lane (row = lane / 8 + 8 pass, c = lane % 8)
+// owns channels 8 c .. 8 c + 7 of its rows and reads its rotary partner chunk c ^ 4 beside its own.
+struct NormRowsIn { uint4 y[4], yp[4]; float rr[4]; };   // y^ chunks (own, partner) and the inverse RMS of the lane's 4 rows
+struct ValueRowsIn { uint4 ex[4], df[4], ya[4]; };       // extra gradient, v_raw - v0, residual-gradient accumulator
+
+template <int KIND>
+__device__ __forceinline__ void norm_rows_request(const QkBwd &f, NormRowsIn &in, const uint16_t *yrows, int64_t ts, int64_t m0, int tok0,
+                                                  int N, int hh, int H, int lane) {
+    const int c = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int tok = tok0 + pass * 8 + (lane >> 3), tc = tok < N ? tok : N - 1;
+        in.y[pass] = *(const uint4 *)(yrows + tc * ts + 8 * c);
+        in.yp[pass] = *(const uint4 *)(yrows + tc * ts + 8 * (c ^ 4));
+        in.rr[pass] = f.rinv[(m0 + tc) * (2 * H) + KIND * H + hh];
+    }
+}
+
+__device__ __forceinline__ void value_rows_request(const QkBwd &f, ValueRowsIn &in, int64_t m0, int tok0, int N, int hh, int H, int lane) {
+    const int c = lane & 7;
+    const bool mix = f.vdiff != nullptr, acc = mix && f.dv0_accumulate, ext = f.dv_extra != nullptr;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int tok = tok0 + pass * 8 + (lane >> 3);
+        const int64_t vo = (m0 + (tok < N ? tok : N - 1)) * ((int64_t)H * 64) + hh * 64 + 8 * c;
+        in.ex[pass] = ext ? *(const uint4 *)(f.dv_extra + vo) : make_uint4(0u, 0u, 0u, 0u);
+        in.df[pass] = mix ? *(const uint4 *)(f.vdiff + vo) : make_uint4(0u, 0u, 0u, 0u);
+        in.ya[pass] = acc ? *(const uint4 *)(f.dv0 + vo) : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// slice: gradient of the rotated, normalised rows y^ of the tile's 32 tokens (first token tok0 of batch row block m0 = b N)
+template <int KIND>
+__device__ __forceinline__ void staged_norm_rope_bwd(const QkBwd &f, const float *slice, const NormRowsIn &in, int64_t m0, int tok0, int N,
+                                                     int hh, int H, int lane) {
+    const int c = lane & 7, cp = c ^ 4;
+    const float sgn = c < 4 ? 1.0f : -1.0f;
+    float wv[8], iw[8], cs[4][8], sn[4][8];
+    load8f((KIND ? f.wk : f.wq) + 8 * c, wv);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {   // the rotary tables of all four rows in one batch (L2-resident)
+        const int tok = tok0 + pass * 8 + (lane >> 3), tc = tok < N ? tok : N - 1;
+        load8f(f.cosT + tc * 32 + 8 * (c & 3), cs[pass]); load8f(f.sinT + tc * 32 + 8 * (c & 3), sn[pass]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) iw[j] = 1.0f / wv[j];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + (lane >> 3), tok = tok0 + row;
+        float g[8], gp[8], y[8], yp[8];
+        load8f(slice + row * AT_ELD + 8 * c, g); load8f(slice + row * AT_ELD + 8 * cp, gp);
+        unpack8(in.y[pass], y); unpack8(in.yp[pass], yp);
+        float cc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cc = fmaf(g[j], y[j], cc);
+        cc += __shfl_xor(cc, 1, 64); cc += __shfl_xor(cc, 2, 64); cc += __shfl_xor(cc, 4, 64);
+        cc *= 1.0f / 64.0f;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = g[j] * cs[pass][j] + sgn * gp[j] * sn[pass][j];   // R^T dy^
+            const float a = y[j] * cs[pass][j] + sgn * yp[j] * sn[pass][j];   // R^T y^ = n w
+            o[j] = in.rr[pass] * (wv[j] * u - a * (cc * iw[j]));
+        }
+        if (tok < N)
+            *(uint4 *)(f.dy + (m0 + tok) * f.ldy + (KIND * H + hh) * 64 + 8 * c) =
+                make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+    }
+}
+
+// slice: gradient of the (mixed) values of the tile's tokens; returns this lane's share of <dv, v_raw - v0>
+__device__ __forceinline__ float staged_value_bwd(const QkBwd &f, const float *slice, const ValueRowsIn &in, int64_t m0, int tok0, int N,
+                                                  int hh, int H, int lane) {
+    const int c = lane & 7;
     const bool mix = f.vdiff != nullptr;
     const float l = mix ? f.lam[0] : 1.0f;
     float dl = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int d0 = 8 * g + 4 * h2;
-        float gl[4] = {a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]}, gh[4] = {a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]};
-        if (f.dv_extra != nullptr) {
-            const uint2 ea = *(const uint2 *)(f.dv_extra + vo + d0), eb = *(const uint2 *)(f.dv_extra + vo + 32 + d0);
-            gl[0] += bfl(ea.x); gl[1] += bfh(ea.x); gl[2] += bfl(ea.y); gl[3] += bfh(ea.y);
-            gh[0] += bfl(eb.x); gh[1] += bfh(eb.x); gh[2] += bfl(eb.y); gh[3] += bfh(eb.y);
-        }
-        if (mix) {
-            const uint2 da = *(const uint2 *)(f.vdiff + vo + d0), db = *(const uint2 *)(f.vdiff + vo + 32 + d0);
-            const float dfl[4] = {bfl(da.x), bfh(da.x), bfl(da.y), bfh(da.y)}, dfh[4] = {bfl(db.x), bfh(db.x), bfl(db.y), bfh(db.y)};
-            float zl[4], zh[4];
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + (lane >> 3), tok = tok0 + row;
+        const bool ok = tok < N;
+        const int64_t vo = (m0 + tok) * ((int64_t)H * 64) + hh * 64 + 8 * c;
+        float g[8], e[8];
+        load8f(slice + row * AT_ELD + 8 * c, g);
+        unpack8(in.ex[pass], e);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dl = fmaf(gl[i], dfl[i], fmaf(gh[i], dfh[i], dl));
-                zl[i] = (1.0f - l) * gl[i]; zh[i] = (1.0f - l) * gh[i];
-                gl[i] *= l; gh[i] *= l;
+        for (int j = 0; j < 8; ++j) g[j] += e[j];
+        if (mix) {
+            float d[8], y[8], z[8];
+            unpack8(in.df[pass], d); unpack8(in.ya[pass], y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (ok) dl = fmaf(g[j], d[j], dl);
+                z[j] = (1.0f - l) * g[j] + y[j];
+                g[j] *= l;
             }
-            if (f.dv0_accumulate) {
-                const uint2 ya = *(const uint2 *)(f.dv0 + vo + d0), yb = *(const uint2 *)(f.dv0 + vo + 32 + d0);
-                zl[0] += bfl(ya.x); zl[1] += bfh(ya.x); zl[2] += bfl(ya.y); zl[3] += bfh(ya.y);
-                zh[0] += bfl(yb.x); zh[1] += bfh(yb.x); zh[2] += bfl(yb.y); zh[3] += bfh(yb.y);
-            }
-            *(uint2 *)(f.dv0 + vo + d0) = make_uint2(pack_bf16(zl[0], zl[1]), pack_bf16(zl[2], zl[3]));
-            *(uint2 *)(f.dv0 + vo + 32 + d0) = make_uint2(pack_bf16(zh[0], zh[1]), pack_bf16(zh[2], zh[3]));
+            if (ok) *(uint4 *)(f.dv0 + vo) = make_uint4(pack_bf16(z[0], z[1]), pack_bf16(z[2], z[3]), pack_bf16(z[4], z[5]), pack_bf16(z[6], z[7]));
         }
-        *(uint2 *)(dst + d0) = make_uint2(pack_bf16(gl[0], gl[1]), pack_bf16(gl[2], gl[3]));
-        *(uint2 *)(dst + 32 + d0) = make_uint2(pack_bf16(gh[0], gh[1]), pack_bf16(gh[2], gh[3]));
-        __builtin_amdgcn_sched_barrier(0);
+        if (ok)
+            *(uint4 *)(f.dy + (m0 + tok) * f.ldy + (2 * H + hh) * 64 + 8 * c) =
+                make_uint4(pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3]), pack_bf16(g[4], g[5]), pack_bf16(g[6], g[7]));
     }
     return dl;
 }
@@ -506,6 +639,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     __syncthreads();
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
+    f32x16 acc0, acc1;
+    int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
     for (int qblk = wave; qblk < p.ntile; qblk += AT_BT / 64) {
         if (qblk != wave) request(qblk);  // later rounds are rare with 12 waves (N <= 384 needs none): fetch on demand
         const int query = qblk * 32 + fr;
@@ -525,7 +660,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
         else dsum += __shfl_xor(dsum, 32, 64);
         const float lse2 = lsen * 1.4426950408889634f;
         if constexpr (!FUSED) { if (qok && h2 == 0) p.delta[srow + query] = dsum; }
-        f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 #pragma unroll 1
         for (int kt = 0; kt < p.ntile; ++kt) {
             const uint16_t *kt_ = Ks + kt * 32 * AT_KLD, *vt_ = Vs + kt * 32 * AT_KLD;
@@ -543,9 +679,25 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
             pack_tile(ds, b0, b1);
             accumulate_transposed(kt_, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
         }
-        if constexpr (FUSED) asm volatile("" ::: "memory");
-        if constexpr (FUSED) norm_rope_bwd_store<0>(p.f, acc0, acc1, p.scale, qf, (int64_t)b * N + query, query, hh, p.H, lane, qok);
+        if constexpr (FUSED) {
+            asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (loop-invariant: hoisted, they spill)
+            if (qblk + AT_BT / 64 >= p.ntile && !(p.f.dbg & 8)) last = qblk;
+            else if (p.f.dbg & 4) { if (qok) store_transposed(p.f.dy + ((int64_t)b * N + query) * p.f.ldy + hh * 64, h2, acc0, acc1, p.scale); }
+            else norm_rope_bwd_store<0>(p.f, acc0, acc1, p.scale, qf, (int64_t)b * N + query, query, hh, p.H, lane, qok);
+        }
         else if (qok) store_transposed(p.dq + base + query * ts, h2, acc0, acc1, p.scale);
+    }
+    if constexpr (FUSED) {
+        NormRowsIn in;
+        if (p.f.dbg & 64) last = -1;
+        if (last >= 0) norm_rows_request<0>(p.f, in, p.q + base, ts, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        __syncthreads();   // every wave is done with K / V: their space becomes the waves' staging slices
+        if (last >= 0) {
+            float *slice = (float *)asmem + wave * AT_ESLICE;
+            stage_acc_tile(slice, acc0, acc1, p.scale, lane);
+            wave_lds_fence();
+            staged_norm_rope_bwd<0>(p.f, slice, in, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        }
     }
 }
 
@@ -574,6 +726,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     }
     __syncthreads();
     const float c2 = p.scale_log2e;
+    f32x16 dk0, dk1, dv0, dv1;
+    int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
     for (int kblk = wave; kblk < p.ntile; kblk += AT_BT / 64) {
         if (kblk != wave) request(kblk);
         const int key = kblk * 32 + fr;
@@ -581,7 +735,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
-        f32x16 dk0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk0[e] = 0.f; dk1[e] = 0.f; dv0[e] = 0.f; dv1[e] = 0.f; }
 #pragma unroll 1
         for (int qt = 0; qt < p.ntile; ++qt) {
             const uint16_t *qt_ = Qs + qt * 32 * AT_KLD, *dot_ = Os + qt * 32 * AT_KLD;
@@ -608,23 +763,52 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         }
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
+            if (kblk + AT_BT / 64 >= p.ntile && !(p.f.dbg & 8)) { last = kblk; continue; }
             const int64_t m = (int64_t)b * N + key;
-            float dl = kok ? value_bwd_store(p.f, dv0, dv1, m, hh, p.H, lane) : 0.f;   // values first: their accumulators die here
+            float dl = 0.f;
+            if (p.f.dbg & 2) { if (kok) store_transposed(p.f.dy + m * p.f.ldy + (2 * p.H + hh) * 64, h2, dv0, dv1, 1.0f); }
+            else dl = kok ? value_bwd_store(p.f, dv0, dv1, m, hh, p.H, lane) : 0.f;   // values first: their accumulators die here
             if (p.f.dlam_partial != nullptr) {   // every key block is owned by exactly one wave: deterministic partials
                 dl = wave_sum(dl);
                 if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + kblk] = dl;
             }
-            norm_rope_bwd_store<1>(p.f, dk0, dk1, p.scale, kf, m, key, hh, p.H, lane, kok);
+            if (p.f.dbg & 1) { if (kok) store_transposed(p.f.dy + m * p.f.ldy + (p.H + hh) * 64, h2, dk0, dk1, p.scale); }
+            else norm_rope_bwd_store<1>(p.f, dk0, dk1, p.scale, kf, m, key, hh, p.H, lane, kok);
         } else if (kok) {
             store_transposed(p.dk + base + key * ts, h2, dk0, dk1, p.scale);
             store_transposed(p.dv + base + key * ts, h2, dv0, dv1, 1.0f);
         }
     }
+    if constexpr (FUSED) {
+        const int64_t m0 = (int64_t)b * N;
+        NormRowsIn kin; ValueRowsIn vin;
+        if (p.f.dbg & 64) last = -1;
+        if (last >= 0) {
+            value_rows_request(p.f, vin, m0, last * 32, N, hh, p.H, lane);
+            norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane);
+        }
+        __syncthreads();   // every wave is done with Q / dO / lse / delta: their space becomes the waves' staging slices
+        if (last >= 0) {
+            float *slice = (float *)asmem + wave * AT_ESLICE;
+            stage_acc_tile(slice, dv0, dv1, 1.0f, lane);
+            wave_lds_fence();
+            float dl = (p.f.dbg & 32) ? 0.f : staged_value_bwd(p.f, slice, vin, m0, last * 32, N, hh, p.H, lane);
+            if (p.f.dlam_partial != nullptr) {
+                dl = wave_sum(dl);
+                if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + last] = dl;
+            }
+            wave_lds_fence();
+            stage_acc_tile(slice, dk0, dk1, p.scale, lane);
+            wave_lds_fence();
+            if (!(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane);
+        }
+    }
 }
 
-// Backward of the sigmoid output gate that the forward folded into the attention store (og = o sigmoid(gate), one gate row per
-// token shared by the heads; primitives/attn.py:107-113): dO = dout s, dgate = (1 - s) sum_h dout og, and the attention
-// backward's D = <dO, O> = <dout, og> per (token, head).  8 threads per token, 8 channels each.
+// Backward of the sigmoid output gate that the forward folded into the attention store (og = o s, s = rnd(sigmoid(logit)), one
+// gate row per token shared by the heads; primitives/attn.py:107-113; `gate` holds s): dO = dout s, the gradient of the LOGITS
+// dgate = (1 - s) sum_h dout og, and the attention backward's D = <dO, O> = <dout, og> per (token, head).
+// 8 threads per token, 8 channels each.
 __global__ void __launch_bounds__(256) gate_bwd_delta_kernel(const uint16_t *__restrict__ dout, const uint16_t *__restrict__ og,
                                                              const uint16_t *__restrict__ gate, int64_t ldg, uint16_t *__restrict__ dattn,
                                                              uint16_t *__restrict__ dgate, int64_t ldd, float *__restrict__ delta,
@@ -638,7 +822,7 @@ __global__ void __launch_bounds__(256) gate_bwd_delta_kernel(const uint16_t *__r
     const uint32_t gw[4] = {g4.x, g4.y, g4.z, g4.w};
     float s[8], acc[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { s[2 * e] = gate_of(bfl(gw[e])); s[2 * e + 1] = gate_of(bfh(gw[e])); }
+    for (int e = 0; e < 4; ++e) { s[2 * e] = bfl(gw[e]); s[2 * e + 1] = bfh(gw[e]); }
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int hh = 0; hh < H; ++hh) {
@@ -777,7 +961,10 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
     p.f.dy = (uint16_t *)dy; p.f.ldy = ldy; p.f.rinv = rinv; p.f.cosT = cosT; p.f.sinT = sinT; p.f.wq = wq; p.f.wk = wk; p.f.lam = lam;
     p.f.vdiff = (const uint16_t *)vdiff; p.f.dv0 = (uint16_t *)dv0; p.f.dv0_accumulate = dv0_accumulate;
     p.f.dv_extra = (const uint16_t *)dv_extra; p.f.dlam_partial = dlam_partial;
-    const size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; } p.f.dbg = dbg; }
+    const size_t stage = (size_t)(AT_BT / 64) * AT_ESLICE * sizeof(float);   // the waves' epilogue slices reuse the operand space
+    size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
+    lds_dq = lds_dq > stage ? lds_dq : stage; lds_dkv = lds_dkv > stage ? lds_dkv : stage;
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;

@@ -50,6 +50,7 @@ struct LinParams {
     const float *cosT, *sinT, *wq, *wk, *lam;   // rotary tables [tokens][32], RMS weights [64], value-mix weight [1]
     const uint16_t *V0;                         // residual values [M][heads*64] or nullptr
     int heads, tokens; float eps;
+    int gate_sigmoid;                           // training: the gate block leaves as rnd(sigmoid(logit)) (what the attention store multiplies by)
     float *Rinv;                                // training: inverse RMS of every q / k head row [M][2 heads], or nullptr
     uint16_t *Vdiff;                            // training: v_raw - v0 [M][heads*64] (what the value-mix weight's gradient needs), or nullptr
     // gated A operand (no-grad out projection): row m of A is multiplied by sigmoid(Gate[m][k % 64]) on its way into the registers
@@ -227,6 +228,17 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
             if (kind <= 1 || (kind == 2 && p.V0 != nullptr)) {
                 const u32x4 v0r[4] = {ureg[0], ureg[1], ureg[2], ureg[3]};
                 qknorm_head(p, stage, kind, hh, row0, lane, cs, sn, v0r, wlds);
+                wave_lds_fence();
+            } else if (kind == 3 && p.gate_sigmoid) {   // one sigmoid per (token, channel) here instead of one per head in every attention epilogue
+                uint16_t *px = stage + r * SLD + 16 * h;
+#pragma unroll
+                for (int part = 0; part < 4; ++part) {
+                    u32x4 *q4 = (u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8);
+                    u32x4 v = *q4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(sigm_f(bf_lo(v[e])), sigm_f(bf_hi(v[e])));
+                    *q4 = v;
+                }
                 wave_lds_fence();
             }
             uint16_t *dst = kind == 0 ? p.Qo : (kind == 1 ? p.Ko : (kind == 2 ? p.Vo : p.Go));
@@ -872,7 +884,7 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
 extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const void *bias, int64_t M, int K, int heads,
                                        int gate_width, int tokens, const float *cosT, const float *sinT, const float *wq,
                                        const float *wk, const void *v0, const float *lam, double eps, void *q, void *k, void *v,
-                                       void *gate, int64_t ldg, float *rinv, void *vdiff, void *stream) {
+                                       void *gate, int64_t ldg, int gate_sigmoid, float *rinv, void *vdiff, void *stream) {
     VSDE_CHECK_ARG(x && w && q && k && v && cosT && sinT && wq && wk && M > 0 && heads > 0 && tokens > 0, VSDE_E_BADARG,
                    "bad linear_qknorm arguments");
     VSDE_CHECK_ARG(K == 256 && gate_width % 64 == 0 && gate_width >= 0 && (gate_width == 0 || (gate && ldg >= gate_width && ldg % 8 == 0)),
@@ -888,7 +900,7 @@ extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w
     p.cosT = cosT; p.sinT = sinT; p.wq = wq; p.wk = wk; p.lam = lam; p.V0 = (const uint16_t *)v0;
     p.heads = heads; p.tokens = tokens; p.eps = (float)eps;
     VSDE_CHECK_ARG(!vdiff || (v0 && ((uintptr_t)vdiff % 16) == 0), VSDE_E_BADARG, "vdiff needs residual values (and 16-byte alignment)");
-    p.Rinv = rinv; p.Vdiff = (uint16_t *)vdiff;
+    p.Rinv = rinv; p.Vdiff = (uint16_t *)vdiff; p.gate_sigmoid = gate_sigmoid;
     return launch_qknorm(p, (hipStream_t)stream);
 }
 

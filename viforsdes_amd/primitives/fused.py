@@ -96,11 +96,12 @@ class _ResidualNorm(torch.autograd.Function):
     its other consumers, the norm backward, gate*dx and the three token sums into one kernel."""
 
     @staticmethod
-    def forward(ctx, x, y, gate, scale, shift, eps):
+    def forward(ctx, x, y, gate, scale, shift, eps, link=None):
         x = x.contiguous()
         y, gate, scale, shift = (t.to(x.dtype).contiguous() for t in (y, gate, scale, shift))
         xnew, h, mean, rstd = _hip.residual_ln_fwd(x, y, gate, scale, shift, eps)
         ctx.save_for_backward(xnew, y, gate, scale, mean, rstd)
+        ctx.link = link
         return xnew, h
 
     @staticmethod
@@ -110,12 +111,16 @@ class _ResidualNorm(torch.autograd.Function):
         dh = torch.zeros_like(xnew) if dh is None else dh.to(xnew.dtype).contiguous()
         dxnew = None if dxnew is None else dxnew.to(xnew.dtype).contiguous()
         dx, dy, dgate, dscale, dshift = _hip.residual_ln_bwd(xnew, y, gate, scale, dh, dxnew, mean, rstd)
-        return dx, dy, dgate, dscale, dshift, None
+        if ctx.link is not None and ctx.needs_input_grad[0]:
+            ctx.link.value, dx = dx, None   # picked up by the ln_modulate backward of the same x (no separate accumulation pass)
+        return dx, dy, dgate, dscale, dshift, None, None
 
 
-def residual_norm(x: Tensor, y: Tensor, gate: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5) -> tuple[Tensor, Tensor]:
-    """``xnew = x + gate[:, None]*y`` and ``h = LayerNorm(xnew)*(1+scale[:, None]) + shift[:, None]`` -> (xnew, h)."""
-    return _ResidualNorm.apply(x, y, gate, scale, shift, eps)
+def residual_norm(x: Tensor, y: Tensor, gate: Tensor, scale: Tensor, shift: Tensor, eps: float = 1e-5,
+                  link: Optional[GradLink] = None) -> tuple[Tensor, Tensor]:
+    """``xnew = x + gate[:, None]*y`` and ``h = LayerNorm(xnew)*(1+scale[:, None]) + shift[:, None]`` -> (xnew, h).
+    ``link``: shared with the ``ln_modulate`` that consumed the same ``x`` upstream of ``y`` (see ``ln_modulate``)."""
+    return _ResidualNorm.apply(x, y, gate, scale, shift, eps, link)
 
 
 class Modulations:
@@ -147,42 +152,45 @@ class Modulations:
 
 class _LnModulateM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, allm, mods, sc, sh, eps, final):
+    def forward(ctx, x, allm, mods, sc, sh, eps, final, link=None):
         x = x.contiguous()
         y, mean, rstd = _hip.ln_modulate_fwd(x, mods.vec(*sc), mods.vec(*sh), eps)
         ctx.save_for_backward(x, mean, rstd)
-        ctx.meta = (mods, sc, sh, final)
+        ctx.meta = (mods, sc, sh, final, link)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
-        mods, sc, sh, final = ctx.meta
-        dx, _, _ = _hip.ln_modulate_bwd(x, mods.vec(*sc), dy.to(x.dtype).contiguous(), mean, rstd, None,
+        mods, sc, sh, final, link = ctx.meta
+        dres = link.take() if link is not None else None   # gradient reaching x through the residual branch
+        dx, _, _ = _hip.ln_modulate_bwd(x, mods.vec(*sc), dy.to(x.dtype).contiguous(), mean, rstd, dres,
                                         dscale=mods.gvec(*sc), dshift=mods.gvec(*sh))
-        return dx, (mods.take_grad() if final else None), None, None, None, None, None
+        return dx, (mods.take_grad() if final else None), None, None, None, None, None, None
 
 
 class _ResidualNormM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, allm, mods, gt, sc, sh, eps):
+    def forward(ctx, x, y, allm, mods, gt, sc, sh, eps, link=None):
         x = x.contiguous(); y = y.to(x.dtype).contiguous()
         xnew, h, mean, rstd = _hip.residual_ln_fwd(x, y, mods.vec(*gt), mods.vec(*sc), mods.vec(*sh), eps)
         ctx.save_for_backward(xnew, y, mean, rstd)
-        ctx.meta = (mods, gt, sc, sh)
+        ctx.meta = (mods, gt, sc, sh, link)
         return xnew, h
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dxnew, dh):
         xnew, y, mean, rstd = ctx.saved_tensors
-        mods, gt, sc, sh = ctx.meta
+        mods, gt, sc, sh, link = ctx.meta
         dh = torch.zeros_like(xnew) if dh is None else dh.to(xnew.dtype).contiguous()
         dxnew = None if dxnew is None else dxnew.to(xnew.dtype).contiguous()
         dx, dy, _, _, _ = _hip.residual_ln_bwd(xnew, y, mods.vec(*gt), mods.vec(*sc), dh, dxnew, mean, rstd,
                                                dgate=mods.gvec(*gt), dscale=mods.gvec(*sc), dshift=mods.gvec(*sh))
-        return dx, dy, None, None, None, None, None, None
+        if link is not None and ctx.needs_input_grad[0]:
+            link.value, dx = dx, None   # picked up by the ln_modulate backward of the same x
+        return dx, dy, None, None, None, None, None, None, None
 
 
 class _GatedResidualM(torch.autograd.Function):
@@ -203,14 +211,15 @@ class _GatedResidualM(torch.autograd.Function):
         return dout, dy, None, None, None
 
 
-def ln_modulate_m(x: Tensor, mods: Modulations, scale: tuple[int, int], shift: tuple[int, int], eps: float, final: bool = False) -> Tensor:
+def ln_modulate_m(x: Tensor, mods: Modulations, scale: tuple[int, int], shift: tuple[int, int], eps: float, final: bool = False,
+                  link: Optional[GradLink] = None) -> Tensor:
     """``ln_modulate`` with scale / shift = chunks ``(block, j)`` of ``mods`` (see ``Modulations``)."""
-    return _LnModulateM.apply(x, mods.allm, mods, scale, shift, eps, final)
+    return _LnModulateM.apply(x, mods.allm, mods, scale, shift, eps, final, link)
 
 
 def residual_norm_m(x: Tensor, y: Tensor, mods: Modulations, gate: tuple[int, int], scale: tuple[int, int], shift: tuple[int, int],
-                    eps: float) -> tuple[Tensor, Tensor]:
-    return _ResidualNormM.apply(x, y, mods.allm, mods, gate, scale, shift, eps)
+                    eps: float, link: Optional[GradLink] = None) -> tuple[Tensor, Tensor]:
+    return _ResidualNormM.apply(x, y, mods.allm, mods, gate, scale, shift, eps, link)
 
 
 def gated_residual_m(x: Tensor, y: Tensor, mods: Modulations, gate: tuple[int, int]) -> Tensor:

@@ -127,21 +127,25 @@ class SiT(nn.Module):
         tokens = tokens.contiguous()  # a broadcast input is materialised once, not by each consumer
         mods = self._packed_modulations(cond)
         SA, HA, GA, SM, HM, GM = range(6)  # chunk order of a block's modulator output (primitives/sit.py:72)
+        # the input stream feeds the first norm and the first residual: their two gradient contributions meet inside the norm's
+        # backward kernel (link0) instead of in a separate accumulation pass
+        link0 = fused.GradLink()
         if mods is None:
             ml = [blk._cond_modulator.net(cond).chunk(6, dim=-1) for blk in blocks]
-            h1 = fused.ln_modulate(tokens, ml[0][SA], ml[0][HA], blocks[0].attn_norm.eps)
+            h1 = fused.ln_modulate(tokens, ml[0][SA], ml[0][HA], blocks[0].attn_norm.eps, link0)
         else:
-            h1 = fused.ln_modulate_m(tokens, mods, (0, SA), (0, HA), blocks[0].attn_norm.eps, final=True)
+            h1 = fused.ln_modulate_m(tokens, mods, (0, SA), (0, HA), blocks[0].attn_norm.eps, final=True, link=link0)
         v0: Optional[Tensor] = None
         v0link = fused.GradLink() if self.config.attn_residual_v else None  # one buffer for the value-residual gradient
         for k, blk in enumerate(blocks):
             attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0, v0link=v0link)
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
+            lk = link0 if k == 0 else None
             if mods is None:
-                x1, h2 = fused.residual_norm(tokens, attn_out, ml[k][GA], ml[k][SM], ml[k][HM], blk.mlp_norm.eps)
+                x1, h2 = fused.residual_norm(tokens, attn_out, ml[k][GA], ml[k][SM], ml[k][HM], blk.mlp_norm.eps, lk)
             else:
-                x1, h2 = fused.residual_norm_m(tokens, attn_out, mods, (k, GA), (k, SM), (k, HM), blk.mlp_norm.eps)
+                x1, h2 = fused.residual_norm_m(tokens, attn_out, mods, (k, GA), (k, SM), (k, HM), blk.mlp_norm.eps, lk)
             mlp_out = blk.mlp(h2)
             if k + 1 < nb:
                 eps = blocks[k + 1].attn_norm.eps
