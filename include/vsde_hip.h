@@ -275,7 +275,7 @@ int vsde_linear_bf16_supported(int64_t M, int N, int K, int epilogue);
 int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const void *bias, void *y, int64_t ldy, int64_t M, int N, int K,
                      int epilogue, void *s_out, int64_t lds, const void *u_in, int64_t ldu, void *stream);
 /* Attention projection (primitives/attn.py:80-103 in one kernel): y = x W^T + b with W = [q | k | v | gate] rows
- * (N = 3 heads*64 + gate_width, K = 256), and in the epilogue RMS-norm (weights wq / wk [64], eps) + RoPE (cos / sin tables
+ * (N = 3 heads*64 + gate_width, K in {128, 256}), and in the epilogue RMS-norm (weights wq / wk [64], eps) + RoPE (cos / sin tables
  * [tokens][32], row m is token m % tokens, rotary pairs (i, i + 32)) on every q / k head, v = lam v + (1 - lam) v0 when residual
  * values are given, everything written straight in the attention layout: q, k, v [M][heads*64] (token-major [B,N,h,64]),
  * gate logits [M][ldg].  Same rounding points as vsde_linear_bf16 followed by vsde_qk_norm_rope_fwd.  For the training step

@@ -131,6 +131,16 @@ def _assert_fused_route_active(tr, bf16):
     if bf16:
         assert fused.attention_usable(torch.empty(2, 41, enc.num_heads, hd, device="cuda:0", dtype=torch.bfloat16))
         assert fused.packed_linear_usable(torch.empty(104, 41, C, device="cuda:0", dtype=torch.bfloat16), 3 * C + hd, C)
+        # ... and, in the training step, the attention block's fused core (projection epilogue + attention-kernel epilogues):
+        # the reference fixture below is what pins its forward and backward
+        att = enc.sit.blocks[1].self_attn
+        xb = torch.zeros(104, 41, C, device="cuda:0", dtype=torch.bfloat16)
+        from viforsdes_amd.primitives.embeddings import RotarySpec
+        rot = RotarySpec.from_freqs(enc.rope_freqs[:41].to("cuda:0"))
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            att.forward_fused(xb, rotary=rot, v0=None)   # builds the packed [q | k | v | gate] operand
+        assert fused.attention_core_usable(xb, att._proj_pack, enc.num_heads, hd, att.q_norm.weight, att.k_norm.weight,
+                                           rot.cos_sin_tables(41)[0]), "the fixture's dims must take the fused attention core"
 
 
 @pytest.mark.gpu

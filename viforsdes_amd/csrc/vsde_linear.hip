@@ -819,8 +819,10 @@ static int launch_deep(const LinParams &p, hipStream_t s) {
     return 0;
 }
 
-// EPI_QKNORM is instantiated for K = 256 only (the encoder width it was written for)
-static int launch_qknorm(const LinParams &p, hipStream_t s) { return launch_rows<256, EPI_QKNORM>(p, s); }
+// EPI_QKNORM: K = 256 (the LV / OU encoder width) and K = 128 (the width of the reference-generated parity fixtures)
+static int launch_qknorm(const LinParams &p, hipStream_t s) {
+    return p.K == 128 ? launch_rows<128, EPI_QKNORM>(p, s) : launch_rows<256, EPI_QKNORM>(p, s);
+}
 
 static bool deep_enabled() {
     static int v = -1;
@@ -887,8 +889,8 @@ extern "C" int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w
                                        void *gate, int64_t ldg, int gate_sigmoid, float *rinv, void *vdiff, void *stream) {
     VSDE_CHECK_ARG(x && w && q && k && v && cosT && sinT && wq && wk && M > 0 && heads > 0 && tokens > 0, VSDE_E_BADARG,
                    "bad linear_qknorm arguments");
-    VSDE_CHECK_ARG(K == 256 && gate_width % 64 == 0 && gate_width >= 0 && (gate_width == 0 || (gate && ldg >= gate_width && ldg % 8 == 0)),
-                   VSDE_E_BADARG, "linear_qknorm is built for K = 256, head_dim 64 and a gate block that is a multiple of 64 wide");
+    VSDE_CHECK_ARG((K == 256 || K == 128) && gate_width % 64 == 0 && gate_width >= 0 && (gate_width == 0 || (gate && ldg >= gate_width && ldg % 8 == 0)),
+                   VSDE_E_BADARG, "linear_qknorm is built for K in {128, 256}, head_dim 64 and a gate block that is a multiple of 64 wide");
     VSDE_CHECK_ARG((!v0) == (!lam), VSDE_E_BADARG, "residual values and their mixing weight go together");
     VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)q % 16) == 0 &&
                    ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)cosT % 16) == 0 && ((uintptr_t)sinT % 16) == 0,

@@ -337,7 +337,7 @@ def projection_split_nograd_usable(x: Tensor, pack: "PackedWeight", heads: int, 
     """The no-grad form of [qkv | gate] projection + attention_projection_split as ONE kernel (GEMM with the QK-norm / RoPE /
     value-mix epilogue): K = 256, head_dim 64, a gate block that is a multiple of 64 wide, fp32 norm weights and tables."""
     rows = x.numel() // x.shape[-1]
-    return (OWN_GEMM and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and d == 64
+    return (OWN_GEMM and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] in (128, 256) and d == 64
             and pack.weight.shape[0] >= 3 * heads * 64 and (pack.weight.shape[0] - 3 * heads * 64) % 64 == 0 and rows > 0
             and wq.dtype == torch.float32 and cos.dtype == torch.float32 and cos.shape[-1] == 32)
 
@@ -814,11 +814,11 @@ class _AttentionCore(torch.autograd.Function):
 
 
 def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, wk: Tensor, cos: Tensor) -> bool:
-    """Training-step form of the attention block's core (see ``_AttentionCore``): K = 256, head_dim 64, a 64-wide gate block,
+    """Training-step form of the attention block's core (see ``_AttentionCore``): K in (128, 256), head_dim 64, a 64-wide gate block,
     a sequence the LDS-resident attention kernels take, fp32 non-zero norm weights and fp32 rotary tables."""
     rows = x.numel() // x.shape[-1]
     return (ENABLED and OWN_GEMM and ATTN_FUSED_TRAIN and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
-            and x.ndim == 3 and x.shape[-1] == 256 and d == 64 and pack.weight.shape[0] == 3 * heads * 64 + 64 and rows >= 4096
+            and x.ndim == 3 and x.shape[-1] in (128, 256) and d == 64 and pack.weight.shape[0] == 3 * heads * 64 + 64 and rows >= 4096
             and wq.dtype == torch.float32 and wk.dtype == torch.float32 and cos.dtype == torch.float32 and cos.shape[-1] == 32
             and _hip.attention_fused_supported(x.shape[1], d) and _all_nonzero(wq) and _all_nonzero(wk))
 
