@@ -805,12 +805,11 @@ class _AttentionCore(torch.autograd.Function):
         if dlam is not None:
             dlam = dlam.to(lam_dtype).reshape(())
         wb = pack.weight
-        if own_gemm(M, wb.shape[1], wb.shape[0]):
-            dx = _hip.linear_bf16(dy, pack.transposed(), None)
-        else:
-            dx = dy @ wb
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (_hip.linear_bf16(dy, pack.transposed(), None) if own_gemm(M, wb.shape[1], wb.shape[0]) else dy @ wb).view(B, N, K)
         dW, db = _hip.linear_wgrad(dy, x2.contiguous(), pack.bias is not None)
-        return (dx.view(B, N, K), None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db))
+        return (dx, None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db))
 
 
 def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, wk: Tensor, cos: Tensor) -> bool:
