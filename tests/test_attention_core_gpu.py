@@ -65,7 +65,7 @@ def _run(att, x, rot, v0, go, gv, mode):
 
 
 @pytest.mark.parametrize("residual_v,value_grad", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3)])
+@pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3), (10, 430, None)])   # 430: two-round waves without spare LDS (direct epilogues)
 def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
     from viforsdes_amd.primitives import fused
     from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis

@@ -290,6 +290,7 @@ struct AttnBwdParams {
     int N, H, ntile;                       // ntile = ceil(N / 32)
     float scale, scale_log2e;
     QkBwd f;                               // FUSED kernels only
+    int park_off;                          // FUSED dk/dv: byte offset of the LDS area where first-round tiles wait (0 = no room: direct epilogue)
 };
 
 __device__ __forceinline__ f32x16 tile_product(const uint16_t *arow, const bf16x8 (&bfrag)[4]) {
@@ -728,6 +729,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     const float c2 = p.scale_log2e;
     f32x16 dk0, dk1, dv0, dv1;
     int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
+    int parked = -1; // FUSED: the wave's first round when a second one follows and spare LDS can hold its tiles
     for (int kblk = wave; kblk < p.ntile; kblk += AT_BT / 64) {
         if (kblk != wave) request(kblk);
         const int key = kblk * 32 + fr;
@@ -764,6 +766,16 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
             if (kblk + AT_BT / 64 >= p.ntile && !(p.f.dbg & 8)) { last = kblk; continue; }
+            if (p.park_off != 0 && kblk < AT_BT / 64 && !(p.f.dbg & 8)) {
+                // a wave with one more round to go (the 13th block at N = 401): its epilogue would sit between its two rounds,
+                // i.e. on the workgroup's critical path with nothing to hide its loads.  The tile waits in spare LDS instead
+                // (already in the staged row layout) and is finished after the barrier below.
+                float *park = (float *)((char *)asmem + p.park_off) + wave * (2 * AT_ESLICE);
+                stage_acc_tile(park, dv0, dv1, 1.0f, lane);
+                stage_acc_tile(park + AT_ESLICE, dk0, dk1, p.scale, lane);
+                parked = kblk;
+                continue;
+            }
             const int64_t m = (int64_t)b * N + key;
             float dl = 0.f;
             if (p.f.dbg & 2) { if (kok) store_transposed(p.f.dy + m * p.f.ldy + (2 * p.H + hh) * 64, h2, dv0, dv1, 1.0f); }
@@ -801,6 +813,18 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
             stage_acc_tile(slice, dk0, dk1, p.scale, lane);
             wave_lds_fence();
             if (!(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane);
+        }
+        if (parked >= 0) {   // wave-uniform; the parked tiles were written by this wave: in-order LDS, no barrier needed
+            const float *park = (const float *)((char *)asmem + p.park_off) + wave * (2 * AT_ESLICE);
+            value_rows_request(p.f, vin, m0, parked * 32, N, hh, p.H, lane);
+            norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, parked * 32, N, hh, p.H, lane);
+            wave_lds_fence();
+            float dl = staged_value_bwd(p.f, park, vin, m0, parked * 32, N, hh, p.H, lane);
+            if (p.f.dlam_partial != nullptr) {
+                dl = wave_sum(dl);
+                if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + parked] = dl;
+            }
+            staged_norm_rope_bwd<1>(p.f, park + AT_ESLICE, kin, m0, parked * 32, N, hh, p.H, lane);
         }
     }
 }
@@ -965,6 +989,11 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
     const size_t stage = (size_t)(AT_BT / 64) * AT_ESLICE * sizeof(float);   // the waves' epilogue slices reuse the operand space
     size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
     lds_dq = lds_dq > stage ? lds_dq : stage; lds_dkv = lds_dkv > stage ? lds_dkv : stage;
+    {   // spare LDS past the operands / staging slices for the first-round tiles of the waves that run two rounds (N = 401: one)
+        const int waves = AT_BT / 64, two_round = p.ntile > waves ? p.ntile - waves : 0;
+        const size_t park = (size_t)two_round * 2 * AT_ESLICE * sizeof(float);
+        if (two_round > 0 && p.ntile <= 2 * waves && lds_dkv + park <= 160 * 1024) { p.park_off = (int)lds_dkv; lds_dkv += park; }
+    }
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
