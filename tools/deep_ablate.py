@@ -14,7 +14,7 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 out = []
-for N, K in ((256, 768), (256, 1536)):
+for N, K in ((256, 704), (256, 768), (256, 1408)):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16); w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
     out.append(f"K={K}: {timeit(lambda: _hip.linear_bf16(x, w, None)):.1f} us")
 print("VSDE_LIN_DEBUG=" + os.environ.get("VSDE_LIN_DEBUG", "0"), " | ".join(out))

@@ -618,8 +618,17 @@ __global__ void __launch_bounds__(C2_THREADS, 2) lin_cols_kernel(LinParams p) {
 //   * waves are laid out 4 (rows) x 2 (columns): a wave owns 64 rows x 128 columns = 2 x 4 accumulator blocks, 6 fragment reads
 //     per 8 MFMAs; products are swapped (D = W_tile x^T) like in the rows kernel, so the epilogue (bias, bf16, 128-byte row
 //     segments through the wave's staging buffer) is shared with it.
-constexpr int DP_THREADS = 512, DP_BK = 32, DP_STAGES = 4, DP_STAGE_BYTES = 2 * 256 * DP_BK * 2, DP_SLD = 72;
+constexpr int DP_THREADS = 512, DP_BK = 64, DP_ASTAGES = 3, DP_WSTAGES = 2, DP_HALF = 256 * DP_BK * 2, DP_SLD = 72;   // 32 KB per operand and chunk
+constexpr int DP_LDS_BYTES = (DP_ASTAGES + DP_WSTAGES) * DP_HALF;   // 160 KB
 
+// Second version (round 3): 64-deep K chunks.  With 32-deep chunks every 128-byte line of both operands was requested as two
+// 64-byte halves one chunk apart (activation stream 3.6 TB/s, weight chunks out of L2 at 5.8 TB/s: profiles/r03_deep_gemm_ablation.txt).
+// A chunk is now [256 rows] x 128 bytes = 32 KB per operand; a DMA instruction fills 8 full rows (8 lanes x 16 bytes each); the
+// eight 16-byte chunks of a row are stored XOR-swizzled by (row >> 1) & 7 (on the source address) so that a 32-row ds_read_b128
+// fragment touches every bank once; the four k-steps of a chunk are software-pipelined inside a wave (fragments of k-step s + 1
+// are requested before the eight MFMAs of k-step s, hand-counted lgkmcnt).  The two operand streams have their own rings: the
+// activations (HBM: latency-bound with one chunk in flight, 3.4 TB/s) THREE stages = two chunks in flight, loaded by waves 0..3;
+// the weight chunks (L2 hits) two stages, loaded by waves 4..7 -- 160 KB of LDS, each wave counts only its own stream.
 __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char dlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -628,39 +637,41 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
     const int64_t range1 = range0 + rows_per_wg < p.M ? range0 + rows_per_wg : p.M;
     if (range0 >= p.M) return;
     const int nk = p.K / DP_BK, ncol = p.N / 256;
-    // ---- this lane's part of the DMA pattern: instruction q of wave w fills LDS bytes [(4 w + q) 1024, + 1024) of a stage; waves
-    // 0..3 the activation half (rows 16 (4 w + q) + lane / 4), waves 4..7 the weight half; chunk c of a row sits at c ^ ((row >> 2) & 3)
-    const int cswz = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;   // element offset of the 16-byte chunk this lane fetches
-    const int lrow = lane >> 2;
-    // ---- fragment addresses (bytes inside a stage): row block base + r * 64 + ((h + 2 ks) ^ swz) * 16
-    const int swz = (r >> 2) & 3;
-    const int fo0 = r * 64 + ((h ^ swz) << 4), fo1 = r * 64 + (((h + 2) ^ swz) << 4);
-    const int a_base = (wm * 64) * 64, w_base = 256 * 64 + (wn * 128) * 64;
-    uint16_t *stage = (uint16_t *)dlds + (DP_STAGES * DP_STAGE_BYTES) / 2 - 0;   // epilogue staging: placed BEHIND the stages
-    (void)stage;
+    // ---- this lane's part of the DMA pattern: instruction q of wave w fills LDS bytes [(8 w + q) 1024, + 1024) of a stage = rows
+    // 8 (8 (w & 3) + q) + lane / 8 of the activation half (waves 0..3) or the weight half (waves 4..7); LDS chunk slot lane % 8 of
+    // row R holds the row's logical chunk (lane % 8) ^ ((R >> 1) & 7), and (R >> 1) & 7 = ((lane >> 4) + 4 (q & 1)) & 7
+    const int cs0 = ((lane & 7) ^ ((lane >> 4) & 7)) * 8, cs1 = ((lane & 7) ^ (((lane >> 4) + 4) & 7)) * 8;   // element offsets, q even / odd
+    const int lrow = lane >> 3;
+    // ---- fragment addresses (bytes inside a stage): row block base + r * 128 + ((2 ks + h) ^ swz) * 16
+    const int swz = (r >> 1) & 7;
+    int fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = r * 128 + (((2 * ks + h) ^ swz) << 4);
+    const int a_base = (wm * 64) * 128, w_base = DP_ASTAGES * DP_HALF + (wn * 128) * 128;
 
     for (int64_t trow = range0; trow < range1; trow += 256) {
         const bool active = trow + wm * 64 < range1;     // wave-uniform: rows of this wave inside the range
         const int64_t bound = range1;                    // rows >= bound belong to the next workgroup (or do not exist)
         for (int ct = 0; ct < ncol; ++ct) {
-            // source pointers of this lane's four DMA instructions (chunk 0 of K)
-            const uint16_t *src[4];
+            // source pointers of this lane's eight DMA instructions (chunk 0 of K)
+            const uint16_t *src[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gi = (wave & 3) * 4 + q;
+            for (int q = 0; q < 8; ++q) {
+                const int gi = (wave & 3) * 8 + q, cs = (q & 1) ? cs1 : cs0;
                 if (wave < 4) {
-                    int64_t m = trow + gi * 16 + lrow;
+                    int64_t m = trow + gi * 8 + lrow;
                     m = m < p.M ? m : p.M - 1;            // rows past the end repeat the last one (never stored)
-                    src[q] = p.A + m * p.lda + cswz;
+                    src[q] = p.A + m * p.lda + cs;
                 } else {
-                    src[q] = p.W + (int64_t)(ct * 256 + gi * 16 + lrow) * p.K + cswz;
+                    src[q] = p.W + (int64_t)(ct * 256 + gi * 8 + lrow) * p.K + cs;
                 }
             }
-            auto issue = [&](int kt) {
-                char *dst = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES + wave * 4096;
+            auto issue = [&](int kt) {   // this wave's eight rows-of-8 of chunk kt of ITS operand
+                char *dst = wave < 4 ? dlds + (kt % DP_ASTAGES) * DP_HALF + wave * 8192
+                                     : dlds + DP_ASTAGES * DP_HALF + (kt % DP_WSTAGES) * DP_HALF + (wave - 4) * 8192;
                 if (p.dbg && kt > 0 && (((p.dbg == 2 || p.dbg == 7) && wave < 4) || ((p.dbg == 3 || p.dbg == 6) && wave >= 4) || p.dbg == 4)) return;   // ablation only
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 8; ++q)
                     __builtin_amdgcn_global_load_lds((const void *)(src[q] + kt * DP_BK), (__attribute__((address_space(3))) void *)(dst + q * 1024),
                                                      16, 0, 0);
             };
@@ -671,50 +682,58 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[rb][nb][e] = 0.f;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's output stores
-#pragma unroll
-            for (int q = 0; q < DP_STAGES - 1; ++q)
-                if (q < nk) issue(q);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's output stores (stores and loads are not ordered against each other)
+            issue(0);
+            if (wave < 4 && nk > 1) issue(1);
             for (int kt = 0; kt < nk; ++kt) {
-                // chunk kt has landed once at most the younger chunks' DMA instructions (4 each) are still in flight
-                const int younger = nk - 1 - kt < DP_STAGES - 2 ? nk - 1 - kt : DP_STAGES - 2;
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                // this wave's part of chunk kt has landed once at most its younger chunk's eight DMA instructions are in flight
+                if (wave < 4 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_barrier" ::: "memory");    // chunk kt is in LDS for everyone; everyone is done with chunk kt - 1
-                if (kt + DP_STAGES - 1 < nk) issue(kt + DP_STAGES - 1);
+                asm volatile("s_barrier" ::: "memory");            // chunk kt is in LDS for everyone; everyone is done with chunk kt - 1
+                if (wave < 4) { if (kt + 2 < nk) issue(kt + 2); }  // into the stage chunk kt - 1 occupied
+                else if (kt + 1 < nk) issue(kt + 1);
                 if (active && p.dbg < 5) {
-                    const char *sb = dlds + (kt % DP_STAGES) * DP_STAGE_BYTES;
-                    bf16x8 fa[2][2], fw[4][2];
-                    // the fragments of k-step 0 first: the second k-step's reads land behind the first k-step's MFMAs.  The reads are
-                    // inline asm with hand-counted waits: with scalar loads in flight hipcc only ever emits lgkmcnt(0) here
-                    const uint32_t sa = (uint32_t)(uintptr_t)(sb + a_base), sw = (uint32_t)(uintptr_t)(sb + w_base);
+                    const uint32_t sa = (uint32_t)(uintptr_t)(dlds + (kt % DP_ASTAGES) * DP_HALF + a_base);
+                    const uint32_t sw = (uint32_t)(uintptr_t)(dlds + (kt % DP_WSTAGES) * DP_HALF + w_base);
+                    bf16x8 fa[2][2], fw[2][4];   // [k-step parity][block]
+                    // inline asm with hand-counted waits: with DMA / scalar loads in flight hipcc only ever emits lgkmcnt(0) here
 #define VSDE_FRAG(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
-                    {
-                        const uint32_t a0 = sa + fo0, w0 = sw + fo0, a1 = sa + fo1, w1 = sw + fo1;
-                        VSDE_FRAG(fa[0][0], a0, 0); VSDE_FRAG(fw[0][0], w0, 0); VSDE_FRAG(fw[1][0], w0, 2048); VSDE_FRAG(fa[1][0], a0, 2048);
-                        VSDE_FRAG(fw[2][0], w0, 4096); VSDE_FRAG(fw[3][0], w0, 6144);
-                        VSDE_FRAG(fa[0][1], a1, 0); VSDE_FRAG(fw[0][1], w1, 0); VSDE_FRAG(fw[1][1], w1, 2048); VSDE_FRAG(fa[1][1], a1, 2048);
-                        VSDE_FRAG(fw[2][1], w1, 4096); VSDE_FRAG(fw[3][1], w1, 6144);
-                    }
-#undef VSDE_FRAG
+#define VSDE_FRAGS(par_, ks_)                                                                                  \
+                    do {                                                                                       \
+                        const uint32_t a_ = sa + fo[ks_], w_ = sw + fo[ks_];                                   \
+                        VSDE_FRAG(fa[par_][0], a_, 0); VSDE_FRAG(fw[par_][0], w_, 0); VSDE_FRAG(fw[par_][1], w_, 4096);   \
+                        VSDE_FRAG(fa[par_][1], a_, 4096); VSDE_FRAG(fw[par_][2], w_, 8192); VSDE_FRAG(fw[par_][3], w_, 12288); \
+                    } while (0)
+#define VSDE_MFMAS(par_)                                                                                       \
+                    do {                                                                                       \
+                        _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                       \
+                            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                   \
+                                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[par_][nb], fa[par_][rb], acc[rb][nb], 0, 0, 0); \
+                    } while (0)
+                    VSDE_FRAGS(0, 0);
+                    VSDE_FRAGS(1, 1);
                     __builtin_amdgcn_s_setprio(1);
                     asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
-                            acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb][0], fa[rb][0], acc[rb][nb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);   // the first k-step's MFMAs stay ABOVE the wait for the second k-step's fragments
+                    VSDE_MFMAS(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    VSDE_FRAGS(0, 2);                                  // overwrites the k-step 0 fragments: their MFMAs have issued (and read them)
+                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // k-step 1 has landed
+                    __builtin_amdgcn_sched_barrier(0);
+                    VSDE_MFMAS(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    VSDE_FRAGS(1, 3);
+                    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    VSDE_MFMAS(0);
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
-                            acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb][1], fa[rb][1], acc[rb][nb], 0, 0, 0);
+                    VSDE_MFMAS(1);
                     __builtin_amdgcn_s_setprio(0);
+#undef VSDE_MFMAS
+#undef VSDE_FRAGS
+#undef VSDE_FRAG
                 }
             }
             // ---- epilogue: stage buffers are free once everyone has left the K loop
@@ -808,7 +827,7 @@ static int launch_deep(const LinParams &p, hipStream_t s) {
         VSDE_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const size_t lds = (size_t)DP_STAGES * DP_STAGE_BYTES;
+    const size_t lds = (size_t)DP_LDS_BYTES;
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t rows = (p.M + cus - 1) / cus;
     rows = (rows + 31) / 32 * 32;                      // contiguous row range per workgroup, whole 32-row blocks
@@ -835,7 +854,7 @@ static bool deep_enabled() {
 // 1 = rows kernel, 2 = cols kernel, 3 = deep kernel (persistent, both operands through LDS), 0 = shape not covered
 static int lin_variant(int64_t M, int N, int K, int epilogue) {
     // deep reductions with a narrow output at sizes that fill the chip (>= 128 rows per CU): the persistent kernel
-    if (epilogue == EPI_PLAIN && deep_enabled() && K >= 512 && K % 32 == 0 && N % 256 == 0 && N <= K && M >= 32768) return 3;
+    if (epilogue == EPI_PLAIN && deep_enabled() && K >= 512 && K % 64 == 0 && N % 256 == 0 && N <= K && M >= 32768) return 3;
     const bool rows_ok = (K == 128 || K == 256 || K == 512) && N % 64 == 0;   // K = 512: two k-halves per output tile
     const bool cols_ok = K % 64 == 0 && N % 128 == 0 && epilogue == EPI_PLAIN;
     if (epilogue != EPI_PLAIN) return rows_ok ? 1 : 0;
