@@ -54,4 +54,4 @@ class ObservationContextEncoder(nn.Module):
         if n > freqs.shape[0]:
             freqs = precompute_freq_cis(self.hidden_dim // self.num_heads, end=n, device=tokens.device)
         cond = self.sde_param_proj(sde_parameters)  # [B, cond], broadcast over tokens inside the blocks
-        return self.sit(tokens.unsqueeze(0).expand(B, -1, -1), cond=cond, rotary=RotarySpec.from_freqs(freqs[:n]))
+        return self.sit(tokens.unsqueeze(0).expand(B, -1, -1), cond=cond, rotary=RotarySpec.from_freqs(freqs[:n]), row_tokens=tokens)

@@ -158,10 +158,13 @@ class SiT(nn.Module):
                           else fused.gated_residual_m(x1, mlp_out, mods, (k, GM)))
         return tokens
 
-    def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None) -> Tensor:
+    def forward(self, x: Tensor, *, cond: Tensor, rotary: Optional[RotarySpec] = None, row_tokens: Optional[Tensor] = None) -> Tensor:
+        """``row_tokens`` (additive): the [N, in_dim] sequence that ``x`` broadcasts over the batch, when the caller has it --
+        ``x[0]`` of the expanded view costs a full-size zero fill + a batch sum in the backward (SelectBackward / ExpandBackward)."""
         if x.ndim == 3 and x.stride(0) == 0 and x.shape[0] > 1:
             # the same token sequence for every batch row (the observation grid): project it once, then broadcast
-            tokens = self.input_proj(x[0]).unsqueeze(0).expand(x.shape[0], -1, -1)
+            row = row_tokens if (row_tokens is not None and row_tokens.shape == x.shape[1:]) else x[0]
+            tokens = self.input_proj(row).unsqueeze(0).expand(x.shape[0], -1, -1)
         else:
             tokens = self.input_proj(x)
         if all(block.fusable(tokens, cond, rotary) for block in self.blocks):
