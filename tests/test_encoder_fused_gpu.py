@@ -231,6 +231,29 @@ def test_attention_kernel_vs_fp32_softmax(B, N, H):
         assert np.abs(a - r).max() <= 2e-2 * np.abs(r).max() + 1e-2
 
 
+@pytest.mark.parametrize("B,N,H", [(150, 401, 4), (300, 37, 2), (131, 416, 4), (140, 385, 4), (600, 101, 1)])
+def test_persistent_attention_forward_many_pairs(B, N, H):
+    """>= 2 (batch, head) pairs per CU and at most 13 query blocks: the forward runs as persistent workgroups that walk the pairs
+    and request the next pair's K / V behind the current pair's last query block (attn_fwd_kernel<true>).  Against the
+    one-workgroup-per-pair kernel (VSDE_ATTN_PERSIST=0 in a child process would be another library load: compared with the fp32
+    softmax instead, per pair, plus the gated store)."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(B + N)
+    q, k, v = (torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
+    o, lse = _hip.attention_fwd(q, k, v, 0.125)
+    gate = torch.sigmoid(torch.randn(B * N, 64, generator=g)).to(DEV, torch.bfloat16)
+    og, lse_g = _hip.attention_fwd_gated(q, k, v, gate, 0.125)
+    assert torch.equal(lse, lse_g)
+    for b0 in range(0, B, 50):   # fp32 reference in slices (memory)
+        qf, kf, vf = (t[b0:b0 + 50].float().transpose(1, 2) for t in (q, k, v))
+        s = (qf @ kf.transpose(-1, -2)) * 0.125
+        ref = (torch.softmax(s, -1) @ vf).transpose(1, 2)
+        assert rel_err(o[b0:b0 + 50].float().cpu().numpy(), ref.cpu().numpy()) < 1e-2, b0
+        assert torch.allclose(lse[b0:b0 + 50], torch.logsumexp(s, -1), atol=1e-4, rtol=1e-5), b0
+        refg = ref * gate[b0 * N:(b0 + 50) * N].float().view(-1, N, 1, 64)
+        assert rel_err(og[b0:b0 + 50].float().cpu().numpy(), refg.cpu().numpy()) < 1e-2, b0
+
+
 def test_attention_kernel_large_scores_take_the_exact_path():
     """|q||k| scale far above the Cauchy-Schwarz-shift limit: the kernel must fall back to true row maxima (no NaN/underflow)."""
     from viforsdes_amd import _hip

@@ -42,6 +42,7 @@ struct AttnParams {
     float scale, scale_log2e;
     const uint16_t *gate;       // optional output gate [B*N][ldg] (64 factors per token, shared by the heads, = rnd(sigmoid(logit))): o *= gate
     int64_t ldg;
+    int64_t pairs;              // B * H (the persistent kernel's loop bound)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -53,39 +54,45 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 __device__ __forceinline__ float bfl(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfh(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
-    uint16_t *Ks = asmem;                      // [npad][AT_KLD]
-    uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H;
-    const int N = p.N, npad = p.npad, vld = p.vld;
-    const int64_t ts = (int64_t)p.H * AT_D;    // token stride in elements
-    const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
-    const uint16_t *qb = p.q + base, *kb = p.k + base, *vb = p.v + base;
-    // ---- stage K [key][d] and V^T [d][key]: every global load of the workgroup is issued before the first use -----
-    constexpr int NT = 768, NW = NT / 64;
-    constexpr int KIT = (AT_MAXN * 8 + NT - 1) / NT, VIT = (AT_MAXN + NT - 1) / NT;
-    uint4 kreg[KIT], vreg[VIT][8];
+// the staging loads of one (batch, head) pair into registers: K rows as 16-byte chunks (8 adjacent lanes = one 128-byte row), V
+// as 8 x 8 blocks (8 keys x 16 bytes per thread) for the in-register transpose; staging thread pt of PT
+template <int KIT, int VIT>
+__device__ __forceinline__ void fwd_request(uint4 (&kreg)[KIT], uint4 (&vreg)[VIT][8], const AttnParams &p, int64_t head, int pt, int PT,
+                                            bool stager, int N, int npad, int64_t ts) {
+    const int64_t hb = head / p.H, base_ = (hb * N * p.H + (head - hb * p.H)) * AT_D;
+    const uint16_t *kb = p.k + base_, *vb = p.v + base_;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-        const int i = tid + it * NT, n = i >> 3, c = i & 7;
-        kreg[it] = (i < npad * 8 && n < N) ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+        const int i = pt + it * PT, n = i >> 3, c = i & 7;
+        kreg[it] = (stager && i < npad * 8 && n < N) ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {  // (npad/8 key blocks) x (8 d-chunks); lanes c = 0..7 read one full 128-byte row
-        const int i = tid + it * NT, kblk = i >> 3, c = i & 7;
+        const int i = pt + it * PT, kblk = i >> 3, c = i & 7;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int n = kblk * 8 + j;
-            vreg[it][j] = (i < npad && n < N) ? *(const uint4 *)(vb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+            vreg[it][j] = (stager && i < npad && n < N) ? *(const uint4 *)(vb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
         }
     }
+}
+
+// PERSIST (N <= 416, i.e. at most one wave with a second query block): the grid is one workgroup per CU and a workgroup walks
+// the (batch, head) pairs blockIdx.x, blockIdx.x + gridDim.x, ...  A wave that has finished its last query block of the current
+// pair requests the K / V rows of the NEXT pair into its staging registers right away (they are free: the block's accumulators have
+// been stored) and parks at the barrier; the wave that owns the 13th block is still computing then, so the HBM latency and part of
+// the transfer of the next pair's operands run behind it instead of in front of everybody.  Only the waves without a second
+// block stage (704 of 768 threads at N = 401).
+// ... and their way into LDS: K rows as they are ([key][AT_KLD]), V through the in-register 8 x 8 transpose as V^T [d][vld]; the
+// wave's maximum squared key norm goes to kred[wave] (the softmax shift needs max_j |k_j|)
+template <int KIT, int VIT>
+__device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vreg)[VIT][8], uint16_t *Ks, uint16_t *Vt, float *kred, int pt,
+                                           int PT, bool stager, int npad, int vld, int lane, int wave) {
     float kss_max = 0.f;  // max_j |k_j|^2 (8 adjacent lanes hold one key row)
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
-        const int i = tid + it * NT, n = i >> 3, c = i & 7;
-        if (i < npad * 8) *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
+        const int i = pt + it * PT, n = i >> 3, c = i & 7;
+        if (stager && i < npad * 8) *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
         const uint32_t w[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
         float ss = 0.f;
 #pragma unroll
@@ -98,14 +105,13 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kss_max = fmaxf(kss_max, __shfl_xor(kss_max, off, 64));
-    __shared__ float kred[NW];
     if (lane == 0) kred[wave] = kss_max;
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
-        const int i = tid + it * NT, kblk = i >> 3, c = i & 7;
+        const int i = pt + it * PT, kblk = i >> 3, c = i & 7;
         uint4 ct[8];
         transpose8x8(vreg[it], ct);
-        if (i < npad) {
+        if (stager && i < npad) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // row d = c*8+j holds keys kblk*8 .. +7; rows are only 8-byte aligned (vld = 4 mod 8)
                 uint2 *dst = (uint2 *)(Vt + (c * 8 + j) * vld + kblk * 8);
@@ -114,12 +120,52 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
             }
         }
     }
-    __syncthreads();
+}
+
+template <bool PERSIST>
+__global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
+    uint16_t *Ks = asmem;                      // [npad][AT_KLD]
+    uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, npad = p.npad, vld = p.vld;
+    const int64_t ts = (int64_t)p.H * AT_D;    // token stride in elements
+    constexpr int NT = 768, NW = NT / 64;
+    const int two_round = PERSIST ? ((npad >> 5) > NW ? (npad >> 5) - NW : 0) : 0;   // waves 0 .. two_round - 1 own two query blocks
+    int pt = tid - 64 * two_round;                                                    // staging thread index ...
+    const int PT = NT - 64 * two_round;                                               // ... and count
+    const bool stager = pt >= 0;
+    // ---- staging of K [key][d] and V^T [d][key]: every global load is issued before the first use; the staging registers live
+    // only inside VSDE_FWD_STAGE (a loop-carried register set is spilled across the tile loop by hipcc)
+    constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (AT_MAXN * 8 + NT - 1) / NT, VIT = PERSIST ? 1 : (AT_MAXN + NT - 1) / NT;
+    __shared__ float kred[NW];
+#define VSDE_FWD_STAGE(head_, first_)                                                                          \
+    do {                                                                                                       \
+        uint4 kreg[KIT], vreg[VIT][8];                                                                         \
+        asm volatile("" : "+v"(pt));   /* staging addresses are recomputed per pair, not kept across the tile loop */ \
+        fwd_request<KIT, VIT>(kreg, vreg, p, (head_), pt, PT, stager, N, npad, ts);                            \
+        if (!(first_)) __syncthreads();   /* everyone is done with the previous pair's K / V */               \
+        fwd_commit<KIT, VIT>(kreg, vreg, Ks, Vt, kred, pt, PT, stager, npad, vld, lane, wave);                 \
+        __syncthreads();                                                                                       \
+    } while (0)
+    const int64_t nheads = p.pairs;              // total (batch, head) pairs
+    int64_t head = blockIdx.x;
+    VSDE_FWD_STAGE(head, true);
+  while (true) {
+    const int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
+    const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
+    const uint16_t *qb = p.q + base;
+    float kss_max = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) kss_max = fmaxf(kss_max, kred[w]);
     const float kmax = sqrtf(kss_max);
+    const int64_t next = head + gridDim.x;
+    const bool has_next = PERSIST && next < nheads;
 
-    const int fr = lane & 31, h2 = lane >> 5;
+    int fr = lane & 31, h2 = lane >> 5;
+    // PERSIST: every LDS address of the tile loop below is invariant across the pair loop; hoisted out of it (LICM) they fill the
+    // register file (194 spilled VGPRs).  An opaque copy of the lane coordinates per pair keeps them where they are used.
+    if constexpr (PERSIST) asm volatile("" : "+v"(fr), "+v"(h2));
     const int nkt = npad >> 5, nqb = npad >> 5;
     const bool ragged = (N & 31) != 0;
     for (int qblk = wave; qblk < nqb; qblk += NW) {
@@ -248,6 +294,14 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
             if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = mx * p.scale + __logf(lsum);
         }
     }
+    if constexpr (!PERSIST) break;
+    if (!has_next) break;
+    // this wave is done with the current pair: its share of the next pair's K / V is requested NOW (a wave with a second block
+    // has pt < 0: no loads) and lands while the wave that owns the 13th block is still computing
+    VSDE_FWD_STAGE(next, false);
+    head = next;
+  }
+#undef VSDE_FWD_STAGE
 }
 
 // ===================================================================================== backward
@@ -883,6 +937,39 @@ static bool force_stream() {
     return f != 0;
 }
 
+// VSDE_ATTN_PERSIST=0: one workgroup per (batch, head) pair for every shape (A/B runs)
+static bool persist_enabled() {
+    static int f = -1;
+    if (f < 0) { const char *e = getenv("VSDE_ATTN_PERSIST"); f = e ? atoi(e) : 1; }
+    return f != 0;
+}
+static int attn_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// forward launch: persistent workgroups (one per CU, next pair's operands requested behind the 13th query block) when a pair
+// has at most 13 query blocks and there are at least two pairs per CU; one workgroup per pair otherwise
+static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipStream_t stream) {
+    const int cus = attn_cus();
+    AttnParams q = p;
+    q.pairs = pairs;
+    if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds, stream, q);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)pairs), dim3(768), lds, stream, q);
+    }
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int vsde_attention_max_tokens(void) { return AT_MAXN; }
 
 extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
@@ -898,10 +985,7 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     p.gate = nullptr; p.ldg = 0;
     const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(768), lds, (hipStream_t)stream, p);
-    VSDE_CHECK_HIP(hipGetLastError());
-    return 0;
+    return launch_attn_fwd(p, B * H, lds, (hipStream_t)stream);
 }
 
 extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse,
@@ -943,10 +1027,7 @@ extern "C" int vsde_attention_fwd_gated_bf16(const void *q, const void *k, const
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     p.gate = (const uint16_t *)gate; p.ldg = ldg;
     const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(768), lds, (hipStream_t)stream, p);
-    VSDE_CHECK_HIP(hipGetLastError());
-    return 0;
+    return launch_attn_fwd(p, B * H, lds, (hipStream_t)stream);
 }
 
 extern "C" int vsde_gate_bwd_delta(const void *dout, const void *og, const void *gate, int64_t ldg, void *dattn, void *dgate, int64_t ldd,
