@@ -1,8 +1,9 @@
 """Times the kernels of the attention block's training core at the LV bench dims (B=512, N=401, H=4, d=64), next to the
 separate-pass kernels they replace.  usage: python tools/attn_core_bench.py [B N]"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from viforsdes_amd import _hip
 
 B, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (512, 401)
