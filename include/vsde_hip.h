@@ -292,6 +292,23 @@ int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const voi
 int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int64_t ldgate, const void *w, const void *bias, void *y,
                            int64_t ldy, int64_t M, int N, int K, void *stream);
 
+/* ---- The optimizer step as two launches over all parameters -----------------------------------------------------------
+ * Replaces, per training step (inference/trainer.py:197-204, inference/exponential_moving_average.py:27-32):
+ * scaler.unscale_ (non-finite check + g *= 1/scale), clip_grad_norm_ (norms + g *= clip coefficient), the multi-tensor AdamW
+ * (torch.optim.AdamW: decoupled weight decay, bias corrections) and the EMA lerp -- with the same arithmetic.
+ * chunks: device array of n_chunks records of vsde_optim_chunk_bytes() = 64 bytes:
+ *   { float *p, *m, *v, *ema; int32 param, n; int64 goff; int32 group, 0; int64 0 }   (<= vsde_optim_chunk_elems() elements each)
+ * grads: device array of the step's gradient base pointers (one per parameter); scale: loss scale (device scalar) or NULL;
+ * partials [n_chunks] scratch; tstate [2] = (t_cur, t_next) float step counts, t_next is the persistent one;
+ * groups [n_groups][5] doubles = lr, beta1, beta2, eps, weight_decay; max_norm <= 0: no clipping; ema_weight = 1 - decay (< 0: no EMA);
+ * out [2] = global gradient norm (unscaled, before clipping), found_inf (0 / 1).  With a loss scale, a non-finite gradient
+ * skips the update (parameters, moments and step count unchanged, as GradScaler.step does; the EMA lerp still runs, as the
+ * reference's ema.update() does).  Deterministic. */
+int vsde_optim_chunk_bytes(void);
+int vsde_optim_chunk_elems(void);
+int vsde_optim_step(const void *chunks, int n_chunks, const void *grads, const float *scale, float *partials, float *tstate,
+                    const double *groups, double max_norm, double ema_weight, float *out, void *stream);
+
 /* ---- Refresh of the cached bf16 GEMM operands after an optimizer step -------------------------------------------------
  * The reference re-casts each nn.Linear weight to bf16 in every forward under autocast (primitives/attn.py:46-54,
  * primitives/mlp.py:41-54); this build keeps the bf16 operands (concatenated / padded / interleaved packs and their

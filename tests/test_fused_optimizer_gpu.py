@@ -1,0 +1,118 @@
+"""GPU: the two-launch optimizer step (csrc/vsde_optim.hip, inference/fused_optimizer.py) against the torch sequence it replaces
+(reference inference/trainer.py:197-204 + exponential_moving_average.py:27-32):
+
+    scaler.unscale_ -> clip_grad_norm_ -> scaler.step(AdamW fused, capturable) -> scaler.update -> EMA lerp
+
+on identical parameters / gradients over several steps, with and without a loss scale, with a step whose gradient holds an inf
+(both must skip it and halve the scale) and with a norm below and above the clipping threshold.  Tolerance: 2e-6 relative to the
+tensor's max (the arithmetic is the same operation sequence; the global norm is summed in a different order)."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        shapes = {"a": (5,), "b": (33, 7), "c": (4097,), "d": (3, 4101), "e": (256, 256), "theta": (3,), "frozen": (4,)}
+        for k, s in shapes.items():
+            self.register_parameter(k, nn.Parameter(torch.randn(*s, generator=g)))
+        self.frozen.requires_grad_(False)
+
+
+def _setup(scaled):
+    from torch.amp import GradScaler
+    from viforsdes_amd.inference.exponential_moving_average import ExponentialMovingAverage
+    model = _Toy().to(DEV)
+    groups = lambda m: [{"params": [p for n, p in m.named_parameters() if n != "theta"], "lr": 1e-3},
+                        {"params": [m.theta], "lr": 1e-2}]
+    opt = torch.optim.AdamW(groups(model), fused=True, capturable=True)
+    scaler = GradScaler("cuda", enabled=scaled, init_scale=1024.0, growth_interval=3)
+    return model, opt, scaler, ExponentialMovingAverage(model, decay=0.99)
+
+
+def _grads(model, step, scale, poison):
+    g = torch.Generator().manual_seed(100 + step)
+    mag = 10.0 if step % 2 else 0.01   # global norm above / below the threshold
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        p.grad = (torch.randn(p.shape, generator=g) * mag).to(DEV) * scale
+        if poison and n == "d":
+            p.grad[1, 17] = float("inf")
+
+
+@pytest.mark.parametrize("scaled", [True, False])
+def test_fused_step_matches_the_torch_sequence(scaled):
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    m_ref, o_ref, s_ref, e_ref = _setup(scaled)
+    m_own, o_own, s_own, e_own = _setup(scaled)
+    assert FusedOptimizerStep.usable(o_own)
+    fs = FusedOptimizerStep(o_own, e_own, s_own, max_norm=1.0)
+    for step in range(7):
+        poison = scaled and step == 3
+        for model, scaler in ((m_ref, s_ref), (m_own, s_own)):
+            if scaled:
+                scaler.scale(torch.zeros((), device=DEV))   # creates / keeps the scale tensor the way the trainer's backward does
+            _grads(model, step, float(scaler.get_scale()) if scaled else 1.0, poison)
+        # reference sequence
+        s_ref.unscale_(o_ref)
+        n_ref = nn.utils.clip_grad_norm_(m_ref.parameters(), 1.0)
+        s_ref.step(o_ref); s_ref.update(); e_ref.update()
+        # fused
+        n_own = fs.step()
+        assert n_own is not None
+        s_own.update(); e_own.update()
+        assert not e_own.fused_step_done
+        if not poison:
+            assert abs(float(n_own) - float(n_ref)) <= 2e-6 * float(n_ref), (step, float(n_own), float(n_ref))
+        else:
+            assert not torch.isfinite(n_own)
+        assert s_own.get_scale() == s_ref.get_scale(), step
+        for (name, p), q in zip(m_ref.named_parameters(), m_own.parameters()):
+            tol = 2e-6 * float(p.detach().abs().max())
+            assert float((p - q).abs().max()) <= tol, (step, name)
+            if p.requires_grad:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    a, b = o_ref.state[p][k], o_own.state[q][k]
+                    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30, (step, name, k)
+            assert float((e_ref.shadow[name] - e_own.shadow[name]).abs().max()) <= tol, (step, name)
+    # the step count is published to the per-parameter tensors torch keeps
+    sd_ref, sd_own = o_ref.state_dict(), o_own.state_dict()
+    for k in sd_ref["state"]:
+        assert float(sd_ref["state"][k]["step"]) == float(sd_own["state"][k]["step"]) == (6.0 if scaled else 7.0)
+
+
+def test_state_dict_round_trip_and_new_shadows():
+    """load_state_dict (new moment tensors) and a rebuilt EMA shadow set must be picked up; the step count survives both."""
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    model, opt, scaler, ema = _setup(False)
+    fs = FusedOptimizerStep(opt, ema, scaler, max_norm=1.0)
+    for step in range(3):
+        _grads(model, step, 1.0, False)
+        assert fs.step() is not None
+        ema.update()
+    snap = copy.deepcopy(opt.state_dict())
+    p_before = [p.detach().clone() for p in model.parameters()]
+    _grads(model, 3, 1.0, False)
+    fs.step(); ema.update()
+    p_after = [p.detach().clone() for p in model.parameters()]
+    with torch.no_grad():
+        for p, q in zip(model.parameters(), p_before):
+            p.copy_(q)
+    opt.load_state_dict(snap)          # new exp_avg / exp_avg_sq / step tensors
+    ema._init_shadow()                 # new shadow tensors
+    _grads(model, 3, 1.0, False)
+    fs.step(); ema.update()
+    for p, q in zip(model.parameters(), p_after):
+        assert torch.equal(p, q)       # the replayed step is bit-identical
+    assert float(opt.state_dict()["state"][0]["step"]) == 4.0
+    for (n, p), q0, q1 in zip(model.named_parameters(), p_before, p_after):
+        if p.requires_grad:   # fresh shadows = the parameters before the step, then one lerp with weight 1 - decay = 0.01
+            assert torch.allclose(ema.shadow[n], q0 + 0.01 * (q1 - q0), rtol=1e-5, atol=1e-7), n

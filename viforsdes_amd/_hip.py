@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16",
-    "vsde_pack_tile_bytes", "vsde_pack_refresh",
+    "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -395,6 +395,26 @@ def pack_refresh(table: torch.Tensor) -> None:
         raise ValueError("pack-refresh table must be a contiguous int64 [n_tiles, 8] tensor")
     with torch.cuda.device(dev):
         _call(lib.vsde_pack_refresh, _ptr(table), ctypes.c_int(table.shape[0]), _stream(dev))
+
+
+def optim_chunk_elems() -> int:
+    return int(load().vsde_optim_chunk_elems())
+
+
+def optim_step(table: torch.Tensor, grad_ptrs: torch.Tensor, scale: Optional[torch.Tensor], partials: torch.Tensor, tstate: torch.Tensor,
+               groups: torch.Tensor, max_norm: float, ema_weight: float, out: torch.Tensor) -> None:
+    """unscale + global-norm clip + AdamW + EMA of every parameter as two launches (csrc/vsde_optim.hip).  ``table``: int64
+    [n_chunks, 8] chunk records; ``grad_ptrs``: int64 [n_params] device pointers of this step's gradients; ``scale``: the loss
+    scale (fp32 device scalar) or None; ``groups``: float64 [n_groups, 5]; ``out``: fp32 [2] <- (gradient norm, found_inf)."""
+    lib = load()
+    dev = _require_hip(table, grad_ptrs, partials, tstate, groups, out)
+    if (table.dtype != torch.int64 or table.ndim != 2 or table.shape[1] * 8 != lib.vsde_optim_chunk_bytes() or not table.is_contiguous()
+            or grad_ptrs.dtype != torch.int64 or groups.dtype != torch.float64 or partials.numel() < table.shape[0]
+            or tstate.dtype != torch.float32 or out.dtype != torch.float32):
+        raise ValueError("bad optimizer-step buffers")
+    with torch.cuda.device(dev):
+        _call(lib.vsde_optim_step, _ptr(table), ctypes.c_int(table.shape[0]), _ptr(grad_ptrs), _ptr(scale), _ptr(partials), _ptr(tstate),
+              _ptr(groups), ctypes.c_double(max_norm), ctypes.c_double(ema_weight), _ptr(out), _stream(dev))
 
 
 def profile_enable(on: bool) -> None:

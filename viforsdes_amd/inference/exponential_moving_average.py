@@ -15,13 +15,19 @@ class ExponentialMovingAverage:
     def __init__(self, model: nn.Module, decay: float = DEFAULT_EMA_DECAY) -> None:
         self.model, self.decay = model, decay
         self.shadow: dict[str, Tensor] = {}
+        self.version = 0               # bumped whenever the shadow tensors are replaced (the fused optimizer step caches their addresses)
+        self.fused_step_done = False   # set by inference/fused_optimizer.py when its kernel already applied this step's update
         self._init_shadow()
 
     def _init_shadow(self) -> None:
         self.shadow = {name: p.detach().clone() for name, p in self.model.named_parameters()}
+        self.version += 1
 
     @torch.no_grad()
     def update(self) -> None:
+        if self.fused_step_done:       # the optimizer kernel updated parameters and shadow in one pass
+            self.fused_step_done = False
+            return
         names, params = zip(*self.model.named_parameters())
         torch._foreach_lerp_([self.shadow[n] for n in names], [p.detach() for p in params], 1.0 - self.decay)
 
@@ -45,3 +51,4 @@ class ExponentialMovingAverage:
 
     def load_state_dict(self, state: dict[str, Tensor]) -> None:
         self.shadow = {k.replace("encoder.sit._orig_mod.", "encoder.sit."): v.clone() for k, v in state.items()}
+        self.version += 1

@@ -26,6 +26,7 @@ from .data_parallel import all_reduce_mean_
 from .diffusion_path_sampler import sample_diffusion_paths
 from .evidence_lower_bound import compute_evidence_lower_bound
 from .exponential_moving_average import ExponentialMovingAverage
+from .fused_optimizer import FusedOptimizerStep
 from .state_space import StateSpace
 from .training_context import TrainingContext
 from .types import EvidenceLowerBoundResult
@@ -99,9 +100,18 @@ class VariationalInferenceTrainer:
     def _optimizer_step(self) -> Tensor:
         """unscale -> clip (global norm) -> AdamW -> scaler update -> refresh of the cached bf16 GEMM operands."""
         ctx, cfg = self.ctx, self.config
-        ctx.scaler.unscale_(ctx.optimizer)
-        grad_norm = nn.utils.clip_grad_norm_(ctx.model.parameters(), cfg.grad_clip_norm)
-        ctx.scaler.step(ctx.optimizer)
+        grad_norm = None
+        if ctx.device.type == "cuda":
+            # one pass for the global norm / non-finite check, one for unscale x clip + AdamW + EMA (inference/fused_optimizer.py)
+            fs = getattr(self, "_fused_opt", None)
+            if fs is None and FusedOptimizerStep.usable(ctx.optimizer):
+                fs = self._fused_opt = FusedOptimizerStep(ctx.optimizer, ctx.ema, ctx.scaler, cfg.grad_clip_norm)
+            if fs is not None:
+                grad_norm = fs.step()
+        if grad_norm is None:
+            ctx.scaler.unscale_(ctx.optimizer)
+            grad_norm = nn.utils.clip_grad_norm_(ctx.model.parameters(), cfg.grad_clip_norm)
+            ctx.scaler.step(ctx.optimizer)
         ctx.scaler.update()
         if ctx.device.type == "cuda":
             # bf16 GEMM operands of the encoder follow the updated parameters (forced: fused AdamW does not bump Tensor._version)
