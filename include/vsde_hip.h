@@ -292,6 +292,15 @@ int vsde_linear_qknorm_bf16(const void *x, int64_t ldx, const void *w, const voi
 int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int64_t ldgate, const void *w, const void *bias, void *y,
                            int64_t ldy, int64_t M, int N, int K, void *stream);
 
+/* Training step: input gradient of the attention output projection with the backward of the sigmoid output gate in its
+ * epilogue (primitives/attn.py:107-113; replaces vsde_linear_bf16 on the transposed weight followed by vsde_gate_bwd_delta):
+ * d = dy w_t^T is the gradient of the merged rows [M][heads*64] (w_t [heads*64][K] = the projection weight transposed; K in
+ * {128, 256}); with og (the merged gated rows) and the gate factors s [M][lds] it leaves as
+ *   dattn = d * s,   delta[b,h,n] = <d, og>,   dgate[m][0..64) = (1 - s) sum_h d og   (gradient of the gate LOGITS, row pitch ldd)
+ * -- d itself is never written.  Rows are (batch, token) pairs, m = b * tokens + n. */
+int vsde_linear_gate_bwd_bf16(const void *dy, int64_t ldy, const void *w_t, const void *og, const void *s, int64_t lds, void *dattn,
+                              void *dgate, int64_t ldd, float *delta, int64_t M, int K, int heads, int tokens, void *stream);
+
 /* ---- The optimizer step as two launches over all parameters -----------------------------------------------------------
  * Replaces, per training step (inference/trainer.py:197-204, inference/exponential_moving_average.py:27-32):
  * scaler.unscale_ (non-finite check + g *= 1/scale), clip_grad_norm_ (norms + g *= clip coefficient), the multi-tensor AdamW

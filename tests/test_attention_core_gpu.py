@@ -169,6 +169,33 @@ def test_gated_attention_store_and_gate_backward(B, N, H):
     assert rel_err(delta.cpu().numpy(), dl.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("B,N,H,K", [(3, 37, 4, 256), (2, 401, 4, 256), (70, 61, 2, 128), (1, 544, 2, 128)])
+def test_output_projection_gradient_with_the_gate_backward_epilogue(B, N, H, K):
+    """vsde_linear_gate_bwd_bf16 = vsde_linear_bf16 on the transposed weight (the projection's input gradient, rounded to bf16)
+    followed by vsde_gate_bwd_delta: same dattn / gate-logit gradient / delta (the fused form keeps the partial sums of a row in
+    fp32 across the heads: 1e-2 of the max covers the different rounding points)."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(B * N + K)
+    M, C = B * N, H * 64
+    dy = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(K, C, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)      # out_proj.weight [out = K, in = C]
+    og = torch.randn(B, N, H, 64, generator=g).to(DEV, torch.bfloat16)
+    wide = torch.sigmoid(torch.randn(M, 80, generator=g)).to(DEV, torch.bfloat16)
+    s = wide[:, 8:72]
+    buf1 = torch.zeros(M, 3 * C + 64, device=DEV, dtype=torch.bfloat16); buf2 = torch.zeros_like(buf1)
+    w_t = w.t().contiguous()                                                       # [C, K]
+    dattn, delta = _hip.linear_gate_bwd(dy, w_t, og, s, buf1[:, 3 * C:], N)
+    dmerged = _hip.linear_bf16(dy, w_t, None) if _hip.linear_supported(M, C, K) else (dy.float() @ w.float()).to(torch.bfloat16)
+    dattn2, delta2 = _hip.gate_bwd_delta(dmerged.view(B, N, H, 64), og, s, buf2[:, 3 * C:])
+    assert rel_err(dattn.float().cpu().numpy(), dattn2.float().cpu().numpy()) < 1e-2
+    assert rel_err(delta.cpu().numpy(), delta2.cpu().numpy()) < 1e-2
+    assert rel_err(buf1[:, 3 * C:].float().cpu().numpy(), buf2[:, 3 * C:].float().cpu().numpy()) < 1e-2
+    assert float(buf1[:, :3 * C].abs().max()) == 0.0
+    ref = (dy.float() @ w.float()).view(B, N, H, 64)                               # against the fp32 product as well
+    assert rel_err(dattn.float().cpu().numpy(), (ref * s.float().view(B, N, 1, 64)).cpu().numpy()) < 1e-2
+    assert rel_err(delta.cpu().numpy(), (ref * og.float()).sum(-1).permute(0, 2, 1).cpu().numpy()) < 1e-2
+
+
 def test_zero_norm_weight_takes_the_separate_passes():
     """The fused backward divides by the frozen RMS weights; a weight vector with a zero entry must not take that route."""
     from viforsdes_amd.primitives import fused

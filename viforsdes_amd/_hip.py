@@ -60,7 +60,7 @@ EXPORTS = (
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
-    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16",
+    "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -820,6 +820,24 @@ def gate_bwd_delta(dout: torch.Tensor, og: torch.Tensor, gate: torch.Tensor, dga
     with torch.cuda.device(dev):
         _call(lib.vsde_gate_bwd_delta, _ptr(dout), _ptr(og), _ptr(gate), _i64(ldg), _ptr(dattn), _ptr(dgate), _i64(ldd), _ptr(delta),
               _i64(B), ctypes.c_int(N), ctypes.c_int(H), _stream(dev))
+    return dattn, delta
+
+
+def linear_gate_bwd(dy: torch.Tensor, w_t: torch.Tensor, og: torch.Tensor, s: torch.Tensor, dgate: torch.Tensor, tokens: int):
+    """Input gradient of the attention output projection fused with the gate backward: dy [M,K] (gradient of the projection
+    output), w_t [H*64, K] (its weight transposed), og [B,N,H,64] the merged gated rows, s / dgate row-pitched [M, >=64] (gate
+    factors in, gate-logit gradient out).  Returns (dattn [B,N,H,64], delta [B,H,N] fp32) like ``gate_bwd_delta``."""
+    lib = load(); dev = _require_hip(dy, w_t, og, s, dgate)
+    dy, ldy = _rows2d(dy); s, lds = _rows2d(s); dgate, ldd = _rows2d(dgate)
+    B, N, H, d = og.shape
+    M, K = dy.shape
+    if d != 64 or N != tokens or M != B * N or tuple(w_t.shape) != (H * 64, K) or not (og.is_contiguous() and w_t.is_contiguous()):
+        raise ValueError("linear_gate_bwd: inconsistent shapes")
+    dattn = torch.empty_like(og)
+    delta = torch.empty(B, H, N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_gate_bwd_bf16, _ptr(dy), _i64(ldy), _ptr(w_t), _ptr(og), _ptr(s), _i64(lds), _ptr(dattn), _ptr(dgate),
+              _i64(ldd), _ptr(delta), _i64(M), ctypes.c_int(K), ctypes.c_int(H), ctypes.c_int(N), _stream(dev))
     return dattn, delta
 
 

@@ -23,6 +23,10 @@
 //                    RMS-normalised and rotated (RoPE) in the wave's staging buffer, v is mixed with the residual values, and every
 //                    head leaves straight in the attention kernels' layout -- the [M, 3C + d] intermediate and the separate
 //                    qk_norm_rope pass of the training path do not exist here
+//   EPI_GATE_BWD     input gradient of the attention output projection with the backward of the sigmoid output gate in its
+//                    epilogue (training step): a tile pair is one head's 64 columns of d(merged); with og = o s (the merged rows) and
+//                    the gate factors s it leaves as dO = d s, D = <d, og> per (token, head), and -- after the wave's last head --
+//                    the gate logits' gradient (1 - s) sum_h d og.  d(merged) itself is never written
 #include <stdlib.h>
 
 #include "vsde_common.h"
@@ -33,7 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a 16-byte register quad (native vector: stays in VGPRs)
 
-constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2, EPI_QKNORM = 3;
+constexpr int EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_SWIGLU_BWD = 2, EPI_QKNORM = 3, EPI_GATE_BWD = 4;
 constexpr int R2_THREADS = 256, R2_SLD = 88;   // rows kernel: 4 waves, staging rows of 64 + 16 (+ 8 pad) elements
 
 struct LinParams {
@@ -51,6 +55,10 @@ struct LinParams {
     const uint16_t *V0;                         // residual values [M][heads*64] or nullptr
     int heads, tokens; float eps;
     int gate_sigmoid;                           // training: the gate block leaves as rnd(sigmoid(logit)) (what the attention store multiplies by)
+    // EPI_GATE_BWD: A = gradient of the projection output, W = its weight transposed, N = heads * 64 = width of the merged rows
+    const uint16_t *Og; const uint16_t *Sg; int64_t ldsg;   // merged gated rows [M][N], gate factors s [M][ldsg]
+    uint16_t *Dgate; int64_t lddg;                          // gradient of the gate logits [M][lddg] (64 columns)
+    float *Delta;                                           // [B][heads][tokens]: <dO, O> of the attention backward
     float *Rinv;                                // training: inverse RMS of every q / k head row [M][2 heads], or nullptr
     uint16_t *Vdiff;                            // training: v_raw - v0 [M][heads*64] (what the value-mix weight's gradient needs), or nullptr
     // gated A operand (no-grad out projection): row m of A is multiplied by sigmoid(Gate[m][k % 64]) on its way into the registers
@@ -207,10 +215,10 @@ __device__ __forceinline__ void qknorm_head(const LinParams &p, uint16_t *stage,
 template <int EPI, int PAR, int RB>
 __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[RB], const uint16_t *bias32, uint16_t *stage,
                                               const u32x4 (&ureg)[4 * RB], int64_t row0, int n0, int lane,
-                                              const float (&cs)[16], const float (&sn)[16], const float *wlds) {
+                                              float (&cs)[16], float (&sn)[16], const float *wlds, bool last_tile) {
     const int r = lane & 31, h = lane >> 5;
     constexpr int SLD = R2_SLD, R = 32 * RB;
-    if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_QKNORM) {
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_QKNORM || EPI == EPI_GATE_BWD) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
@@ -221,6 +229,61 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 64 + 8 * g + 4 * h) = make_uint2(s0[2 * g], s0[2 * g + 1]);
             }
         }
+        if constexpr (EPI == EPI_GATE_BWD && PAR == 1) {
+            // the staged pair = d(merged) of head hh for the wave's 32 rows (bf16, as the unfused chain stores it); lane (r, h) owns
+            // columns 16 h .. 16 h + 15 and 32 + 16 h .. of row r.  cs / sn (unused rotary registers of this epilogue) carry this
+            // lane's 32 partial sums of d og over the heads visited so far.
+            const int hh = (n0 - 32) >> 6;
+            const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
+            const uint16_t *ogp = p.Og + m * (int64_t)p.N + hh * 64 + 16 * h, *sp = p.Sg + m * p.ldsg + 16 * h;
+            u32x4 ogv[4], sv[4];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const int off = (part >> 1) * 32 + (part & 1) * 8;
+                ogv[part] = *(const u32x4 *)(ogp + off); sv[part] = *(const u32x4 *)(sp + off);
+            }
+            wave_lds_fence();
+            uint16_t *px = stage + r * SLD + 16 * h;
+            float dsum = 0.f;
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                u32x4 *q4 = (u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8);
+                const u32x4 d4 = *q4;
+                u32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = bf_lo(d4[e]), d1 = bf_hi(d4[e]);
+                    const float p0 = d0 * bf_lo(ogv[part][e]), p1 = d1 * bf_hi(ogv[part][e]);
+                    dsum += p0 + p1;
+                    float *g = part < 2 ? cs : sn;
+                    g[(part & 1) * 8 + 2 * e] += p0; g[(part & 1) * 8 + 2 * e + 1] += p1;
+                    o4[e] = pack_bf16x2(d0 * bf_lo(sv[part][e]), d1 * bf_hi(sv[part][e]));
+                }
+                *q4 = o4;
+            }
+            dsum += __shfl_xor(dsum, 32, 64);
+            if (h == 0 && row0 + r < p.M) {
+                const int64_t bb = (row0 + r) / p.tokens, nn = (row0 + r) - bb * p.tokens;
+                p.Delta[(bb * p.heads + hh) * p.tokens + nn] = dsum;
+            }
+            wave_lds_fence();
+            flush_rows64<SLD, R>(stage, p.C + hh * 64, p.ldc, row0, p.M, lane);
+            wave_lds_fence();
+            if (last_tile) {   // wave-uniform: every head of these rows has been visited
+#pragma unroll
+                for (int part = 0; part < 4; ++part) {
+                    const float *g = part < 2 ? cs : sn;
+                    u32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o4[e] = pack_bf16x2(g[(part & 1) * 8 + 2 * e] * (1.0f - bf_lo(sv[part][e])), g[(part & 1) * 8 + 2 * e + 1] * (1.0f - bf_hi(sv[part][e])));
+                    *(u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8) = o4;
+                }
+                wave_lds_fence();
+                flush_rows64<SLD, R>(stage, p.Dgate, p.lddg, row0, p.M, lane);
+                wave_lds_fence();
+            }
+        } else
         if constexpr (EPI == EPI_QKNORM && PAR == 1) {
             // ureg[0..3] (RB = 1): this lane's 4 x 16 bytes of the residual values of the head, requested when the pair began
             const int pp = (n0 - 32) >> 6, kind = pp / p.heads, hh = pp - kind * p.heads;
@@ -311,7 +374,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
 // Outputs leave in pairs of tiles (64 columns = 128-byte row segments, non-temporal) through the wave's staging buffer.
 // EPI_SWIGLU_BWD runs with RB = 1: the tile's slice of the saved u is requested a tile ahead into registers, so its HBM
 // latency is hidden behind the MFMAs (with RB = 2 there are no registers left for that and every tile waited for its u).
-template <int EPI, int NKH = 1> constexpr int rows_rb() { return (EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || NKH > 1) ? 1 : 2; }
+template <int EPI, int NKH = 1> constexpr int rows_rb() { return (EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || EPI == EPI_GATE_BWD || NKH > 1) ? 1 : 2; }
 
 // KC: depth of the LDS weight tile; the wave's resident operand holds KSTOT = NKH * KC / 16 fragments per row block and this call
 // multiplies the slice [K0, K0 + KC / 16) of them (K = 512 runs as two k-halves of 256 through the same 17 KB tile buffers).
@@ -416,7 +479,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
     if constexpr (EPI == EPI_QKNORM) { if (tid < 128) wlds[tid] = tid < 64 ? p.wq[tid] : p.wk[tid - 64]; }   // visible after the first barrier
     float cs[16], sn[16];   // EPI_QKNORM: (cos, sin) of this lane's 16 rotary pairs of ITS row (token = row % tokens)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { cs[e] = 1.f; sn[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { cs[e] = EPI == EPI_GATE_BWD ? 0.f : 1.f; sn[e] = 0.f; }   // EPI_GATE_BWD: the gate gradient's partial sums
     if constexpr (EPI == EPI_QKNORM) {
         const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
         const int64_t tok = m % p.tokens;
@@ -478,7 +541,7 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
         const uint16_t *Bs = lsm + q_par * TILE;                                                              \
         rows_tile_mfma<KC, RB, KS, (KH_) * (KC / 16), (KH_) == 0>(acc, afr, Bs + r * LDB + 8 * h);            \
         if constexpr ((KH_) == NKH - 1)                                                                       \
-            rows_epilogue<EPI, TPAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds); \
+            rows_epilogue<EPI, TPAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds, (t_) + 1 == ntiles); \
         if (q_ + 1 < NKH * ntiles) VSDE_TILE_STORE(lsm + (1 - q_par) * TILE);                                 \
         lds_barrier();                                                                                        \
         if (q_ + 2 < NKH * ntiles) VSDE_TILE_LOAD(q_ + 2);                                                    \
@@ -795,6 +858,7 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
         const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
         if (stripes >= 512 && want > 1 && (pairs % want == 0 || (uneven_ok && pairs >= 2 * want))) chunks = want;
     }
+    if (EPI == EPI_GATE_BWD) chunks = 1;   // a wave must visit every head of its rows (the gate gradient sums over them)
     LinParams q = p;
     q.chunks = chunks;
     q.xstage = rows_xstage();
@@ -936,4 +1000,21 @@ extern "C" int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void 
     p.A = (const uint16_t *)attn; p.lda = ldx; p.W = (const uint16_t *)w; p.bias = (const uint16_t *)bias;
     p.C = (uint16_t *)y; p.ldc = ldy; p.M = M; p.N = N; p.K = K; p.Gate = (const uint16_t *)gate; p.ldgate = ldgate;
     return launch_rows_k<EPI_PLAIN>(p, (hipStream_t)stream);
+}
+
+extern "C" int vsde_linear_gate_bwd_bf16(const void *dy, int64_t ldy, const void *w_t, const void *og, const void *s, int64_t lds,
+                                         void *dattn, void *dgate, int64_t ldd, float *delta, int64_t M, int K, int heads, int tokens,
+                                         void *stream) {
+    VSDE_CHECK_ARG(dy && w_t && og && s && dattn && dgate && delta && M > 0 && heads > 0 && tokens > 0, VSDE_E_BADARG, "bad linear_gate_bwd arguments");
+    VSDE_CHECK_ARG(K == 128 || K == 256, VSDE_E_BADARG, "linear_gate_bwd runs on the rows kernel: K in {128, 256}");
+    VSDE_CHECK_ARG(ldy >= K && ldy % 8 == 0 && lds >= 64 && lds % 8 == 0 && ldd >= 64 && ldd % 8 == 0 && ((uintptr_t)dy % 16) == 0 &&
+                   ((uintptr_t)w_t % 16) == 0 && ((uintptr_t)og % 16) == 0 && ((uintptr_t)s % 16) == 0 && ((uintptr_t)dattn % 16) == 0 &&
+                   ((uintptr_t)dgate % 16) == 0, VSDE_E_BADARG,
+                   "linear_gate_bwd operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    LinParams p = {};
+    p.A = (const uint16_t *)dy; p.lda = ldy; p.W = (const uint16_t *)w_t; p.bias = nullptr;
+    p.C = (uint16_t *)dattn; p.ldc = (int64_t)heads * 64; p.M = M; p.N = heads * 64; p.K = K;
+    p.Og = (const uint16_t *)og; p.Sg = (const uint16_t *)s; p.ldsg = lds; p.Dgate = (uint16_t *)dgate; p.lddg = ldd; p.Delta = delta;
+    p.heads = heads; p.tokens = tokens;
+    return K == 128 ? launch_rows<128, EPI_GATE_BWD>(p, (hipStream_t)stream) : launch_rows<256, EPI_GATE_BWD>(p, (hipStream_t)stream);
 }

@@ -81,10 +81,11 @@ class Attention(nn.Module):
             if fused.attention_core_usable(hidden_states, pack, self.num_heads, self.head_dim, self.q_norm.weight, self.k_norm.weight, cos):
                 # training step: projection epilogue = QK-norm / RoPE / value mix, attention store = gate + head merge, and the
                 # attention backward's epilogues write the projection's gradient buffer (no raw [B,N,3C+d] tensor either way)
-                merged, v = fused.attention_core(hidden_states, pack, cos, sin, self.q_norm.weight, self.k_norm.weight,
-                                                 v0.transpose(1, 2) if mix else None, self.v_residual_lambda if mix else None,
-                                                 self.num_heads, self.q_norm.eps, self.head_dim ** -0.5, v0link)
-                return lin(merged, self.out_proj.weight, self.out_proj.bias), v.transpose(1, 2)
+                out, v = fused.attention_core(hidden_states, pack, cos, sin, self.q_norm.weight, self.k_norm.weight,
+                                              v0.transpose(1, 2) if mix else None, self.v_residual_lambda if mix else None,
+                                              self.num_heads, self.q_norm.eps, self.head_dim ** -0.5, v0link,
+                                              out_pack=fused.plain_pack(self.out_proj.weight, self.out_proj.bias))
+                return out, v.transpose(1, 2)
             if fused.projection_split_nograd_usable(hidden_states, pack, self.num_heads, self.head_dim, self.q_norm.weight, cos):
                 # posterior sampling: projection, QK-norm, RoPE, value mix and head layout in ONE kernel; no [B,N,3C+d] intermediate
                 q, k, v, glog = fused.projection_split_nograd(hidden_states, pack, cos, sin, self.q_norm.weight, self.k_norm.weight,

@@ -741,6 +741,8 @@ def swiglu_mlp(x: Tensor, pin: PackedWeight, pout: PackedWeight) -> Tensor:
 
 # VSDE_ATTN_FUSED_TRAIN=0: keep the separate qk_norm_rope / gate_merge passes in the training step (A/B runs)
 ATTN_FUSED_TRAIN = os.environ.get("VSDE_ATTN_FUSED_TRAIN", "1") != "0"
+# VSDE_GATE_BWD_GEMM=0: output projection's input gradient and the gate backward as two kernels (A/B runs)
+GATE_BWD_GEMM = os.environ.get("VSDE_GATE_BWD_GEMM", "1") != "0"
 _NONZERO: dict[int, tuple] = {}   # id(weight) -> (weakref, version, all entries non-zero)
 
 
@@ -757,16 +759,18 @@ def _all_nonzero(w: Tensor) -> bool:
 class _AttentionCore(torch.autograd.Function):
     """x -> [q | k | v | gate] projection -> QK-RMS-norm, RoPE, value mix -> softmax(q k^T) v -> sigmoid gate, head merge
     (reference primitives/attn.py:80-113) as TWO kernels forward (``vsde_linear_qknorm_bf16``: everything up to the attention
-    inputs in the GEMM epilogue; ``vsde_attention_fwd_gated_bf16``: the gate in the attention store) and three + the projection's
-    two GEMMs backward (``vsde_gate_bwd_delta``, the dq and dk/dv attention kernels whose epilogues undo RoPE / RMS-norm / the
-    value mix and write the projection's gradient buffer directly).  The raw projection [B,N,3C+d] is never materialised; the
+    inputs in the GEMM epilogue; ``vsde_attention_fwd_gated_bf16``: the gate in the attention store; + the output projection when
+    its pack is handed in) and three + the projections' GEMMs backward (``vsde_linear_gate_bwd_bf16``: the output projection's
+    input gradient with the gate backward in its epilogue -- or ``vsde_gate_bwd_delta`` --, the dq and dk/dv attention kernels
+    whose epilogues undo RoPE / RMS-norm / the value mix and write the projection's gradient buffer directly).  The raw projection [B,N,3C+d] is never materialised; the
     backward works from the attention inputs, one inverse RMS per (token, head) and v_raw - v0.
 
     Value-residual gradient: as in ``_QkNormRopeJoint`` -- consumer blocks accumulate into ``v0link`` inside their dk/dv kernel,
     the producing block (``v0 is None``) folds that buffer into its own dv."""
 
     @staticmethod
-    def forward(ctx, x, pack, cos, sin, wq, wk, v0, lam, heads, eps, scale, v0link, *params):
+    def forward(ctx, x, pack, opack, cos, sin, wq, wk, v0, lam, heads, eps, scale, v0link, *params):
+        """``opack``: the output projection (or None: the merged rows are returned and the caller projects them)."""
         B, N, K = x.shape
         w, b = pack.operands()
         mix = v0 is not None
@@ -777,22 +781,37 @@ class _AttentionCore(torch.autograd.Function):
         shape = (B, N, heads, 64)
         og, lse = _hip.attention_fwd_gated(q.view(shape), k.view(shape), v.view(shape), glog, scale)
         ctx.save_for_backward(x2, q, k, v, glog, og, lse, rinv, vdiff, cos, sin, wq, wk, lamc)
-        ctx.meta = (pack, heads, scale, lam.dtype if mix else None, v0link, (B, N, K))
+        ctx.meta = (pack, opack, heads, scale, lam.dtype if mix else None, v0link, (B, N, K))
         ctx.set_materialize_grads(False)
-        return og.view(B, N, heads * 64), v.view(shape)
+        if opack is None:
+            return og.view(B, N, heads * 64), v.view(shape)
+        wo, bo = opack.operands()
+        return _mm_nt(og.view(B * N, heads * 64), wo, bo).view(B, N, wo.shape[0]), v.view(shape)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dmerged, dv_out):
+    def backward(ctx, dout, dv_out):
         x2, q, k, v, glog, og, lse, rinv, vdiff, cos, sin, wq, wk, lamc = ctx.saved_tensors
-        pack, heads, scale, lam_dtype, v0link, (B, N, K) = ctx.meta
-        M, C3, G = B * N, 3 * heads * 64, glog.shape[1]
+        pack, opack, heads, scale, lam_dtype, v0link, (B, N, K) = ctx.meta
+        M, C, C3, G = B * N, heads * 64, 3 * heads * 64, glog.shape[1]
         shape = (B, N, heads, 64)
         mix = vdiff is not None
         dy = torch.empty(M, C3 + G, device=x2.device, dtype=torch.bfloat16)
-        if dmerged is None:
-            dmerged = torch.zeros(B, N, heads * 64, device=x2.device, dtype=torch.bfloat16)
-        dattn, delta = _hip.gate_bwd_delta(dmerged.to(torch.bfloat16).contiguous().view(shape), og, glog, dy[:, C3:])
+        ograds: tuple = ()
+        if opack is None:
+            dmerged = torch.zeros(M, C, device=x2.device, dtype=torch.bfloat16) if dout is None else dout.to(torch.bfloat16).reshape(M, C)
+            dattn, delta = _hip.gate_bwd_delta(dmerged.contiguous().view(shape), og, glog, dy[:, C3:])
+        else:
+            wo = opack.weight
+            do2 = (torch.zeros(M, wo.shape[0], device=x2.device, dtype=torch.bfloat16) if dout is None
+                   else dout.to(torch.bfloat16).reshape(M, wo.shape[0]).contiguous())
+            if GATE_BWD_GEMM and wo.shape[0] in (128, 256) and own_gemm(M, C, wo.shape[0]):
+                # the projection's input gradient with the gate backward in its epilogue: d(merged) is never written
+                dattn, delta = _hip.linear_gate_bwd(do2, opack.transposed(), og, glog, dy[:, C3:], N)
+            else:
+                dattn, delta = _hip.gate_bwd_delta((do2 @ wo).view(shape), og, glog, dy[:, C3:])
+            dWo, dbo = _hip.linear_wgrad(do2, og.view(M, C), opack.bias is not None)
+            ograds = tuple(opack.split_grads(dWo, dbo))
         acc = v0link.value if (v0link is not None and mix) else None
         extra = v0link.take() if (v0link is not None and not mix) else None
         if dv_out is not None:   # the values were consumed outside the link protocol (a direct use of the returned tensor)
@@ -809,7 +828,7 @@ class _AttentionCore(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (_hip.linear_bf16(dy, pack.transposed(), None) if own_gemm(M, wb.shape[1], wb.shape[0]) else dy @ wb).view(B, N, K)
         dW, db = _hip.linear_wgrad(dy, x2.contiguous(), pack.bias is not None)
-        return (dx, None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db))
+        return (dx, None, None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db), *ograds)
 
 
 def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, wk: Tensor, cos: Tensor) -> bool:
@@ -823,10 +842,14 @@ def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, w
 
 
 def attention_core(x: Tensor, pack: "PackedWeight", cos: Tensor, sin: Tensor, wq: Tensor, wk: Tensor, v0: Optional[Tensor],
-                   lam: Optional[Tensor], heads: int, eps: float, scale: float, v0link: Optional[GradLink]):
-    """(merged gated attention output [B,N,heads*64], values [B,N,heads,64]) for x [B,N,256]; v0 token-major or None."""
-    return _AttentionCore.apply(x, pack, cos.contiguous(), sin.contiguous(), wq.contiguous(), wk.contiguous(), v0,
-                                lam if v0 is not None else None, heads, eps, scale, v0link, *pack.params)
+                   lam: Optional[Tensor], heads: int, eps: float, scale: float, v0link: Optional[GradLink],
+                   out_pack: Optional["PackedWeight"] = None):
+    """(merged gated attention output [B,N,heads*64] -- or, with ``out_pack``, its output projection --, values [B,N,heads,64])
+    for x [B,N,K]; v0 token-major or None.  With ``out_pack`` the projection's input gradient and the gate backward are one
+    kernel in the backward (``vsde_linear_gate_bwd_bf16``)."""
+    oparams = () if out_pack is None else tuple(out_pack.params)
+    return _AttentionCore.apply(x, pack, out_pack, cos.contiguous(), sin.contiguous(), wq.contiguous(), wk.contiguous(), v0,
+                                lam if v0 is not None else None, heads, eps, scale, v0link, *pack.params, *oparams)
 
 
 def row_pack(weights: list[Tensor], biases: Optional[list[Tensor]], pad_to: Optional[int] = None) -> PackedWeight:
