@@ -50,3 +50,7 @@ o, _ = _hip.attention_fwd(q, k, v, 0.125)
 print(f"attention bwd (separate)              {t(lambda: _hip.attention_bwd(dattn, q, k, v, o, lse, 0.125)):8.1f} us")
 dq, dk, dv = _hip.attention_bwd(dattn, q, k, v, o, lse, 0.125)
 print(f"qk_norm_rope_bwd                      {t(lambda: _hip.qk_norm_rope_bwd(y[..., :768], cos, sin, wq, wk, v0.view(sh), lam, dq, dk, dv, H, 1e-6, True, dqkv=dy.view(B, N, 832)[..., :768], dv0=acc)):8.1f} us")
+wo = R(256, 256) * 0.06
+dy_o = R(M, 256)
+print(f"out-proj dgrad + gate backward (1 GEMM) {t(lambda: _hip.linear_gate_bwd(dy_o, wo, og, glog, dy[:, 768:], N)):8.1f} us")
+print(f"out-proj dgrad (plain)                {t(lambda: _hip.linear_bf16(dy_o, wo, None)):8.1f} us")

@@ -235,20 +235,30 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
             // lane's 32 partial sums of d og over the heads visited so far.
             const int hh = (n0 - 32) >> 6;
             const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
-            const uint16_t *ogp = p.Og + m * (int64_t)p.N + hh * 64 + 16 * h, *sp = p.Sg + m * p.ldsg + 16 * h;
-            u32x4 ogv[4], sv[4];
+            // the gate factors of the row: 4 x 16 bytes in the lane's own column set (reloaded per head: L1 hits)
+            const uint16_t *sp = p.Sg + m * p.ldsg + 16 * h;
+            u32x4 sv[4];
 #pragma unroll
-            for (int part = 0; part < 4; ++part) {
-                const int off = (part >> 1) * 32 + (part & 1) * 8;
-                ogv[part] = *(const u32x4 *)(ogp + off); sv[part] = *(const u32x4 *)(sp + off);
-            }
+            for (int part = 0; part < 4; ++part) sv[part] = *(const u32x4 *)(sp + (part >> 1) * 32 + (part & 1) * 8);
             wave_lds_fence();
             uint16_t *px = stage + r * SLD + 16 * h;
+            u32x4 dv[4], ogv[4];
+#pragma unroll
+            for (int part = 0; part < 4; ++part) dv[part] = *(const u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8);
+            wave_lds_fence();
+            // ureg: the head's 32 x 64 slice of og, requested when the pair began as full 128-byte rows (8 rows per instruction; in
+            // the lane's own column set every load would touch 32 rows for 16 bytes each and the texture path becomes the bound):
+            // through the staging rows into the lane's column set
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4 *)(stage + ((lane >> 3) + 8 * i) * SLD + (lane & 7) * 8) = ureg[i];
+            wave_lds_fence();
+#pragma unroll
+            for (int part = 0; part < 4; ++part) ogv[part] = *(const u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8);
+            wave_lds_fence();
             float dsum = 0.f;
 #pragma unroll
             for (int part = 0; part < 4; ++part) {
-                u32x4 *q4 = (u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8);
-                const u32x4 d4 = *q4;
+                const u32x4 d4 = dv[part];
                 u32x4 o4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -259,7 +269,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                     g[(part & 1) * 8 + 2 * e] += p0; g[(part & 1) * 8 + 2 * e + 1] += p1;
                     o4[e] = pack_bf16x2(d0 * bf_lo(sv[part][e]), d1 * bf_hi(sv[part][e]));
                 }
-                *q4 = o4;
+                *(u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8) = o4;
             }
             dsum += __shfl_xor(dsum, 32, 64);
             if (h == 0 && row0 + r < p.M) {
@@ -521,6 +531,16 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
                 const uint16_t *v_ = p.V0 + m_ * ((int64_t)p.heads * 64) + (pp_ - 2 * p.heads) * 64 + 16 * h; \
                 ureg[0] = *(const u32x4 *)v_; ureg[1] = *(const u32x4 *)(v_ + 8);                             \
                 ureg[2] = *(const u32x4 *)(v_ + 32); ureg[3] = *(const u32x4 *)(v_ + 40);                     \
+            }                                                                                                 \
+        }                                                                                                     \
+        if constexpr (EPI == EPI_GATE_BWD) {   /* the head's slice of og as full rows: requested when its tile pair begins */ \
+            const int tl_ = tile0 + ((t_) + rot) % ntiles;                                                    \
+            if ((tl_ & 1) == 0) {                                                                             \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+                    const int row = (lane >> 3) + 8 * i, c = lane & 7;                                        \
+                    const int64_t m_ = row0 + row < p.M ? row0 + row : p.M - 1;                               \
+                    ureg[i] = *(const u32x4 *)(p.Og + m_ * (int64_t)p.N + (tl_ >> 1) * 64 + c * 8);           \
+                }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
         if constexpr (EPI == EPI_SWIGLU_BWD) {                                                                \
