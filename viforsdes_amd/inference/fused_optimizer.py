@@ -12,6 +12,10 @@ told the outcome (``found_inf``) the way ``GradScaler.step`` would, so ``scaler.
 
 Used on CUDA for fp32, contiguous parameters with plain AdamW (no amsgrad / maximize); ``VSDE_FUSED_OPTIMIZER=0`` keeps the torch
 sequence.  Deterministic (fixed-order reductions), graph-capture safe (step count and outcome stay on the device).
+
+EMA contract: the kernel applies this step's EMA lerp and sets ``ema.fused_step_done``; the ``ema.update()`` call that the
+trainer's loops (and the reference's) issue after every step then returns at once.  A caller that steps WITHOUT updating the EMA
+must construct the step with ``ema=None`` (``VariationalInferenceTrainer.fuse_ema = False``).
 """
 from __future__ import annotations
 
@@ -35,9 +39,17 @@ class FusedOptimizerStep:
 
     # ------------------------------------------------------------------------------------------------ eligibility
     @staticmethod
-    def usable(optimizer: torch.optim.Optimizer) -> bool:
+    def usable(optimizer: torch.optim.Optimizer, scaler=None) -> bool:
         if not (ENABLED and isinstance(optimizer, torch.optim.AdamW)):
             return False
+        if scaler is not None and scaler.is_enabled():
+            # the outcome of the step is handed to GradScaler through the two attributes its own step() fills
+            try:
+                from torch.amp.grad_scaler import OptState  # noqa: F401
+            except ImportError:
+                return False
+            if not (hasattr(scaler, "_per_optimizer_states") and hasattr(scaler, "_scale")):
+                return False
         for g in optimizer.param_groups:
             if g.get("amsgrad", False) or g.get("maximize", False) or isinstance(g["lr"], Tensor):
                 return False

@@ -104,8 +104,9 @@ class VariationalInferenceTrainer:
         if ctx.device.type == "cuda":
             # one pass for the global norm / non-finite check, one for unscale x clip + AdamW + EMA (inference/fused_optimizer.py)
             fs = getattr(self, "_fused_opt", None)
-            if fs is None and FusedOptimizerStep.usable(ctx.optimizer):
-                fs = self._fused_opt = FusedOptimizerStep(ctx.optimizer, ctx.ema, ctx.scaler, cfg.grad_clip_norm)
+            if fs is None and FusedOptimizerStep.usable(ctx.optimizer, ctx.scaler):
+                fs = self._fused_opt = FusedOptimizerStep(ctx.optimizer, ctx.ema if getattr(self, "fuse_ema", True) else None,
+                                                          ctx.scaler, cfg.grad_clip_norm)
             if fs is not None:
                 grad_norm = fs.step()
         if grad_norm is None:
