@@ -585,9 +585,23 @@ OWN_GEMM = os.environ.get("VSDE_OWN_GEMM", "1") != "0"
 OWN_GEMM_COLS = os.environ.get("VSDE_OWN_GEMM_COLS", "0") == "1"
 
 
+# Rows below which the encoder Linears keep the library GEMM (the own kernels are laid out for stripes of 128 / 256 rows on 256
+# CUs: a few thousand rows do not fill them).  VSDE_OWN_GEMM_MIN_ROWS changes it; the first call below it says so once.
+OWN_GEMM_MIN_ROWS = int(os.environ.get("VSDE_OWN_GEMM_MIN_ROWS", "4096"))
+_small_m_logged = False
+
+
 def own_gemm(M: int, N: int, K: int, epilogue: int = 0) -> bool:
     """Whether y[M,N] = x[M,K] W[N,K]^T runs on the own MFMA kernels."""
-    if not (ENABLED and OWN_GEMM) or M < 4096:
+    global _small_m_logged
+    if not (ENABLED and OWN_GEMM):
+        return False
+    if M < OWN_GEMM_MIN_ROWS:
+        if not _small_m_logged:
+            _small_m_logged = True
+            import logging
+            logging.getLogger("viforsdes_amd").info(
+                "encoder Linear with %d rows (< %d): hipBLASLt instead of the own MFMA kernels (VSDE_OWN_GEMM_MIN_ROWS)", M, OWN_GEMM_MIN_ROWS)
         return False
     variant = _hip.linear_variant(M, N, K, epilogue)
     return variant in (1, 3) or (variant == 2 and OWN_GEMM_COLS)
@@ -630,7 +644,7 @@ class _PackedLinear(torch.autograd.Function):
 
 def packed_linear_usable(x: Tensor, rows: int, cols: int) -> bool:
     n = x.numel() // x.shape[-1]
-    return ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and n >= 4096 and rows % 8 == 0 and cols % 8 == 0
+    return ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and n >= OWN_GEMM_MIN_ROWS and rows % 8 == 0 and cols % 8 == 0
 
 
 def packed_linear(x: Tensor, pack: PackedWeight) -> Tensor:
@@ -684,7 +698,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
             and packed_linear_usable(x, weight.shape[0], weight.shape[1])):
         return packed_linear(x, plain_pack(weight, bias))
     rows = x.numel() // x.shape[-1]
-    if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and rows >= 4096 and weight.shape[0] % 8 == 0
+    if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and rows >= OWN_GEMM_MIN_ROWS and weight.shape[0] % 8 == 0
             and weight.shape[1] % 8 == 0 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
         return _Linear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
@@ -836,7 +850,7 @@ def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, w
     a sequence the LDS-resident attention kernels take, fp32 non-zero norm weights and fp32 rotary tables."""
     rows = x.numel() // x.shape[-1]
     return (ENABLED and OWN_GEMM and ATTN_FUSED_TRAIN and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
-            and x.ndim == 3 and x.shape[-1] in (128, 256) and d == 64 and pack.weight.shape[0] == 3 * heads * 64 + 64 and rows >= 4096
+            and x.ndim == 3 and x.shape[-1] in (128, 256) and d == 64 and pack.weight.shape[0] == 3 * heads * 64 + 64 and rows >= OWN_GEMM_MIN_ROWS
             and wq.dtype == torch.float32 and wk.dtype == torch.float32 and cos.dtype == torch.float32 and cos.shape[-1] == 32
             and _hip.attention_fused_supported(x.shape[1], d) and _all_nonzero(wq) and _all_nonzero(wk))
 
