@@ -116,3 +116,26 @@ def test_state_dict_round_trip_and_new_shadows():
     for (n, p), q0, q1 in zip(model.named_parameters(), p_before, p_after):
         if p.requires_grad:   # fresh shadows = the parameters before the step, then one lerp with weight 1 - decay = 0.01
             assert torch.allclose(ema.shadow[n], q0 + 0.01 * (q1 - q0), rtol=1e-5, atol=1e-7), n
+
+
+def test_a_step_that_falls_back_to_torch_keeps_the_step_counts_in_sync():
+    """A parameter without gradient sends one step to the torch sequence: the shared device step count must reach torch's
+    per-parameter counters before it and be re-read from them afterwards (bias corrections depend on it)."""
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    m_ref, o_ref, s_ref, e_ref = _setup(False)
+    m_own, o_own, s_own, e_own = _setup(False)
+    fs = FusedOptimizerStep(o_own, e_own, s_own, max_norm=1.0)
+    for step in range(5):
+        for model in (m_ref, m_own):
+            _grads(model, step, 1.0, False)
+            if step == 2:
+                model.b.grad = None
+        nn.utils.clip_grad_norm_(m_ref.parameters(), 1.0); o_ref.step(); e_ref.update()
+        if fs.step() is None:
+            assert step >= 2   # from the fallback step on torch's per-parameter counts differ: the torch sequence keeps the optimizer
+            nn.utils.clip_grad_norm_(m_own.parameters(), 1.0); o_own.step()
+        e_own.update()
+        for (name, p), q in zip(m_ref.named_parameters(), m_own.parameters()):
+            assert float((p - q).abs().max()) <= 3e-6 * float(p.detach().abs().max()), (step, name)
+    steps = {n: float(o_own.state_dict()["state"][i]["step"]) for i, n in enumerate(["a", "b", "c", "d", "e"])}
+    assert steps["a"] == 5.0 and steps["b"] == 4.0, steps

@@ -34,6 +34,7 @@ class FusedOptimizerStep:
     def __init__(self, optimizer: torch.optim.Optimizer, ema, scaler, max_norm: float) -> None:
         self.optimizer, self.ema, self.scaler, self.max_norm = optimizer, ema, scaler, float(max_norm)
         self._key = None
+        self._disabled = False
         self._hooks = [optimizer.register_state_dict_pre_hook(lambda opt: self._publish_steps()),
                        optimizer.register_load_state_dict_post_hook(lambda opt: self._invalidate())]
 
@@ -65,7 +66,7 @@ class FusedOptimizerStep:
     def _params(self) -> list[Tensor]:
         return [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
 
-    def _build(self, params: list[Tensor]) -> None:
+    def _build(self, params: list[Tensor]) -> bool:
         opt, dev = self.optimizer, params[0].device
         chunk = _hip.optim_chunk_elems()
         shadow_of = {}
@@ -92,7 +93,10 @@ class FusedOptimizerStep:
                     rows.append((p.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off,
                                  0 if sh is None else sh.data_ptr() + 4 * off, index[id(p)] | (n << 32), off, gi, 0))
         if len(set(steps)) > 1:
-            raise RuntimeError("parameters with different AdamW step counts")
+            # e.g. a parameter had no gradient in a step the torch sequence ran: torch counts steps per parameter, the kernel has
+            # ONE count -- leave this optimizer to the torch sequence from here on
+            self._disabled = True
+            return False
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.partials = torch.zeros(len(rows), device=dev, dtype=torch.float32)
         self.tstate = torch.tensor([steps[0], steps[0]], dtype=torch.float32).to(dev)
@@ -106,6 +110,7 @@ class FusedOptimizerStep:
         self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=dev)
         self.has_ema = self.ema is not None and all(id(p) in shadow_of for p in params)
         self._groups_key = None
+        return True
 
     def _hyper(self) -> Tensor:
         key = tuple((float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
@@ -128,15 +133,21 @@ class FusedOptimizerStep:
     def step(self) -> Optional[Tensor]:
         """Runs the step and returns the global gradient norm (0-dim device tensor), or None when this step cannot take the
         fused route (a parameter without gradient, a non-contiguous gradient): the caller then runs the torch sequence."""
+        if self._disabled:
+            return None
         params = self._params()
         grads = [p.grad for p in params]
         if not params or any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+            # the torch sequence runs this step: hand it the current step counts, and re-read them from its state next time
+            self._publish_steps()
+            self._invalidate()
             return None
         ema_v = getattr(self.ema, "version", 0) if self.ema is not None else 0
         key = (tuple(id(p) for p in params), ema_v)
         if key != self._key:
             self._publish_steps()   # a rebuild (new EMA shadows) must not lose the step count
-            self._build(params)
+            if not self._build(params):
+                return None
             self._key = key
         slot = self.ptr_slot = (self.ptr_slot + 1) % 4
         if self.ptr_events[slot] is not None:
