@@ -8,6 +8,8 @@
 //   dq        same ownership; K and V tiles stream; also emits delta_i = <dO_i, O_i>.
 //   dk / dv   workgroup = (batch, head, 128 keys); Q and dO tiles (+ their lse, delta) stream.
 // Deterministic: every output element has one owner, no atomics.
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -19,14 +21,16 @@ typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int AS_THREADS = 256, AS_TOK = 128;   // 4 waves x 32 owned tokens per workgroup
+// workgroup = NT threads = NT / 64 waves x 32 owned tokens (NT / 2 tokens): 256 (4 waves), or 512 for head_dim 128 -- every streamed
+// 32-token tile then serves 8 waves, half the L2 -> LDS traffic of the other side's re-reads per owned token
 
-template <int D> struct ASCfg {
+template <int D, int NT = 256> struct ASCfg {
     static constexpr int KS = D / 16;            // k-steps of a product contracting over the channels
     static constexpr int DB = D / 32;            // 32-channel blocks of an accumulator
     static constexpr int LD = D == 64 ? 72 : 144;   // LDS row stride (bf16): conflict-free ds_read_b64_tr_b16, <= 2-way ds_read_b128
     static constexpr int CH = D / 8;             // 16-byte chunks per row
-    static constexpr int NLD = 32 * CH / AS_THREADS;   // chunks per thread and 32-row tile (1 or 2)
+    static constexpr int NLD = 32 * CH / NT;     // chunks per thread and 32-row tile (1 or 2)
+    static_assert(32 * CH % NT == 0, "a 32-row tile must split evenly over the workgroup");
 };
 
 struct ASParams {
@@ -105,47 +109,47 @@ __device__ __forceinline__ void as_store_t(uint16_t *row, int h2, const f32x16 (
 }
 
 // tile `t` (32 token rows, zero beyond N) of two row-major operands: global -> registers / registers -> LDS
-template <int D>
-__device__ __forceinline__ void as_tile_load(u32x4 (&ra)[ASCfg<D>::NLD], u32x4 (&rb)[ASCfg<D>::NLD], const uint16_t *a, const uint16_t *b,
+template <int D, int NT>
+__device__ __forceinline__ void as_tile_load(u32x4 (&ra)[32 * (D / 8) / NT], u32x4 (&rb)[32 * (D / 8) / NT], const uint16_t *a, const uint16_t *b,
                                              int64_t ts, int t, int N, int tid) {
     constexpr int CH = ASCfg<D>::CH;
 #pragma unroll
-    for (int i = 0; i < ASCfg<D>::NLD; ++i) {
-        const int idx = tid + AS_THREADS * i, row = idx / CH, c = idx % CH, n = t * 32 + row;
+    for (int i = 0; i < ASCfg<D, NT>::NLD; ++i) {
+        const int idx = tid + NT * i, row = idx / CH, c = idx % CH, n = t * 32 + row;
         const u32x4 z = {0u, 0u, 0u, 0u};
         ra[i] = n < N ? *(const u32x4 *)(a + n * ts + c * 8) : z;
         rb[i] = n < N ? *(const u32x4 *)(b + n * ts + c * 8) : z;
     }
 }
-template <int D>
-__device__ __forceinline__ void as_tile_store(const u32x4 (&ra)[ASCfg<D>::NLD], const u32x4 (&rb)[ASCfg<D>::NLD], uint16_t *sa, uint16_t *sb, int tid) {
+template <int D, int NT>
+__device__ __forceinline__ void as_tile_store(const u32x4 (&ra)[32 * (D / 8) / NT], const u32x4 (&rb)[32 * (D / 8) / NT], uint16_t *sa, uint16_t *sb, int tid) {
     constexpr int CH = ASCfg<D>::CH, LD = ASCfg<D>::LD;
 #pragma unroll
-    for (int i = 0; i < ASCfg<D>::NLD; ++i) {
-        const int idx = tid + AS_THREADS * i, row = idx / CH, c = idx % CH;
+    for (int i = 0; i < ASCfg<D, NT>::NLD; ++i) {
+        const int idx = tid + NT * i, row = idx / CH, c = idx % CH;
         *(u32x4 *)(sa + row * LD + c * 8) = ra[i];
         *(u32x4 *)(sb + row * LD + c * 8) = rb[i];
     }
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
-template <int D>
-__global__ void __launch_bounds__(AS_THREADS) attn_fwd_stream_kernel(ASParams p) {
+template <int D, int NT>
+__global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
     constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D;
     const uint16_t *kb = p.k + base, *vb = p.v + base;
-    const int query = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const int query = blockIdx.y * (NT / 2) + wave * 32 + fr;
     const bool qok = query < N;
     bf16x8 qf[D / 16];
     as_load_frag<D>(p.q + base, ts, query, qok, h2, qf);
-    u32x4 rk[ASCfg<D>::NLD], rv[ASCfg<D>::NLD];
-    as_tile_load<D>(rk, rv, kb, vb, ts, 0, N, tid);
-    as_tile_store<D>(rk, rv, Ks, Vs, tid);
+    u32x4 rk[ASCfg<D, NT>::NLD], rv[ASCfg<D, NT>::NLD];
+    as_tile_load<D, NT>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D, NT>(rk, rv, Ks, Vs, tid);
     as_barrier();
-    if (p.ntile > 1) as_tile_load<D>(rk, rv, kb, vb, ts, 1, N, tid);
+    if (p.ntile > 1) as_tile_load<D, NT>(rk, rv, kb, vb, ts, 1, N, tid);
     const float c2 = p.scale_log2e;
     float m = -INFINITY, lsum = 0.f;   // running maximum (log2 units, equal in the two lanes of a query) and this lane's share of the sum
     f32x16 o[DB];
@@ -180,9 +184,9 @@ __global__ void __launch_bounds__(AS_THREADS) attn_fwd_stream_kernel(ASParams p)
         bf16x8 pb0, pb1;
         as_pack_tile(pr, pb0, pb1);
         as_accumulate_t<D>(vt_, lane, pb0, pb1, o);   // O^T += V^T P^T
-        if (kt + 1 < p.ntile) as_tile_store<D>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+        if (kt + 1 < p.ntile) as_tile_store<D, NT>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
         as_barrier();
-        if (kt + 2 < p.ntile) as_tile_load<D>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+        if (kt + 2 < p.ntile) as_tile_load<D, NT>(rk, rv, kb, vb, ts, kt + 2, N, tid);
     }
     lsum += __shfl_xor(lsum, 32, 64);
     if (qok) {
@@ -192,15 +196,15 @@ __global__ void __launch_bounds__(AS_THREADS) attn_fwd_stream_kernel(ASParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------ backward: dq
-template <int D>
-__global__ void __launch_bounds__(AS_THREADS) attn_bwd_dq_stream_kernel(ASParams p) {
+template <int D, int NT>
+__global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
     constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
     const uint16_t *kb = p.k + base, *vb = p.v + base;
-    const int query = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const int query = blockIdx.y * (NT / 2) + wave * 32 + fr;
     const bool qok = query < N;
     bf16x8 qf[D / 16], dof[D / 16];
     float dsum = 0.f;   // delta_i = <dO_i, O_i>: this lane holds half of the channels of its query
@@ -218,11 +222,11 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dq_stream_kernel(ASParams
     dsum += __shfl_xor(dsum, 32, 64);
     if (qok && h2 == 0) p.delta[srow + query] = dsum;
     const float lse2 = (qok ? p.lse_in[srow + query] : INFINITY) * 1.4426950408889634f;   // padded queries: P = 0
-    u32x4 rk[ASCfg<D>::NLD], rv[ASCfg<D>::NLD];
-    as_tile_load<D>(rk, rv, kb, vb, ts, 0, N, tid);
-    as_tile_store<D>(rk, rv, Ks, Vs, tid);
+    u32x4 rk[ASCfg<D, NT>::NLD], rv[ASCfg<D, NT>::NLD];
+    as_tile_load<D, NT>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D, NT>(rk, rv, Ks, Vs, tid);
     as_barrier();
-    if (p.ntile > 1) as_tile_load<D>(rk, rv, kb, vb, ts, 1, N, tid);
+    if (p.ntile > 1) as_tile_load<D, NT>(rk, rv, kb, vb, ts, 1, N, tid);
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
     f32x16 acc[DB];
@@ -243,16 +247,16 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dq_stream_kernel(ASParams
         bf16x8 b0, b1;
         as_pack_tile(ds, b0, b1);
         as_accumulate_t<D>(kt_, lane, b0, b1, acc);   // dQ^T += K^T dS^T
-        if (kt + 1 < p.ntile) as_tile_store<D>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+        if (kt + 1 < p.ntile) as_tile_store<D, NT>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
         as_barrier();
-        if (kt + 2 < p.ntile) as_tile_load<D>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+        if (kt + 2 < p.ntile) as_tile_load<D, NT>(rk, rv, kb, vb, ts, kt + 2, N, tid);
     }
     if (qok) as_store_t<D>(p.dq + base + query * ts, h2, acc, p.scale);
 }
 
 // ------------------------------------------------------------------------------------------------- backward: dk, dv
-template <int D>
-__global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParams p) {
+template <int D, int NT>
+__global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
     constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
     __shared__ __attribute__((aligned(16))) uint16_t Qs[2 * TILE], Os[2 * TILE];
     __shared__ __attribute__((aligned(16))) float lse2s[2 * 32], dels[2 * 32];
@@ -260,12 +264,12 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParam
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
     const uint16_t *qb = p.q + base, *dob = p.dout + base;
-    const int key = blockIdx.y * AS_TOK + wave * 32 + fr;
+    const int key = blockIdx.y * (NT / 2) + wave * 32 + fr;
     const bool kok = key < N;
     bf16x8 kf[D / 16], vf[D / 16];
     as_load_frag<D>(p.k + base, ts, key, kok, h2, kf);
     as_load_frag<D>(p.v + base, ts, key, kok, h2, vf);
-    u32x4 rq[ASCfg<D>::NLD], rdo[ASCfg<D>::NLD];
+    u32x4 rq[ASCfg<D, NT>::NLD], rdo[ASCfg<D, NT>::NLD];
     float rl = 0.f, rd = 0.f;   // per-query statistics of the tile in flight (threads 0..31)
     auto stat_load = [&](int t) {
         if (tid < 32) {
@@ -275,10 +279,10 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParam
         }
     };
     auto stat_store = [&](int buf) { if (tid < 32) { lse2s[buf * 32 + tid] = rl; dels[buf * 32 + tid] = rd; } };
-    as_tile_load<D>(rq, rdo, qb, dob, ts, 0, N, tid); stat_load(0);
-    as_tile_store<D>(rq, rdo, Qs, Os, tid); stat_store(0);
+    as_tile_load<D, NT>(rq, rdo, qb, dob, ts, 0, N, tid); stat_load(0);
+    as_tile_store<D, NT>(rq, rdo, Qs, Os, tid); stat_store(0);
     as_barrier();
-    if (p.ntile > 1) { as_tile_load<D>(rq, rdo, qb, dob, ts, 1, N, tid); stat_load(1); }
+    if (p.ntile > 1) { as_tile_load<D, NT>(rq, rdo, qb, dob, ts, 1, N, tid); stat_load(1); }
     const float c2 = p.scale_log2e;
     f32x16 dk[DB], dv[DB];
 #pragma unroll
@@ -308,9 +312,9 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParam
         as_pack_tile(ds, s0, s1);
         as_accumulate_t<D>(dot_, lane, p0, p1, dv);   // dV^T += dO^T P
         as_accumulate_t<D>(qt_, lane, s0, s1, dk);    // dK^T += Q^T dS
-        if (qt + 1 < p.ntile) { as_tile_store<D>(rq, rdo, Qs + (1 - buf) * TILE, Os + (1 - buf) * TILE, tid); stat_store(1 - buf); }
+        if (qt + 1 < p.ntile) { as_tile_store<D, NT>(rq, rdo, Qs + (1 - buf) * TILE, Os + (1 - buf) * TILE, tid); stat_store(1 - buf); }
         as_barrier();
-        if (qt + 2 < p.ntile) { as_tile_load<D>(rq, rdo, qb, dob, ts, qt + 2, N, tid); stat_load(qt + 2); }
+        if (qt + 2 < p.ntile) { as_tile_load<D, NT>(rq, rdo, qb, dob, ts, qt + 2, N, tid); stat_load(qt + 2); }
     }
     if (kok) {
         as_store_t<D>(p.dk + base + key * ts, h2, dk, p.scale);
@@ -318,19 +322,25 @@ __global__ void __launch_bounds__(AS_THREADS) attn_bwd_dkv_stream_kernel(ASParam
     }
 }
 
-template <int D>
+template <int D, int NT>
 static int as_forward(const ASParams &p, int64_t BH, hipStream_t s) {
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<D>), dim3((unsigned)BH, (p.N + AS_TOK - 1) / AS_TOK), dim3(AS_THREADS), 0, s, p);
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<D, NT>), dim3((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2)), dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int D>
+template <int D, int NT>
 static int as_backward(const ASParams &p, int64_t BH, hipStream_t s) {
-    const dim3 grid((unsigned)BH, (p.N + AS_TOK - 1) / AS_TOK);
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D>), grid, dim3(AS_THREADS), 0, s, p);    // also writes delta, read by the next kernel
-    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D>), grid, dim3(AS_THREADS), 0, s, p);
+    const dim3 grid((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2));
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, NT>), grid, dim3(NT), 0, s, p);    // also writes delta, read by the next kernel
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT>), grid, dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
+}
+// VSDE_ATTN_STREAM_NT=256: four-wave workgroups for head_dim 128 too (A/B runs)
+static bool as_wide() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VSDE_ATTN_STREAM_NT"); v = e ? (atoi(e) == 512) : 1; }
+    return v != 0;
 }
 
 int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
@@ -338,7 +348,8 @@ int launch_attention_stream_fwd(const void *q, const void *k, const void *v, voi
     ASParams p = {};
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.out = (uint16_t *)o; p.lse = lse;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    return D == 64 ? as_forward<64>(p, B * H, s) : as_forward<128>(p, B * H, s);
+    if (D == 64) return as_forward<64, 256>(p, B * H, s);
+    return as_wide() ? as_forward<128, 512>(p, B * H, s) : as_forward<128, 256>(p, B * H, s);
 }
 
 int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse, void *dq,
@@ -347,7 +358,8 @@ int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, 
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o; p.dout = (const uint16_t *)dout;
     p.lse_in = lse; p.delta = delta; p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    return D == 64 ? as_backward<64>(p, B * H, s) : as_backward<128>(p, B * H, s);
+    if (D == 64) return as_backward<64, 256>(p, B * H, s);
+    return as_wide() ? as_backward<128, 512>(p, B * H, s) : as_backward<128, 256>(p, B * H, s);
 }
 
 }  // namespace vsde
