@@ -17,4 +17,4 @@ def t(fn, n=10):
 sc = D ** -0.5
 o, lse = _hip.attention_fwd(q, k, v, sc)
 print(f"forward  {t(lambda: _hip.attention_fwd(q, k, v, sc)):8.1f} us")
-print(f"backward {t(lambda: _hip.attention_bwd(go, q, k, v, o, lse, sc)):8.1f} us")
+if not os.environ.get("VSDE_AS_FWD_ONLY"): print(f"backward {t(lambda: _hip.attention_bwd(go, q, k, v, o, lse, sc)):8.1f} us")

@@ -1,9 +1,10 @@
 // Self-attention core for sequences that do not fit the LDS-resident kernels of vsde_attn.hip (N > 544 tokens) or for
 // head_dim 128 -- the synthetic stress configuration (1001 grid tokens, encoder 512 / 4 heads).  Same math, same token-major
 // layout [B][N][H][D] and the same lane = token orientation of the products (see vsde_attn.hip), but the "other side" of the
-// product streams through LDS in tiles of 32 tokens (double-buffered, one barrier per tile) and the forward keeps a running
-// maximum (online softmax; the rescale of the accumulators is skipped while the maximum grows by < 2^8, so it runs once or
-// twice per query).  D in {64, 128}; reference: F.scaled_dot_product_attention at primitives/attn.py:104-106.
+// product streams through LDS in stages of TR tokens (double-buffered, one barrier per stage; TR = 32, or 128 = four 32-token
+// sub-tiles for the 8-wave forward / dq kernels) and the forward keeps a running maximum (online softmax; the rescale of the
+// accumulators is skipped while the maximum grows by < 2^8, so it runs once or twice per query).  D in {64, 128}; reference:
+// F.scaled_dot_product_attention at primitives/attn.py:104-106.  The blocks of one (batch, head) pair share an XCD (as_block_map).
 //   forward   workgroup = (batch, head, 128 queries): 4 waves x 32 queries; K and V tiles stream.
 //   dq        same ownership; K and V tiles stream; also emits delta_i = <dO_i, O_i>.
 //   dk / dv   workgroup = (batch, head, 128 keys); Q and dO tiles (+ their lse, delta) stream.
@@ -109,47 +110,62 @@ __device__ __forceinline__ void as_store_t(uint16_t *row, int h2, const f32x16 (
 }
 
 // tile `t` (32 token rows, zero beyond N) of two row-major operands: global -> registers / registers -> LDS
-template <int D, int NT>
-__device__ __forceinline__ void as_tile_load(u32x4 (&ra)[32 * (D / 8) / NT], u32x4 (&rb)[32 * (D / 8) / NT], const uint16_t *a, const uint16_t *b,
+template <int D, int NT, int TR>
+__device__ __forceinline__ void as_tile_load(u32x4 (&ra)[TR * (D / 8) / NT], u32x4 (&rb)[TR * (D / 8) / NT], const uint16_t *a, const uint16_t *b,
                                              int64_t ts, int t, int N, int tid) {
     constexpr int CH = ASCfg<D>::CH;
 #pragma unroll
-    for (int i = 0; i < ASCfg<D, NT>::NLD; ++i) {
-        const int idx = tid + NT * i, row = idx / CH, c = idx % CH, n = t * 32 + row;
+    for (int i = 0; i < TR * CH / NT; ++i) {
+        const int idx = tid + NT * i, row = idx / CH, c = idx % CH, n = t * TR + row;
         const u32x4 z = {0u, 0u, 0u, 0u};
         ra[i] = n < N ? *(const u32x4 *)(a + n * ts + c * 8) : z;
         rb[i] = n < N ? *(const u32x4 *)(b + n * ts + c * 8) : z;
     }
 }
-template <int D, int NT>
-__device__ __forceinline__ void as_tile_store(const u32x4 (&ra)[32 * (D / 8) / NT], const u32x4 (&rb)[32 * (D / 8) / NT], uint16_t *sa, uint16_t *sb, int tid) {
+template <int D, int NT, int TR>
+__device__ __forceinline__ void as_tile_store(const u32x4 (&ra)[TR * (D / 8) / NT], const u32x4 (&rb)[TR * (D / 8) / NT], uint16_t *sa, uint16_t *sb, int tid) {
     constexpr int CH = ASCfg<D>::CH, LD = ASCfg<D>::LD;
 #pragma unroll
-    for (int i = 0; i < ASCfg<D, NT>::NLD; ++i) {
+    for (int i = 0; i < TR * CH / NT; ++i) {
         const int idx = tid + NT * i, row = idx / CH, c = idx % CH;
         *(u32x4 *)(sa + row * LD + c * 8) = ra[i];
         *(u32x4 *)(sb + row * LD + c * 8) = rb[i];
     }
 }
 
+
+// Workgroup -> ((batch, head) pair, owned-token block).  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+// (one L2 each); the blocks of one pair all stream the same K / V (or Q / dO) rows, so they are given consecutive slots of ONE
+// XCD: they run at the same time on the same L2 and the pair's rows come from HBM once instead of once per block.
+__device__ __forceinline__ void as_block_map(int &pair, int &blk) {
+    const int nblk = gridDim.y, npair = gridDim.x;
+    if (npair & 7) { pair = blockIdx.x; blk = blockIdx.y; return; }
+    const int L = blockIdx.x + npair * blockIdx.y, xcd = L & 7, slot = L >> 3;
+    blk = slot % nblk;
+    pair = (slot / nblk) * 8 + xcd;
+}
+
 // ------------------------------------------------------------------------------------------------------ forward
-template <int D, int NT>
+template <int D, int NT, int TR>
 __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
-    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = TR * LD, SUBS = TR / 32;   // TR streamed rows per stage (one barrier)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
-    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    int pair, blk;
+    as_block_map(pair, blk);
+    const int b = pair / p.H, hh = pair - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D;
     const uint16_t *kb = p.k + base, *vb = p.v + base;
-    const int query = blockIdx.y * (NT / 2) + wave * 32 + fr;
+    const int query = blk * (NT / 2) + wave * 32 + fr;
     const bool qok = query < N;
     bf16x8 qf[D / 16];
     as_load_frag<D>(p.q + base, ts, query, qok, h2, qf);
-    u32x4 rk[ASCfg<D, NT>::NLD], rv[ASCfg<D, NT>::NLD];
-    as_tile_load<D, NT>(rk, rv, kb, vb, ts, 0, N, tid);
-    as_tile_store<D, NT>(rk, rv, Ks, Vs, tid);
+    u32x4 rk[TR * (D / 8) / NT], rv[TR * (D / 8) / NT];
+    as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D, NT, TR>(rk, rv, Ks, Vs, tid);
     as_barrier();
-    if (p.ntile > 1) as_tile_load<D, NT>(rk, rv, kb, vb, ts, 1, N, tid);
+    const int nstage = (N + TR - 1) / TR;
+    if (nstage > 1) as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, 1, N, tid);
     const float c2 = p.scale_log2e;
     float m = -INFINITY, lsum = 0.f;   // running maximum (log2 units, equal in the two lanes of a query) and this lane's share of the sum
     f32x16 o[DB];
@@ -158,17 +174,28 @@ __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
     const bool ragged = (N & 31) != 0;
-    for (int kt = 0; kt < p.ntile; ++kt) {
-        const uint16_t *kt_ = Ks + (kt & 1) * TILE, *vt_ = Vs + (kt & 1) * TILE;
-        f32x16 s = as_product<D>(kt_ + fr * LD + h2 * 8, qf);   // S^T [key][query]
-        float t[16], mx = -INFINITY;
+    for (int st = 0; st < nstage; ++st) {
+        // Software pipeline inside the stage: the score product of sub-tile i + 1 is issued before the exponentials of sub-tile i,
+        // so the matrix pipe works on it while the VALU runs the softmax (tools/probes/overlap_probe.hip: the two only overlap when
+        // independent work of both kinds is in flight -- waves in lock step after a barrier otherwise run phase after phase).
+        f32x16 s = as_product<D>(Ks + (st & 1) * TILE + fr * LD + h2 * 8, qf);   // S^T [key][query] of the stage's first sub-tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            t[r] = s[r] * c2;
-            if (ragged && kt == p.ntile - 1 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) t[r] = -INFINITY;
-            mx = fmaxf(mx, t[r]);
+      for (int sub = 0; sub < SUBS; ++sub) {
+        const int kt = st * SUBS + sub;
+        if (kt >= p.ntile) break;   // the last stage's tail lies beyond the sequence (workgroup-uniform)
+        const uint16_t *vt_ = Vs + (st & 1) * TILE + sub * 32 * LD;
+        f32x16 sn = s;
+        if (sub + 1 < SUBS && kt + 1 < p.ntile) sn = as_product<D>(Ks + (st & 1) * TILE + (sub + 1) * 32 * LD + fr * LD + h2 * 8, qf);
+        if (ragged && kt == p.ntile - 1) {   // wave-uniform branch: only the last tile pays for the mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) s[r] = -INFINITY;
+            asm volatile("" ::: "memory");   // keeps the branch (if-converted, the 48 mask instructions would run for every tile)
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(s[r], s[r + 1]), mx);   // v_max3_f32
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;   // scale > 0
         if (__any(mx > m + 8.0f)) {   // wave-uniform: rescale every accumulator of the wave (factor 1 where the maximum held)
             const float mn = fmaxf(m, mx), alpha = fast_exp2(m - mn);   // m = -inf: alpha = 0
             lsum *= alpha;
@@ -178,15 +205,21 @@ __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
                 for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
             m = mn;
         }
-        float pr[16];
+        float pr[16], l2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(t[r] - m); lsum += pr[r]; }
+        for (int r = 0; r < 16; r += 2) {
+            pr[r] = fast_exp2(fmaf(s[r], c2, -m)); lsum += pr[r];
+            pr[r + 1] = fast_exp2(fmaf(s[r + 1], c2, -m)); l2 += pr[r + 1];
+        }
+        lsum += l2;
         bf16x8 pb0, pb1;
         as_pack_tile(pr, pb0, pb1);
         as_accumulate_t<D>(vt_, lane, pb0, pb1, o);   // O^T += V^T P^T
-        if (kt + 1 < p.ntile) as_tile_store<D, NT>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+        s = sn;
+      }
+        if (st + 1 < nstage) as_tile_store<D, NT, TR>(rk, rv, Ks + ((st + 1) & 1) * TILE, Vs + ((st + 1) & 1) * TILE, tid);
         as_barrier();
-        if (kt + 2 < p.ntile) as_tile_load<D, NT>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+        if (st + 2 < nstage) as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, st + 2, N, tid);
     }
     lsum += __shfl_xor(lsum, 32, 64);
     if (qok) {
@@ -196,15 +229,17 @@ __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ backward: dq
-template <int D, int NT>
+template <int D, int NT, int TR>
 __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
-    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = TR * LD, SUBS = TR / 32;   // TR streamed rows per stage (one barrier)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * TILE], Vs[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
-    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    int pair, blk;
+    as_block_map(pair, blk);
+    const int b = pair / p.H, hh = pair - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
     const uint16_t *kb = p.k + base, *vb = p.v + base;
-    const int query = blockIdx.y * (NT / 2) + wave * 32 + fr;
+    const int query = blk * (NT / 2) + wave * 32 + fr;
     const bool qok = query < N;
     bf16x8 qf[D / 16], dof[D / 16];
     float dsum = 0.f;   // delta_i = <dO_i, O_i>: this lane holds half of the channels of its query
@@ -222,11 +257,12 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
     dsum += __shfl_xor(dsum, 32, 64);
     if (qok && h2 == 0) p.delta[srow + query] = dsum;
     const float lse2 = (qok ? p.lse_in[srow + query] : INFINITY) * 1.4426950408889634f;   // padded queries: P = 0
-    u32x4 rk[ASCfg<D, NT>::NLD], rv[ASCfg<D, NT>::NLD];
-    as_tile_load<D, NT>(rk, rv, kb, vb, ts, 0, N, tid);
-    as_tile_store<D, NT>(rk, rv, Ks, Vs, tid);
+    u32x4 rk[TR * (D / 8) / NT], rv[TR * (D / 8) / NT];
+    as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, 0, N, tid);
+    as_tile_store<D, NT, TR>(rk, rv, Ks, Vs, tid);
     as_barrier();
-    if (p.ntile > 1) as_tile_load<D, NT>(rk, rv, kb, vb, ts, 1, N, tid);
+    const int nstage = (N + TR - 1) / TR;
+    if (nstage > 1) as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, 1, N, tid);
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
     f32x16 acc[DB];
@@ -234,8 +270,12 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[db][e] = 0.f;
-    for (int kt = 0; kt < p.ntile; ++kt) {
-        const uint16_t *kt_ = Ks + (kt & 1) * TILE, *vt_ = Vs + (kt & 1) * TILE;
+    for (int st = 0; st < nstage; ++st) {
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub) {
+        const int kt = st * SUBS + sub;
+        if (kt >= p.ntile) break;
+        const uint16_t *kt_ = Ks + (st & 1) * TILE + sub * 32 * LD, *vt_ = Vs + (st & 1) * TILE + sub * 32 * LD;
         const f32x16 stl = as_product<D>(kt_ + fr * LD + h2 * 8, qf);    // S^T  [key][query]
         const f32x16 dpt = as_product<D>(vt_ + fr * LD + h2 * 8, dof);   // dP^T [key][query]
         float ds[16];
@@ -247,58 +287,65 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
         bf16x8 b0, b1;
         as_pack_tile(ds, b0, b1);
         as_accumulate_t<D>(kt_, lane, b0, b1, acc);   // dQ^T += K^T dS^T
-        if (kt + 1 < p.ntile) as_tile_store<D, NT>(rk, rv, Ks + ((kt + 1) & 1) * TILE, Vs + ((kt + 1) & 1) * TILE, tid);
+      }
+        if (st + 1 < nstage) as_tile_store<D, NT, TR>(rk, rv, Ks + ((st + 1) & 1) * TILE, Vs + ((st + 1) & 1) * TILE, tid);
         as_barrier();
-        if (kt + 2 < p.ntile) as_tile_load<D, NT>(rk, rv, kb, vb, ts, kt + 2, N, tid);
+        if (st + 2 < nstage) as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, st + 2, N, tid);
     }
     if (qok) as_store_t<D>(p.dq + base + query * ts, h2, acc, p.scale);
 }
 
 // ------------------------------------------------------------------------------------------------- backward: dk, dv
-template <int D, int NT>
+template <int D, int NT, int TR>
 __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
-    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = 32 * LD;
+    constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = TR * LD, SUBS = TR / 32;   // TR streamed rows per stage (one barrier)
     __shared__ __attribute__((aligned(16))) uint16_t Qs[2 * TILE], Os[2 * TILE];
-    __shared__ __attribute__((aligned(16))) float lse2s[2 * 32], dels[2 * 32];
+    __shared__ __attribute__((aligned(16))) float lse2s[2 * TR], dels[2 * TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
-    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N;
+    int pair, blk;
+    as_block_map(pair, blk);
+    const int b = pair / p.H, hh = pair - b * p.H, N = p.N;
     const int64_t ts = (int64_t)p.H * D, base = ((int64_t)b * N * p.H + hh) * D, srow = ((int64_t)b * p.H + hh) * N;
     const uint16_t *qb = p.q + base, *dob = p.dout + base;
-    const int key = blockIdx.y * (NT / 2) + wave * 32 + fr;
+    const int key = blk * (NT / 2) + wave * 32 + fr;
     const bool kok = key < N;
     bf16x8 kf[D / 16], vf[D / 16];
     as_load_frag<D>(p.k + base, ts, key, kok, h2, kf);
     as_load_frag<D>(p.v + base, ts, key, kok, h2, vf);
-    u32x4 rq[ASCfg<D, NT>::NLD], rdo[ASCfg<D, NT>::NLD];
+    u32x4 rq[TR * (D / 8) / NT], rdo[TR * (D / 8) / NT];
     float rl = 0.f, rd = 0.f;   // per-query statistics of the tile in flight (threads 0..31)
     auto stat_load = [&](int t) {
-        if (tid < 32) {
-            const int n = t * 32 + tid;
+        if (tid < TR) {
+            const int n = t * TR + tid;
             rl = n < N ? p.lse_in[srow + n] * 1.4426950408889634f : INFINITY;   // padded queries: P = 0
             rd = n < N ? p.delta[srow + n] : 0.f;
         }
     };
-    auto stat_store = [&](int buf) { if (tid < 32) { lse2s[buf * 32 + tid] = rl; dels[buf * 32 + tid] = rd; } };
-    as_tile_load<D, NT>(rq, rdo, qb, dob, ts, 0, N, tid); stat_load(0);
-    as_tile_store<D, NT>(rq, rdo, Qs, Os, tid); stat_store(0);
+    auto stat_store = [&](int buf) { if (tid < TR) { lse2s[buf * TR + tid] = rl; dels[buf * TR + tid] = rd; } };
+    as_tile_load<D, NT, TR>(rq, rdo, qb, dob, ts, 0, N, tid); stat_load(0);
+    as_tile_store<D, NT, TR>(rq, rdo, Qs, Os, tid); stat_store(0);
     as_barrier();
-    if (p.ntile > 1) { as_tile_load<D, NT>(rq, rdo, qb, dob, ts, 1, N, tid); stat_load(1); }
+    const int nstage = (N + TR - 1) / TR;
+    if (nstage > 1) { as_tile_load<D, NT, TR>(rq, rdo, qb, dob, ts, 1, N, tid); stat_load(1); }
     const float c2 = p.scale_log2e;
     f32x16 dk[DB], dv[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[db][e] = 0.f; dv[db][e] = 0.f; }
-    for (int qt = 0; qt < p.ntile; ++qt) {
-        const int buf = qt & 1;
-        const uint16_t *qt_ = Qs + buf * TILE, *dot_ = Os + buf * TILE;
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub) {
+        if (st * SUBS + sub >= p.ntile) break;
+        const uint16_t *qt_ = Qs + buf * TILE + sub * 32 * LD, *dot_ = Os + buf * TILE + sub * 32 * LD;
         const f32x16 sc = as_product<D>(qt_ + fr * LD + h2 * 8, kf);     // S  [query][key]
         const f32x16 dp = as_product<D>(dot_ + fr * LD + h2 * 8, vf);    // dP [query][key]
         float pr[16], ds[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {   // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
-            const float4 l4 = *(const float4 *)(lse2s + buf * 32 + 8 * g + 4 * h2);
-            const float4 d4 = *(const float4 *)(dels + buf * 32 + 8 * g + 4 * h2);
+            const float4 l4 = *(const float4 *)(lse2s + buf * TR + sub * 32 + 8 * g + 4 * h2);
+            const float4 d4 = *(const float4 *)(dels + buf * TR + sub * 32 + 8 * g + 4 * h2);
             const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -312,9 +359,10 @@ __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
         as_pack_tile(ds, s0, s1);
         as_accumulate_t<D>(dot_, lane, p0, p1, dv);   // dV^T += dO^T P
         as_accumulate_t<D>(qt_, lane, s0, s1, dk);    // dK^T += Q^T dS
-        if (qt + 1 < p.ntile) { as_tile_store<D, NT>(rq, rdo, Qs + (1 - buf) * TILE, Os + (1 - buf) * TILE, tid); stat_store(1 - buf); }
+      }
+        if (st + 1 < nstage) { as_tile_store<D, NT, TR>(rq, rdo, Qs + (1 - buf) * TILE, Os + (1 - buf) * TILE, tid); stat_store(1 - buf); }
         as_barrier();
-        if (qt + 2 < p.ntile) { as_tile_load<D, NT>(rq, rdo, qb, dob, ts, qt + 2, N, tid); stat_load(qt + 2); }
+        if (st + 2 < nstage) { as_tile_load<D, NT, TR>(rq, rdo, qb, dob, ts, st + 2, N, tid); stat_load(st + 2); }
     }
     if (kok) {
         as_store_t<D>(p.dk + base + key * ts, h2, dk, p.scale);
@@ -322,20 +370,21 @@ __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
     }
 }
 
-template <int D, int NT>
+template <int D, int NT, int TR>
 static int as_forward(const ASParams &p, int64_t BH, hipStream_t s) {
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<D, NT>), dim3((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2)), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<D, NT, TR>), dim3((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2)), dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
-template <int D, int NT>
+template <int D, int NT, int TR>
 static int as_backward(const ASParams &p, int64_t BH, hipStream_t s) {
     const dim3 grid((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2));
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, NT>), grid, dim3(NT), 0, s, p);    // also writes delta, read by the next kernel
-    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT>), grid, dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, NT, TR>), grid, dim3(NT), 0, s, p);    // also writes delta, read by the next kernel
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT, 32>), grid, dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
+constexpr int AS_WIDE_TR = 128;   // streamed rows per stage of the 8-wave kernels
 // VSDE_ATTN_STREAM_NT=256: four-wave workgroups for head_dim 128 too (A/B runs)
 static bool as_wide() {
     static int v = -1;
@@ -348,8 +397,8 @@ int launch_attention_stream_fwd(const void *q, const void *k, const void *v, voi
     ASParams p = {};
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.out = (uint16_t *)o; p.lse = lse;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    if (D == 64) return as_forward<64, 256>(p, B * H, s);
-    return as_wide() ? as_forward<128, 512>(p, B * H, s) : as_forward<128, 256>(p, B * H, s);
+    if (D == 64) return as_forward<64, 256, 32>(p, B * H, s);
+    return as_wide() ? as_forward<128, 512, AS_WIDE_TR>(p, B * H, s) : as_forward<128, 256, 32>(p, B * H, s);
 }
 
 int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, const void *v, const void *o, const float *lse, void *dq,
@@ -358,8 +407,8 @@ int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, 
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o; p.dout = (const uint16_t *)dout;
     p.lse_in = lse; p.delta = delta; p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    if (D == 64) return as_backward<64, 256>(p, B * H, s);
-    return as_wide() ? as_backward<128, 512>(p, B * H, s) : as_backward<128, 256>(p, B * H, s);
+    if (D == 64) return as_backward<64, 256, 32>(p, B * H, s);
+    return as_wide() ? as_backward<128, 512, AS_WIDE_TR>(p, B * H, s) : as_backward<128, 256, 32>(p, B * H, s);
 }
 
 }  // namespace vsde
