@@ -276,14 +276,17 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
         const int kt = st * SUBS + sub;
         if (kt >= p.ntile) break;
         const uint16_t *kt_ = Ks + (st & 1) * TILE + sub * 32 * LD, *vt_ = Vs + (st & 1) * TILE + sub * 32 * LD;
-        const f32x16 stl = as_product<D>(kt_ + fr * LD + h2 * 8, qf);    // S^T  [key][query]
+        f32x16 stl = as_product<D>(kt_ + fr * LD + h2 * 8, qf);          // S^T  [key][query]
         const f32x16 dpt = as_product<D>(vt_ + fr * LD + h2 * 8, dof);   // dP^T [key][query]
+        if (ragged && kt == p.ntile - 1) {   // wave-uniform branch: zero rows of K have P != 0 -- score -inf makes it 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) stl[r] = -INFINITY;
+            asm volatile("" ::: "memory");   // keeps the branch (if-converted, the mask instructions would run for every tile)
+        }
         float ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
-            if (ragged && kt == p.ntile - 1 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;   // zero rows of K: P != 0
-        }
+        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
         bf16x8 b0, b1;
         as_pack_tile(ds, b0, b1);
         as_accumulate_t<D>(kt_, lane, b0, b1, acc);   // dQ^T += K^T dS^T
