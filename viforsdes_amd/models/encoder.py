@@ -40,18 +40,39 @@ class ObservationContextEncoder(nn.Module):
                     dtype: torch.dtype) -> Tensor:
         """``[T+1, C]`` tokens shared by all batch rows (reference: encoder.py:70-81)."""
         n = int(round(time_horizon / time_step)) + 1
-        grid = torch.linspace(0, time_horizon, n, device=obs_values.device, dtype=dtype)
         idx = torch.round(obs_times / time_step).long().clamp(max=n - 1)
         tokens = self.bridge_token.to(dtype).expand(n, -1).index_put((idx,), self.obs_proj(obs_values).to(dtype))
-        return tokens + self.time_embed(grid).to(dtype)
+        return tokens + self._grid_embedding(n, float(time_horizon), obs_values.device, dtype)
+
+    def _grid_embedding(self, n: int, time_horizon: float, device: torch.device, dtype: torch.dtype) -> Tensor:
+        """Sinusoidal embedding of the time grid: a parameter-free function of (n, horizon), computed once per grid instead of nine
+        small kernels per step."""
+        key = (n, time_horizon, device, dtype, torch.is_autocast_enabled())
+        cache = self.__dict__.setdefault("_grid_embed_cache", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            grid = torch.linspace(0, time_horizon, n, device=device, dtype=dtype)
+            cache[key] = self.time_embed(grid).to(dtype).detach()
+        return cache[key]
+
+    def _rotary(self, n: int, device: torch.device) -> RotarySpec:
+        """Rotary tables of the first n positions (the spec caches its contiguous cos / sin copies: keep the spec across steps)."""
+        key = (n, device)
+        cache = self.__dict__.setdefault("_rotary_cache", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            freqs = self.rope_freqs
+            if n > freqs.shape[0]:
+                freqs = precompute_freq_cis(self.hidden_dim // self.num_heads, end=n, device=device)
+            cache[key] = RotarySpec.from_freqs(freqs[:n])
+        return cache[key]
 
     def forward(self, obs_values: Tensor, obs_times: Tensor, sde_parameters: Tensor, time_horizon: float,
                 time_step: float) -> Tensor:
         B = sde_parameters.shape[0]
         tokens = self.grid_tokens(obs_values, obs_times, time_horizon, time_step, sde_parameters.dtype)
         n = tokens.shape[0]
-        freqs = self.rope_freqs
-        if n > freqs.shape[0]:
-            freqs = precompute_freq_cis(self.hidden_dim // self.num_heads, end=n, device=tokens.device)
         cond = self.sde_param_proj(sde_parameters)  # [B, cond], broadcast over tokens inside the blocks
-        return self.sit(tokens.unsqueeze(0).expand(B, -1, -1), cond=cond, rotary=RotarySpec.from_freqs(freqs[:n]), row_tokens=tokens)
+        return self.sit(tokens.unsqueeze(0).expand(B, -1, -1), cond=cond, rotary=self._rotary(n, tokens.device), row_tokens=tokens)
