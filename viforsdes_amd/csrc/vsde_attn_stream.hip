@@ -299,10 +299,12 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------- backward: dk, dv
-template <int D, int NT, int TR>
+template <int D, int NT, int TR, bool VLDS>
 __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
     constexpr int LD = ASCfg<D>::LD, DB = ASCfg<D>::DB, TILE = TR * LD, SUBS = TR / 32;   // TR streamed rows per stage (one barrier)
     __shared__ __attribute__((aligned(16))) uint16_t Qs[2 * TILE], Os[2 * TILE];
+    // VLDS: the owned V rows wait in LDS instead of 32 registers per lane (the B fragments of dP = dO V^T are read per tile)
+    __shared__ __attribute__((aligned(16))) uint16_t Vown[VLDS ? (NT / 2) * LD : 8];
     __shared__ __attribute__((aligned(16))) float lse2s[2 * TR], dels[2 * TR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     int pair, blk;
@@ -312,9 +314,18 @@ __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
     const uint16_t *qb = p.q + base, *dob = p.dout + base;
     const int key = blk * (NT / 2) + wave * 32 + fr;
     const bool kok = key < N;
-    bf16x8 kf[D / 16], vf[D / 16];
+    bf16x8 kf[D / 16], vf[VLDS ? 1 : D / 16];
     as_load_frag<D>(p.k + base, ts, key, kok, h2, kf);
-    as_load_frag<D>(p.v + base, ts, key, kok, h2, vf);
+    if constexpr (VLDS) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (kok) t = *(const uint4 *)(p.v + base + key * ts + ks * 16 + h2 * 8);
+            *(uint4 *)(Vown + (wave * 32 + fr) * LD + ks * 16 + h2 * 8) = t;   // read back by this wave only
+        }
+    } else {
+        as_load_frag<D>(p.v + base, ts, key, kok, h2, *(bf16x8(*)[D / 16]) & vf);
+    }
     u32x4 rq[TR * (D / 8) / NT], rdo[TR * (D / 8) / NT];
     float rl = 0.f, rd = 0.f;   // per-query statistics of the tile in flight (threads 0..31)
     auto stat_load = [&](int t) {
@@ -343,7 +354,16 @@ __global__ void __launch_bounds__(NT) attn_bwd_dkv_stream_kernel(ASParams p) {
         if (st * SUBS + sub >= p.ntile) break;
         const uint16_t *qt_ = Qs + buf * TILE + sub * 32 * LD, *dot_ = Os + buf * TILE + sub * 32 * LD;
         const f32x16 sc = as_product<D>(qt_ + fr * LD + h2 * 8, kf);     // S  [query][key]
-        const f32x16 dp = as_product<D>(dot_ + fr * LD + h2 * 8, vf);    // dP [query][key]
+        f32x16 dp;                                                        // dP [query][key]
+        if constexpr (VLDS) {
+            dp = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const uint16_t *arow = dot_ + fr * LD + h2 * 8, *brow = Vown + (wave * 32 + fr) * LD + h2 * 8;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks)
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(arow + ks * 16), *(const bf16x8 *)(brow + ks * 16), dp, 0, 0, 0);
+        } else {
+            dp = as_product<D>(dot_ + fr * LD + h2 * 8, *(const bf16x8(*)[D / 16]) & vf);
+        }
         float pr[16], ds[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {   // registers 4g..4g+3 are queries 8g + 4h2 + 0..3 of the tile
@@ -383,7 +403,7 @@ template <int D, int NT, int TR>
 static int as_backward(const ASParams &p, int64_t BH, hipStream_t s) {
     const dim3 grid((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2));
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, NT, TR>), grid, dim3(NT), 0, s, p);    // also writes delta, read by the next kernel
-    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT, 32>), grid, dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT, 32, (D == 128 && NT == 512)>), grid, dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
