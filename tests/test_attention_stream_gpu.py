@@ -42,7 +42,9 @@ def _check(q, k, v, go, scale):
 
 
 @pytest.mark.parametrize("B,N,H,D", [(3, 1001, 4, 128), (2, 545, 2, 64), (2, 100, 2, 128), (1, 33, 1, 128), (2, 1, 2, 128),
-                                      (1, 640, 1, 64), (2, 257, 3, 128)])
+                                      (1, 640, 1, 64), (2, 257, 3, 128),
+                                      # pair counts that are multiples of 8 take the XCD-aware (pair, block) mapping
+                                      (4, 1001, 4, 128), (8, 300, 2, 128), (2, 513, 4, 128), (4, 600, 2, 64), (8, 31, 1, 128)])
 def test_streamed_attention_vs_fp32_softmax(B, N, H, D):
     g = torch.Generator().manual_seed(N + D)
     q, k, v, go = (torch.randn(B, N, H, D, generator=g).to(DEV, torch.bfloat16) for _ in range(4))
