@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from viforsdes_amd import _hip
-B, N, H, D = 256, 1001, 4, 128
+B, N, H, D = (int(os.environ.get("AS_" + k, v)) for k, v in (("B", 256), ("N", 1001), ("H", 4), ("D", 128)))
 g = torch.Generator().manual_seed(0)
 q, k, v, go = (torch.randn(B, N, H, D, generator=g).to("cuda:0", torch.bfloat16) for _ in range(4))
 def t(fn, n=10):

@@ -30,8 +30,6 @@ template <int D, int NT = 256> struct ASCfg {
     static constexpr int DB = D / 32;            // 32-channel blocks of an accumulator
     static constexpr int LD = D == 64 ? 72 : 144;   // LDS row stride (bf16): conflict-free ds_read_b64_tr_b16, <= 2-way ds_read_b128
     static constexpr int CH = D / 8;             // 16-byte chunks per row
-    static constexpr int NLD = 32 * CH / NT;     // chunks per thread and 32-row tile (1 or 2)
-    static_assert(32 * CH % NT == 0, "a 32-row tile must split evenly over the workgroup");
 };
 
 struct ASParams {
@@ -403,12 +401,13 @@ template <int D, int NT, int TR>
 static int as_backward(const ASParams &p, int64_t BH, hipStream_t s) {
     const dim3 grid((unsigned)BH, (p.N + NT / 2 - 1) / (NT / 2));
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<D, NT, TR>), grid, dim3(NT), 0, s, p);    // also writes delta, read by the next kernel
-    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT, 32, (D == 128 && NT == 512)>), grid, dim3(NT), 0, s, p);
+    // head_dim 128: no registers for wider stages, V rows in LDS; head_dim 64 has both to spare
+    hipLaunchKernelGGL((attn_bwd_dkv_stream_kernel<D, NT, (D == 64 && NT == 512) ? 128 : 32, (D == 128 && NT == 512)>), grid, dim3(NT), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 constexpr int AS_WIDE_TR = 128;   // streamed rows per stage of the 8-wave kernels
-// VSDE_ATTN_STREAM_NT=256: four-wave workgroups for head_dim 128 too (A/B runs)
+// VSDE_ATTN_STREAM_NT=256: four-wave workgroups with 32-token stages (A/B runs)
 static bool as_wide() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("VSDE_ATTN_STREAM_NT"); v = e ? (atoi(e) == 512) : 1; }
@@ -420,7 +419,7 @@ int launch_attention_stream_fwd(const void *q, const void *k, const void *v, voi
     ASParams p = {};
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.out = (uint16_t *)o; p.lse = lse;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    if (D == 64) return as_forward<64, 256, 32>(p, B * H, s);
+    if (D == 64) return as_wide() ? as_forward<64, 512, AS_WIDE_TR>(p, B * H, s) : as_forward<64, 256, 32>(p, B * H, s);
     return as_wide() ? as_forward<128, 512, AS_WIDE_TR>(p, B * H, s) : as_forward<128, 256, 32>(p, B * H, s);
 }
 
@@ -430,7 +429,7 @@ int launch_attention_stream_bwd(const void *dout, const void *q, const void *k, 
     p.q = (const uint16_t *)q; p.k = (const uint16_t *)k; p.v = (const uint16_t *)v; p.o = (const uint16_t *)o; p.dout = (const uint16_t *)dout;
     p.lse_in = lse; p.delta = delta; p.dq = (uint16_t *)dq; p.dk = (uint16_t *)dk; p.dv = (uint16_t *)dv;
     p.N = N; p.H = H; p.ntile = (N + 31) / 32; p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
-    if (D == 64) return as_backward<64, 256, 32>(p, B * H, s);
+    if (D == 64) return as_wide() ? as_backward<64, 512, AS_WIDE_TR>(p, B * H, s) : as_backward<64, 256, 32>(p, B * H, s);
     return as_wide() ? as_backward<128, 512, AS_WIDE_TR>(p, B * H, s) : as_backward<128, 256, 32>(p, B * H, s);
 }
 
