@@ -182,8 +182,6 @@ __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
         const int kt = st * SUBS + sub;
         if (kt >= p.ntile) break;   // the last stage's tail lies beyond the sequence (workgroup-uniform)
         const uint16_t *vt_ = Vs + (st & 1) * TILE + sub * 32 * LD;
-        f32x16 sn = s;
-        if (sub + 1 < SUBS && kt + 1 < p.ntile) sn = as_product<D>(Ks + (st & 1) * TILE + (sub + 1) * 32 * LD + fr * LD + h2 * 8, qf);
         if (ragged && kt == p.ntile - 1) {   // wave-uniform branch: only the last tile pays for the mask
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -203,6 +201,10 @@ __global__ void __launch_bounds__(NT) attn_fwd_stream_kernel(ASParams p) {
                 for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
             m = mn;
         }
+        // the next sub-tile's score product shares a basic block with the exponentials (no branch between them)
+        f32x16 sn = s;
+        // (unconditional inside a stage: beyond the sequence it multiplies stale rows and nobody reads the result)
+        if (sub + 1 < SUBS) sn = as_product<D>(Ks + (st & 1) * TILE + (sub + 1) * 32 * LD + fr * LD + h2 * 8, qf);
         float pr[16], l2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -269,6 +271,10 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[db][e] = 0.f;
     for (int st = 0; st < nstage; ++st) {
+        // dQ^T += K^T dS^T of sub-tile i - 1 is issued together with the exponentials of sub-tile i (one basic block: the matrix
+        // pipe and the VALU then overlap inside the wave, see the forward kernel); the last one of a stage follows the loop
+        bf16x8 pb0 = {0, 0, 0, 0, 0, 0, 0, 0}, pb1 = pb0;
+        int done = 0;
 #pragma unroll
       for (int sub = 0; sub < SUBS; ++sub) {
         const int kt = st * SUBS + sub;
@@ -282,13 +288,14 @@ __global__ void __launch_bounds__(NT) attn_bwd_dq_stream_kernel(ASParams p) {
                 if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) stl[r] = -INFINITY;
             asm volatile("" ::: "memory");   // keeps the branch (if-converted, the mask instructions would run for every tile)
         }
+        if (sub > 0) as_accumulate_t<D>(kt_ - 32 * LD, lane, pb0, pb1, acc);   // sub-tile i - 1 (zero fragments would also be harmless)
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
-        bf16x8 b0, b1;
-        as_pack_tile(ds, b0, b1);
-        as_accumulate_t<D>(kt_, lane, b0, b1, acc);   // dQ^T += K^T dS^T
+        as_pack_tile(ds, pb0, pb1);
+        done = sub + 1;
       }
+        as_accumulate_t<D>(Ks + (st & 1) * TILE + (done - 1) * 32 * LD, lane, pb0, pb1, acc);   // dQ^T += K^T dS^T, last sub-tile
         if (st + 1 < nstage) as_tile_store<D, NT, TR>(rk, rv, Ks + ((st + 1) & 1) * TILE, Vs + ((st + 1) & 1) * TILE, tid);
         as_barrier();
         if (st + 2 < nstage) as_tile_load<D, NT, TR>(rk, rv, kb, vb, ts, st + 2, N, tid);
