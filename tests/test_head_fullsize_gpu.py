@@ -36,6 +36,10 @@ WORKLOADS = {
     "ou_like_l1": (12, 4, 48, 1, 256, 3, 64, 1, 0.05, True, 5e-5, 2e-4),
     "s3_l3_fp32ctx": (8, 4, 32, 3, 128, 5, 64, 3, 0.05, False, 5e-5, 2e-4),
     "c64_t16": (6, 2, 16, 2, 64, 3, 64, 2, 0.1, False, 5e-5, 2e-4),
+    # emission rows wider than 16 (state dimensions 5..9): the swapped weight-gradient tile is split into 16-column pieces
+    # (20 = 16 + 4 and 54 = 3 x 16 + 6 columns)
+    "s5_l1": (8, 4, 32, 5, 128, 4, 64, 1, 0.05, False, 5e-5, 2e-4),
+    "s9_l2": (8, 4, 32, 9, 64, 5, 64, 2, 0.05, True, 5e-5, 2e-4),
 }
 TF_FWD_TOL, TF_BWD_TOL = 2e-5, 2e-4
 

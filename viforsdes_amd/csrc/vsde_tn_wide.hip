@@ -31,7 +31,7 @@ constexpr int TW_LDX = TW_N + 16, TW_LDY = TW_K + 16;   // row pitches (floats),
                                                          // 32-lane ds_read_b32 group touches fall on disjoint banks
 constexpr int TW_BUF = TW_BM * (TW_LDX + TW_LDY);        // floats per buffer
 constexpr int TW_PART = TW_N * TW_K + TW_N;              // partial tile + bias row
-constexpr int TW_MAXTILES = 16;
+constexpr int TW_MAXTILES = 24;
 
 struct TwTile {
     const float *x;          // X view base
@@ -289,20 +289,22 @@ __global__ void __launch_bounds__(256) tn_wide_reduce_kernel(TwArgs a) {
 
 // ---- planning -----------------------------------------------------------------------------------------------------------
 // kind of a problem by its shapes only (the same answer for the sizing call with dummy pointers and for the launch):
-//   0: NX = 192, NY % 64 == 0 (NY / 64 tiles)   1: NX = 192, NY <= 16   2: NX <= 16, NY = 64 (roles swapped)   -1: not ours
+//   0: NX = 192, NY % 64 == 0 (NY / 64 tiles)   1: NX = 192, NY <= 16   2: NX <= 64, NY = 64 (roles swapped; one tile per 16 columns
+//   of the narrow operand: the emission rows of state dimensions 5..9 are 20..54 wide)   -1: not ours
 static int tw_kind(const TnProblem &q) {
     if (q.NX == TW_N && q.NY > 0 && q.NY % TW_K == 0) return 0;
     if (q.NX == TW_N && q.NY > 0 && q.NY <= 16) return 1;
-    if (q.NX > 0 && q.NX <= 16 && q.NY == 64) return 2;
+    if (q.NX > 0 && q.NX <= 64 && q.NY == 64) return 2;
     return -1;
 }
+static int tw_ntiles(const TnProblem &q, int kind) { return kind == 0 ? q.NY / TW_K : (kind == 2 ? (q.NX + 15) / 16 : 1); }
 static bool tw_plan_shapes(const TnProblem *probs, int nprob, int &tiles) {
     tiles = 0;
     bool any_wide = false;
     for (int i = 0; i < nprob; ++i) {
         const int k = tw_kind(probs[i]);
         if (k < 0) return false;
-        tiles += k == 0 ? probs[i].NY / TW_K : 1;
+        tiles += tw_ntiles(probs[i], k);
         any_wide |= k == 0;
     }
     return any_wide && tiles <= TW_MAXTILES;
@@ -327,7 +329,7 @@ static int tw_tile_kinds(const TnProblem *probs, int nprob, int *kinds) {
     int nt = 0;
     for (int i = 0; i < nprob; ++i) {
         const int k = tw_kind(probs[i]);
-        for (int kt = 0; kt < (k == 0 ? probs[i].NY / TW_K : 1); ++kt) kinds[nt++] = k;
+        for (int kt = 0; kt < tw_ntiles(probs[i], k); ++kt) kinds[nt++] = k;
     }
     return nt;
 }
@@ -366,15 +368,22 @@ int launch_tn_wide(const TnProblem *probs, int nprob, int M, void *workspace, si
         if (X.dtype != 0 || (uintptr_t)X.base % 16 || X.batch_stride % 4 || X.row_stride % 4 || X.shift != 0 || Y.shift > 0) return 0;
         if (X.col_split < nx && (X.col_split % 4 || X.col_skip % 4)) return 0;
         if (kind == 0 ? !tw_vec_view(Y, ny, Y.dtype == 0 ? 16 : 8) : (Y.dtype != 0 || Y.col_split < ny)) return 0;
-        for (int kt = 0; kt < (kind == 0 ? q.NY / TW_K : 1); ++kt) {
+        for (int kt = 0; kt < tw_ntiles(q, kind); ++kt) {
             TwTile &t = a.tile[nt++];
-            t.kind = kind; t.ny = ny;
+            // kind 0: tile kt = columns 64 kt.. of the wide Y; kind 2: tile kt = columns 16 kt.. of the narrow operand = rows of out
+            const int yoff = kind == 0 ? kt * TW_K : (kind == 2 ? kt * 16 : 0);
+            t.kind = kind; t.ny = kind == 2 ? (ny - yoff < 16 ? ny - yoff : 16) : ny;
             t.x = (const float *)X.base; t.xbs = X.batch_stride; t.xrs = X.row_stride; t.xshift = X.shift;
             t.x_split = X.col_split < nx ? X.col_split : nx; t.x_skip = X.col_split < nx ? X.col_skip : 0;
             t.y_bf16 = Y.dtype != 0;
-            t.y = Y.dtype == 0 ? (const void *)((const float *)Y.base + kt * TW_K) : (const void *)((const uint16_t *)Y.base + kt * TW_K);
+            t.y = Y.dtype == 0 ? (const void *)((const float *)Y.base + yoff) : (const void *)((const uint16_t *)Y.base + yoff);
             t.ybs = Y.batch_stride; t.yrs = Y.row_stride; t.yshift = Y.shift;
-            t.out = q.out; t.ldo = q.ldo; t.col_off = q.col_off + kt * TW_K; t.bias_out = kt == 0 ? q.bias_out : nullptr;
+            if (kind == 2) {
+                t.out = q.out + (int64_t)yoff * q.ldo; t.ldo = q.ldo; t.col_off = q.col_off;
+                t.bias_out = q.bias_out ? q.bias_out + yoff : nullptr;
+            } else {
+                t.out = q.out; t.ldo = q.ldo; t.col_off = q.col_off + kt * TW_K; t.bias_out = kt == 0 ? q.bias_out : nullptr;
+            }
         }
     }
     a.ntiles = nt; a.M = M; a.T = T; a.chunks = ((int64_t)M + TW_BM - 1) / TW_BM;
