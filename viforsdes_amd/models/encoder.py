@@ -50,10 +50,13 @@ class ObservationContextEncoder(nn.Module):
         key = (n, time_horizon, device, dtype, torch.is_autocast_enabled())
         cache = self.__dict__.setdefault("_grid_embed_cache", {})
         if key not in cache:
+            grid = torch.linspace(0, time_horizon, n, device=device, dtype=dtype)
+            value = self.time_embed(grid).to(dtype).detach()
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return value   # memory of a graph's private pool: valid for that graph only, never cached
             if len(cache) >= 8:
                 cache.clear()
-            grid = torch.linspace(0, time_horizon, n, device=device, dtype=dtype)
-            cache[key] = self.time_embed(grid).to(dtype).detach()
+            cache[key] = value
         return cache[key]
 
     def _rotary(self, n: int, device: torch.device) -> RotarySpec:
@@ -66,7 +69,10 @@ class ObservationContextEncoder(nn.Module):
             freqs = self.rope_freqs
             if n > freqs.shape[0]:
                 freqs = precompute_freq_cis(self.hidden_dim // self.num_heads, end=n, device=device)
-            cache[key] = RotarySpec.from_freqs(freqs[:n])
+            spec = RotarySpec.from_freqs(freqs[:n])
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                return spec    # its cos / sin copies would live in the capturing graph's pool
+            cache[key] = spec
         return cache[key]
 
     def forward(self, obs_values: Tensor, obs_times: Tensor, sde_parameters: Tensor, time_horizon: float,
