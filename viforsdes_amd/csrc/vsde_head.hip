@@ -1083,7 +1083,8 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
             float dcur = 0.f;  // d h_top[i] = sum_r dO_r out_W[r][i]
             if (WIDE) {
                 __syncthreads();  // the rows live in different waves: exchange through the staged record
-                for (int r = 0; r < NO; ++r) dcur = fmaf(s_dO[tt * NO + r], owl[r * 64 + i_unit], dcur);
+                for (int r = kq; r < NO; r += 4) dcur = fmaf(s_dO[tt * NO + r], owl[r * 64 + i_unit], dcur);   // a quarter of the rows per lane
+                dcur = quad_sum(dcur);
             } else {
                 for (int r = 0; r < NO; ++r)
                     dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
