@@ -894,7 +894,7 @@ __host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool
     auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
     o.acts = take((two_act_buffers ? 2 : 1) * (CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
     o.gp = take(CH * S); o.gm = take(CH * S); o.gl = take(CH * S * S); o.raw = take(CH * ntril); o.eps = take(CH * S);
-    o.owl = take(NO * 64); o.dxp = take(4 * 16);
+    o.owl = take(NO * 64); o.dxp = take(wide ? 16 * 16 : 4 * 16);   // wide: [state component][wave x 16-lane row] partial sums
     o.wxl = take(wide ? S * 3 * 64 : 0);  // wide variant: state rows of W_ih_l0 live in LDS
     o.total = off;
     return o;
@@ -1107,11 +1107,15 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                     spi[0] += dr_pre; spi[1] += du_pre; spi[2] += dn_pre;
                     // d z_t += W_ih_l0[:, state rows]^T . d_pre (backward.py:494-509): per-wave partial sums
                     if (WIDE) {
+                        // the four quads of every 16-lane row are folded with two DPP adds; the 16 row sums per state component
+                        // (4 waves x 4 rows) are added by the lane that consumes them, after the barrier below -- v_readlane +
+                        // scalar adds per component sat on the critical path
                         for (int i = 0; i < S; ++i) {
                             const float *wx = wxl + i * 192 + i_unit;
                             float v = wx[0] * dr_pre + wx[64] * du_pre + wx[128] * dn_pre;
-                            v = wave_sum_of_quads(v);
-                            if (lane == 0) dxp[wave * 16 + i] = v;
+                            v = dpp_add<0x141>(v);  // row_half_mirror
+                            v = dpp_add<0x140>(v);  // row_mirror: lanes 0 / 16 / 32 / 48 hold their row's sum over its four units
+                            if ((lane & 15) == 0) dxp[i * 16 + wave * 4 + (lane >> 4)] = v;
                         }
                     } else {
 #pragma unroll
@@ -1168,7 +1172,14 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                     dcur = quad_sum(sy);
                 } else {
                     dh[0] = carry + quad_sum(sx + sy);
-                    if (lane < S) dxreg += dxp[lane] + dxp[16 + lane] + dxp[32 + lane] + dxp[48 + lane];
+                    if (WIDE) {
+                        if (lane < S) {
+                            const float4 q0 = *(const float4 *)(dxp + lane * 16), q1 = *(const float4 *)(dxp + lane * 16 + 4);
+                            const float4 q2 = *(const float4 *)(dxp + lane * 16 + 8), q3 = *(const float4 *)(dxp + lane * 16 + 12);
+                            dxreg += (((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w))) +
+                                     (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
+                        }
+                    } else if (lane < S) dxreg += dxp[lane] + dxp[16 + lane] + dxp[32 + lane] + dxp[48 + lane];
                 }
                 VSDE_TPB(25 + 3 * (L - 1 - l));
             }
