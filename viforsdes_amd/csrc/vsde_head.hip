@@ -1066,9 +1066,15 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
             // ---- upstream gradients for this step (backward.py:257-349); every wave redundantly
             if (lane < S) dxreg += s_gp[tt * S + lane];
             float mydx = 0.f;
-            for (int i = 0; i < S; ++i) {
-                const float dxi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dxreg), i));
-                if ((orow < S ? orow : trow) == i) mydx = dxi;
+            if (WIDE) {   // one cross-lane read instead of S x (v_readlane, compare, select)
+                const int sel = orow < S ? orow : trow;
+                mydx = __shfl(dxreg, (sel >= 0 && sel < S) ? sel : 0, 64);
+                if (!(sel >= 0 && sel < S)) mydx = 0.f;
+            } else {
+                for (int i = 0; i < S; ++i) {
+                    const float dxi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dxreg), i));
+                    if ((orow < S ? orow : trow) == i) mydx = dxi;
+                }
             }
             float dO = 0.f;
             if (orow < S) dO = mydx * p.dt + s_gm[tt * S + orow];
