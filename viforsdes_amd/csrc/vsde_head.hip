@@ -1066,7 +1066,7 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
             // ---- upstream gradients for this step (backward.py:257-349); every wave redundantly
             if (lane < S) dxreg += s_gp[tt * S + lane];
             float mydx = 0.f;
-            if (WIDE) {   // one cross-lane read instead of S x (v_readlane, compare, select)
+            if (WIDE || SS == 0) {   // run-time state dimension: one cross-lane read instead of S x (v_readlane, compare, select)
                 const int sel = orow < S ? orow : trow;
                 mydx = __shfl(dxreg, (sel >= 0 && sel < S) ? sel : 0, 64);
                 if (!(sel >= 0 && sel < S)) mydx = 0.f;
