@@ -4,11 +4,11 @@ import ctypes, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = "/tmp/libvsde_trace.so"
+so = os.path.join(ROOT, "tools", "libvsde_trace.so")   # built here or shipped prebuilt (hipcc -DVSDE_TRACE)
 sys.path.insert(0, ROOT)
 from viforsdes_amd.build import SOURCES
 src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in SOURCES]
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
+if not os.path.exists(so): subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
 import viforsdes_amd.build as b
 b.LIB_PATH = so
 from viforsdes_amd import _hip

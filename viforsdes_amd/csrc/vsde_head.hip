@@ -596,6 +596,16 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
         wol[r * kWoStride + kk] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
     }
     const float *wop = wol + (row_ok ? orow : NO) * kWoStride + k0;
+    // wide variant (NO > 16, S <= 9): element e = lane, 64 + lane of the dense Cholesky block reads obuf[cidx] (-1: strict upper
+    // triangle = 0, -2: beyond S * S) -- the division by the run-time S happens here, not in wave 1's every time step
+    int cidx[2] = {-2, -2};
+    if (!SMALL) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = 64 * q + lane;
+            if (e < S * S) { const int rr = e / S, cl = e - rr * S; cidx[q] = cl <= rr ? S + rr * (rr + 1) / 2 + cl : -1; }
+        }
+    }
     // biases enter through the accumulators: only lane kq == 0 of a quad carries them into the quad sum
     float bhh[L][3], bih[L][3];
 #pragma unroll
@@ -614,7 +624,10 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
     }
     for (int e = tid; e < S * 3 * 64; e += 256) {  // state rows of W_ih_l0: wxl[i][g][unit]
         int un = e & 63, g = (e >> 6) % 3, i = e / 192;
-        wxl[e] = un < H ? gsc[g] * p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
+        // wide variant: the four lanes of a quad read four different i (= kq mod 4) of the same unit: rotating the unit index by
+        // 16 (i & 3) puts them on different banks
+        const int slot = SMALL ? un : ((un + 16 * (i & 3)) & 63);
+        wxl[(e - un) + slot] = un < H ? gsc[g] * p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
     }
     float wxr[SSN][3], xu[SSN];  // SS > 0: state rows of W_ih_l0 and z_t as wave-uniform values
 #pragma unroll
@@ -640,8 +653,11 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) cc[l][g] = quad_sum(bhh[l][g]);   // W_hh h_{-1} + b_hh with h_{-1} = 0
     }
-    float xreg = lane < S ? p.x0[(int64_t)b * S + lane] : 0.f;  // every wave keeps z_t[i] on its lane i
-    if (wave == 0 && lane < S) p.paths[(int64_t)b * (T + 1) * S + lane] = xreg;
+    // every wave keeps z_t[i] on its lane i -- wide variant: on the four lanes of its quad i (u = i)
+    const int xi_own = SMALL ? lane : u;
+    const bool x_own = SMALL ? lane < S : (u < S);
+    float xreg = x_own ? p.x0[(int64_t)b * S + xi_own] : 0.f;
+    if (wave == 0 && x_own && (SMALL || kq == 0)) p.paths[(int64_t)b * (T + 1) * S + xi_own] = xreg;
     __syncthreads();   // gthl complete
 
     // ---- chunked staging of the projected context record G[b, t, 3H] and eps ---------------
@@ -705,10 +721,30 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g) a[g] = fmaf(xu[i], wxr[i][g], a[g]);
             } else {
-                for (int i = 0; i < S; ++i) {
-                    const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xreg), i));
+                if (SMALL) {
+                    for (int i = 0; i < S; ++i) {
+                        const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xreg), i));
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) a[g] = fmaf(xi, wxl[(i * 3 + g) * 64 + j], a[g]);
+                        for (int g = 0; g < 3; ++g) a[g] = fmaf(xi, wxl[(i * 3 + g) * 64 + j], a[g]);
+                    }
+                } else {
+                    // S <= 12 here (NO <= 64 gives S <= 9).  Lane kq of a quad multiplies the components i = kq, kq + 4, kq + 8 (z_t[i]
+                    // from quad i by one cross-lane read each, all LDS reads in flight together), the quad adds up: a loop over
+                    // a run-time S waited for an LDS round trip per component and ran in all four lanes of the quad.
+                    float xs[3], wv[3][3], part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii) {
+                        const int i = kq + 4 * ii, ic = i < S ? i : 0;
+                        xs[ii] = __shfl(xreg, 4 * ic, 64);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) wv[ii][g] = wxl[(ic * 3 + g) * 64 + ((j + 16 * kq) & 63)];   // ic & 3 == kq (or 0: unused)
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) part[g] = (kq + 4 * ii) < S ? fmaf(xs[ii], wv[ii][g], part[g]) : part[g];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) a[g] += quad_sum(part[g]);
                 }
             }
             VSDE_TP(1);
@@ -825,19 +861,26 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
                 }
                 __syncthreads();
                 VSDE_TP(11);
-                if (lane < S) {
-                    float acc = 0.f;
-                    const int base = S + lane * (lane + 1) / 2;
-                    for (int q = 0; q <= lane; ++q) acc = fmaf(obuf[base + q], ech[tt * S + q], acc);
-                    const float mu = obuf[lane];
-                    xreg = xreg + mu * p.dt + acc * p.sqdt;
-                    if (wave == 0) { s_means[tt * S + lane] = mu; s_paths[tt * S + lane] = xreg; }
-                }
-                if (wave == 1) {
-                    for (int e = lane; e < S * S; e += 64) {
-                        int rr = e / S, cl = e - rr * S;
-                        s_chol[tt * S * S + e] = cl <= rr ? obuf[S + rr * (rr + 1) / 2 + cl] : 0.f;
+                if (u < S) {
+                    // row u of L_t eps_t by quad u: lane kq takes the columns kq, kq + 4, kq + 8 (<= u), the quad adds up; z_t[u] lives
+                    // on the quad's four lanes.  (A loop `q <= lane` on lane = row waited for an LDS round trip per column.)
+                    const int base = S + u * (u + 1) / 2;
+                    float lv[3], evv[3], acc = 0.f;
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii) {
+                        const int q = kq + 4 * ii, qc = q <= u ? q : 0;
+                        lv[ii] = obuf[base + qc]; evv[ii] = ech[tt * S + qc];
                     }
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii) acc = (kq + 4 * ii) <= u ? fmaf(lv[ii], evv[ii], acc) : acc;
+                    acc = quad_sum(acc);
+                    const float mu = obuf[u];
+                    xreg = xreg + mu * p.dt + acc * p.sqdt;
+                    if (wave == 0 && kq == 0) { s_means[tt * S + u] = mu; s_paths[tt * S + u] = xreg; }
+                }
+                if (wave == 1) {   // L_t as a dense [S][S] block; the source index of each element is fixed (cidx, set up once)
+                    if (cidx[0] >= -1) s_chol[tt * S * S + lane] = cidx[0] >= 0 ? obuf[cidx[0]] : 0.f;
+                    if (cidx[1] >= -1) s_chol[tt * S * S + 64 + lane] = cidx[1] >= 0 ? obuf[cidx[1]] : 0.f;
                 }
             }
             VSDE_TP(12);
