@@ -3,15 +3,16 @@ import ctypes, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = "/tmp/libvsde_trace.so"
-src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in ("vsde_gemm.hip", "vsde_head.hip", "vsde_elbo.hip", "vsde_encoder.hip", "vsde_wgrad.hip", "vsde_attn.hip")]
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
+so = os.path.join(ROOT, "tools", "libvsde_trace.so")   # built here or shipped prebuilt (hipcc -DVSDE_TRACE)
+from viforsdes_amd.build import SOURCES
+src = [os.path.join(ROOT, "viforsdes_amd/csrc", f) for f in SOURCES]
+if not os.path.exists(so): subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DVSDE_TRACE", "-shared", "-fPIC", "-o", so] + src, check=True)
 import viforsdes_amd.build as b
 b.LIB_PATH = so
 from viforsdes_amd import _hip
 _hip.LIB_PATH = so
 dev = torch.device("cuda:0")
-B, T, S, C, P, H, L = 512, 400, int(sys.argv[1]) if len(sys.argv) > 1 else 2, 256, 3, 64, 2
+B, T, S, C, P, H, L = int(sys.argv[2]) if len(sys.argv) > 2 else 512, 400, int(sys.argv[1]) if len(sys.argv) > 1 else 2, 256, 3, 64, 2
 g = torch.Generator().manual_seed(0)
 rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
 NO = S + S * (S + 1) // 2

@@ -929,7 +929,7 @@ __global__ void __launch_bounds__(256, 2) head_fwd_v2_kernel(FwdParams p) {
 // the kernel's output), one workgroup barrier per layer.  All global traffic (saved activations,
 // upstream gradients in; D4/DO out) is staged per chunk of CH steps as contiguous bursts.
 struct BwdV2Lds {
-    int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, wxl, total;
+    int acts, d4, dO, gp, gm, gl, raw, eps, owl, dxp, wxl, dOT, total;
 };
 __host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool two_act_buffers = false, bool wide = false) {
     const int ntril = S * (S + 1) / 2, NO = S + ntril;
@@ -937,7 +937,10 @@ __host__ __device__ inline BwdV2Lds bwd_v2_lds(int H, int S, int L, int CH, bool
     auto take = [&](int n) { int r = off; off += (n + 3) & ~3; return r; };
     o.acts = take((two_act_buffers ? 2 : 1) * (CH + 1) * L * 5 * H); o.d4 = take(CH * L * 4 * H); o.dO = take(CH * NO);
     o.gp = take(CH * S); o.gm = take(CH * S); o.gl = take(CH * S * S); o.raw = take(CH * ntril); o.eps = take(CH * S);
-    o.owl = take(NO * 64); o.dxp = take(wide ? 16 * 16 : 4 * 16);   // wide: [state component][wave x 16-lane row] partial sums
+    // wide: the emission weights transposed per lane, [unit][kq][16 rows r = kq + 4 q] with a pitch of 20 floats (conflict-free
+    // ds_read_b128), and this step's dO in the same order [kq][16]
+    o.owl = take(wide ? 256 * 20 : NO * 64); o.dOT = take(wide ? 64 : 0);
+    o.dxp = take(wide ? 16 * 16 : 4 * 16);   // wide: [state component][wave x 16-lane row] partial sums
     o.wxl = take(wide ? S * 3 * 64 : 0);  // wide variant: state rows of W_ih_l0 live in LDS
     o.total = off;
     return o;
@@ -966,7 +969,7 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     float *s_acts = smem + lay.acts, *s_d4 = smem + lay.d4, *s_dO = smem + lay.dO;
     float *const acts_buf0 = smem + lay.acts;
     float *s_gp = smem + lay.gp, *s_gm = smem + lay.gm, *s_gl = smem + lay.gl, *s_raw = smem + lay.raw, *s_eps = smem + lay.eps;
-    float *owl = smem + lay.owl, *dxp = smem + lay.dxp, *wxl = smem + lay.wxl;
+    float *owl = smem + lay.owl, *dxp = smem + lay.dxp, *wxl = smem + lay.wxl, *dOT = smem + lay.dOT;
     const int REC = L * 5 * H, DREC = L * 4 * H;
     // For H < 64 a lane's 16-wide j-slice can reach past the H valid entries of a staged record; its
     // weights are zero there, so the data only has to be finite: start from an all-zero LDS image.
@@ -988,9 +991,16 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 wih[g][jj] = 0.f;
             }
         }
-    for (int e = tid; e < NO * 64; e += 256) {
-        int kk = e & 63, r = e >> 6;
-        owl[e] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
+    if (WIDE) {
+        for (int e = tid; e < 256 * 16; e += 256) {   // owl[(unit * 4 + kq) * 20 + q] = W_out[kq + 4 q][unit], zero beyond NO / H
+            const int q = e & 15, kqq = (e >> 4) & 3, un = e >> 6, r = kqq + 4 * q;
+            owl[(un * 4 + kqq) * 20 + q] = (r < NO && un < H) ? p.out_W[(int64_t)r * H + un] : 0.f;
+        }
+    } else {
+        for (int e = tid; e < NO * 64; e += 256) {
+            int kk = e & 63, r = e >> 6;
+            owl[e] = kk < H ? p.out_W[(int64_t)r * H + kk] : 0.f;
+        }
     }
     float wxr[kMaxSRegV2][3];  // state rows of W_ih_l0 for this lane's unit
 #pragma unroll
@@ -998,9 +1008,9 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
 #pragma unroll
         for (int i = 0; i < kMaxSRegV2; ++i) wxr[i][g] = (!WIDE && unit_ok && i < S) ? p.W_ih0[(int64_t)(g * H + i_unit) * I + i] : 0.f;
     if (WIDE)
-        for (int e = tid; e < S * 3 * 64; e += 256) {  // wxl[i][g][unit]
+        for (int e = tid; e < S * 3 * 64; e += 256) {  // wxl[i][g][unit rotated by 16 (i & 3)]: lane kq reads i = kq mod 4, see below
             const int un = e & 63, g = (e >> 6) % 3, i = e / 192;
-            wxl[e] = un < H ? p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
+            wxl[(e - un) + ((un + 16 * (i & 3)) & 63)] = un < H ? p.W_ih0[(int64_t)(g * H + un) * I + i] : 0.f;
         }
     int trow = 0, tcol = 0;
     if (orow >= S && orow < NO) {
@@ -1128,12 +1138,24 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                 dO = dL;
             }
             if ((WIDE || wave == 0) && kq == 0 && row_ok) s_dO[tt * NO + orow] = dO;
+            if (WIDE && kq == 0 && row_ok) dOT[(orow & 3) * 16 + (orow >> 2)] = dO;   // the order the lanes read it back in (rows >= NO stay 0)
             VSDE_TPB(21);
             float dcur = 0.f;  // d h_top[i] = sum_r dO_r out_W[r][i]
             if (WIDE) {
                 __syncthreads();  // the rows live in different waves: exchange through the staged record
-                for (int r = kq; r < NO; r += 4) dcur = fmaf(s_dO[tt * NO + r], owl[r * 64 + i_unit], dcur);   // a quarter of the rows per lane
-                dcur = quad_sum(dcur);
+                // a quarter of the rows per lane (r = kq + 4 q), weights and dO in that order: float4 reads, zero padding instead of
+                // a run-time trip count (a loop over the rows waited for two LDS round trips per row)
+                const float *wT = owl + (i_unit * 4 + kq) * 20, *dT = dOT + kq * 16;
+                float dc2 = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (hf == 1 && NO <= 32) break;   // rows 32.. exist from S = 7 on (workgroup-uniform)
+                    const float4 w0 = *(const float4 *)(wT + 8 * hf), w1 = *(const float4 *)(wT + 8 * hf + 4);
+                    const float4 d0 = *(const float4 *)(dT + 8 * hf), d1 = *(const float4 *)(dT + 8 * hf + 4);
+                    dcur = fmaf(d0.x, w0.x, dcur); dc2 = fmaf(d0.y, w0.y, dc2); dcur = fmaf(d0.z, w0.z, dcur); dc2 = fmaf(d0.w, w0.w, dc2);
+                    dcur = fmaf(d1.x, w1.x, dcur); dc2 = fmaf(d1.y, w1.y, dc2); dcur = fmaf(d1.z, w1.z, dcur); dc2 = fmaf(d1.w, w1.w, dc2);
+                }
+                dcur = quad_sum(dcur + dc2);
             } else {
                 for (int r = 0; r < NO; ++r)
                     dcur = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dO), 4 * r)), owl[r * 64 + i_unit], dcur);
@@ -1156,15 +1178,23 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
                     spi[0] += dr_pre; spi[1] += du_pre; spi[2] += dn_pre;
                     // d z_t += W_ih_l0[:, state rows]^T . d_pre (backward.py:494-509): per-wave partial sums
                     if (WIDE) {
-                        // the four quads of every 16-lane row are folded with two DPP adds; the 16 row sums per state component
-                        // (4 waves x 4 rows) are added by the lane that consumes them, after the barrier below -- v_readlane +
-                        // scalar adds per component sat on the critical path
-                        for (int i = 0; i < S; ++i) {
-                            const float *wx = wxl + i * 192 + i_unit;
-                            float v = wx[0] * dr_pre + wx[64] * du_pre + wx[128] * dn_pre;
-                            v = dpp_add<0x141>(v);  // row_half_mirror
-                            v = dpp_add<0x140>(v);  // row_mirror: lanes 0 / 16 / 32 / 48 hold their row's sum over its four units
-                            if ((lane & 15) == 0) dxp[i * 16 + wave * 4 + (lane >> 4)] = v;
+                        // lane kq of a quad takes the state components i = kq, kq + 4, kq + 8 (S <= 9 here; the four lanes of a quad hold the
+                        // same gate gradients), two DPP row rotations add the four units of a 16-lane row per kq, and the 16 row sums per
+                        // component (4 waves x 4 rows) are added by the lane that consumes them, after the barrier below.  (A loop over the
+                        // run-time S in every lane, with v_readlane + scalar adds per component, sat on the critical path.)
+                        float wv[3][3], v[3];
+#pragma unroll
+                        for (int ii = 0; ii < 3; ++ii) {
+                            const int i = kq + 4 * ii, ic = i < S ? i : 0;
+                            const float *wx = wxl + ic * 192 + ((i_unit + 16 * kq) & 63);
+                            wv[ii][0] = wx[0]; wv[ii][1] = wx[64]; wv[ii][2] = wx[128];
+                        }
+#pragma unroll
+                        for (int ii = 0; ii < 3; ++ii) {
+                            v[ii] = wv[ii][0] * dr_pre + wv[ii][1] * du_pre + wv[ii][2] * dn_pre;
+                            v[ii] = dpp_add<0x124>(v[ii]);   // row_ror:4
+                            v[ii] = dpp_add<0x128>(v[ii]);   // row_ror:8: every lane holds the sum over its row's four units for its kq
+                            if ((lane & 15) < 4 && kq + 4 * ii < S) dxp[(kq + 4 * ii) * 16 + wave * 4 + (lane >> 4)] = v[ii];
                         }
                     } else {
 #pragma unroll
@@ -1834,7 +1864,7 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
         int ch = 0;
         for (int pass = 0; pass < 2 && !ch; ++pass)
             for (int q = 0; q < 3 && !ch; ++q)
-                if ((size_t)bwd_v2_lds(d->H, d->S, d->L, cand[q], true, true).total * sizeof(float) <= (pass == 0 ? 80u : 150u) * 1024) ch = cand[q];
+                if ((size_t)bwd_v2_lds(d->H, d->S, d->L, cand[q], true, true).total * sizeof(float) <= (pass == 0 ? 80u : 156u) * 1024) ch = cand[q];
         VSDE_CHECK_ARG(ch != 0, VSDE_E_STATE, "LDS budget exceeded for the wide backward kernel");
         const size_t lds2 = (size_t)bwd_v2_lds(d->H, d->S, d->L, ch, true, true).total * sizeof(float);
 #define VSDE_LAUNCH_BWD_WIDE(LL, CC)                                                                                \
