@@ -58,9 +58,11 @@ constexpr int PJ_THREADS = 256;
 
 // ---------------------------------------------------------------------------------------------------- forward projection
 // KC = context width (A bf16), three weight planes; tile = 32 output columns x 3 KC; fp32 output.
-template <int KC>
+// NKH > 1: context width NKH * KC; a 32-column tile is multiplied in NKH k-slices of KC through the same LDS tile buffer.
+template <int KC, int NKH = 1>
 __global__ void __launch_bounds__(PJ_THREADS, 2) proj_fwd_kernel(ProjParams p) {
     constexpr int KS = KC / 16, KW = 3 * KC, LDB = KW + 8, TILE = 32 * LDB, NLD = 32 * KW / 8 / PJ_THREADS, SLD = 36;
+    constexpr int KT = KC * NKH, KWT = 3 * KT;   // full context width, row pitch of the planes
     extern __shared__ __attribute__((aligned(16))) uint16_t psm[];
     float *stage_all = (float *)(psm + TILE);
     __shared__ float sbias[512];
@@ -68,23 +70,23 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) proj_fwd_kernel(ProjParams p) {
     float *stage = stage_all + wave * 32 * SLD;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
     for (int i = tid; i < p.N; i += PJ_THREADS) sbias[i] = p.bias ? p.bias[i] : 0.f;
-    pbf16x8 afr[KS];
+    pbf16x8 afr[KS * NKH];
     {
         const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const int64_t b = m / p.T, t = m - b * p.T;
         const uint16_t *src = (const uint16_t *)p.A + b * p.abs_ + t * p.ars + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afr[ks] = *(const pbf16x8 *)(src + ks * 16);
+        for (int ks = 0; ks < KS * NKH; ++ks) afr[ks] = *(const pbf16x8 *)(src + ks * 16);
     }
     const int ntiles = p.N / 32;
     const int rot = blockIdx.x % ntiles;   // workgroups pull different tiles out of L2 at any moment
     pu32x4 breg[NLD];
 #define PJ_LOAD(t_)                                                                                           \
     do {                                                                                                      \
-        const uint16_t *w_ = p.planes + (int64_t)(((t_) + rot) % ntiles) * 32 * KW;                           \
+        const uint16_t *w_ = p.planes + (int64_t)(((t_) / NKH + rot) % ntiles) * 32 * KWT + ((t_) % NKH) * KC; \
         _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                                     \
             const int idx = tid + PJ_THREADS * i, row = idx / (KW / 8), c = idx % (KW / 8);                   \
-            breg[i] = *(const pu32x4 *)(w_ + (int64_t)row * KW + c * 8);                                      \
+            breg[i] = *(const pu32x4 *)(w_ + (int64_t)row * KWT + (c * 8 / KC) * KT + (c * 8) % KC);          \
         }                                                                                                     \
     } while (0)
 #define PJ_STORE()                                                                                            \
@@ -97,24 +99,29 @@ __global__ void __launch_bounds__(PJ_THREADS, 2) proj_fwd_kernel(ProjParams p) {
     PJ_LOAD(0);
     PJ_STORE();
     __syncthreads();
-    if (ntiles > 1) PJ_LOAD(1);
-    for (int t = 0; t < ntiles; ++t) {
-        pf32x16 acc;
+    const int nsteps = ntiles * NKH;
+    if (nsteps > 1) PJ_LOAD(1);
+    pf32x16 acc;
+    for (int t = 0; t < nsteps; ++t) {
+        const int kh = t % NKH;
+        if (kh == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        }
         const uint16_t *bsrc = psm + r * LDB + 8 * h;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const pbf16x8 *)(bsrc + pl * KC + ks * 16), afr[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const pbf16x8 *)(bsrc + pl * KC + ks * 16), NKH == 1 ? afr[ks] : (kh == 0 ? afr[ks] : afr[(NKH - 1) * KS + ks]), acc, 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         p_barrier();   // every wave is done with the tile
-        if (t + 1 < ntiles) PJ_STORE();
-        if (t + 2 < ntiles) PJ_LOAD(t + 2);
+        if (t + 1 < nsteps) PJ_STORE();
+        if (t + 2 < nsteps) PJ_LOAD(t + 2);
+        if (kh != NKH - 1) { p_barrier(); continue; }   // more k-slices of this tile to come
         // epilogue: this lane holds row r, columns 8 g + 4 h + i of the tile
-        const int n0 = ((t + rot) % ntiles) * 32;
+        const int n0 = ((t / NKH + rot) % ntiles) * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 v = make_float4(acc[4 * g + 0] + sbias[n0 + 8 * g + 4 * h + 0], acc[4 * g + 1] + sbias[n0 + 8 * g + 4 * h + 1],
@@ -240,7 +247,7 @@ size_t proj_planes_bytes(int N, int K) { return (size_t)N * 3 * K * sizeof(uint1
 
 int launch_proj_fwd_bf16(const RowView &A, int64_t M, int K, const float *W, int ldw, int N, const float *bias, float *G, int64_t ldc,
                          void *scratch, size_t scratch_bytes, hipStream_t s) {
-    if (A.dtype != 1 || K != 256 || N % 32 || N > 512 || M <= 0) return 0;
+    if (A.dtype != 1 || (K != 256 && K != 512) || N % 32 || N > 512 || M <= 0) return 0;
     if ((uintptr_t)A.base % 16 || A.batch_stride % 8 || A.row_stride % 8 || A.col_split < K || A.shift != 0) return 0;
     if ((uintptr_t)G % 16 || ldc % 4 || scratch == nullptr || scratch_bytes < proj_planes_bytes(N, K) || (uintptr_t)scratch % 16) return 0;
     hipLaunchKernelGGL(split_planes_kernel<3>, dim3((N * K + 255) / 256), dim3(256), 0, s, W, ldw, (uint16_t *)scratch, N, K);
@@ -250,8 +257,13 @@ int launch_proj_fwd_bf16(const RowView &A, int64_t M, int K, const float *W, int
     p.bias = bias; p.C = G; p.ldc = ldc; p.M = M; p.N = N;
     constexpr int KC = 256, LDB = 3 * KC + 8;
     const size_t lds = (size_t)32 * LDB * sizeof(uint16_t) + (size_t)4 * 32 * 36 * sizeof(float);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)proj_fwd_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(proj_fwd_kernel<KC>, dim3((unsigned)((M + 127) / 128)), dim3(PJ_THREADS), lds, s, p);
+    if (K == 512) {   // two k-slices per tile (the synthetic stress configuration's context width)
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)proj_fwd_kernel<KC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((proj_fwd_kernel<KC, 2>), dim3((unsigned)((M + 127) / 128)), dim3(PJ_THREADS), lds, s, p);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)proj_fwd_kernel<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(proj_fwd_kernel<KC>, dim3((unsigned)((M + 127) / 128)), dim3(PJ_THREADS), lds, s, p);
+    }
     VSDE_CHECK_HIP(hipGetLastError());
     return 1;
 }
