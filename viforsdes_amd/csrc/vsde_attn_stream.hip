@@ -5,9 +5,10 @@
 // sub-tiles for the 8-wave forward / dq kernels) and the forward keeps a running maximum (online softmax; the rescale of the
 // accumulators is skipped while the maximum grows by < 2^8, so it runs once or twice per query).  D in {64, 128}; reference:
 // F.scaled_dot_product_attention at primitives/attn.py:104-106.  The blocks of one (batch, head) pair share an XCD (as_block_map).
-//   forward   workgroup = (batch, head, 128 queries): 4 waves x 32 queries; K and V tiles stream.
+//   forward   workgroup = (batch, head, 256 queries): 8 waves x 32 queries (128 / 4 waves with VSDE_ATTN_STREAM_NT=256); K, V stream.
 //   dq        same ownership; K and V tiles stream; also emits delta_i = <dO_i, O_i>.
-//   dk / dv   workgroup = (batch, head, 128 keys); Q and dO tiles (+ their lse, delta) stream.
+//   dk / dv   workgroup = (batch, head, 256 keys); Q and dO tiles (+ their lse, delta) stream; head_dim 128 keeps the owned V rows
+//             in LDS (no registers left for their fragments).
 // Deterministic: every output element has one owner, no atomics.
 #include <stdlib.h>
 
@@ -22,8 +23,8 @@ typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// workgroup = NT threads = NT / 64 waves x 32 owned tokens (NT / 2 tokens): 256 (4 waves), or 512 for head_dim 128 -- every streamed
-// 32-token tile then serves 8 waves, half the L2 -> LDS traffic of the other side's re-reads per owned token
+// workgroup = NT threads = NT / 64 waves x 32 owned tokens (NT / 2 tokens): 512 (8 waves) by default, 256 for A/B runs -- every
+// streamed 32-token tile then serves 8 waves, half the L2 -> LDS traffic of the other side's re-reads per owned token
 
 template <int D, int NT = 256> struct ASCfg {
     static constexpr int KS = D / 16;            // k-steps of a product contracting over the channels
