@@ -417,11 +417,13 @@ __device__ __forceinline__ void rows_tile_mfma(f32x16 (&acc)[RB], const bf16x8 (
     __builtin_amdgcn_s_setprio(0);
 }
 
-template <int KC, int EPI, int NKH>
-__global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
-    constexpr int RB = rows_rb<EPI, NKH>(), ROWS = 128 * RB;
+// NW = waves per workgroup: 4 (two workgroups per CU), or 8 = ONE 256-row workgroup per CU for the epilogues that only leave
+// registers for 32-row waves (VSDE_ROWS_NW=4 restores four): a weight tile then still serves 256 rows per trip through LDS.
+template <int KC, int EPI, int NKH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinParams p) {
+    constexpr int RB = rows_rb<EPI, NKH>(), ROWS = 32 * NW * RB, THREADS = 64 * NW;
     constexpr int KS = NKH * KC / 16, KT = NKH * KC, LDB = KC + 8, TILE = 33 * LDB;   // 32 weight rows + 1 bias row
-    constexpr int NLD = 32 * KC / 8 / R2_THREADS;                // 16-byte loads per thread and tile
+    constexpr int NLD = 32 * KC / 8 / THREADS;                   // 16-byte loads per thread and tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     uint16_t *stage = lsm + 2 * TILE + wave * (32 * RB * R2_SLD);
@@ -514,12 +516,12 @@ __global__ void __launch_bounds__(R2_THREADS, 2) lin_rows_kernel(LinParams p) {
 #define VSDE_TILE_LOAD(q_)                                                                                    \
     do {                                                                                                      \
         const int tile_ = tile0 + ((q_) / NKH + rot) % ntiles;                                                \
-        wtile_load<NLD, KC, R2_THREADS>(breg, p.W + (int64_t)tile_ * 32 * KT + ((q_) % NKH) * KC, KT, tid);   \
+        wtile_load<NLD, KC, THREADS>(breg, p.W + (int64_t)tile_ * 32 * KT + ((q_) % NKH) * KC, KT, tid);      \
         if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * tid) : 0u;             \
     } while (0)
 #define VSDE_TILE_STORE(Bs_)                                                                                  \
     do {                                                                                                      \
-        wtile_store<NLD, KC, LDB, R2_THREADS>(breg, (Bs_), tid);                                              \
+        wtile_store<NLD, KC, LDB, THREADS>(breg, (Bs_), tid);                                                 \
         if (tid < 16) *(uint32_t *)((Bs_) + 32 * LDB + 2 * tid) = biasreg;                                    \
     } while (0)
 #define VSDE_U_LOAD(t_)                                                                                       \
@@ -849,18 +851,19 @@ static int rows_xstage() {   // VSDE_ROWS_XSTAGE=0: fragment-shaped activation l
     return v;
 }
 
-template <int KC, int EPI, int NKH> static size_t rows_lds_bytes() {
-    const size_t need = (size_t)(2 * 33 * (KC + 8) + 4 * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t);
-    const size_t xstage = NKH == 1 ? (size_t)4 * 32 * KC * 2 : 0;   // the waves' activation slices of the prologue
+template <int KC, int EPI, int NKH, int NW> static size_t rows_lds_bytes() {
+    const size_t need = (size_t)(2 * 33 * (KC + 8) + NW * 32 * rows_rb<EPI, NKH>() * R2_SLD) * sizeof(uint16_t);
+    const size_t xstage = NKH == 1 ? (size_t)NW * 32 * KC * 2 : 0;   // the waves' activation slices of the prologue
     return need > xstage ? need : xstage;
 }
 template <int NB> static size_t cols_lds_bytes() { return (size_t)(2 * 32 * NB * C2_LDB) * sizeof(uint16_t); }   // two weight buffers (the epilogue reuses them)
 
-template <int KC, int EPI, int NKH = 1>
-static int launch_rows(const LinParams &p, hipStream_t s) {
-    const size_t lds = rows_lds_bytes<KC, EPI, NKH>();
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI, NKH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int rows = 128 * rows_rb<EPI, NKH>();
+template <int KC, int EPI, int NKH, int NW>
+static int launch_rows_nw(const LinParams &p, hipStream_t s) {
+    const size_t lds = rows_lds_bytes<KC, EPI, NKH, NW>();
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)lin_rows_kernel<KC, EPI, NKH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int rows = 32 * NW * rows_rb<EPI, NKH>();
+    constexpr int resident = NW == 4 ? 512 : 256;   // workgroups on the chip at a time
     // Column chunks per row stripe (a chunk is a whole number of tile pairs; its workgroup re-reads the stripe's rows, L2 hits):
     //  * few stripes (the OU example has 12.9 k tokens = 51 stripes on 256 CUs): enough chunks for about two workgroups per CU;
     //  * many stripes: the grid is a non-integer number of rounds of the 512 resident workgroups (802 stripes = 1.57 rounds:
@@ -868,7 +871,7 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     const int64_t stripes = (p.M + rows - 1) / rows;
     const int pairs = p.N / 64;
     int chunks = 1;
-    while (stripes * chunks < 512 && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
+    while (stripes * chunks < resident && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
     {
         static int big = -1;   // VSDE_ROWS_CHUNKS: chunks at large M (A/B runs; 0 = the default below)
         if (big < 0) { const char *e = getenv("VSDE_ROWS_CHUNKS"); big = e ? atoi(e) : 0; }
@@ -876,15 +879,31 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
         // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
         const int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
         const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
-        if (stripes >= 512 && want > 1 && (pairs % want == 0 || (uneven_ok && pairs >= 2 * want))) chunks = want;
+        if (stripes >= resident && want > 1 && (pairs % want == 0 || (uneven_ok && pairs >= 2 * want))) chunks = want;
     }
     if (EPI == EPI_GATE_BWD) chunks = 1;   // a wave must visit every head of its rows (the gate gradient sums over them)
     LinParams q = p;
     q.chunks = chunks;
     q.xstage = rows_xstage();
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(R2_THREADS), lds, s, q);
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH, NW>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(64 * NW), lds, s, q);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+static int rows_wide_wg() {   // VSDE_ROWS_NW=4: four-wave workgroups for every epilogue (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("VSDE_ROWS_NW"); v = e ? atoi(e) : 8; }
+    return v;
+}
+template <int KC, int EPI, int NKH = 1>
+static int launch_rows(const LinParams &p, hipStream_t s) {
+    // eight waves (one 256-row workgroup per CU) for the gate-backward epilogue, whose registers only allow 32-row waves, when M fills
+    // the chip: 109.5 -> 95 us at the LV shape.  The QK-norm epilogue (also 32-row waves) loses with it: 242 -> 260 us (training) /
+    // 205 -> 221 (no grad), whatever the column-chunk count -- its long epilogues want a second workgroup on the CU to hide behind.
+    if constexpr (EPI == EPI_GATE_BWD && NKH == 1) {
+        if (rows_wide_wg() == 8 && p.M >= 256 * 256) return launch_rows_nw<KC, EPI, NKH, 8>(p, s);
+    }
+    return launch_rows_nw<KC, EPI, NKH, 4>(p, s);
 }
 
 template <int EPI>
