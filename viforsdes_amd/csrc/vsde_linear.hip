@@ -900,7 +900,9 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     // eight waves (one 256-row workgroup per CU) for the gate-backward epilogue, whose registers only allow 32-row waves, when M fills
     // the chip: 109.5 -> 95 us at the LV shape.  The QK-norm epilogue (also 32-row waves) loses with it: 242 -> 260 us (training) /
     // 205 -> 221 (no grad), whatever the column-chunk count -- its long epilogues want a second workgroup on the CU to hide behind.
-    if constexpr (EPI == EPI_GATE_BWD && NKH == 1) {
+    // K = 512 (two k-halves, 32-row waves for every epilogue): synthetic step 146.0 -> 145.1 ms with eight waves; the SwiGLU backward
+    // at K = 256 (172 registers, two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step with them.
+    if constexpr ((EPI == EPI_GATE_BWD && NKH == 1) || (NKH > 1 && EPI != EPI_QKNORM)) {
         if (rows_wide_wg() == 8 && p.M >= 256 * 256) return launch_rows_nw<KC, EPI, NKH, 8>(p, s);
     }
     return launch_rows_nw<KC, EPI, NKH, 4>(p, s);
