@@ -901,7 +901,8 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     // the chip: 109.5 -> 95 us at the LV shape.  The QK-norm epilogue (also 32-row waves) loses with it: 242 -> 260 us (training) /
     // 205 -> 221 (no grad), whatever the column-chunk count -- its long epilogues want a second workgroup on the CU to hide behind.
     // K = 512 (two k-halves, 32-row waves for every epilogue): synthetic step 146.0 -> 145.1 ms with eight waves; the SwiGLU backward
-    // at K = 256 (172 registers, two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step with them.
+    // at K = 256 (172 registers, two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step with them, the plain /
+    // SwiGLU-forward epilogues (64-row waves, 512-row workgroups) 0.1-0.25 ms.
     if constexpr ((EPI == EPI_GATE_BWD && NKH == 1) || (NKH > 1 && EPI != EPI_QKNORM)) {
         if (rows_wide_wg() == 8 && p.M >= 256 * 256) return launch_rows_nw<KC, EPI, NKH, 8>(p, s);
     }
