@@ -268,6 +268,19 @@ static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
     if (nsplit < 8) nsplit = 8;
     if (nsplit > 256) nsplit = 256;
     if (nsplit > chunks) nsplit = chunks;
+    // One round of workgroups can leave the chip badly filled when the tile count does not divide it (dW[2816, 512]: 22 tiles x 8
+    // splits = 176 workgroups on 256 CUs).  Then finer splits in several rounds: rounds x (rows per split), plus the partial
+    // tiles' share of the traffic (each workgroup writes, and the reduction reads, one fp32 tile against (TN + 256) x 2 bytes per row).
+    if (p.tiles >= 3 && p.tiles * nsplit < (wgs * 85) / 100 && !getenv("VSDE_WGRAD_ONE_ROUND")) {
+        double best = 1e30; int64_t pick = nsplit;
+        for (int64_t ns = 8; ns <= 64 && ns <= chunks; ns += 8) {
+            const double rounds = (double)((p.tiles * ns + wgs - 1) / wgs);
+            const double partial = (double)p.tn * W2_TK * 8.0 / ((double)(p.tn + W2_TK) * 2.0 * 32.0 * (double)chunks / (double)ns);
+            const double cost = rounds / (double)ns * (1.0 + partial);
+            if (cost < best * 0.98) { best = cost; pick = ns; }
+        }
+        nsplit = pick;
+    }
     p.nsplit = (int)nsplit; p.chunks = chunks;
 }
 static size_t wgrad2_workspace(const Wgrad2Params &p) {
