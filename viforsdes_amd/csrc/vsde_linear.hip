@@ -877,8 +877,18 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
         if (big < 0) { const char *e = getenv("VSDE_ROWS_CHUNKS"); big = e ? atoi(e) : 0; }
         // measured at M = 205 k: SwiGLU forward 290 | 277 | 272 | 307 us and backward 303 | 287 | 295 | 305 us for 1 | 2 | 4 | 8
         // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
-        const int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
         const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
+        int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
+        if (big <= 0 && uneven_ok) {
+            // the chunk count that leaves the fullest last round of resident workgroups (802 stripes on 512 slots: 2 chunks = 3.13
+            // rounds, 3 chunks = 4.70: LV step -0.08 ms), a little in favour of fewer chunks (every chunk re-reads the stripe's rows)
+            double best = 0.0;
+            for (int c = 2; c <= 4; ++c) {
+                if (pairs < 2 * c) break;
+                const double rounds = (double)stripes * c / resident, eff = rounds / (double)(int64_t)(rounds + 0.999999) - 0.02 * c;
+                if (eff > best) { best = eff; want = c; }
+            }
+        }
         if (stripes >= resident && want > 1 && (pairs % want == 0 || (uneven_ok && pairs >= 2 * want))) chunks = want;
     }
     if (EPI == EPI_GATE_BWD) chunks = 1;   // a wave must visit every head of its rows (the gate gradient sums over them)
