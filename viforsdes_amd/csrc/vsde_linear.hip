@@ -878,6 +878,7 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
         // measured at M = 205 k: SwiGLU forward 290 | 277 | 272 | 307 us and backward 303 | 287 | 295 | 305 us for 1 | 2 | 4 | 8
         // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
         const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
+        // (the QK-norm epilogue would also allow whole-head chunks, but its workgroup prologue is heavy: 240 | 241 | 254 | 296 us for 1..4 chunks)
         int want = big > 0 ? big : (EPI == EPI_PLAIN ? 1 : 2);
         if (big <= 0 && uneven_ok) {
             // the chunk count that leaves the fullest last round of resident workgroups (802 stripes on 512 slots: 2 chunks = 3.13
