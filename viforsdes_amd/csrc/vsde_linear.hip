@@ -49,6 +49,7 @@ struct LinParams {
     const uint16_t *U; int64_t ldu;    // EPI_SWIGLU_BWD: saved u [M][2N]
     int64_t M; int N, K;
     int chunks;                        // rows kernel: column chunks per row stripe
+    int tail_local, tail_chunks;       // rows kernel: workgroups with `local` >= tail_local own the LAST stripes, in tail_chunks column chunks
     // EPI_QKNORM: N = 3 heads*64 + gate columns; a tile pair = one 64-wide head of q / k / v (or the gate block)
     uint16_t *Qo, *Ko, *Vo, *Go; int64_t ldg;   // q, k, v [M][heads*64] token-major; gate logits [M][ldg]
     const float *cosT, *sinT, *wq, *wk, *lam;   // rotary tables [tokens][32], RMS weights [64], value-mix weight [1]
@@ -429,9 +430,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinP
     uint16_t *stage = lsm + 2 * TILE + wave * (32 * RB * R2_SLD);
     // Workgroup id = 8 * local + xcd (consecutive ids go round-robin over the XCDs); the column chunks of one row stripe take
     // consecutive `local` on ONE XCD: they run together and share the stripe's activation rows through that XCD's L2.
-    const int nchunks = p.chunks, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int chunk = local % nchunks;
-    const int64_t stripe = (int64_t)(local / nchunks) * 8 + xcd;
+    // The stripes of the last, partly filled round of resident workgroups are cut into more column chunks (launch_rows_nw): the
+    // tail then runs on all CUs for a fraction of a stripe's time instead of on a few CUs for a whole one.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const bool tail = local >= p.tail_local;
+    const int nchunks = tail ? p.tail_chunks : p.chunks, lrel = tail ? local - p.tail_local : local;
+    const int chunk = lrel % nchunks;
+    const int64_t stripe = (int64_t)(lrel / nchunks + (tail ? p.tail_local / p.chunks : 0)) * 8 + xcd;
     if (stripe * ROWS >= p.M) return;
     const int64_t row0 = stripe * ROWS + wave * (32 * RB);
 
@@ -896,7 +901,27 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
     LinParams q = p;
     q.chunks = chunks;
     q.xstage = rows_xstage();
-    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH, NW>), dim3((unsigned)(((stripes + 7) / 8) * 8 * chunks)), dim3(64 * NW), lds, s, q);
+    // tail: stripe groups (8 stripes, one per XCD) beyond the last full round of resident workgroups
+    const int64_t groups = (stripes + 7) / 8, wg_main = groups * 8 * chunks;
+    int64_t tail_groups = 0; int tail_chunks = chunks;
+    {
+        static int on = -1;   // VSDE_ROWS_TAIL=0: no finer chunks for the last round (A/B runs)
+        if (on < 0) { const char *e = getenv("VSDE_ROWS_TAIL"); on = e ? atoi(e) : 1; }
+        const int64_t full = wg_main / resident * resident, rest = wg_main - full;   // workgroups of the partly filled last round
+        const bool can_chunk = EPI != EPI_GATE_BWD && (EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || EPI == EPI_PLAIN);
+        if (on && can_chunk && full > 0 && rest > 0 && rest * 2 <= resident) {
+            const int64_t tg = (rest / chunks + 7) / 8;                 // stripe groups in the last round
+            int tc = (int)(resident / (tg * 8));                         // chunks that fill the chip once
+            if (tc > pairs) tc = pairs;
+            const bool even_only = EPI == EPI_PLAIN;                     // plain epilogue: chunks in equal numbers of tile pairs
+            while (tc > chunks && even_only && pairs % tc != 0) --tc;
+            if (tc > chunks) { tail_groups = tg; tail_chunks = tc; }
+        }
+    }
+    q.tail_local = (int)((groups - tail_groups) * chunks);
+    q.tail_chunks = tail_chunks;
+    const int64_t nwg = ((groups - tail_groups) * chunks + tail_groups * tail_chunks) * 8;
+    hipLaunchKernelGGL((lin_rows_kernel<KC, EPI, NKH, NW>), dim3((unsigned)nwg), dim3(64 * NW), lds, s, q);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
