@@ -65,7 +65,10 @@ def _run(att, x, rot, v0, go, gv, mode):
 
 
 @pytest.mark.parametrize("residual_v,value_grad", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3), (10, 430, None)])   # 430: two-round waves without spare LDS (direct epilogues)
+@pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3), (10, 430, None),   # 430: two-round waves without spare LDS (direct epilogues)
+                                        # 70,576 rows: the QK-norm projection's last round of workgroups in finer column chunks, the
+                                        # gate-backward GEMM on eight-wave workgroups (M >= 65,536)
+                                        (176, 401, None)])
 def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
     from viforsdes_amd.primitives import fused
     from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis
@@ -169,7 +172,7 @@ def test_gated_attention_store_and_gate_backward(B, N, H):
     assert rel_err(delta.cpu().numpy(), dl.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("B,N,H,K", [(3, 37, 4, 256), (2, 401, 4, 256), (70, 61, 2, 128), (1, 544, 2, 128)])
+@pytest.mark.parametrize("B,N,H,K", [(3, 37, 4, 256), (2, 401, 4, 256), (70, 61, 2, 128), (1, 544, 2, 128), (170, 401, 4, 256), (1100, 61, 2, 128)])   # the last two: eight-wave workgroups
 def test_output_projection_gradient_with_the_gate_backward_epilogue(B, N, H, K):
     """vsde_linear_gate_bwd_bf16 = vsde_linear_bf16 on the transposed weight (the projection's input gradient, rounded to bf16)
     followed by vsde_gate_bwd_delta: same dattn / gate-logit gradient / delta (the fused form keeps the partial sums of a row in

@@ -23,7 +23,10 @@ def _rel(a, b):
 SHAPES = [(4264, 448, 128), (4264, 128, 128), (4264, 128, 384), (4264, 128, 448), (4264, 128, 768),
           (20000, 832, 256), (20000, 256, 256), (20000, 256, 768), (20000, 256, 832), (20000, 256, 1536),
           (3000, 1664 + 128, 512), (3000, 512, 512), (9000, 1664, 512), (3000, 512, 1408), (3000, 512, 1664), (3000, 512, 2816),
-          (257, 256, 256), (31, 128, 64)]
+          (257, 256, 256), (31, 128, 64),
+          # more than one round of resident workgroups: the stripes of the last, partly filled round run in finer column chunks
+          # (133,000 rows = 520 stripes of 256 on 512 slots), K = 512 on eight-wave workgroups with a ragged last stripe
+          (133000, 256, 256), (133000, 832, 256), (66000 + 77, 512, 512)]
 # the persistent deep-reduction kernel (opt-in: VSDE_DEEP_GEMM=1, M >= 32768): LV and config-5 shapes, ragged M, a row range that
 # is not a multiple of the 256-row tile, M just past a tile boundary
 DEEP_SHAPES = [(40000, 256, 768), (33001, 256, 832), (65536 + 32, 256, 1536), (35001, 512, 1408), (32768, 512, 512), (70000, 256, 1664)]
@@ -52,7 +55,9 @@ def _interleave(w_a, w_b):
     return torch.stack([w_a.reshape(H // 16, 16, -1), w_b.reshape(H // 16, 16, -1)], dim=1).reshape(2 * H, -1)
 
 
-@pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128), (9000, 1408, 512), (200, 128, 512)])
+@pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128), (9000, 1408, 512), (200, 128, 512),
+                                   # >= 512 stripes: three uneven column chunks (704 = 11 tile pairs), tail chunks; K = 512 on eight waves
+                                   (133000 + 5, 704, 256), (66000 + 77, 1408, 512)])
 def test_swiglu_epilogues(M, H, K):
     from viforsdes_amd import _hip
     x = _rand(M, K, seed=5)
