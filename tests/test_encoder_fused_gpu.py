@@ -113,7 +113,9 @@ def test_encoder_fused_vs_unfused_full_module_bf16_autocast():
     assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 3e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(8192 + 37, 768, 256), (5000, 64, 256), (4100, 256, 768), (20000, 1536, 256), (4096, 8, 16)])
+@pytest.mark.parametrize("M,N,K", [(8192 + 37, 768, 256), (5000, 64, 256), (4100, 256, 768), (20000, 1536, 256), (4096, 8, 16),
+                                   # tile counts that underfill one round of workgroups: finer splits in several rounds
+                                   (20000 + 13, 2816, 512), (9000, 512, 1408)])
 def test_linear_wgrad_kernel(M, N, K):
     """dW = dy^T x, db = colsum(dy): bf16 inputs, fp32 accumulation; reference in float64 on the same bf16 values."""
     from viforsdes_amd import _hip
