@@ -1,4 +1,5 @@
-"""Streamed attention kernels at the config-5 shape (B=256, N=1001, H=4, head_dim 128): forward and backward times."""
+"""Streamed attention kernels at the config-5 shape (B=256, N=1001, H=4, head_dim 128; AS_B / AS_N / AS_H / AS_D override):
+forward and backward times."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -17,4 +18,4 @@ def t(fn, n=10):
 sc = D ** -0.5
 o, lse = _hip.attention_fwd(q, k, v, sc)
 print(f"forward  {t(lambda: _hip.attention_fwd(q, k, v, sc)):8.1f} us")
-if not os.environ.get("VSDE_AS_FWD_ONLY"): print(f"backward {t(lambda: _hip.attention_bwd(go, q, k, v, o, lse, sc)):8.1f} us")
+print(f"backward {t(lambda: _hip.attention_bwd(go, q, k, v, o, lse, sc)):8.1f} us")
