@@ -68,7 +68,8 @@ def _run(att, x, rot, v0, go, gv, mode):
 @pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3), (10, 430, None),   # 430: two-round waves without spare LDS (direct epilogues)
                                         # 70,576 rows: the QK-norm projection's last round of workgroups in finer column chunks, the
                                         # gate-backward GEMM on eight-wave workgroups (M >= 65,536)
-                                        (176, 401, None)])
+                                        (176, 401, None),
+                                        (512, 401, None)])   # the LV benchmark's own shape (205,312 rows)
 def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
     from viforsdes_amd.primitives import fused
     from viforsdes_amd.primitives.embeddings import RotarySpec, precompute_freq_cis

@@ -57,7 +57,7 @@ def _interleave(w_a, w_b):
 
 @pytest.mark.parametrize("M,H,K", [(20000, 768, 256), (4264, 384, 128), (300, 64, 128), (9000, 1408, 512), (200, 128, 512),
                                    # >= 512 stripes: three uneven column chunks (704 = 11 tile pairs), tail chunks; K = 512 on eight waves
-                                   (133000 + 5, 704, 256), (66000 + 77, 1408, 512)])
+                                   (133000 + 5, 704, 256), (66000 + 77, 1408, 512), (205312, 704, 256)])   # the last: the LV benchmark's shape
 def test_swiglu_epilogues(M, H, K):
     from viforsdes_amd import _hip
     x = _rand(M, K, seed=5)
