@@ -23,6 +23,8 @@ What is recorded (inputs and expected outputs only -- no reference source text):
                   where the build's fused encoder route is active (hidden 128, 2 heads, depth 2, batch 104).
 * encoder_d128.npz  ``ObservationContextEncoder`` forward + gradients at head_dim 128 (hidden 128, one head, depth 2, batch 104).
 * euler_maruyama.npz  ``euler_maruyama`` trajectories + gradients for the example OU / LV SDEs with injected noise.
+* posterior_sample.npz  ``VariationalPosterior.sample`` / ``.summary`` under the EMA swap (live weights != shadow), draws recorded.
+* pretrain.npz     ``pretrain_sde_parameters`` (OU with a free dimension, LV with one non-finite iteration), draws recorded.
 * trajectory_tiny.npz  a K-step ``VariationalInferenceTrainer`` run on CPU with the head's
                   kernel call replaced by O1 and every ``torch.randn`` draw recorded.
 """
@@ -559,6 +561,167 @@ def make_sde_coeffs():
     print("wrote sde_coefficients.npz")
 
 
+# ------------------------------------------------ eval-side caller: VariationalPosterior.sample / summary under the EMA swap
+def _record_randn():
+    draws, real = [], torch.randn
+
+    def rec(*a, **kw):
+        t = real(*a, **kw)
+        draws.append(t.detach().clone())
+        return t
+    return draws, real, rec
+
+
+def make_posterior_sample():
+    """``VariationalPosterior.sample(n)`` and ``.summary(n)`` of the reference (posterior/variational_posterior.py:93-144) on a
+    model whose EMA shadow differs from its live weights, with the head's kernel call replaced by O1 and every ``torch.randn``
+    draw recorded: {live state_dict, EMA shadow, draws} -> {theta, diffusion_paths, summary statistics}."""
+    from variational_sde.inference.exponential_moving_average import ExponentialMovingAverage
+    from variational_sde.posterior.variational_posterior import VariationalPosterior
+
+    def patched(self, x0, context, sde_parameters, standard_noise, time_step):
+        return o1(self, x0, context, sde_parameters, standard_noise, time_step)
+    DiffusionTransitionHead.sample_diffusion_paths = patched
+    rec = {}
+    cases = {
+        "lv": dict(S=2, P=3, state_pos=[0, 1], theta_pos=[0, 1, 2], dt=0.1, horizon=1.0,
+                   times=[0.0, 0.5, 1.0], values=[[1.2, 0.7], [0.9, 1.1], [0.6, 1.4]],
+                   prior=Prior(type=PriorType.LOG_NORMAL, mean=0.0, std=1.5, dim=3), n=7, n_summary=48, seed=31),
+        "ou": dict(S=1, P=3, state_pos=[], theta_pos=[0, 2], dt=0.05, horizon=1.0,
+                   times=[0.0, 0.5, 1.0], values=[[2.0], [1.5], [0.8]],
+                   prior=Prior(type=PriorType.NORMAL, mean=0.0, std=1.0, dim=3), n=5, n_summary=40, seed=32),
+    }
+    for name, c in cases.items():
+        torch.manual_seed(c["seed"])
+        model = VariationalSDEPosterior(c["S"], c["S"], c["P"], EncoderConfig(hidden_dim=32, cond_dim=16, num_heads=4, depth=2),
+                                        HeadConfig(hidden_dim=16, num_layers=2), c["theta_pos"])
+        g = torch.Generator().manual_seed(c["seed"] + 100)
+        randomize_(model.encoder, g, 0.1)
+        with torch.no_grad():
+            model.head.out_proj.weight.add_(torch.randn(model.head.out_proj.weight.shape, generator=g) * 0.2)
+            model.sde_parameter_posterior.mean.add_(torch.randn(c["P"], generator=g) * 0.3)
+            model.sde_parameter_posterior.log_std.add_(torch.randn(c["P"], generator=g) * 0.2 - 1.0)
+        ema = ExponentialMovingAverage(model)
+        with torch.no_grad():  # the averaged weights are NOT the live ones: sample() must run on the shadow
+            for k, v in ema.shadow.items():
+                v.add_(torch.randn(v.shape, generator=g) * 0.05 * (v.abs().mean() + 0.05))
+        obs = Observations(times=torch.tensor(c["times"]), values=torch.tensor(c["values"]))
+        vp = VariationalPosterior(model=model, exponential_moving_average=ema, prior=c["prior"], observations=obs,
+                                  time_horizon=c["horizon"], time_step=c["dt"], state_space=StateSpace(c["S"], c["state_pos"]),
+                                  evidence_lower_bound_history=[-3.0, -2.0], device=torch.device("cpu"))
+        for k, v in model.state_dict().items():
+            rec[f"{name}::init::{k}"] = torch.view_as_real(v).numpy().copy() if v.is_complex() else v.numpy().copy()
+        for k, v in ema.shadow.items():
+            rec[f"{name}::ema::{k}"] = v.numpy().copy()
+        draws, real, recfn = _record_randn()
+        torch.randn = recfn
+        try:
+            s = vp.sample(c["n"])
+            summ = vp.summary(c["n_summary"])
+        finally:
+            torch.randn = real
+        assert len(draws) == 4 and draws[0].shape == (c["n"], c["P"])
+        for k, v in model.state_dict().items():  # the swap was undone
+            ref = rec[f"{name}::init::{k}"]
+            assert np.array_equal(torch.view_as_real(v).numpy() if v.is_complex() else v.numpy(), ref)
+        q = summ.sde_parameter_quantiles
+        rec.update({f"{name}::sample_theta_eps": draws[0].numpy(), f"{name}::sample_noise": draws[1].numpy(),
+                    f"{name}::summary_theta_eps": draws[2].numpy(), f"{name}::summary_noise": draws[3].numpy(),
+                    f"{name}::sde_parameters": s.sde_parameters.numpy(), f"{name}::diffusion_paths": s.diffusion_paths.numpy(),
+                    f"{name}::summary_mean": summ.sde_parameter_mean.numpy(), f"{name}::summary_std": summ.sde_parameter_std.numpy(),
+                    f"{name}::summary_quantiles": torch.stack([q.q05, q.q25, q.q50, q.q75, q.q95]).numpy(),
+                    f"{name}::summary_path_mean": summ.diffusion_path_mean.numpy(),
+                    f"{name}::summary_path_std": summ.diffusion_path_std.numpy(),
+                    f"{name}::obs_times": obs.times.numpy(), f"{name}::obs_values": obs.values.numpy(),
+                    f"{name}::cfg": np.array([c["S"], c["P"], c["n"], c["n_summary"]]),
+                    f"{name}::state_pos": np.array(c["state_pos"], dtype=np.int64),
+                    f"{name}::theta_pos": np.array(c["theta_pos"], dtype=np.int64),
+                    f"{name}::dt": np.array(c["dt"]), f"{name}::horizon": np.array(c["horizon"])})
+        d = vp.diagnostics()
+        rec[f"{name}::diagnostics"] = np.array([d.final_evidence_lower_bound, d.n_iterations])
+        print(f"  posterior_sample {name}: theta[0] {s.sde_parameters[0].tolist()}, path mean {float(s.diffusion_paths.mean()):.4f}")
+    np.savez_compressed(os.path.join(OUT, "posterior_sample.npz"), **rec)
+    print("wrote posterior_sample.npz")
+
+
+# ------------------------------------------------------------------ pre-training loop (trainer.py:208-259) with recorded draws
+def make_pretrain():
+    """``VariationalInferenceTrainer.pretrain_sde_parameters`` of the reference on CPU, every ``torch.randn`` draw recorded (the
+    free-dimension init, then per iteration the theta noise [B, P] and the path noise [B, T, S]); per-iteration loss, best loss,
+    median sigma as the reference reports them to its progress sink, and the returned mean.  One iteration's theta noise is
+    scaled up so that the loss is non-finite there: the reference then skips that update (trainer.py:243-246)."""
+    from contextlib import contextmanager
+    from variational_sde.config import PretrainConfig
+    from variational_sde.console import Console
+    from variational_sde.inference.trainer import VariationalInferenceTrainer
+    ou, lv = example_sdes()
+    rec = {}
+    cases = {
+        "ou": dict(sde=ou, state_pos=[], theta_pos=[0, 2], dt=0.05, horizon=2.0, times=[0.0, 1.0, 2.0],
+                   values=[[2.0], [1.5], [0.8]], prior=Prior(type=PriorType.NORMAL, mean=0.0, std=1.0, dim=3),
+                   var=0.1, K=10, B=48, bad_step=None, seed=41),
+        "lv": dict(sde=lv, state_pos=[0, 1], theta_pos=[0, 1, 2], dt=0.1, horizon=2.0, times=[0.0, 1.0, 2.0],
+                   values=[[1.2, 0.7], [0.9, 1.1], [0.6, 1.4]], prior=Prior(type=PriorType.LOG_NORMAL, mean=0.0, std=1.5, dim=3),
+                   var=0.25, K=10, B=48, bad_step=4, seed=42),
+    }
+    for name, c in cases.items():
+        log = []
+
+        class Sink:
+            def update(self, step, mse, best, sigma_median):
+                log.append([float(mse), float(best), float(sigma_median)])
+
+        class RecConsole(Console):
+            @contextmanager
+            def pretrain_progress(self, n_iterations):
+                yield Sink()
+
+        torch.manual_seed(c["seed"])
+        obs = Observations(times=torch.tensor(c["times"]), values=torch.tensor(c["values"]))
+        tr = VariationalInferenceTrainer(
+            sde=c["sde"], observations=obs, observation_likelihood=GaussianObservationLikelihood(variance=c["var"]),
+            prior=c["prior"], time_horizon=c["horizon"],
+            config=TrainingConfig(time_step=c["dt"], batch_size=4, n_iterations=2),
+            encoder_config=EncoderConfig(hidden_dim=32, cond_dim=16, num_heads=4, depth=1),
+            head_config=HeadConfig(hidden_dim=16, num_layers=1), state_positive_dims=c["state_pos"],
+            sde_param_positive_dims=c["theta_pos"], device="cpu", mixed_precision=False, console=RecConsole(enabled=False),
+            accelerator=None)
+        draws, real = [], torch.randn
+        P = c["sde"].sde_param_dim
+        n_free = P - len(c["theta_pos"])
+
+        def rec_randn(*a, **kw):
+            t = real(*a, **kw)
+            k_theta = (len(draws) - (1 if n_free else 0))
+            if c["bad_step"] is not None and tuple(t.shape) == (c["B"], P) and k_theta // 2 == c["bad_step"]:
+                t = t * 200.0  # exp(mu + sigma * 200 eps) overflows: a non-finite loss, the update must be skipped
+            draws.append(t.detach().clone())
+            return t
+        torch.randn = rec_randn
+        try:
+            best_mu = tr.pretrain_sde_parameters(PretrainConfig(n_iterations=c["K"], batch_size=c["B"], learning_rate=0.02))
+        finally:
+            torch.randn = real
+        off = 1 if n_free else 0
+        assert len(draws) == off + 2 * c["K"], (len(draws), off)
+        if off:
+            rec[f"{name}::init_draw"] = draws[0].numpy()
+        rec[f"{name}::theta_eps"] = torch.stack(draws[off::2]).numpy()
+        rec[f"{name}::path_noise"] = torch.stack(draws[off + 1::2]).numpy()
+        rec[f"{name}::log"] = np.array(log)
+        rec[f"{name}::best_mu"] = best_mu.numpy()
+        rec[f"{name}::obs_times"] = obs.times.numpy(); rec[f"{name}::obs_values"] = obs.values.numpy()
+        rec[f"{name}::cfg"] = np.array([c["K"], c["B"], -1 if c["bad_step"] is None else c["bad_step"]])
+        rec[f"{name}::dt"] = np.array(c["dt"]); rec[f"{name}::horizon"] = np.array(c["horizon"]); rec[f"{name}::var"] = np.array(c["var"])
+        rec[f"{name}::state_pos"] = np.array(c["state_pos"], dtype=np.int64)
+        rec[f"{name}::theta_pos"] = np.array(c["theta_pos"], dtype=np.int64)
+        nonfinite = [i for i, r in enumerate(log) if not np.isfinite(r[0])]
+        print(f"  pretrain {name}: mse {log[0][0]:.4g} -> {log[-1][0]:.4g}, best {log[-1][1]:.4g}, non-finite steps {nonfinite}, "
+              f"best_mu {best_mu.tolist()}")
+    np.savez_compressed(os.path.join(OUT, "pretrain.npz"), **rec)
+    print("wrote pretrain.npz")
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"head", "elbo", "encoder", "manifest", "trajectory"}
     if "head" in which:
@@ -599,3 +762,7 @@ if __name__ == "__main__":
         make_em_cases()
     if "sde_coeffs" in which:
         make_sde_coeffs()
+    if "posterior_sample" in which:
+        make_posterior_sample()
+    if "pretrain" in which:
+        make_pretrain()
