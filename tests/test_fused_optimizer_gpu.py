@@ -139,3 +139,125 @@ def test_a_step_that_falls_back_to_torch_keeps_the_step_counts_in_sync():
             assert float((p - q).abs().max()) <= 3e-6 * float(p.detach().abs().max()), (step, name)
     steps = {n: float(o_own.state_dict()["state"][i]["step"]) for i, n in enumerate(["a", "b", "c", "d", "e"])}
     assert steps["a"] == 5.0 and steps["b"] == 4.0, steps
+
+
+def test_unscaled_nan_gradient_poisons_like_the_torch_sequence():
+    """No loss scaling and a NaN in one gradient: ``clip_grad_norm_`` makes the clip coefficient NaN (``torch.clamp`` propagates
+    it) and every gradient, hence every trainable parameter, becomes NaN -- a loud divergence.  The fused step must not apply a
+    silent unclipped update instead."""
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    m_ref, o_ref, s_ref, e_ref = _setup(False)
+    m_own, o_own, s_own, e_own = _setup(False)
+    fs = FusedOptimizerStep(o_own, e_own, s_own, max_norm=1.0)
+    for model in (m_ref, m_own):
+        _grads(model, 1, 1.0, False)
+        model.d.grad[1, 17] = float("nan")
+    nn.utils.clip_grad_norm_(m_ref.parameters(), 1.0); o_ref.step()
+    n_own = fs.step()
+    assert n_own is not None and torch.isnan(n_own)
+    for (name, p), q in zip(m_ref.named_parameters(), m_own.parameters()):
+        if p.requires_grad:
+            assert torch.isnan(p).all() and torch.isnan(q).all(), name
+        else:
+            assert torch.equal(p, q)
+
+
+def test_grad_norms_of_successive_eager_steps_do_not_alias():
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    model, opt, scaler, ema = _setup(False)
+    fs = FusedOptimizerStep(opt, ema, scaler, max_norm=1.0)
+    norms = []
+    for step in range(3):
+        _grads(model, step, 1.0, False)
+        norms.append(fs.step())
+        ema.update()
+    vals = [float(n) for n in norms]
+    assert vals[0] < 1.0 < vals[1] and vals[2] < 1.0 and len({n.data_ptr() for n in norms}) == 3, vals
+
+
+def test_moved_parameter_storage_rebuilds_the_tables():
+    """``p.data = ...`` keeps the Parameter object but moves its storage: the chunk table must follow."""
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    m_ref, o_ref, s_ref, e_ref = _setup(False)
+    m_own, o_own, s_own, e_own = _setup(False)
+    fs = FusedOptimizerStep(o_own, e_own, s_own, max_norm=1.0)
+    for step in range(4):
+        for model in (m_ref, m_own):
+            _grads(model, step, 1.0, False)
+        if step == 2:
+            m_own.e.data = m_own.e.data.clone()      # new storage, same values
+        nn.utils.clip_grad_norm_(m_ref.parameters(), 1.0); o_ref.step(); e_ref.update()
+        assert fs.step() is not None
+        e_own.update()
+        for (name, p), q in zip(m_ref.named_parameters(), m_own.parameters()):
+            assert float((p - q).abs().max()) <= 2e-6 * float(p.detach().abs().max()), (step, name)
+
+
+def test_captured_step_survives_interleaved_eager_steps():
+    """capture -> replay -> 5 eager steps -> replay: the captured H2D copy of the gradient-address table
+    re-reads its pinned host buffer at every replay, so that buffer must never be a slot of the eager ring (5 eager steps
+    overwrite all 4 slots with the addresses of freed eager gradients).  Compared against the torch sequence fed the same
+    gradients: the captured step always consumes the graph's own static gradient tensors."""
+    from viforsdes_amd.inference.fused_optimizer import FusedOptimizerStep
+    m_ref, o_ref, s_ref, e_ref = _setup(False)
+    m_own, o_own, s_own, e_own = _setup(False)
+    fs = FusedOptimizerStep(o_own, e_own, s_own, max_norm=1.0)
+
+    def ref_step(gr):
+        for p, g in zip([p for p in m_ref.parameters() if p.requires_grad], gr):
+            p.grad = g.clone()
+        nn.utils.clip_grad_norm_(m_ref.parameters(), 1.0); o_ref.step(); e_ref.update()
+
+    def rand_grads(seed):
+        g = torch.Generator().manual_seed(seed)
+        return [(torch.randn(p.shape, generator=g) * 0.3).to(DEV) for p in m_own.parameters() if p.requires_grad]
+
+    train = [p for p in m_own.parameters() if p.requires_grad]
+    static_src = [torch.zeros_like(p) for p in train]       # what the captured "backward" copies into its gradients
+    # warm-up (creates optimizer state) on a side stream, as trainer.capture_step_graph does
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gr = rand_grads(0)
+        for p, g in zip(train, gr):
+            p.grad = g.clone()
+        fs.step(); e_own.update()
+    torch.cuda.current_stream().wait_stream(side)
+    ref_step(gr)
+    graph = torch.cuda.CUDAGraph()
+    for p in train:
+        p.grad = None
+    gr = rand_grads(1)
+    for s_, g in zip(static_src, gr):
+        s_.copy_(g)
+    with torch.cuda.graph(graph):
+        for p, s_ in zip(train, static_src):
+            p.grad = s_ * 1.0                                # gradient tensors allocated in the graph's pool
+        fs.step(); e_own.update()
+    graph.replay()                                           # capture does not execute: this is the step for seed 1
+    ref_step(gr)
+    captured = [p.grad for p in train]
+    for k in range(5):                                       # eager steps with fresh gradient allocations
+        gr = rand_grads(10 + k)
+        for p, g in zip(train, gr):
+            p.grad = g.clone()
+        assert fs.step() is not None
+        e_own.update()
+        ref_step(gr)
+    del gr
+    torch.cuda.empty_cache()                                 # the eager gradients' memory is really gone
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]   # and may be reused by anything
+    gr = rand_grads(99)
+    for s_, g in zip(static_src, gr):
+        s_.copy_(g)
+    for p, g in zip(train, captured):
+        p.grad = g
+    graph.replay()
+    ref_step(gr)
+    torch.cuda.synchronize()
+    for (name, p), q in zip(m_ref.named_parameters(), m_own.parameters()):
+        assert torch.isfinite(q).all(), name
+        assert float((p - q).abs().max()) <= 5e-6 * float(p.detach().abs().max()), name
+        if p.requires_grad:
+            assert float((e_ref.shadow[name] - e_own.shadow[name]).abs().max()) <= 5e-6 * float(p.detach().abs().max()), name
+    del junk

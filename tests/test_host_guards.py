@@ -120,10 +120,12 @@ def test_disabled_console_emits_nothing(tmp_path):
 
 
 def test_packed_operands_follow_a_fused_optimizer_step():
-    """The cached bf16 GEMM operands must follow the parameters through the optimizer step the trainer uses.  The fused
-    (multi-tensor) AdamW kernel updates the parameters in place WITHOUT bumping ``Tensor._version``, so the version check of
-    ``PackedWeight`` alone would keep serving the first step's weights: ``refresh_all(force=True)`` is what the trainer
-    calls (reference semantics: ``nn.Linear`` under autocast re-casts its weight every forward, primitives/mlp.py:50-54)."""
+    """The cached bf16 GEMM operands must follow the parameters through ANY optimizer step.  torch's fused AdamW kernel (and the
+    trainer's own optimizer kernel) update the parameters in place WITHOUT bumping ``Tensor._version``, so a version check
+    alone kept serving the first step's weights (the round-3 defect).  Since round 4 every ``Optimizer.step`` also advances
+    ``fused._param_epoch`` (global step post-hook; the own kernel bumps versions + epoch itself): the pack notices by itself, no
+    ``refresh_all(force=True)`` needed (reference semantics: ``nn.Linear`` under autocast re-casts its weight every forward,
+    primitives/mlp.py:50-54).  The forced refresh the trainer still issues is checked below too."""
     from viforsdes_amd.primitives.fused import PackedWeight, plain_pack
     torch.manual_seed(0)
     w = torch.nn.Parameter(torch.randn(16, 8))
@@ -133,14 +135,20 @@ def test_packed_operands_follow_a_fused_optimizer_step():
     assert torch.equal(wb, w.detach().to(torch.bfloat16))
     opt = torch.optim.AdamW([w, b], lr=0.1, fused=True)
     w.grad, b.grad = torch.randn_like(w), torch.randn_like(b)
+    v0 = w._version
     opt.step()
+    assert w._version == v0, "torch's fused AdamW started bumping Tensor._version: the epoch hook is no longer the only guard"
     moved = not torch.equal(wb, w.detach().to(torch.bfloat16))
     assert moved, "the step must have changed the bf16 image of the weight for this test to mean anything"
-    PackedWeight.refresh_all(force=True)
-    wb2, bb2 = pack.operands()
+    assert pack.stale()
+    wb2, bb2 = pack.operands()                 # no forced refresh: the pack saw the optimizer step
     assert torch.equal(wb2, w.detach().to(torch.bfloat16)) and torch.equal(bb2, b.detach().to(torch.bfloat16))
     tr = pack.transposed()
     w.grad = torch.randn_like(w)
     opt.step()
-    PackedWeight.refresh_all(force=True)
+    assert torch.equal(pack.transposed(), w.detach().to(torch.bfloat16).t()) and tr is pack.transposed()
+    w.grad = torch.randn_like(w)
+    opt.step()
+    PackedWeight.refresh_all(force=True)       # what the trainer does: one pass over every live pack
+    assert not pack.stale()
     assert torch.equal(pack.transposed(), w.detach().to(torch.bfloat16).t()) and tr is pack.transposed()

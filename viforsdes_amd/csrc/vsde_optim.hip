@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(OPT_THREADS) optim_update_kernel(OptParams q) 
     const bool found_inf = !(fabsf(total) <= 3.402823466e38f);   // inf or nan
     const float norm = sqrtf(total);
     float clip = 1.0f;
-    if (q.max_norm > 0.f) { clip = q.max_norm / (norm + 1e-6f); clip = clip < 1.0f ? clip : 1.0f; }   // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1)
+    // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1); torch.clamp propagates NaN, so a NaN norm without loss scaling
+    // poisons every gradient (and parameter) like the reference sequence does -- loud, not a silent unclipped step
+    if (q.max_norm > 0.f) { clip = q.max_norm / (norm + 1e-6f); clip = (clip < 1.0f || clip != clip) ? clip : 1.0f; }
     const float t_cur = q.tstate[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         q.out[0] = norm; q.out[1] = found_inf ? 1.0f : 0.0f;

@@ -35,6 +35,7 @@ class FusedOptimizerStep:
         self.optimizer, self.ema, self.scaler, self.max_norm = optimizer, ema, scaler, float(max_norm)
         self._key = None
         self._disabled = False
+        self._captured_ptr_hosts: list[Tensor] = []   # pinned address tables of captured steps (alive as long as this object)
         self._hooks = [optimizer.register_state_dict_pre_hook(lambda opt: self._publish_steps()),
                        optimizer.register_load_state_dict_post_hook(lambda opt: self._invalidate())]
 
@@ -108,15 +109,28 @@ class FusedOptimizerStep:
         self.ptr_events: list = [None] * 4
         self.ptr_slot = 0
         self.ptr_dev = torch.zeros(len(params), dtype=torch.int64, device=dev)
+        self._capture_pool = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(8)]
         self.has_ema = self.ema is not None and all(id(p) in shadow_of for p in params)
+        # hyper-parameters: ONE device tensor for the life of these tables (a captured launch keeps its address), refilled in
+        # place through a pinned staging buffer when a group's lr / betas / eps / weight decay changes
         self._groups_key = None
+        self.groups = torch.zeros(len(opt.param_groups), 5, dtype=torch.float64, device=dev)
+        self.groups_host = torch.zeros(len(opt.param_groups), 5, dtype=torch.float64).pin_memory()
+        self.groups_event = None
         return True
 
     def _hyper(self) -> Tensor:
         key = tuple((float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
                     for g in self.optimizer.param_groups)
         if key != self._groups_key:
-            self._groups_key, self.groups = key, torch.tensor(key, dtype=torch.float64).to(self.table.device)
+            if self.groups_event is not None:
+                self.groups_event.synchronize()
+            self.groups_host.copy_(torch.tensor(key, dtype=torch.float64))
+            self.groups.copy_(self.groups_host, non_blocking=True)
+            if not torch.cuda.is_current_stream_capturing():
+                self.groups_event = torch.cuda.Event()
+                self.groups_event.record()
+            self._groups_key = key
         return self.groups
 
     def _publish_steps(self) -> None:
@@ -143,20 +157,27 @@ class FusedOptimizerStep:
             self._invalidate()
             return None
         ema_v = getattr(self.ema, "version", 0) if self.ema is not None else 0
-        key = (tuple(id(p) for p in params), ema_v)
+        # identity AND storage: model.to(...) / p.data = ... keep the Parameter object and move what the table points at
+        key = (tuple((id(p), p.data_ptr()) for p in params), ema_v)
         if key != self._key:
             self._publish_steps()   # a rebuild (new EMA shadows) must not lose the step count
             if not self._build(params):
                 return None
             self._key = key
-        slot = self.ptr_slot = (self.ptr_slot + 1) % 4
-        if self.ptr_events[slot] is not None:
-            self.ptr_events[slot].synchronize()
-        self.ptr_np[slot][:] = [g.data_ptr() for g in grads]   # the gradients are new allocations every step
-        self.ptr_dev.copy_(self.ptr_host[slot], non_blocking=True)
         if torch.cuda.is_current_stream_capturing():
-            self.ptr_events[slot] = None   # a captured copy re-reads the buffer at every replay: it keeps these addresses (graph pool)
+            # a captured copy re-reads its host buffer at EVERY replay: it gets a pinned buffer of its own that nothing else ever
+            # writes (the gradients of a captured step live in the graph's pool: these addresses stay valid for the graph's life)
+            # (taken from a pool pinned outside of any capture: hipHostMalloc is not a legal call on a capturing thread)
+            host = self._capture_pool.pop() if self._capture_pool else torch.zeros(len(params), dtype=torch.int64).pin_memory()
+            host.numpy()[:] = [g.data_ptr() for g in grads]
+            self._captured_ptr_hosts.append(host)
+            self.ptr_dev.copy_(host, non_blocking=True)
         else:
+            slot = self.ptr_slot = (self.ptr_slot + 1) % 4
+            if self.ptr_events[slot] is not None:
+                self.ptr_events[slot].synchronize()
+            self.ptr_np[slot][:] = [g.data_ptr() for g in grads]   # the gradients are new allocations every step
+            self.ptr_dev.copy_(self.ptr_host[slot], non_blocking=True)
             ev = self.ptr_events[slot] = torch.cuda.Event()
             ev.record()
         scaler = self.scaler
@@ -170,4 +191,11 @@ class FusedOptimizerStep:
             st["stage"] = OptState.STEPPED
         if self.has_ema:
             self.ema.fused_step_done = True
-        return self.out[0]
+        # Tensor._version is what cached views of the parameters (primitives/fused.py::PackedWeight) compare: the kernel wrote
+        # the parameters behind autograd's back, so say so (host-side counters; under capture this runs once, and the captured
+        # forward re-fills its packs on every replay anyway)
+        torch.autograd.graph.increment_version(params)
+        from ..primitives import fused
+        fused.note_parameters_changed()
+        # a fresh scalar per eager step (clip_grad_norm_ returns one too); a captured step hands out the static output slot
+        return self.out[0] if torch.cuda.is_current_stream_capturing() else self.out[0].clone()

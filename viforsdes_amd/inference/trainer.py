@@ -101,6 +101,9 @@ class VariationalInferenceTrainer:
         """unscale -> clip (global norm) -> AdamW -> scaler update -> refresh of the cached bf16 GEMM operands."""
         ctx, cfg = self.ctx, self.config
         grad_norm = None
+        # a flag left over from an earlier fused step whose caller never ran ema.update() must not swallow the update that
+        # follows THIS step (which may take the torch sequence)
+        ctx.ema.fused_step_done = False
         if ctx.device.type == "cuda":
             # one pass for the global norm / non-finite check, one for unscale x clip + AdamW + EMA (inference/fused_optimizer.py)
             fs = getattr(self, "_fused_opt", None)
@@ -115,7 +118,9 @@ class VariationalInferenceTrainer:
             ctx.scaler.step(ctx.optimizer)
         ctx.scaler.update()
         if ctx.device.type == "cuda":
-            # bf16 GEMM operands of the encoder follow the updated parameters (forced: fused AdamW does not bump Tensor._version)
+            # bf16 GEMM operands of the encoder follow the updated parameters: ONE kernel over all packs now, instead of a
+            # staleness check + copies per pack inside the next forward (the check alone is sufficient since round 4: the
+            # optimizer step advances fused._param_epoch and the parameters' version counters)
             fused.PackedWeight.refresh_all(force=True)
         return grad_norm.detach()
 

@@ -423,6 +423,23 @@ def attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
     return _Attention.apply(q, k, v, scale)
 
 
+# Parameters change behind ``Tensor._version``'s back in two common ways: torch's own fused AdamW / Adam kernels do not bump it
+# (measured on torch 2.10: ``AdamW(fused=True).step()`` leaves ``p._version`` untouched) and neither does the trainer's own
+# optimizer kernel.  Every optimizer step therefore also advances this epoch (a global ``Optimizer.step`` post-hook, and
+# inference/fused_optimizer.py calls ``note_parameters_changed`` itself): a pack is fresh only if versions AND epoch match.
+_param_epoch = 0
+
+
+def note_parameters_changed() -> None:
+    global _param_epoch
+    _param_epoch += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
+
+_register_step_post_hook(lambda opt, args, kwargs: note_parameters_changed())
+
+
 class PackedWeight:
     """bf16 GEMM operand (weight [rows, cols] and optional bias [rows]) assembled from fp32 parameter row blocks, kept across
     optimizer steps.
@@ -468,10 +485,10 @@ class PackedWeight:
         return dst, src
 
     def stale(self) -> bool:
-        return self._versions != [p._version for p in self.params]
+        return self._versions != [_param_epoch] + [p._version for p in self.params]
 
     def mark_fresh(self) -> None:
-        self._versions = [p._version for p in self.params]
+        self._versions = [_param_epoch] + [p._version for p in self.params]
 
     @torch.no_grad()
     def operands(self):
@@ -507,8 +524,9 @@ class PackedWeight:
             out.append(None if not blocks else blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=0))
         return out
 
-    _tables: dict = {}      # key (device, pack identities, buffer addresses) -> device table of refresh tiles (kept alive: a
-                            # captured HIP graph replays the launch with the table it was captured with)
+    _tables: dict = {}      # key (device, pack identities, buffer addresses) -> device table of refresh tiles
+    _captured_tables: list = []   # tables a HIP-graph capture has seen: a replay launches with the table it was captured with,
+                                  # so these are never freed (~90 KB each)
 
     def _refresh_tiles(self) -> list[tuple]:
         """(src, dst, dst_t, src_pitch, dst_pitch, pitch_t, rows, cols) per tile of <= 16 rows: csrc/vsde_pack.hip."""
@@ -556,8 +574,10 @@ class PackedWeight:
                     if not ok:
                         break
                     if len(PackedWeight._tables) > 64:   # a long-lived process that keeps building models: drop old tables
-                        PackedWeight._tables.clear()
+                        PackedWeight._tables.clear()     # (captured ones stay referenced from _captured_tables)
                     table = PackedWeight._tables[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+                if torch.cuda.is_current_stream_capturing() and not any(t is table for t in PackedWeight._captured_tables):
+                    PackedWeight._captured_tables.append(table)
                 _hip.pack_refresh(table)
             if ok:
                 for pk in live:
