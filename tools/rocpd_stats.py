@@ -1,6 +1,8 @@
 """Summarise kernel durations from a rocprofv3 rocpd (.db) or kernel-trace CSV into a text table.
 
     python tools/rocpd_stats.py gpurun_out/prof/x_results.db [> profiles/r01_x.txt]
+    python tools/rocpd_stats.py x_results.db busy [marker kernel, one launch per step; default optim_update_kernel]
+    python tools/rocpd_stats.py x_results.db categories
 """
 import sqlite3
 import sys
@@ -20,7 +22,7 @@ def main(path):
         print(f"{n[:90]:<90} {c:>7} {s/1e6:>10.3f} {a/1e3:>10.2f} {mn/1e3:>10.2f} {mx/1e3:>10.2f} {100*s/tot:>6.2f}")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 2:
     main(sys.argv[1])
 
 
@@ -48,37 +50,7 @@ def categories(path):
         print(f"{k:<32} {v/1e6:>10.3f} ms {100*v/tot:>6.2f}%")
 
 
-def busy(path, tail_frac=0.5):
-    """GPU busy fraction (union of kernel intervals / wall) over the last ``tail_frac`` of the trace, and the idle-gap histogram."""
-    db = sqlite3.connect(path)
-    cur = db.cursor()
-    rows = sorted(cur.execute("select start, end from kernels").fetchall())
-    t0, t1 = rows[0][0], max(r[1] for r in rows)
-    lo = t1 - (t1 - t0) * tail_frac
-    rows = [r for r in rows if r[0] >= lo]
-    busy_ns, cur_end, gaps = 0, rows[0][0], []
-    for st, en in rows:
-        if st > cur_end:
-            gaps.append(st - cur_end)
-            busy_ns += en - st
-            cur_end = en
-        elif en > cur_end:
-            busy_ns += en - cur_end
-            cur_end = en
-    wall = cur_end - rows[0][0]
-    print(f"window {wall/1e6:.1f} ms, kernels {len(rows)}, busy {100*busy_ns/wall:.1f} %, idle {(wall-busy_ns)/1e6:.2f} ms in {len(gaps)} gaps")
-    for lim in (2e3, 5e3, 1e4, 5e4, 1e9):
-        sel = [g for g in gaps if g <= lim]
-        print(f"  gaps <= {lim/1e3:.0f} us: {len(sel)} totalling {sum(sel)/1e6:.2f} ms")
-
-
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--busy":
-    busy(sys.argv[1])
-elif __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--categories":
-    categories(sys.argv[1])
-
-
-def busy(path, marker="head_fwd_v2_kernel<2, true", first=8, last=28):
+def busy(path, marker="optim_update_kernel", first=8, last=28):
     """GPU busy fraction between the `first`-th and `last`-th launch of the marker kernel (one per training step): sum of kernel
     durations / wall span, plus the per-step wall time and the number of launches per step."""
     db = sqlite3.connect(path)
@@ -106,4 +78,6 @@ def busy(path, marker="head_fwd_v2_kernel<2, true", first=8, last=28):
 
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "busy":
-    busy(sys.argv[1])
+    busy(sys.argv[1], *(sys.argv[3:4]))
+elif __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "categories":
+    categories(sys.argv[1])
