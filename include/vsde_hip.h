@@ -382,6 +382,10 @@ int vsde_sde_coefficients_bwd(int kind, int B, int T, int S, int P, const float 
 int vsde_profile_enable(int on);
 /* Test hook: route L <= 2 through the LDS-resident one-wave-per-path kernels that serve L = 3, 4. */
 int vsde_debug_force_v1(int on);
+/* Which forward time-stepping kernel serves hidden_dim 64 / L <= 2 / state_dim <= 2 (reference kernels/forward.py:137-375):
+ * mode 1 = the multi-path MFMA kernel (16 paths per workgroup, csrc/vsde_head_mp.hip) whenever applicable, 0 = never (the
+ * four-waves-per-path kernel), < 0 = default (environment VSDE_HEAD_MP, else by batch size). */
+int vsde_debug_head_mp(int mode);
 int vsde_profile_elapsed_ms(int which, float *ms);
 
 #ifdef __cplusplus

@@ -171,8 +171,8 @@ def test_grad_norms_of_successive_eager_steps_do_not_alias():
         _grads(model, step, 1.0, False)
         norms.append(fs.step())
         ema.update()
-    vals = [float(n) for n in norms]
-    assert vals[0] < 1.0 < vals[1] and vals[2] < 1.0 and len({n.data_ptr() for n in norms}) == 3, vals
+    vals = [float(n) for n in norms]   # read AFTER all three steps: each must still hold its own step's norm
+    assert vals[1] > 100 * vals[0] and vals[1] > 100 * vals[2] and len({n.data_ptr() for n in norms}) == 3, vals
 
 
 def test_moved_parameter_storage_rebuilds_the_tables():

@@ -63,6 +63,24 @@ def test_forward_backward_vs_golden(name):
         assert rel_err(g.cpu().numpy(), ref) < BWD_TOL, gname
 
 
+@pytest.mark.parametrize("name", ["ou_dims", "lv_dims"])
+def test_multi_path_mfma_forward_vs_golden(name):
+    """The reference-generated cases with hidden_dim 64 / two layers / state_dim 1, 2 through the multi-path MFMA forward kernel
+    (csrc/vsde_head_mp.hip, forced; batches of 3 / 2 paths = one partly filled 16-path group): same tolerances as the v2 kernel,
+    the backward consumes the activations this forward saved."""
+    from viforsdes_amd import _hip
+    _hip.debug_head_mp(1)
+    try:
+        test_forward_backward_vs_golden(name)
+        d = load_head_case(name)
+        (paths, means, chol, chol_raw, acts), _, _ = _run_case(d)
+    finally:
+        _hip.debug_head_mp(-1)
+    (p2, m2, c2, r2, a2), _, _ = _run_case(d)          # default route at this batch size: the v2 kernel
+    for a, b_ in ((paths, p2), (means, m2), (chol, c2), (chol_raw, r2), (acts, a2)):
+        assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) < 5e-6
+
+
 @pytest.mark.parametrize("name", ["tiny_l2", "clamp", "lv_dims"])
 def test_matches_oracle_including_saved_activations(name):
     from oracle import vsde_oracle as vo

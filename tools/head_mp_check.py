@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""The multi-path MFMA forward kernel (csrc/vsde_head_mp.hip) against the four-waves-per-path kernel and the float64 oracle on small
+ragged shapes (first diverging record printed), then timings of both at the LV head dims over a batch sweep.
+    python tools/head_mp_check.py [check|time|all]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viforsdes_amd import _hip  # noqa: E402
+
+dev = "cuda:0"
+
+
+def inputs(B, T, S, C, P, H, L, seed, bf16=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    NO = S + S * (S + 1) // 2
+    bias = torch.zeros(NO)
+    for k in range(S):
+        bias[S + k * (k + 3) // 2] = 1.0
+    ws = [rn(3 * H, S + C + P, sc=0.08), rn(3 * H, H, sc=0.12), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1),
+          rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1),
+          rn(NO, H, sc=0.1), bias]
+    ctx = rn(B, T + 1, C)
+    if bf16:
+        ctx = ctx.to(torch.bfloat16)
+    return ws, rn(B, S), ctx, rn(B, P).abs(), rn(B, T, S)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def check():
+    from oracle import vsde_oracle as vo
+    ok = True
+    for (B, T, S, L, C, P) in [(37, 21, 2, 2, 64, 3), (5, 9, 1, 2, 64, 3), (16, 8, 2, 1, 32, 2), (33, 7, 1, 1, 256, 3), (64, 40, 2, 2, 256, 3)]:
+        ws, x0, ctx, theta, eps = inputs(B, T, S, C, P, 64, L, 11 + B)
+        d = lambda t: t.to(dev)
+        wd = [d(w) for w in ws]
+        outs = {}
+        for mode in (0, 1):
+            _hip.debug_head_mp(mode)
+            outs[mode] = [None if t is None else t.cpu().numpy() for t in
+                          _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, True)]
+            ev = _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, False)
+            same = all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(ev[:3], outs[mode][:3]))
+            print(f"  mode {mode}: eval launch bit-equal to training launch: {same}")
+        _hip.debug_head_mp(-1)
+        n = lambda t: t.detach().cpu().numpy()
+        w = vo.HeadWeights(*[n(t) for t in ws])
+        f = vo.head_forward(n(x0), n(ctx.float())[:, :-1], n(theta), n(eps), w, 0.1, True, np.float64)
+        names = ["paths", "means", "chol", "chol_raw", "acts"]
+        ref = [f.paths, f.means, f.chol, f.chol_raw, f.acts]
+        line = f"B={B} T={T} S={S} L={L} C={C}:"
+        for k, nm in enumerate(names):
+            e_mp, e_v2, e_x = rel(outs[1][k], ref[k]), rel(outs[0][k], ref[k]), rel(outs[1][k], outs[0][k])
+            line += f" {nm} mp/f64 {e_mp:.1e} v2/f64 {e_v2:.1e} mp/v2 {e_x:.1e};"
+            if not (e_mp < 2e-5):
+                ok = False
+        print(line)
+        if not ok:
+            a, r = outs[1][4], f.acts          # [B, T, L, 5, H]: first diverging record
+            for t in range(T):
+                for l in range(L):
+                    for k in range(5):
+                        e = np.abs(a[:, t, l, k] - r[:, t, l, k]).max()
+                        if e > 1e-4:
+                            bad = np.argwhere(np.abs(a[:, t, l, k] - r[:, t, l, k]) > 1e-4)
+                            print(f"   first bad record: t={t} layer={l} kind={'h r z n nhh'.split()[k]} max abs {e:.3e}; "
+                                  f"bad (path, unit) x{len(bad)}: {bad[:12].tolist()}")
+                            print("   got", a[bad[0][0], t, l, k, :8], "\n   ref", r[bad[0][0], t, l, k, :8])
+                            return False
+            print("   acts agree; means[:, 0]:", outs[1][1][:3, 0], "ref", f.means[:3, 0])
+            return False
+    return ok
+
+
+def timing():
+    T, S, C, P, H, L = 400, 2, 256, 3, 64, 2
+    print("LV head dims (T=400, S=2, C=256 bf16 context, H=64, L=2); serial forward kernel, HIP events, us")
+    for B in (128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        ws, x0, ctx, theta, eps = inputs(B, T, S, C, P, H, L, 3)
+        d = lambda t: t.to(dev)
+        wd = [d(w) for w in ws]
+        x0, ctx, theta, eps = d(x0), d(ctx), d(theta), d(eps)
+        row = f"B={B:6d}"
+        for mode in (0, 1):
+            _hip.debug_head_mp(mode)
+            for save in (True, False):
+                _hip.profile_enable(True)
+                ms = []
+                for i in range(6):
+                    _hip.head_forward(x0, ctx[:, :-1], theta, eps, wd, 0.1, save)
+                    if i >= 2:
+                        ms.append(_hip.profile_elapsed_ms(0))
+                _hip.profile_enable(False)
+                row += f" | {'mp' if mode else 'v2'} {'train' if save else 'eval'} {1e3 * sum(ms) / len(ms):8.0f}"
+        _hip.debug_head_mp(-1)
+        print(row, flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    good = True
+    if what in ("check", "all"):
+        good = check()
+        print("CHECK", "PASS" if good else "FAIL")
+    if what in ("time", "all") and good:
+        timing()

@@ -148,6 +148,21 @@ int launch_proj_fwd_bf16(const RowView &A, int64_t M, int K, const float *W, int
 int launch_proj_bwd_bf16(const RowView &A, int64_t M, int K, const float *Wt, int ldw, int N, void *C, int64_t ldc, int out_rpb,
                          int64_t out_bstride, void *scratch, size_t scratch_bytes, hipStream_t s);
 
+// ---- multi-path MFMA forward of the GRU head (vsde_head_mp.hip): hidden_dim 64, L <= 2, state_dim <= 2 ----------------------
+struct MpLaunch {
+    int B, T, S, P, C, L, save;
+    const float *x0, *theta, *eps, *G;
+    const float *W_ih0, *W_hh0, *W_ih_st, *W_hh_st, *out_W;
+    const float *b_hh0, *b_ih_st, *b_hh_st, *out_b;
+    void *frags;                 // mp_frag_bytes(L, S) of workspace
+    float dt, sqdt, diag_min;
+    float *paths, *means, *chol, *chol_raw, *acts;
+};
+bool mp_applicable(int H, int L, int S);
+size_t mp_frag_bytes(int L, int S);
+// mark: the profile-event hook of vsde_head.hip (slot 0 = the time-stepping kernel), may be nullptr
+int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t));
+
 // ---- streamed attention kernels (vsde_attn_stream.hip): any N, head_dim 64 or 128 ------------
 int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
                                 double scale, hipStream_t s);

@@ -1534,7 +1534,7 @@ static bool proj_fast_path() {
     return generic == 0;
 }
 
-struct FwdLayout { size_t packF, packO, Wc, planes, G, total; };
+struct FwdLayout { size_t packF, packO, Wc, planes, G, frags, total; };
 static FwdLayout fwd_layout(const vsde_head_dims *d) {
     const int NO = d->S + d->S * (d->S + 1) / 2;
     FwdLayout o; size_t off = 0;
@@ -1543,8 +1543,32 @@ static FwdLayout fwd_layout(const vsde_head_dims *d) {
     o.Wc = off; off += align256((size_t)3 * d->H * d->C * sizeof(float));
     o.planes = off; off += align256(proj_planes_bytes(3 * d->H, d->C));   // bf16 planes of W_c (vsde_proj.hip)
     o.G = off; off += align256((size_t)d->B * d->T * 3 * d->H * sizeof(float));
+    o.frags = off; off += mp_applicable(d->H, d->L, d->S) ? align256(mp_frag_bytes(d->L, d->S)) : 0;   // vsde_head_mp.hip
     o.total = off;
     return o;
+}
+
+// Which forward time-stepping kernel takes hidden_dim 64 / L <= 2 / state_dim <= 2: the multi-path MFMA kernel (vsde_head_mp.hip) or
+// the four-waves-per-path v2 kernel.  VSDE_HEAD_MP = 0 / 1 forces one of them (A/B runs); vsde_debug_head_mp() does the same
+// from tests.  Default: see mp_auto().
+static int g_mp_mode = -1;   // -1 = environment / auto, 0 = never, 1 = whenever applicable
+static int mp_env() {
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("VSDE_HEAD_MP"); mode = e ? atoi(e) : -1; }
+    return mode;
+}
+static bool mp_auto(const vsde_head_dims *d, int save) {
+    // 16 paths per workgroup: the chip is full from 4096 paths on; below that the time of a launch is T x the latency of
+    // one step either way, and a multi-path step is shorter than a v2 step (measured: profiles/r04_head_mp.txt)
+    (void)save;
+    return d->B >= 256;
+}
+static bool use_mp(const vsde_head_dims *d, int save) {
+    if (!mp_applicable(d->H, d->L, d->S)) return false;
+    const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    return mp_auto(d, save);
 }
 
 static int pick_wpb(int B, size_t lds_fixed, size_t lds_per_wave) {
@@ -1600,6 +1624,11 @@ extern "C" int vsde_debug_read_trace(long long *host64) {
 
 extern "C" int vsde_debug_force_v1(int on) {
     g_force_v1 = on != 0;
+    return 0;
+}
+
+extern "C" int vsde_debug_head_mp(int mode) {
+    g_mp_mode = mode < 0 ? -1 : (mode != 0);
     return 0;
 }
 
@@ -1677,6 +1706,19 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
         VSDE_CHECK_HIP(hipGetLastError());
         if (save) prof_mark(2, 1, s);
         return 0;
+    }
+    if (!g_force_v1 && use_mp(d, save)) {   // 16 paths per workgroup on the matrix cores
+        MpLaunch a = {};
+        a.B = d->B; a.T = d->T; a.S = d->S; a.P = d->P; a.C = d->C; a.L = d->L; a.save = save;
+        a.x0 = x0; a.theta = theta; a.eps = eps; a.G = G;
+        a.W_ih0 = w->W_ih_l0; a.W_hh0 = w->W_hh_l0; a.W_ih_st = w->W_ih_stack; a.W_hh_st = w->W_hh_stack; a.out_W = w->out_weight;
+        a.b_hh0 = w->b_hh_l0; a.b_ih_st = w->b_ih_stack; a.b_hh_st = w->b_hh_stack; a.out_b = w->out_bias;
+        a.frags = ws + lay.frags;
+        a.dt = p.dt; a.sqdt = p.sqdt; a.diag_min = p.diag_min;
+        a.paths = paths; a.means = means; a.chol = chol; a.chol_raw = chol_raw; a.acts = acts;
+        rc = launch_head_fwd_mp(a, s, prof_mark);
+        if (save && rc == 0) prof_mark(2, 1, s);
+        return rc;
     }
     if (d->L <= 2 && !g_force_v1) {  // register-resident 4-waves-per-path kernels
         p.wpb = 1;

@@ -1,0 +1,390 @@
+// Multi-path GRU path sampler on the matrix cores (round 4): 16 sample paths per workgroup, split-precision f16 MFMA.
+//
+// Reference semantics: kernels/forward.py:137-375 (the same time loop as head_fwd_v2_kernel in vsde_head.hip).
+//
+// Why a second forward kernel.  head_fwd_v2_kernel gives one sample path four wavefronts and multiplies on the VALU: with
+// 2 paths per CU every time step is a ~2,700-cycle dependency chain (LDS round trips, barriers, 276 VALU issues) and the
+// design saturates at 512 paths per GPU -- from there on time doubles with the batch (1.0 M sampled paths/s at any batch,
+// 0.027 of the HBM roofline for the no-grad sampling launch).  The recurrent products W h are tiny matrix-vector products per
+// path; over a GROUP of paths they are GEMMs with N = paths, which is what the matrix pipe wants:
+//
+//   * workgroup = 4 waves = 16 paths.  Wave w owns the hidden units 16 w .. 16 w + 15 of every gate; its three A tiles of a
+//     recurrent matrix are the r / u / n rows of those units, the B operand is h^T [64 x 16 paths].  v_mfma_f32_16x16x32_f16
+//     leaves lane (q = lane >> 4, p = lane & 15) with D[rows 4 q .. 4 q + 3][column p]: the r, u and n pre-activations of FOUR
+//     units of ONE path in one lane -- the whole gate algebra is lane-local, no cross-lane traffic.
+//   * fp32-equivalent results from f16 operands: every operand is split x = hi + lo / 2048 with hi = f16(x), lo = f16((x - hi)
+//     * 2048) (22 mantissa bits; the 2^11 scale keeps lo out of the f16 subnormals) and a product is three MFMAs,
+//     hi*hi into one accumulator, hi*lo + lo*hi into a second one that is folded in with one v_fma (x 2^-11); the dropped
+//     lo*lo term is 2^-22 relative.  Accumulation is fp32.  Gate rows are pre-scaled into the exp2 domain like the v2 kernel's.
+//   * all recurrent weights live in VGPRs as ready-made A fragments (built once per launch by mp_prep_kernel): 48 VGPRs per
+//     matrix, 144 + 32 (emission rows) for two layers; the time loop issues no weight loads.
+//   * the hidden state crosses the four waves as f16 hi / lo planes through 4 KB of LDS per layer, stored by its owners in
+//     B-fragment order (each lane one ds_write_b64 per plane, each reader one conflict-free ds_read_b128 per k-step and plane),
+//     one workgroup barrier per layer.
+//   * the emission rows are replicated four times down their A tile (tile row i holds out_proj row 4 tile + (i & 3)), so EVERY
+//     lane ends up with all S + S(S+1)/2 emission values of its path: the Euler-Maruyama update and the state-input term of the
+//     next step are lane-local as well (z_t is fp32 on the VALU: it is not bounded like h).
+//   * the products a step does not need at once -- W_hh h_t of both layers, used by step t + 1 -- are issued behind the ones
+//     on the critical path, so they run on the matrix pipe while the VALU does the next gate block.
+//   * global traffic: the projected context record G[b, t, 3H] is read straight into registers two steps ahead (16 B per lane
+//     and gate), saved activations leave as 16-byte lanes (four waves complete each 256-byte row), outputs from 16 lanes each.
+//
+// Scope: hidden_dim 64, 1 or 2 layers, state_dim 1 or 2 (the OU and Lotka-Volterra heads); everything else keeps the v2 / v1 /
+// generic kernels.  Weights must fit f16 range after the exp2 scaling (|W| < 2.2e4; a GRU gate saturates long before).
+#include "vsde_common.h"
+
+namespace vsde {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kMpLo = 2048.0f, kMpLoInv = 1.0f / 2048.0f;
+constexpr float kMpSr = -1.4426950408889634f, kMpSn = 2.8853900817779268f, kMpInvSn = 1.0f / 2.8853900817779268f;
+template <int V> struct MpSlot { static constexpr int value = V; };
+using C0 = MpSlot<0>;
+using C1 = MpSlot<1>;
+constexpr int kMpMatFrags = 4 * 3 * 2 * 2 * 64;   // f16x8 fragments of one recurrent matrix: [wave][gate][k-step][plane][lane]
+
+__device__ __forceinline__ void mp_split(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kMpLo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// A fragments of the recurrent matrices and the emission rows, in the register order of the main kernel.
+// k-slot (lane group q, element e) of k-step ks stands for reduction index k = 32 ks + 8 q + e on BOTH operands (the hardware
+// contracts A slot with B slot; any consistent labelling sums over all k).
+struct MpPrep {
+    int nm, no, nto;
+    const float *W[3];     // W_hh_l0, W_ih_l1, W_hh_l1  ([192][64], nn.GRU layout)
+    const float *out_W;    // [no][64]
+    f16x8 *frags;
+};
+
+__global__ void __launch_bounds__(256) mp_prep_kernel(MpPrep q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nmat = q.nm * 1536;                     // (wave, gate, k-step, lane) tuples per matrix
+    if (i < nmat) {
+        const int m = i / 1536, r = i - m * 1536;
+        const int lane = r & 63, ks = (r >> 6) & 1, wg = r >> 7, g = wg % 3, w = wg / 3;
+        const int row = g * 64 + 16 * w + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+        const float sc = g < 2 ? kMpSr : kMpSn;
+        const float *W = q.W[m] + (int64_t)row * 64 + k0;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(sc * W[e], a, b); hi[e] = a; lo[e] = b; }
+        f16x8 *dst = q.frags + (int64_t)m * kMpMatFrags + (((w * 3 + g) * 2 + ks) * 2) * 64 + lane;
+        dst[0] = hi; dst[64] = lo;
+    } else if (i - nmat < q.nto * 128) {
+        const int r = i - nmat, lane = r & 63, ks = (r >> 6) & 1, tl = r >> 7;
+        const int orow = 4 * tl + (lane & 3), k0 = 32 * ks + 8 * (lane >> 4);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 a, b;
+            mp_split(orow < q.no ? q.out_W[(int64_t)orow * 64 + k0 + e] : 0.0f, a, b);
+            hi[e] = a; lo[e] = b;
+        }
+        f16x8 *dst = q.frags + (int64_t)q.nm * kMpMatFrags + ((tl * 2 + ks) * 2) * 64 + lane;
+        dst[0] = hi; dst[64] = lo;
+    }
+}
+
+struct MpParams {
+    int B, T, P, C;
+    const float *x0, *theta, *eps, *G;
+    const float *W_ih0;                          // [192][S + C + P]: state and theta columns are read here
+    const float *b_hh0, *b_ih1, *b_hh1, *out_b;
+    const f16x8 *frags;
+    float dt, sqdt, diag_min;
+    float *paths, *means, *chol, *chol_raw, *acts;
+};
+
+__device__ __forceinline__ f32x4 mp_mfma(const f16x8 &a, const f16x8 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// [W (three gate tiles of this wave's units)] x [h^T of the 16 paths]: hi*hi -> A1, hi*lo' + lo'*hi -> A2 (scaled by 2^11)
+__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], f32x4 (&A1)[3], f32x4 (&A2)[3]) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { A1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; A2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) A1[g] = mp_mfma(wf[g][ks][0], hb[0][ks], A1[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][0], hb[1][ks], A2[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][1], hb[0][ks], A2[g]);
+    }
+}
+
+template <int L, bool SAVE, int S>
+__global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
+    constexpr int NM = 2 * L - 1, NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4;
+    static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2, "multi-path kernel: L <= 2, state_dim <= 2");
+    // hidden state planes in B-fragment order: [step parity][layer][plane hi / lo][k-step][lane group][path] x 8 f16
+    __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][2][2][4][16];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, pp = lane & 15;
+    const int b_raw = blockIdx.x * 16 + pp;
+    const bool live = b_raw < p.B;
+    const int b = live ? b_raw : p.B - 1;          // lanes beyond the batch recompute the last path and store nothing
+    const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+
+    // ---- register-resident A fragments
+    f16x8 wf[NM][3][2][2], of[NTO][2][2];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wf[m][g][ks][pl] = p.frags[(int64_t)m * kMpMatFrags + ((((w * 3 + g) * 2 + ks) * 2) + pl) * 64 + lane];
+#pragma unroll
+    for (int tl = 0; tl < NTO; ++tl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                of[tl][ks][pl] = p.frags[(int64_t)NM * kMpMatFrags + (((tl * 2 + ks) * 2) + pl) * 64 + lane];
+
+    // ---- per-lane constants of the 4 owned units (exp2 domain): biases, hoisted theta projection, state columns of W_ih_l0
+    float k0[3][4], bn0[4], wx[S][3][4], k1[3][4], bn1[4], ob[NO];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = g * 64 + j0 + r;
+            const float sc = g < 2 ? kMpSr : kMpSn;
+            float th = 0.f;   // theta term (forward.py:157-175)
+            for (int e = 0; e < p.P; ++e) th = fmaf(p.theta[(int64_t)b * p.P + e], p.W_ih0[(int64_t)row * I + S + p.C + e], th);
+            k0[g][r] = sc * th + (g < 2 ? sc * p.b_hh0[row] : 0.f);
+#pragma unroll
+            for (int i = 0; i < S; ++i) wx[i][g][r] = sc * p.W_ih0[(int64_t)row * I + i];
+            if (L > 1) k1[g][r] = sc * p.b_ih1[row] + (g < 2 ? sc * p.b_hh1[row] : 0.f);
+            else k1[g][r] = 0.f;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bn0[r] = kMpSn * p.b_hh0[128 + j0 + r];
+        bn1[r] = L > 1 ? kMpSn * p.b_hh1[128 + j0 + r] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NO; ++r) ob[r] = p.out_b[r];
+
+    // ---- state
+    float z[S], h0[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0a[3], c0b[3], c1a[3], c1b[3];          // W_hh^l h^l_{t-1}: h_{-1} = 0
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { c0a[g] = c0b[g] = c1a[g] = c1b[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) z[i] = p.x0[(int64_t)b * S + i];
+    if (w == 0 && q == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) p.paths[(int64_t)b * (T + 1) * S + i] = z[i];
+    }
+
+    // ---- the projected context record and eps, two steps ahead in registers
+    const float *Gb = p.G + (int64_t)b * T * 192 + j0;
+    const float *eb = p.eps + (int64_t)b * T * S;
+    f32x4 gq[2][3];
+    float ev[2][S];
+    auto fetch = [&](int t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int tc = t < T ? t : T - 1;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gq[slot][g] = *(const f32x4 *)(Gb + (int64_t)tc * 192 + g * 64);
+#pragma unroll
+        for (int i = 0; i < S; ++i) ev[slot][i] = eb[(int64_t)tc * S + i];
+    };
+    fetch(0, C0{});
+    fetch(1, C1{});
+
+    // gate block of one layer for the 4 owned units (exp2 domain: r = 1 / (1 + 2^x_r), n = 1 - 2 / (1 + 2^(a_n + r c_n)))
+    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&ca)[3], const f32x4 (&cb)[3],
+                     const float (&bn)[4], float (&h)[4], int t, int l) {
+        float rg[4], ug[4], ng[4], cn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xr = ar[r] + fmaf(cb[0][r], kMpLoInv, ca[0][r]);
+            const float xu = au[r] + fmaf(cb[1][r], kMpLoInv, ca[1][r]);
+            cn[r] = bn[r] + fmaf(cb[2][r], kMpLoInv, ca[2][r]);
+            rg[r] = fast_rcp(1.0f + fast_exp2(xr));
+            ug[r] = fast_rcp(1.0f + fast_exp2(xu));
+            ng[r] = fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(rg[r], cn[r], an[r]))), 1.0f);
+            h[r] = fmaf(ug[r], h[r] - ng[r], ng[r]);           // (1 - u) n + u h
+        }
+        // exchange: f16 hi / lo planes of the new state, in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane
+        // group (j >> 3) & 3, element j & 7)
+        f16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(h[r], a, c); hi[r] = a; lo[r] = c; }
+        const int par = t & 1;
+        f16x4 *d0 = (f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1);
+        f16x4 *d1 = (f16x4 *)&hbuf[par][l][1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1);
+        *d0 = hi; *d1 = lo;
+        if (SAVE && live) {   // acts[b][t][l][{h, r, z, n, n_hh}][64]  (kernels/weights.py:11-23)
+            float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
+            *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
+            *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
+            *(f32x4 *)(ab + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
+            *(f32x4 *)(ab + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
+            *(f32x4 *)(ab + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto read_state = [&](int t, int l, f16x8 (&hb)[2][2]) {
+        const int par = t & 1;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][pp];
+    };
+
+    auto step = [&](int t, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        f32x4 g0 = gq[slot][0], g1 = gq[slot][1], g2 = gq[slot][2];
+        float e[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) e[i] = ev[slot][i];
+        fetch(t + 2, slot_c);
+        // ---- layer 0: a = G_t (context projection + b_ih) + theta term + z_t W_x   (forward.py:195-219)
+        float ar[4], au[4], an[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ar[r] = fmaf(g0[r], kMpSr, k0[0][r]); au[r] = fmaf(g1[r], kMpSr, k0[1][r]); an[r] = fmaf(g2[r], kMpSn, k0[2][r]);
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                ar[r] = fmaf(z[i], wx[i][0][r], ar[r]); au[r] = fmaf(z[i], wx[i][1][r], au[r]); an[r] = fmaf(z[i], wx[i][2][r], an[r]);
+            }
+        }
+        gates(ar, au, an, c0a, c0b, bn0, h0, t, 0);
+        f16x8 hb[2][2];
+        read_state(t, 0, hb);
+        f32x4 O1[NTO], O2[NTO];
+#pragma unroll
+        for (int tl = 0; tl < NTO; ++tl) { O1[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; O2[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (L > 1) {
+            constexpr int M_IH1 = L > 1 ? 1 : 0, M_HH1 = L > 1 ? 2 : 0;
+            f32x4 a1a[3], a1b[3];
+            mp_matmul(wf[M_IH1], hb, a1a, a1b);      // W_ih^1 h^0_t: needed now
+            mp_matmul(wf[0], hb, c0a, c0b);          // W_hh^0 h^0_t: needed by step t + 1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ar[r] = k1[0][r] + fmaf(a1b[0][r], kMpLoInv, a1a[0][r]);
+                au[r] = k1[1][r] + fmaf(a1b[1][r], kMpLoInv, a1a[1][r]);
+                an[r] = k1[2][r] + fmaf(a1b[2][r], kMpLoInv, a1a[2][r]);
+            }
+            gates(ar, au, an, c1a, c1b, bn1, h1, t, L - 1);
+            read_state(t, L - 1, hb);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tl = 0; tl < NTO; ++tl) {
+                    O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
+                    O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
+                    O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
+                }
+            mp_matmul(wf[M_HH1], hb, c1a, c1b);      // W_hh^1 h^1_t: needed by step t + 1
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tl = 0; tl < NTO; ++tl) {
+                    O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
+                    O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
+                    O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
+                }
+            mp_matmul(wf[0], hb, c0a, c0b);
+        }
+        // ---- emission (forward.py:314-375): every lane holds all NO values of its path
+        float o[NO];
+#pragma unroll
+        for (int r = 0; r < NO; ++r) o[r] = ob[r] + fmaf(O2[r >> 2][r & 3], kMpLoInv, O1[r >> 2][r & 3]);
+        float mu[S], Lc[S][S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            mu[i] = o[i];
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                if (c > i) { Lc[i][c] = 0.f; continue; }
+                const float v = o[S + i * (i + 1) / 2 + c];
+                Lc[i][c] = (c == i && v < p.diag_min) ? p.diag_min : v;   // NaN propagates (torch.max semantics)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c <= i; ++c) acc = fmaf(Lc[i][c], e[c], acc);
+            z[i] = z[i] + mu[i] * p.dt + acc * p.sqdt;
+        }
+        if (q == 0 && live) {
+            const int64_t bt = (int64_t)b * T + t;
+            if (w == 0) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) p.paths[(bt + b + 1) * S + i] = z[i];
+            } else if (w == 1) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) p.means[bt * S + i] = mu[i];
+            } else if (w == 2) {
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int c = 0; c < S; ++c) p.chol[bt * S * S + i * S + c] = Lc[i][c];
+            } else if (SAVE) {
+#pragma unroll
+                for (int r = 0; r < NTRIL; ++r) p.chol_raw[bt * NTRIL + r] = o[S + r];
+            }
+        }
+    };
+
+    for (int t = 0; t < T; t += 2) {
+        step(t, C0{});
+        if (t + 1 < T) step(t + 1, C1{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+size_t mp_frag_bytes(int L, int S) {
+    const int no = S + S * (S + 1) / 2, nto = (no + 3) / 4;
+    return ((size_t)(2 * L - 1) * kMpMatFrags + (size_t)nto * 2 * 2 * 64) * sizeof(f16x8);
+}
+
+bool mp_applicable(int H, int L, int S) { return H == 64 && L >= 1 && L <= 2 && S >= 1 && S <= 2; }
+
+int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t)) {
+    const int no = a.S + a.S * (a.S + 1) / 2, nto = (no + 3) / 4, nm = 2 * a.L - 1;
+    MpPrep q = {};
+    q.nm = nm; q.no = no; q.nto = nto;
+    q.W[0] = a.W_hh0; q.W[1] = a.W_ih_st; q.W[2] = a.W_hh_st; q.out_W = a.out_W;
+    q.frags = (f16x8 *)a.frags;
+    const int nthr = nm * 1536 + nto * 128;
+    hipLaunchKernelGGL(mp_prep_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, q);
+    MpParams p = {};
+    p.B = a.B; p.T = a.T; p.P = a.P; p.C = a.C;
+    p.x0 = a.x0; p.theta = a.theta; p.eps = a.eps; p.G = a.G; p.W_ih0 = a.W_ih0;
+    p.b_hh0 = a.b_hh0; p.b_ih1 = a.b_ih_st; p.b_hh1 = a.b_hh_st; p.out_b = a.out_b;
+    p.frags = (const f16x8 *)a.frags;
+    p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
+    p.paths = a.paths; p.means = a.means; p.chol = a.chol; p.chol_raw = a.chol_raw; p.acts = a.acts;
+    const dim3 grid((a.B + 15) / 16), block(256);
+    if (mark) mark(0, 0, s);
+#define VSDE_MP_LAUNCH(LL, SV, SS) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS>), grid, block, 0, s, p)
+    if (a.L == 1) {
+        if (a.save) { if (a.S == 1) VSDE_MP_LAUNCH(1, true, 1); else VSDE_MP_LAUNCH(1, true, 2); }
+        else { if (a.S == 1) VSDE_MP_LAUNCH(1, false, 1); else VSDE_MP_LAUNCH(1, false, 2); }
+    } else {
+        if (a.save) { if (a.S == 1) VSDE_MP_LAUNCH(2, true, 1); else VSDE_MP_LAUNCH(2, true, 2); }
+        else { if (a.S == 1) VSDE_MP_LAUNCH(2, false, 1); else VSDE_MP_LAUNCH(2, false, 2); }
+    }
+#undef VSDE_MP_LAUNCH
+    if (mark) mark(0, 1, s);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vsde
