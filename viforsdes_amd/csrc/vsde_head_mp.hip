@@ -8,7 +8,7 @@
 // 0.027 of the HBM roofline for the no-grad sampling launch).  The recurrent products W h are tiny matrix-vector products per
 // path; over a GROUP of paths they are GEMMs with N = paths, which is what the matrix pipe wants:
 //
-//   * workgroup = 4 waves = 16 paths.  Wave w owns the hidden units 16 w .. 16 w + 15 of every gate; its three A tiles of a
+//   * workgroup = 16 paths; 4 waves per GRU layer (roles: see the kernel).  Wave w of a layer owns the hidden units 16 w .. 16 w + 15 of every gate; its three A tiles of a
 //     recurrent matrix are the r / u / n rows of those units, the B operand is h^T [64 x 16 paths].  v_mfma_f32_16x16x32_f16
 //     leaves lane (q = lane >> 4, p = lane & 15) with D[rows 4 q .. 4 q + 3][column p]: the r, u and n pre-activations of FOUR
 //     units of ONE path in one lane -- the whole gate algebra is lane-local, no cross-lane traffic.
@@ -120,39 +120,133 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
     }
 }
 
+// Roles.  One layer: four waves (wave w = units 16 w ..).  Two layers: EIGHT waves, two per SIMD -- waves 0-3 are layer 0 (W_hh_l0
+// and the emission rows in registers, the Euler-Maruyama update, the context record), waves 4-7 are layer 1 (W_ih_l1, W_hh_l1).
+// With all three matrices in one wave the kernel needed 432 registers and hipcc moved ~180 values per step between the
+// accumulator and the vector half of the file; split by layer each role stays below 256 registers, and the products a step
+// does not need at once (W_hh h_t, consumed by step t + 1) run on one role's matrix pipe while the other role's VALU does gates.
+//   step t:  [L0: gates -> h0_t]  barrier A  [L1: W_ih1 h0_t, gates -> h1_t | L0: W_hh0 h0_t]  barrier B
+//            [L0: emission rows x h1_t, z_{t+1}, outputs, then gates of step t + 1 | L1: W_hh1 h1_t]
 template <int L, bool SAVE, int S>
-__global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
-    constexpr int NM = 2 * L - 1, NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4;
+__global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p) {
+    constexpr int NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4;
     static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2, "multi-path kernel: L <= 2, state_dim <= 2");
     // hidden state planes in B-fragment order: [step parity][layer][plane hi / lo][k-step][lane group][path] x 8 f16
     __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][2][2][4][16];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane >> 4, pp = lane & 15;
+    const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
     const int b_raw = blockIdx.x * 16 + pp;
     const bool live = b_raw < p.B;
     const int b = live ? b_raw : p.B - 1;          // lanes beyond the batch recompute the last path and store nothing
     const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
 
-    // ---- register-resident A fragments
-    f16x8 wf[NM][3][2][2], of[NTO][2][2];
+    // the 4 owned units' new state -> f16 hi / lo planes in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane group
+    // (j >> 3) & 3, element j & 7), the saved activations, and the barrier that publishes the planes
+    auto publish = [&](const float (&h)[4], const float (&rg)[4], const float (&ug)[4], const float (&ng)[4], const float (&cn)[4],
+                       int t, int l) {
+        f16x4 hi, lo;
 #pragma unroll
-    for (int m = 0; m < NM; ++m)
+        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(h[r], a, c); hi[r] = a; lo[r] = c; }
+        const int par = t & 1;
+        *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
+        *((f16x4 *)&hbuf[par][l][1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = lo;
+        if (SAVE && live) {   // acts[b][t][l][{h, r, z, n, n_hh}][64]  (kernels/weights.py:11-23)
+            float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
+            *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
+            *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
+            *(f32x4 *)(ab + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
+            *(f32x4 *)(ab + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
+            *(f32x4 *)(ab + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
+        }
+    };
+    // gate block of one layer for the 4 owned units (exp2 domain: r = 1 / (1 + 2^x_r), n = 1 - 2 / (1 + 2^(a_n + r c_n)))
+    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&ca)[3], const f32x4 (&cb)[3],
+                     const float (&bn)[4], float (&h)[4], int t, int l) {
+        float rg[4], ug[4], ng[4], cn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xr = ar[r] + fmaf(cb[0][r], kMpLoInv, ca[0][r]);
+            const float xu = au[r] + fmaf(cb[1][r], kMpLoInv, ca[1][r]);
+            cn[r] = bn[r] + fmaf(cb[2][r], kMpLoInv, ca[2][r]);
+            rg[r] = fast_rcp(1.0f + fast_exp2(xr));
+            ug[r] = fast_rcp(1.0f + fast_exp2(xu));
+            ng[r] = fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(rg[r], cn[r], an[r]))), 1.0f);
+            h[r] = fmaf(ug[r], h[r] - ng[r], ng[r]);           // (1 - u) n + u h
+        }
+        publish(h, rg, ug, ng, cn, t, l);
+    };
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto read_state = [&](int t, int l, f16x8 (&hb)[2][2]) {
+        const int par = t & 1;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][pp];
+    };
+    auto load_matrix = [&](int m, f16x8 (&wf)[3][2][2]) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    wf[m][g][ks][pl] = p.frags[(int64_t)m * kMpMatFrags + ((((w * 3 + g) * 2 + ks) * 2) + pl) * 64 + lane];
+                    wf[g][ks][pl] = p.frags[(int64_t)m * kMpMatFrags + ((((w * 3 + g) * 2 + ks) * 2) + pl) * 64 + lane];
+    };
+
+    if (role == 1) {
+        // =================================================================== layer-1 waves (two-layer heads only)
+        if (L > 1) {
+            f16x8 wi[3][2][2], wh[3][2][2];
+            load_matrix(1, wi);
+            load_matrix(2, wh);
+            float k1[3][4], bn1[4], h1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = g * 64 + j0 + r;
+                    const float sc = g < 2 ? kMpSr : kMpSn;
+                    k1[g][r] = sc * p.b_ih1[row] + (g < 2 ? sc * p.b_hh1[row] : 0.f);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bn1[r] = kMpSn * p.b_hh1[128 + j0 + r];
+            f32x4 c1a[3], c1b[3];                     // W_hh^1 h^1_{t-1}: h_{-1} = 0
+#pragma unroll
+            for (int g = 0; g < 3; ++g) c1a[g] = c1b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T; ++t) {
+                barrier();                             // A: h^0_t published
+                f16x8 hb[2][2];
+                read_state(t, 0, hb);
+                f32x4 a1a[3], a1b[3];
+                mp_matmul(wi, hb, a1a, a1b);           // W_ih^1 h^0_t
+                float ar[4], au[4], an[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ar[r] = k1[0][r] + fmaf(a1b[0][r], kMpLoInv, a1a[0][r]);
+                    au[r] = k1[1][r] + fmaf(a1b[1][r], kMpLoInv, a1a[1][r]);
+                    an[r] = k1[2][r] + fmaf(a1b[2][r], kMpLoInv, a1a[2][r]);
+                }
+                gates(ar, au, an, c1a, c1b, bn1, h1, t, L - 1);
+                barrier();                             // B: h^1_t published
+                read_state(t, L - 1, hb);
+                mp_matmul(wh, hb, c1a, c1b);           // W_hh^1 h^1_t: consumed by step t + 1
+            }
+        }
+        return;
+    }
+
+    // ======================================================================= layer-0 waves
+    f16x8 wf[3][2][2], of[NTO][2][2];
+    load_matrix(0, wf);
 #pragma unroll
     for (int tl = 0; tl < NTO; ++tl)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                of[tl][ks][pl] = p.frags[(int64_t)NM * kMpMatFrags + (((tl * 2 + ks) * 2) + pl) * 64 + lane];
+                of[tl][ks][pl] = p.frags[(int64_t)(2 * L - 1) * kMpMatFrags + (((tl * 2 + ks) * 2) + pl) * 64 + lane];
 
-    // ---- per-lane constants of the 4 owned units (exp2 domain): biases, hoisted theta projection, state columns of W_ih_l0
-    float k0[3][4], bn0[4], wx[S][3][4], k1[3][4], bn1[4], ob[NO];
+    // per-lane constants of the 4 owned units (exp2 domain): biases, hoisted theta projection, state columns of W_ih_l0
+    float k0[3][4], bn0[4], wx[S][3][4], ob[NO];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -164,22 +258,16 @@ __global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
             k0[g][r] = sc * th + (g < 2 ? sc * p.b_hh0[row] : 0.f);
 #pragma unroll
             for (int i = 0; i < S; ++i) wx[i][g][r] = sc * p.W_ih0[(int64_t)row * I + i];
-            if (L > 1) k1[g][r] = sc * p.b_ih1[row] + (g < 2 ? sc * p.b_hh1[row] : 0.f);
-            else k1[g][r] = 0.f;
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bn0[r] = kMpSn * p.b_hh0[128 + j0 + r];
-        bn1[r] = L > 1 ? kMpSn * p.b_hh1[128 + j0 + r] : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) bn0[r] = kMpSn * p.b_hh0[128 + j0 + r];
 #pragma unroll
     for (int r = 0; r < NO; ++r) ob[r] = p.out_b[r];
 
-    // ---- state
-    float z[S], h0[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c0a[3], c0b[3], c1a[3], c1b[3];          // W_hh^l h^l_{t-1}: h_{-1} = 0
+    float z[S], h0[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0a[3], c0b[3];                              // W_hh^0 h^0_{t-1}: h_{-1} = 0
 #pragma unroll
-    for (int g = 0; g < 3; ++g) { c0a[g] = c0b[g] = c1a[g] = c1b[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int g = 0; g < 3; ++g) c0a[g] = c0b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < S; ++i) z[i] = p.x0[(int64_t)b * S + i];
     if (w == 0 && q == 0 && live) {
@@ -187,7 +275,7 @@ __global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
         for (int i = 0; i < S; ++i) p.paths[(int64_t)b * (T + 1) * S + i] = z[i];
     }
 
-    // ---- the projected context record and eps, two steps ahead in registers
+    // the projected context record and eps, two steps ahead in registers
     const float *Gb = p.G + (int64_t)b * T * 192 + j0;
     const float *eb = p.eps + (int64_t)b * T * S;
     f32x4 gq[2][3];
@@ -203,45 +291,29 @@ __global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
     fetch(0, C0{});
     fetch(1, C1{});
 
-    // gate block of one layer for the 4 owned units (exp2 domain: r = 1 / (1 + 2^x_r), n = 1 - 2 / (1 + 2^(a_n + r c_n)))
-    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&ca)[3], const f32x4 (&cb)[3],
-                     const float (&bn)[4], float (&h)[4], int t, int l) {
-        float rg[4], ug[4], ng[4], cn[4];
+    // Outputs of step t are stored during step t + 1, in the slack behind barrier A (where the layer-0 waves wait for layer 1):
+    // hipcc's wait for the prefetched context record at the top of the loop is a vmcnt(0) (stores sit in conditional blocks it
+    // cannot count), and a store issued just before it would put a full store round trip on every second step.
+    float pz[S], pmu[S], pL[S][S], praw[NTRIL];
+    auto store_outputs = [&](int t) {     // paths[b, t + 1], means[b, t], chol[b, t], chol_raw[b, t]: one wave each, 16 lanes
+        if (q == 0 && live) {
+            const int64_t bt = (int64_t)b * T + t;
+            if (w == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float xr = ar[r] + fmaf(cb[0][r], kMpLoInv, ca[0][r]);
-            const float xu = au[r] + fmaf(cb[1][r], kMpLoInv, ca[1][r]);
-            cn[r] = bn[r] + fmaf(cb[2][r], kMpLoInv, ca[2][r]);
-            rg[r] = fast_rcp(1.0f + fast_exp2(xr));
-            ug[r] = fast_rcp(1.0f + fast_exp2(xu));
-            ng[r] = fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(rg[r], cn[r], an[r]))), 1.0f);
-            h[r] = fmaf(ug[r], h[r] - ng[r], ng[r]);           // (1 - u) n + u h
+                for (int i = 0; i < S; ++i) p.paths[(bt + b + 1) * S + i] = pz[i];
+            } else if (w == 1) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) p.means[bt * S + i] = pmu[i];
+            } else if (w == 2) {
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int c = 0; c < S; ++c) p.chol[bt * S * S + i * S + c] = pL[i][c];
+            } else if (SAVE) {
+#pragma unroll
+                for (int r = 0; r < NTRIL; ++r) p.chol_raw[bt * NTRIL + r] = praw[r];
+            }
         }
-        // exchange: f16 hi / lo planes of the new state, in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane
-        // group (j >> 3) & 3, element j & 7)
-        f16x4 hi, lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(h[r], a, c); hi[r] = a; lo[r] = c; }
-        const int par = t & 1;
-        f16x4 *d0 = (f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1);
-        f16x4 *d1 = (f16x4 *)&hbuf[par][l][1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1);
-        *d0 = hi; *d1 = lo;
-        if (SAVE && live) {   // acts[b][t][l][{h, r, z, n, n_hh}][64]  (kernels/weights.py:11-23)
-            float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
-            *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
-            *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
-            *(f32x4 *)(ab + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
-            *(f32x4 *)(ab + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
-            *(f32x4 *)(ab + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    auto read_state = [&](int t, int l, f16x8 (&hb)[2][2]) {
-        const int par = t & 1;
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][pp];
     };
 
     auto step = [&](int t, auto slot_c) {
@@ -262,43 +334,30 @@ __global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
             }
         }
         gates(ar, au, an, c0a, c0b, bn0, h0, t, 0);
+        barrier();                                     // A: h^0_t published
         f16x8 hb[2][2];
         read_state(t, 0, hb);
         f32x4 O1[NTO], O2[NTO];
 #pragma unroll
         for (int tl = 0; tl < NTO; ++tl) { O1[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; O2[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (L > 1) {
-            constexpr int M_IH1 = L > 1 ? 1 : 0, M_HH1 = L > 1 ? 2 : 0;
-            f32x4 a1a[3], a1b[3];
-            mp_matmul(wf[M_IH1], hb, a1a, a1b);      // W_ih^1 h^0_t: needed now
-            mp_matmul(wf[0], hb, c0a, c0b);          // W_hh^0 h^0_t: needed by step t + 1
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ar[r] = k1[0][r] + fmaf(a1b[0][r], kMpLoInv, a1a[0][r]);
-                au[r] = k1[1][r] + fmaf(a1b[1][r], kMpLoInv, a1a[1][r]);
-                an[r] = k1[2][r] + fmaf(a1b[2][r], kMpLoInv, a1a[2][r]);
-            }
-            gates(ar, au, an, c1a, c1b, bn1, h1, t, L - 1);
+            mp_matmul(wf, hb, c0a, c0b);               // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
+            if (t > 0) store_outputs(t - 1);
+            __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs are not ordered by the barrier's "memory" clobber)
+            barrier();                                 // B: h^1_t published
             read_state(t, L - 1, hb);
+        }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int tl = 0; tl < NTO; ++tl) {
-                    O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
-                    O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
-                    O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
-                }
-            mp_matmul(wf[M_HH1], hb, c1a, c1b);      // W_hh^1 h^1_t: needed by step t + 1
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int tl = 0; tl < NTO; ++tl) {
-                    O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
-                    O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
-                    O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
-                }
-            mp_matmul(wf[0], hb, c0a, c0b);
+            for (int tl = 0; tl < NTO; ++tl) {
+                O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
+                O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
+                O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
+            }
+        if (L == 1) {
+            mp_matmul(wf, hb, c0a, c0b);
+            if (t > 0) store_outputs(t - 1);
         }
         // ---- emission (forward.py:314-375): every lane holds all NO values of its path
         float o[NO];
@@ -322,30 +381,22 @@ __global__ void __launch_bounds__(256) head_fwd_mp_kernel(MpParams p) {
             for (int c = 0; c <= i; ++c) acc = fmaf(Lc[i][c], e[c], acc);
             z[i] = z[i] + mu[i] * p.dt + acc * p.sqdt;
         }
-        if (q == 0 && live) {
-            const int64_t bt = (int64_t)b * T + t;
-            if (w == 0) {
+        // outputs leave one step late (store_outputs below): kept in registers until the next step's barrier A
 #pragma unroll
-                for (int i = 0; i < S; ++i) p.paths[(bt + b + 1) * S + i] = z[i];
-            } else if (w == 1) {
+        for (int i = 0; i < S; ++i) { pz[i] = z[i]; pmu[i] = mu[i]; }
 #pragma unroll
-                for (int i = 0; i < S; ++i) p.means[bt * S + i] = mu[i];
-            } else if (w == 2) {
+        for (int i = 0; i < S; ++i)
 #pragma unroll
-                for (int i = 0; i < S; ++i)
+            for (int c = 0; c < S; ++c) pL[i][c] = Lc[i][c];
 #pragma unroll
-                    for (int c = 0; c < S; ++c) p.chol[bt * S * S + i * S + c] = Lc[i][c];
-            } else if (SAVE) {
-#pragma unroll
-                for (int r = 0; r < NTRIL; ++r) p.chol_raw[bt * NTRIL + r] = o[S + r];
-            }
-        }
+        for (int r = 0; r < NTRIL; ++r) praw[r] = o[S + r];
     };
 
     for (int t = 0; t < T; t += 2) {
         step(t, C0{});
         if (t + 1 < T) step(t + 1, C1{});
     }
+    store_outputs(T - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -371,7 +422,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     p.frags = (const f16x8 *)a.frags;
     p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
     p.paths = a.paths; p.means = a.means; p.chol = a.chol; p.chol_raw = a.chol_raw; p.acts = a.acts;
-    const dim3 grid((a.B + 15) / 16), block(256);
+    const dim3 grid((a.B + 15) / 16), block(256 * a.L);
     if (mark) mark(0, 0, s);
 #define VSDE_MP_LAUNCH(LL, SV, SS) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS>), grid, block, 0, s, p)
     if (a.L == 1) {
