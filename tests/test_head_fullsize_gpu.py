@@ -62,7 +62,7 @@ def _inputs(B, T, S, C, P, H, L, seed, bf16_ctx):
 
 # workloads the multi-path MFMA forward kernel (csrc/vsde_head_mp.hip: hidden_dim 64, L <= 2, state_dim <= 2) can take run twice,
 # once per forward kernel (forced: the sub-batch launch below must take the same kernel as the full launch)
-CASES = [(n, mp) for n, v in WORKLOADS.items() for mp in ((0, 1) if (v[3] <= 2 and v[7] <= 2 and v[6] == 64) else (0,))]
+CASES = [(n, mp) for n, v in WORKLOADS.items() for mp in ((0, 4, 16) if (v[3] <= 2 and v[7] <= 2 and v[6] == 64) else (0,))]
 
 
 @pytest.fixture()
@@ -74,7 +74,7 @@ def forward_kernel(request):
 
 
 @pytest.mark.parametrize("name,forward_kernel", CASES, indirect=["forward_kernel"],
-                         ids=[f"{n}-{'mfma16' if mp else 'v2'}" for n, mp in CASES])
+                         ids=[f"{n}-{'mfma%d' % mp if mp else 'v2'}" for n, mp in CASES])
 def test_head_full_size_vs_f64_oracle(name, forward_kernel):
     from oracle import vsde_oracle as vo
     from viforsdes_amd import _hip

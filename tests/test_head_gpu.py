@@ -63,13 +63,14 @@ def test_forward_backward_vs_golden(name):
         assert rel_err(g.cpu().numpy(), ref) < BWD_TOL, gname
 
 
+@pytest.mark.parametrize("np_group", [4, 8, 16])
 @pytest.mark.parametrize("name", ["ou_dims", "lv_dims"])
-def test_multi_path_mfma_forward_vs_golden(name):
+def test_multi_path_mfma_forward_vs_golden(name, np_group):
     """The reference-generated cases with hidden_dim 64 / two layers / state_dim 1, 2 through the multi-path MFMA forward kernel
-    (csrc/vsde_head_mp.hip, forced; batches of 3 / 2 paths = one partly filled 16-path group): same tolerances as the v2 kernel,
-    the backward consumes the activations this forward saved."""
+    (csrc/vsde_head_mp.hip, forced, 4 / 8 / 16 paths per workgroup; batches of 3 / 2 paths = one partly filled group): same
+    tolerances as the v2 kernel, the backward consumes the activations this forward saved."""
     from viforsdes_amd import _hip
-    _hip.debug_head_mp(1)
+    _hip.debug_head_mp(np_group)
     try:
         test_forward_backward_vs_golden(name)
         d = load_head_case(name)
@@ -131,7 +132,18 @@ def test_argument_errors_raise():
                           float(d["dt"]), False)
 
 
-def test_full_size_properties_lv():
+@pytest.fixture()
+def forward_kernel(request):
+    """Forces the forward time-stepping kernel: 0 = four waves per path (v2), 4 / 8 / 16 = the multi-path MFMA kernel with that
+    many paths per workgroup (the default picks by batch size, so a sub-batch could take another kernel than the full batch)."""
+    from viforsdes_amd import _hip
+    _hip.debug_head_mp(request.param)
+    yield request.param
+    _hip.debug_head_mp(-1)
+
+
+@pytest.mark.parametrize("forward_kernel", [0, 4, 8, 16], indirect=True, ids=["v2", "mfma4", "mfma8", "mfma16"])
+def test_full_size_properties_lv(forward_kernel):
     """LV size (B=512, T=400, S=2, C=256, H=64, L=2): size-independent properties.
 
     * each sample path only depends on its own inputs -> running a sub-batch reproduces it;

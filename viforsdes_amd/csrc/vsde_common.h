@@ -151,6 +151,7 @@ int launch_proj_bwd_bf16(const RowView &A, int64_t M, int K, const float *Wt, in
 // ---- multi-path MFMA forward of the GRU head (vsde_head_mp.hip): hidden_dim 64, L <= 2, state_dim <= 2 ----------------------
 struct MpLaunch {
     int B, T, S, P, C, L, save;
+    int np;                      // paths per workgroup: 4, 8 or 16; anything else = chosen by batch size
     const float *x0, *theta, *eps, *G;
     const float *W_ih0, *W_hh0, *W_ih_st, *W_hh_st, *out_W;
     const float *b_hh0, *b_ih_st, *b_hh_st, *out_b;

@@ -1551,23 +1551,24 @@ static FwdLayout fwd_layout(const vsde_head_dims *d) {
 // Which forward time-stepping kernel takes hidden_dim 64 / L <= 2 / state_dim <= 2: the multi-path MFMA kernel (vsde_head_mp.hip) or
 // the four-waves-per-path v2 kernel.  VSDE_HEAD_MP = 0 / 1 forces one of them (A/B runs); vsde_debug_head_mp() does the same
 // from tests.  Default: see mp_auto().
-static int g_mp_mode = -1;   // -1 = environment / auto, 0 = never, 1 = whenever applicable
+static int g_mp_mode = -1;   // -1 = environment / auto, 0 = never, 1 = whenever applicable; 4 / 8 / 16 = applicable + that many paths per group
 static int mp_env() {
     static int mode = -2;
     if (mode == -2) { const char *e = getenv("VSDE_HEAD_MP"); mode = e ? atoi(e) : -1; }
     return mode;
 }
 static bool mp_auto(const vsde_head_dims *d, int save) {
-    // 16 paths per workgroup: the chip is full from 4096 paths on; below that the time of a launch is T x the latency of
-    // one step either way, and a multi-path step is shorter than a v2 step (measured: profiles/r04_head_mp.txt)
+    // Measured at the LV head dims (profiles/r04_head_mp.txt; us, training / no-grad launch): up to 256 paths the v2 kernel has one
+    // path per CU and wins (502 / 425 vs 550 / 466); from 2 paths per CU on the multi-path kernel does (512 paths: 663 / 548 vs
+    // 550 / 464; 4096 paths: 4705 / 3793 vs 1366 / 583).
     (void)save;
-    return d->B >= 256;
+    return d->B > 256;
 }
 static bool use_mp(const vsde_head_dims *d, int save) {
     if (!mp_applicable(d->H, d->L, d->S)) return false;
     const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
     if (mode == 0) return false;
-    if (mode == 1) return true;
+    if (mode > 0) return true;
     return mp_auto(d, save);
 }
 
@@ -1628,7 +1629,7 @@ extern "C" int vsde_debug_force_v1(int on) {
 }
 
 extern "C" int vsde_debug_head_mp(int mode) {
-    g_mp_mode = mode < 0 ? -1 : (mode != 0);
+    g_mp_mode = mode < 0 ? -1 : mode;
     return 0;
 }
 
@@ -1710,6 +1711,7 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
     if (!g_force_v1 && use_mp(d, save)) {   // 16 paths per workgroup on the matrix cores
         MpLaunch a = {};
         a.B = d->B; a.T = d->T; a.S = d->S; a.P = d->P; a.C = d->C; a.L = d->L; a.save = save;
+        a.np = g_mp_mode >= 0 ? g_mp_mode : mp_env();   // 4 / 8 / 16 force the group size, anything else: by batch size
         a.x0 = x0; a.theta = theta; a.eps = eps; a.G = G;
         a.W_ih0 = w->W_ih_l0; a.W_hh0 = w->W_hh_l0; a.W_ih_st = w->W_ih_stack; a.W_hh_st = w->W_hh_stack; a.out_W = w->out_weight;
         a.b_hh0 = w->b_hh_l0; a.b_ih_st = w->b_ih_stack; a.b_hh_st = w->b_hh_stack; a.out_b = w->out_bias;

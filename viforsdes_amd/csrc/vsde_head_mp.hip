@@ -13,7 +13,7 @@
 //     leaves lane (q = lane >> 4, p = lane & 15) with D[rows 4 q .. 4 q + 3][column p]: the r, u and n pre-activations of FOUR
 //     units of ONE path in one lane -- the whole gate algebra is lane-local, no cross-lane traffic.
 //   * fp32-equivalent results from f16 operands: every operand is split x = hi + lo / 2048 with hi = f16(x), lo = f16((x - hi)
-//     * 2048) (22 mantissa bits; the 2^11 scale keeps lo out of the f16 subnormals) and a product is three MFMAs,
+//     * 2048) (22 mantissa bits; the 2^11 scale keeps lo out of the f16 subnormals, which the matrix pipe flushes) and a product is three MFMAs,
 //     hi*hi into one accumulator, hi*lo + lo*hi into a second one that is folded in with one v_fma (x 2^-11); the dropped
 //     lo*lo term is 2^-22 relative.  Accumulation is fp32.  Gate rows are pre-scaled into the exp2 domain like the v2 kernel's.
 //   * all recurrent weights live in VGPRs as ready-made A fragments (built once per launch by mp_prep_kernel): 48 VGPRs per
@@ -26,7 +26,7 @@
 //     next step are lane-local as well (z_t is fp32 on the VALU: it is not bounded like h).
 //   * the products a step does not need at once -- W_hh h_t of both layers, used by step t + 1 -- are issued behind the ones
 //     on the critical path, so they run on the matrix pipe while the VALU does the next gate block.
-//   * global traffic: the projected context record G[b, t, 3H] is read straight into registers two steps ahead (16 B per lane
+//   * global traffic: the projected context record G[b, t, 3H] is read straight into registers one step ahead (16 B per lane
 //     and gate), saved activations leave as 16-byte lanes (four waves complete each 256-byte row), outputs from 16 lanes each.
 //
 // Scope: hidden_dim 64, 1 or 2 layers, state_dim 1 or 2 (the OU and Lotka-Volterra heads); everything else keeps the v2 / v1 /
@@ -41,14 +41,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kMpLo = 2048.0f, kMpLoInv = 1.0f / 2048.0f;
 constexpr float kMpSr = -1.4426950408889634f, kMpSn = 2.8853900817779268f, kMpInvSn = 1.0f / 2.8853900817779268f;
-template <int V> struct MpSlot { static constexpr int value = V; };
-using C0 = MpSlot<0>;
-using C1 = MpSlot<1>;
 constexpr int kMpMatFrags = 4 * 3 * 2 * 2 * 64;   // f16x8 fragments of one recurrent matrix: [wave][gate][k-step][plane][lane]
 
+// x = hi + lo / 2048.  The matrix pipe flushes f16 DENORMAL inputs to zero (measured: rows of W holding an element below
+// 2^-14 lost it entirely, 2e-5 .. 7e-5 on their dot products), so a value whose hi would be subnormal goes into lo alone
+// (lo = 2048 x is normal down to |x| = 2^-25; below that the flush costs < 3e-8).
 __device__ __forceinline__ void mp_split(float v, _Float16 &hi, _Float16 &lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * kMpLo);
+    const float h = fabsf(v) < 6.103515625e-5f ? 0.0f : (float)(_Float16)v;
+    hi = (_Float16)h;
+    lo = (_Float16)((v - h) * kMpLo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -105,19 +106,36 @@ __device__ __forceinline__ f32x4 mp_mfma(const f16x8 &a, const f16x8 &b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// [W (three gate tiles of this wave's units)] x [h^T of the 16 paths]: hi*hi -> A1, hi*lo' + lo'*hi -> A2 (scaled by 2^11)
-__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], f32x4 (&A1)[3], f32x4 (&A2)[3]) {
+template <int N> __device__ __forceinline__ float mp_row_shl(float v) {   // lane i <- lane i + N of its 16-lane row
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
+// [W (three gate tiles of this wave's units)] x [h^T of the group's paths] -> R (fp32-equivalent), three MFMA products per tile:
+//   NP == 16: the B operand has 16 path columns per plane: hi*hi -> A1, hi*lo' + lo'*hi -> A2, R = A1 + A2 / 2048;
+//   NP < 16 : ONE B operand holds both planes side by side -- columns [0, NP) the hi parts of the NP paths, [NP, 2 NP) their lo'
+//             parts -- so W_hi x B gives hi*hi (column c) AND hi*lo' (column c + NP) in one MFMA and W_lo' x B adds lo'*hi: two
+//             MFMAs per tile and k-step instead of three; lane c pulls the hi*lo' sum from lane c + NP of its row (one DPP op).
+template <int NP>
+__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], f32x4 (&R)[3]) {
+    f32x4 A1[3], A2[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) { A1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; A2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) A1[g] = mp_mfma(wf[g][ks][0], hb[0][ks], A1[g]);
+        if (NP == 16) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][0], hb[1][ks], A2[g]);
+            for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][0], hb[1][ks], A2[g]);
+        }
 #pragma unroll
         for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][1], hb[0][ks], A2[g]);
     }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            R[g][r] = NP == 16 ? fmaf(A2[g][r], kMpLoInv, A1[g][r]) : fmaf(mp_row_shl<NP & 15>(A1[g][r]) + A2[g][r], kMpLoInv, A1[g][r]);
 }
 
 // Roles.  One layer: four waves (wave w = units 16 w ..).  Two layers: EIGHT waves, two per SIMD -- waves 0-3 are layer 0 (W_hh_l0
@@ -127,29 +145,44 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
 // does not need at once (W_hh h_t, consumed by step t + 1) run on one role's matrix pipe while the other role's VALU does gates.
 //   step t:  [L0: gates -> h0_t]  barrier A  [L1: W_ih1 h0_t, gates -> h1_t | L0: W_hh0 h0_t]  barrier B
 //            [L0: emission rows x h1_t, z_{t+1}, outputs, then gates of step t + 1 | L1: W_hh1 h1_t]
-template <int L, bool SAVE, int S>
+template <int L, bool SAVE, int S, int NP>
 __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p) {
-    constexpr int NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4;
-    static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2, "multi-path kernel: L <= 2, state_dim <= 2");
-    // hidden state planes in B-fragment order: [step parity][layer][plane hi / lo][k-step][lane group][path] x 8 f16
-    __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][2][2][4][16];
+    constexpr int NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4, PL = NP == 16 ? 2 : 1;
+    static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2 && (NP == 16 || NP == 8 || NP == 4), "multi-path kernel: L <= 2, state_dim <= 2");
+    // hidden state in B-fragment order: [step parity][layer][plane][k-step][lane group][column] x 8 f16 (NP < 16: one plane, the hi parts
+    // in columns [0, NP), the lo' parts in [NP, 2 NP), the rest zero)
+    __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][PL][2][4][16];
     const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
-    const int b_raw = blockIdx.x * 16 + pp;
-    const bool live = b_raw < p.B;
-    const int b = live ? b_raw : p.B - 1;          // lanes beyond the batch recompute the last path and store nothing
+    const int b_raw = blockIdx.x * NP + (pp & (NP - 1));
+    const bool owner = pp < NP;                    // NP < 16: lanes of the other columns run along and store nothing
+    const bool live = owner && b_raw < p.B;
+    const int b = b_raw < p.B ? b_raw : p.B - 1;   // lanes beyond the batch recompute the last path and store nothing
     const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+    if (NP < 16) {
+        for (int e = tid; e < 2 * L * PL * 2 * 4 * 16; e += 256 * L) (&hbuf[0][0][0][0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        __syncthreads();
+    }
 
-    // the 4 owned units' new state -> f16 hi / lo planes in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane group
-    // (j >> 3) & 3, element j & 7), the saved activations, and the barrier that publishes the planes
-    auto publish = [&](const float (&h)[4], const float (&rg)[4], const float (&ug)[4], const float (&ng)[4], const float (&cn)[4],
-                       int t, int l) {
+    // the 4 owned units' new state -> f16 hi / lo' in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane group (j >> 3) & 3,
+    // element j & 7)
+    auto publish = [&](const float (&h)[4], int t, int l) {
         f16x4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(h[r], a, c); hi[r] = a; lo[r] = c; }
         const int par = t & 1;
-        *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
-        *((f16x4 *)&hbuf[par][l][1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = lo;
-        if (SAVE && live) {   // acts[b][t][l][{h, r, z, n, n_hh}][64]  (kernels/weights.py:11-23)
+        if (NP == 16) {
+            *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
+            *((f16x4 *)&hbuf[par][l][PL - 1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = lo;
+        } else if (owner) {
+            *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
+            *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp + (NP & 15)] + (q & 1)) = lo;
+        }
+    };
+    // saved activations acts[b][t][l][{h, r, z, n, n_hh}][64] (kernels/weights.py:11-23): 16-byte lanes, issued BEHIND the barrier that
+    // publishes the state -- in the slack where this role waits for the other one, not on the step's critical path
+    auto save_acts = [&](const float (&h)[4], const float (&rg)[4], const float (&ug)[4], const float (&ng)[4], const float (&cn)[4],
+                         int t, int l) {
+        if (SAVE && live) {
             float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
             *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
             *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
@@ -159,26 +192,23 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         }
     };
     // gate block of one layer for the 4 owned units (exp2 domain: r = 1 / (1 + 2^x_r), n = 1 - 2 / (1 + 2^(a_n + r c_n)))
-    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&ca)[3], const f32x4 (&cb)[3],
-                     const float (&bn)[4], float (&h)[4], int t, int l) {
-        float rg[4], ug[4], ng[4], cn[4];
+    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&c)[3],
+                     const float (&bn)[4], float (&h)[4], float (&rg)[4], float (&ug)[4], float (&ng)[4], float (&cn)[4], int t, int l) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xr = ar[r] + fmaf(cb[0][r], kMpLoInv, ca[0][r]);
-            const float xu = au[r] + fmaf(cb[1][r], kMpLoInv, ca[1][r]);
-            cn[r] = bn[r] + fmaf(cb[2][r], kMpLoInv, ca[2][r]);
-            rg[r] = fast_rcp(1.0f + fast_exp2(xr));
-            ug[r] = fast_rcp(1.0f + fast_exp2(xu));
+            cn[r] = bn[r] + c[2][r];
+            rg[r] = fast_rcp(1.0f + fast_exp2(ar[r] + c[0][r]));
+            ug[r] = fast_rcp(1.0f + fast_exp2(au[r] + c[1][r]));
             ng[r] = fmaf(-2.0f, fast_rcp(1.0f + fast_exp2(fmaf(rg[r], cn[r], an[r]))), 1.0f);
             h[r] = fmaf(ug[r], h[r] - ng[r], ng[r]);           // (1 - u) n + u h
         }
-        publish(h, rg, ug, ng, cn, t, l);
+        publish(h, t, l);
     };
     auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto read_state = [&](int t, int l, f16x8 (&hb)[2][2]) {
         const int par = t & 1;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][pp];
     };
@@ -209,26 +239,23 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) bn1[r] = kMpSn * p.b_hh1[128 + j0 + r];
-            f32x4 c1a[3], c1b[3];                     // W_hh^1 h^1_{t-1}: h_{-1} = 0
+            f32x4 c1[3];                               // W_hh^1 h^1_{t-1}: h_{-1} = 0
 #pragma unroll
-            for (int g = 0; g < 3; ++g) c1a[g] = c1b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 3; ++g) c1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int t = 0; t < T; ++t) {
                 barrier();                             // A: h^0_t published
                 f16x8 hb[2][2];
                 read_state(t, 0, hb);
-                f32x4 a1a[3], a1b[3];
-                mp_matmul(wi, hb, a1a, a1b);           // W_ih^1 h^0_t
-                float ar[4], au[4], an[4];
+                f32x4 a1[3];
+                mp_matmul<NP>(wi, hb, a1);             // W_ih^1 h^0_t
+                float ar[4], au[4], an[4], rg[4], ug[4], ng[4], cn[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ar[r] = k1[0][r] + fmaf(a1b[0][r], kMpLoInv, a1a[0][r]);
-                    au[r] = k1[1][r] + fmaf(a1b[1][r], kMpLoInv, a1a[1][r]);
-                    an[r] = k1[2][r] + fmaf(a1b[2][r], kMpLoInv, a1a[2][r]);
-                }
-                gates(ar, au, an, c1a, c1b, bn1, h1, t, L - 1);
+                for (int r = 0; r < 4; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
+                gates(ar, au, an, c1, bn1, h1, rg, ug, ng, cn, t, L - 1);
                 barrier();                             // B: h^1_t published
                 read_state(t, L - 1, hb);
-                mp_matmul(wh, hb, c1a, c1b);           // W_hh^1 h^1_t: consumed by step t + 1
+                mp_matmul<NP>(wh, hb, c1);             // W_hh^1 h^1_t: consumed by step t + 1
+                save_acts(h1, rg, ug, ng, cn, t, L - 1);
             }
         }
         return;
@@ -265,9 +292,9 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     for (int r = 0; r < NO; ++r) ob[r] = p.out_b[r];
 
     float z[S], h0[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c0a[3], c0b[3];                              // W_hh^0 h^0_{t-1}: h_{-1} = 0
+    f32x4 c0[3];                                       // W_hh^0 h^0_{t-1}: h_{-1} = 0
 #pragma unroll
-    for (int g = 0; g < 3; ++g) c0a[g] = c0b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 3; ++g) c0[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < S; ++i) z[i] = p.x0[(int64_t)b * S + i];
     if (w == 0 && q == 0 && live) {
@@ -275,27 +302,25 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         for (int i = 0; i < S; ++i) p.paths[(int64_t)b * (T + 1) * S + i] = z[i];
     }
 
-    // the projected context record and eps, two steps ahead in registers
+    // the projected context record and eps, one step ahead in registers (the wait for them at the top of a step is a vmcnt(0))
     const float *Gb = p.G + (int64_t)b * T * 192 + j0;
     const float *eb = p.eps + (int64_t)b * T * S;
-    f32x4 gq[2][3];
-    float ev[2][S];
-    auto fetch = [&](int t, auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
+    f32x4 gq[3];
+    float ev[S];
+    auto fetch = [&](int t) {
         const int tc = t < T ? t : T - 1;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gq[slot][g] = *(const f32x4 *)(Gb + (int64_t)tc * 192 + g * 64);
+        for (int g = 0; g < 3; ++g) gq[g] = *(const f32x4 *)(Gb + (int64_t)tc * 192 + g * 64);
 #pragma unroll
-        for (int i = 0; i < S; ++i) ev[slot][i] = eb[(int64_t)tc * S + i];
+        for (int i = 0; i < S; ++i) ev[i] = eb[(int64_t)tc * S + i];
     };
-    fetch(0, C0{});
-    fetch(1, C1{});
+    fetch(0);
 
     // Outputs of step t are stored during step t + 1, in the slack behind barrier A (where the layer-0 waves wait for layer 1):
     // hipcc's wait for the prefetched context record at the top of the loop is a vmcnt(0) (stores sit in conditional blocks it
-    // cannot count), and a store issued just before it would put a full store round trip on every second step.
+    // cannot count), and a store issued just before it would put a full store round trip on every step.
     float pz[S], pmu[S], pL[S][S], praw[NTRIL];
-    auto store_outputs = [&](int t) {     // paths[b, t + 1], means[b, t], chol[b, t], chol_raw[b, t]: one wave each, 16 lanes
+    auto store_outputs = [&](int t) {     // paths[b, t + 1], means[b, t], chol[b, t], chol_raw[b, t]: one wave each
         if (q == 0 && live) {
             const int64_t bt = (int64_t)b * T + t;
             if (w == 0) {
@@ -316,15 +341,14 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         }
     };
 
-    auto step = [&](int t, auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
-        f32x4 g0 = gq[slot][0], g1 = gq[slot][1], g2 = gq[slot][2];
+    for (int t = 0; t < T; ++t) {
+        f32x4 g0 = gq[0], g1 = gq[1], g2 = gq[2];
         float e[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) e[i] = ev[slot][i];
-        fetch(t + 2, slot_c);
+        for (int i = 0; i < S; ++i) e[i] = ev[i];
+        fetch(t + 1);
         // ---- layer 0: a = G_t (context projection + b_ih) + theta term + z_t W_x   (forward.py:195-219)
-        float ar[4], au[4], an[4];
+        float ar[4], au[4], an[4], rg[4], ug[4], ng[4], cn[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ar[r] = fmaf(g0[r], kMpSr, k0[0][r]); au[r] = fmaf(g1[r], kMpSr, k0[1][r]); an[r] = fmaf(g2[r], kMpSn, k0[2][r]);
@@ -333,36 +357,41 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 ar[r] = fmaf(z[i], wx[i][0][r], ar[r]); au[r] = fmaf(z[i], wx[i][1][r], au[r]); an[r] = fmaf(z[i], wx[i][2][r], an[r]);
             }
         }
-        gates(ar, au, an, c0a, c0b, bn0, h0, t, 0);
+        gates(ar, au, an, c0, bn0, h0, rg, ug, ng, cn, t, 0);
         barrier();                                     // A: h^0_t published
         f16x8 hb[2][2];
         read_state(t, 0, hb);
-        f32x4 O1[NTO], O2[NTO];
-#pragma unroll
-        for (int tl = 0; tl < NTO; ++tl) { O1[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; O2[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (L > 1) {
-            mp_matmul(wf, hb, c0a, c0b);               // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
+            mp_matmul<NP>(wf, hb, c0);                 // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
+            save_acts(h0, rg, ug, ng, cn, t, 0);
             if (t > 0) store_outputs(t - 1);
             __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs are not ordered by the barrier's "memory" clobber)
             barrier();                                 // B: h^1_t published
             read_state(t, L - 1, hb);
         }
+        // ---- emission (forward.py:314-375): every owner lane ends up with all NO values of its path
+        f32x4 O1[NTO], O2[NTO];
+#pragma unroll
+        for (int tl = 0; tl < NTO; ++tl) { O1[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; O2[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int tl = 0; tl < NTO; ++tl) {
                 O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
-                O2[tl] = mp_mfma(of[tl][ks][0], hb[1][ks], O2[tl]);
+                if (NP == 16) O2[tl] = mp_mfma(of[tl][ks][0], hb[PL - 1][ks], O2[tl]);
                 O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
             }
         if (L == 1) {
-            mp_matmul(wf, hb, c0a, c0b);
+            mp_matmul<NP>(wf, hb, c0);
+            save_acts(h0, rg, ug, ng, cn, t, 0);
             if (t > 0) store_outputs(t - 1);
         }
-        // ---- emission (forward.py:314-375): every lane holds all NO values of its path
         float o[NO];
 #pragma unroll
-        for (int r = 0; r < NO; ++r) o[r] = ob[r] + fmaf(O2[r >> 2][r & 3], kMpLoInv, O1[r >> 2][r & 3]);
+        for (int r = 0; r < NO; ++r) {
+            const float a1 = O1[r >> 2][r & 3], a2 = O2[r >> 2][r & 3];
+            o[r] = ob[r] + (NP == 16 ? fmaf(a2, kMpLoInv, a1) : fmaf(mp_row_shl<NP & 15>(a1) + a2, kMpLoInv, a1));
+        }
         float mu[S], Lc[S][S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
@@ -381,7 +410,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
             for (int c = 0; c <= i; ++c) acc = fmaf(Lc[i][c], e[c], acc);
             z[i] = z[i] + mu[i] * p.dt + acc * p.sqdt;
         }
-        // outputs leave one step late (store_outputs below): kept in registers until the next step's barrier A
+        // outputs leave one step late (store_outputs): kept in registers until the next step's barrier A
 #pragma unroll
         for (int i = 0; i < S; ++i) { pz[i] = z[i]; pmu[i] = mu[i]; }
 #pragma unroll
@@ -390,11 +419,6 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
             for (int c = 0; c < S; ++c) pL[i][c] = Lc[i][c];
 #pragma unroll
         for (int r = 0; r < NTRIL; ++r) praw[r] = o[S + r];
-    };
-
-    for (int t = 0; t < T; t += 2) {
-        step(t, C0{});
-        if (t + 1 < T) step(t + 1, C1{});
     }
     store_outputs(T - 1);
 }
@@ -422,9 +446,20 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     p.frags = (const f16x8 *)a.frags;
     p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
     p.paths = a.paths; p.means = a.means; p.chol = a.chol; p.chol_raw = a.chol_raw; p.acts = a.acts;
-    const dim3 grid((a.B + 15) / 16), block(256 * a.L);
+    // paths per workgroup: 16 fills the matrix pipe (large batches); a small batch takes 4 or 8 so that its groups spread over more CUs --
+    // the time of a launch is T x one step's latency whatever the group size, and ONE CU's vector-memory pipe would have to carry the
+    // saved activations of all its paths (41 KB per step for 16 paths: +30 % at 512 paths, profiles/r04_head_mp.txt)
+    int np = a.np;
+    if (np != 4 && np != 8 && np != 16) np = a.B <= 1024 ? 4 : (a.B <= 2048 ? 8 : 16);
+    const dim3 grid((a.B + np - 1) / np), block(256 * a.L);
     if (mark) mark(0, 0, s);
-#define VSDE_MP_LAUNCH(LL, SV, SS) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS>), grid, block, 0, s, p)
+#define VSDE_MP_LAUNCH_(LL, SV, SS, NN) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS, NN>), grid, block, 0, s, p)
+#define VSDE_MP_LAUNCH(LL, SV, SS)                                  \
+    do {                                                            \
+        if (np == 4) VSDE_MP_LAUNCH_(LL, SV, SS, 4);                \
+        else if (np == 8) VSDE_MP_LAUNCH_(LL, SV, SS, 8);           \
+        else VSDE_MP_LAUNCH_(LL, SV, SS, 16);                       \
+    } while (0)
     if (a.L == 1) {
         if (a.save) { if (a.S == 1) VSDE_MP_LAUNCH(1, true, 1); else VSDE_MP_LAUNCH(1, true, 2); }
         else { if (a.S == 1) VSDE_MP_LAUNCH(1, false, 1); else VSDE_MP_LAUNCH(1, false, 2); }
@@ -433,6 +468,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
         else { if (a.S == 1) VSDE_MP_LAUNCH(2, false, 1); else VSDE_MP_LAUNCH(2, false, 2); }
     }
 #undef VSDE_MP_LAUNCH
+#undef VSDE_MP_LAUNCH_
     if (mark) mark(0, 1, s);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
