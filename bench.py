@@ -70,13 +70,12 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
     return tr
 
 
-PMC_FILE = "profiles/r03_pmc_head_lv.txt"
+PMC_FILE = "profiles/r04_pmc_head_lv.txt"
 
 
 def pmc_traffic_bytes(workload, batch):
     """HBM bytes per launch of the serial forward kernel (training variant) from the committed rocprofv3 --pmc passes
-    (profiles/r02_pmc_head_lv.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed
-    over the XCDs).  The kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
+    (PMC_FILE: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed over the XCDs).  The kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
     counter is used; null for other workloads."""
     path = os.path.join(ROOT, PMC_FILE)
     if workload != "lv" or batch != 512 or not os.path.exists(path):
@@ -85,7 +84,7 @@ def pmc_traffic_bytes(workload, batch):
     for line in open(path):
         if not line.startswith(" ") and "dispatches=" in line:
             kernel = line
-        elif "head_fwd_v2_kernel<2, true" in kernel and "mean=" in line:
+        elif ("head_fwd_mp_kernel<2, true" in kernel or "head_fwd_v2_kernel<2, true" in kernel) and "mean=" in line:
             name = line.split()[0]
             if name in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[name] = float(line.split("mean=")[1])
@@ -438,7 +437,8 @@ def measure(workload, batch, args, device, distributed, world):
         p.grad = None
 
     traffic = pmc_traffic_bytes(workload, batch)
-    kinds = _hip.head_kernel_names() if hasattr(_hip, "head_kernel_names") else {}
+    fwd_kernel = ("multi-path MFMA kernel (csrc/vsde_head_mp.hip), " + ("4" if batch <= 1024 else "8" if batch <= 2048 else "16") + " paths per workgroup"
+                  if (batch > 256 and H == 64 and L <= 2 and S <= 2) else "four-waves-per-path VALU kernel (csrc/vsde_head.hip)")
     out = {
         "value": global_batch * iters_per_sec, "unit": "paths/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "config": {"workload": f"{workload}: state_dim={S}, T={T} Euler steps (dt={dt}), batch={batch}/GPU, "
@@ -452,7 +452,7 @@ def measure(workload, batch, args, device, distributed, world):
         "rccl_ranks": dist.get_world_size() if distributed else 1,
         "allreduce_ms_per_step": allreduce_ms,
         "dp_pack_ms": dp_pack_ms,
-        "roofline": {"kernel": f"vsde head forward, GRU time-stepping kernel (training variant, L={L})" + (f" [{kinds.get('fwd_train')}]" if kinds else ""),
+        "roofline": {"kernel": f"vsde head forward, GRU time-stepping kernel (training variant, L={L}): {fwd_kernel}",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, "
