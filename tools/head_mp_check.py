@@ -42,11 +42,17 @@ def check():
         ws, x0, ctx, theta, eps = inputs(B, T, S, C, P, 64, L, 11 + B)
         d = lambda t: t.to(dev)
         wd = [d(w) for w in ws]
-        outs = {}
+        outs, grads = {}, {}
+        gg = torch.Generator(device="cpu").manual_seed(5)
+        gp, gm, gl = (torch.randn(B, T + 1, S, generator=gg), torch.randn(B, T, S, generator=gg), torch.randn(B, T, S, S, generator=gg))
         for mode in (0, 4, 8, 16):
             _hip.debug_head_mp(mode)
-            outs[mode] = [None if t is None else t.cpu().numpy() for t in
-                          _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, True)]
+            fo = _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, True)
+            outs[mode] = [None if t is None else t.cpu().numpy() for t in fo]
+            if L == 2 and mode in (0, 4, 8):
+                for gscale in (1.0, 65536.0 * 3.0, 1e-9):   # the sweep is normalised by max |g|: any upstream scale must work
+                    gr = _hip.head_backward(d(gp) * gscale, d(gm) * gscale, d(gl) * gscale, d(ctx)[:, :-1], d(theta), d(eps), fo[0], fo[3], fo[4], wd, 0.1)
+                    grads[(mode, gscale)] = [t.float().cpu().numpy() / gscale for t in gr]
             ev = _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, False)
             same = all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(ev[:3], outs[mode][:3]))
             print(f"  mode {mode}: eval launch bit-equal to training launch: {same}")
@@ -65,6 +71,16 @@ def check():
                 ok = False
         outs[1] = outs[4] if max(rel(outs[4][4], ref[4]), 0) >= rel(outs[16][4], ref[4]) else outs[16]   # the worse one for the breakdown below
         print(line + "   (rel. to max vs the float64 oracle)")
+        if L == 2:
+            n_ = lambda t: t.detach().cpu().numpy()
+            gref = vo.head_backward(n_(gp), n_(gm), n_(gl), n_(ctx.float())[:, :-1], n_(theta), n_(eps), f, w, 0.1, np.float64)
+            gn = ["x0", "ctx", "theta", "W_ih0", "W_hh0", "b_ih0", "b_hh0", "W_ih1", "W_hh1", "b_ih1", "b_hh1", "out_W", "out_b"]
+            for key, gr in grads.items():
+                errs = [rel(a, r_) for a, r_ in zip(gr, gref) if r_.size]
+                worst = max(range(len(errs)), key=lambda i: errs[i])
+                print(f"   backward mode {key[0]} upstream x{key[1]:g}: worst gradient {gn[worst]} {errs[worst]:.1e}; x0 {errs[0]:.1e} ctx {errs[1]:.1e} theta {errs[2]:.1e} W_hh0 {errs[4]:.1e} W_hh1 {errs[8]:.1e}")
+                if key[0] and not (max(errs) < 2e-4):
+                    ok = False
         if os.environ.get("MP_DUMP"):
             np.savez_compressed(os.path.join(os.environ["MP_DUMP"], f"mp_dump_B{B}_S{S}_L{L}.npz"), mp_acts=outs[1][4], v2_acts=outs[0][4],
                                 mp_means=outs[1][1], mp_paths=outs[1][0])
@@ -97,7 +113,7 @@ def check():
 def timing():
     T, S, C, P, H, L = 400, 2, 256, 3, 64, 2
     print("LV head dims (T=400, S=2, C=256 bf16 context, H=64, L=2); serial forward kernel, HIP events, us")
-    for B in (128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+    for B in (128, 256, 512, 1024, 2048, 4096, 8192):
         ws, x0, ctx, theta, eps = inputs(B, T, S, C, P, H, L, 3)
         d = lambda t: t.to(dev)
         wd = [d(w) for w in ws]
@@ -114,6 +130,18 @@ def timing():
                         ms.append(_hip.profile_elapsed_ms(0))
                 _hip.profile_enable(False)
                 row += f" | {'mp%d' % mode if mode else 'v2'} {'train' if save else 'eval'} {1e3 * sum(ms) / len(ms):6.0f}"
+                if save and mode in (0, 4, 8):
+                    fo = _hip.head_forward(x0, ctx[:, :-1], theta, eps, wd, 0.1, True)
+                    gp_, gm_, gl_ = torch.randn(B, T + 1, S, device=dev), torch.randn(B, T, S, device=dev), torch.randn(B, T, S, S, device=dev)
+                    _hip.profile_enable(True)
+                    ms = []
+                    for i in range(5):
+                        _hip.head_backward(gp_, gm_, gl_, ctx[:, :-1], theta, eps, fo[0], fo[3], fo[4], wd, 0.1)
+                        if i >= 2:
+                            ms.append(_hip.profile_elapsed_ms(1))
+                    _hip.profile_enable(False)
+                    row += f" bwd {1e3 * sum(ms) / len(ms):6.0f}"
+                    del fo
         _hip.debug_head_mp(-1)
         print(row, flush=True)
 

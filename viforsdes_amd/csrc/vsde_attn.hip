@@ -122,7 +122,9 @@ __device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vre
     }
 }
 
-template <bool PERSIST>
+// ABL: timing-only ablations of the tile loop's VALU work (results are wrong): 1 = exponentials of the raw scores (no scale / shift
+// fma), 2 = no row-sum adds, 4 = no exponentials at all (tools/attn_core_bench.py with VSDE_ATTN_FWD_ABL)
+template <bool PERSIST, int ABL = 0>
 __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     uint16_t *Ks = asmem;                      // [npad][AT_KLD]
@@ -239,8 +241,10 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
             float pr[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                pr[r] = fast_exp2(fmaf(scur[r], c2, -mc)); lsum += pr[r];
-                pr[r + 1] = fast_exp2(fmaf(scur[r + 1], c2, -mc)); lsum2 += pr[r + 1];
+                if constexpr (ABL & 4) { pr[r] = scur[r]; pr[r + 1] = scur[r + 1]; }
+                else if constexpr (ABL & 1) { pr[r] = fast_exp2(scur[r]); pr[r + 1] = fast_exp2(scur[r + 1]); }
+                else { pr[r] = fast_exp2(fmaf(scur[r], c2, -mc)); pr[r + 1] = fast_exp2(fmaf(scur[r + 1], c2, -mc)); }
+                if constexpr (!(ABL & 2)) { lsum += pr[r]; lsum2 += pr[r + 1]; }
             }
             // registers 0..7 are keys {4h2..4h2+3, 8+4h2..11+4h2} of the tile, 8..15 the same + 16: used as the two
             // k-steps of the second product, with V^T read at exactly those key columns
@@ -959,7 +963,17 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
     const int cus = attn_cus();
     AttnParams q = p;
     q.pairs = pairs;
-    if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("VSDE_ATTN_FWD_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // timing-only variants (wrong results)
+#define VSDE_ABL_LAUNCH(A_)                                                                                                      \
+    do {                                                                                                                         \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((attn_fwd_kernel<true, A_>), dim3((unsigned)cus), dim3(768), lds, stream, q);                          \
+    } while (0)
+        if (abl == 1) VSDE_ABL_LAUNCH(1); else if (abl == 2) VSDE_ABL_LAUNCH(2); else if (abl == 3) VSDE_ABL_LAUNCH(3); else VSDE_ABL_LAUNCH(7);
+#undef VSDE_ABL_LAUNCH
+    } else if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds, stream, q);
     } else {

@@ -164,6 +164,20 @@ size_t mp_frag_bytes(int L, int S);
 // mark: the profile-event hook of vsde_head.hip (slot 0 = the time-stepping kernel), may be nullptr
 int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t));
 
+// multi-path MFMA reverse-time sweep (two layers, state_dim <= 2): writes D4, DO, g_x0, g_theta like head_bwd_v2_kernel
+struct MpBwdLaunch {
+    int B, T, S, P, C;
+    int np;                      // paths per workgroup: 4 or 8 (16 -> 8); anything else = chosen by batch size
+    const float *g_paths, *g_means, *g_chol, *eps, *chol_raw, *acts;
+    const float *W_ih0, *W_hh0, *W_ih_st, *W_hh_st, *out_W;
+    void *frags;                 // mp_bwd_frag_bytes() of workspace
+    float dt, sqdt, diag_min;
+    float *D4, *DO, *g_x0, *g_theta;
+};
+bool mp_bwd_applicable(int H, int L, int S);
+size_t mp_bwd_frag_bytes(void);
+int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t));
+
 // ---- streamed attention kernels (vsde_attn_stream.hip): any N, head_dim 64 or 128 ------------
 int launch_attention_stream_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H, int D,
                                 double scale, hipStream_t s);

@@ -1571,6 +1571,16 @@ static bool use_mp(const vsde_head_dims *d, int save) {
     if (mode > 0) return true;
     return mp_auto(d, save);
 }
+// The reverse-time sweep on the matrix cores pays from ~700 paths on (profiles/r04_head_mp.txt: 512 paths 1055 us against 810 us for
+// the v2 kernel -- sixteen operand splits per unit and layer sit on the step's critical path -- 1024 paths 1083 against 1630 us,
+// 4096 paths 2670 against 6322 us).
+static bool use_mp_bwd(const vsde_head_dims *d) {
+    if (!mp_bwd_applicable(d->H, d->L, d->S)) return false;
+    const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
+    if (mode == 0) return false;
+    if (mode > 0) return true;
+    return d->B > 640;
+}
 
 static int pick_wpb(int B, size_t lds_fixed, size_t lds_per_wave) {
     int wpb = (B + 255) / 256;  // fill all 256 CUs first
@@ -1773,7 +1783,7 @@ extern "C" int vsde_head_forward(const vsde_head_dims *d, const float *x0, const
 }
 
 namespace vsde {
-struct BwdLayout { size_t packB, WcT, D4, DO, tn, total; };
+struct BwdLayout { size_t packB, WcT, D4, DO, frags, tn, total; };
 
 static int build_tn(const vsde_head_dims *d, const vsde_context_view *ctx, const float *theta, const float *paths,
                     const float *acts, const float *D4, const float *DO, const vsde_head_grads *g, TnProblem *pr) {
@@ -1840,6 +1850,7 @@ static BwdLayout bwd_layout(const vsde_head_dims *d) {
     o.WcT = off; off += align256((size_t)3 * d->H * d->C * sizeof(float));
     o.D4 = off; off += align256((size_t)d->B * d->T * d->L * 4 * d->H * sizeof(float));
     o.DO = off; off += align256((size_t)d->B * d->T * NO * sizeof(float));
+    o.frags = off; off += mp_bwd_applicable(d->H, d->L, d->S) ? align256(mp_bwd_frag_bytes()) : 0;   // vsde_head_mp.hip
     o.tn = off;
     // the TN plan only depends on shapes; build it with dummy pointers
     TnProblem pr[kMaxTnProblems];
@@ -1894,7 +1905,17 @@ extern "C" int vsde_head_backward(const vsde_head_dims *d, const float *g_paths,
     p.W_hh0 = w->W_hh_l0; p.W_ih_st = w->W_ih_stack; p.W_hh_st = w->W_hh_stack;
     p.dt = (float)time_step; p.sqdt = (float)sqrt(time_step); p.diag_min = (float)diag_min;
     p.D4 = (float *)(ws + lay.D4); p.DO = (float *)(ws + lay.DO); p.g_x0 = g->x0; p.g_theta = g->theta;
-    if (d->H > kHP || NO > kWave) {  // generic kernels
+    if (!g_force_v1 && use_mp_bwd(d)) {   // 4 / 8 paths per workgroup on the matrix cores
+        MpBwdLaunch a = {};
+        a.B = d->B; a.T = d->T; a.S = d->S; a.P = d->P; a.C = d->C;
+        a.np = g_mp_mode >= 0 ? g_mp_mode : mp_env();
+        a.g_paths = g_paths; a.g_means = g_means; a.g_chol = g_chol; a.eps = eps; a.chol_raw = chol_raw; a.acts = acts;
+        a.W_ih0 = w->W_ih_l0; a.W_hh0 = w->W_hh_l0; a.W_ih_st = w->W_ih_stack; a.W_hh_st = w->W_hh_stack; a.out_W = w->out_weight;
+        a.frags = ws + lay.frags;
+        a.dt = p.dt; a.sqdt = p.sqdt; a.diag_min = p.diag_min;
+        a.D4 = p.D4; a.DO = p.DO; a.g_x0 = p.g_x0; a.g_theta = p.g_theta;
+        rc = launch_head_bwd_mp(a, s, prof_mark);
+    } else if (d->H > kHP || NO > kWave) {  // generic kernels
         const int block = ((d->H > NO ? d->H : NO) + 63) / 64 * 64 > 1024 ? 1024 : ((d->H > NO ? d->H : NO) + 63) / 64 * 64;
         const size_t ldsw = (size_t)(4 * d->H + NO + d->S + d->S * d->H + 8) * sizeof(float);
         hipLaunchKernelGGL(head_bwd_wide_kernel, dim3(d->B), dim3(block), ldsw, s, p, d->L);

@@ -423,6 +423,340 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     store_outputs(T - 1);
 }
 
+// ===========================================================================================================================
+// Reverse-time sweep on the matrix cores (reference kernels/backward.py:208-624), two GRU layers, 4 or 8 paths
+// per workgroup.  Same machinery as the forward kernel, transposed: the products are W^T d with d = the gate gradients of a layer
+// (K = 192 = six k-steps; a wave owns 16 OUTPUT units, one A tile per k-step), the B operand carries the hi parts of the group's
+// paths in columns [0, NP) and the lo' parts in [NP, 2 NP).
+//   layer-1 waves (4): W_hh_l1^T, the state columns of W_ih_l0 (transposed, replicated down their tile like the forward's emission
+//       rows, so every lane gets the S components of d z_t), out_proj^T.
+//       [W_x^T pi0(t+1) -> dz; dO_t; out_proj^T dO_t (through a wave-private LDS tile); layer-1 gate gradients] barrier 2
+//       [W_hh_l1^T ph1 -> carried dh1 (slack)] barrier 3
+//   layer-0 waves (4): W_ih_l1^T, W_hh_l0^T.
+//       barrier 2 [W_ih_l1^T pi1 -> gradient of layer 0's output; layer-0 gate gradients] barrier 3 [W_hh_l0^T ph0 -> carried dh0]
+// Range: gradients have no natural scale (a GradScaler multiplies the loss by 65536), f16 does.  The sweep is linear in the
+// upstream gradients, so it runs on g / Sg with Sg = 2^(6 + exponent of max |g|) (mp_absmax_kernel; |g| / Sg <= 1/32: headroom of
+// 2^21 before an f16 operand overflows, values below 2^-14 keep 11 bits through the lo' plane alone) and every stored record is
+// multiplied by Sg -- a power of two, exact.
+struct MpBwdPrep {
+    int S, no, I;
+    const float *W_hh0, *W_ih1, *W_hh1, *W_ih0, *out_W;
+    f16x8 *frags;
+};
+constexpr int kMpBwdWx = 3 * kMpMatFrags, kMpBwdOut = kMpBwdWx + 6 * 2 * 64, kMpBwdTotal = kMpBwdOut + 4 * 2 * 64;
+
+__global__ void __launch_bounds__(256) mp_bwd_prep_kernel(MpBwdPrep q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    f16x8 hi, lo;
+    if (i < 3 * 1536) {                               // W^T tiles: A[i = unit 16 w + (lane & 15)][k = 32 ks + 8 (lane >> 4) + e] = W[k][unit]
+        const int m = i / 1536, r = i - m * 1536, lane = r & 63, ks = (r >> 6) % 6, w = r / 384;
+        const float *W = m == 0 ? q.W_hh0 : (m == 1 ? q.W_ih1 : q.W_hh1);
+        const int unit = 16 * w + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(W[(int64_t)(k0 + e) * 64 + unit], a, b); hi[e] = a; lo[e] = b; }
+        f16x8 *dst = q.frags + (int64_t)m * kMpMatFrags + ((w * 6 + ks) * 2) * 64 + lane;
+        dst[0] = hi; dst[64] = lo;
+    } else if (i < 3 * 1536 + 384) {                  // state columns of W_ih_l0: tile row i holds column i & 3 (zero beyond S)
+        const int r = i - 3 * 1536, lane = r & 63, ks = r >> 6, col = lane & 3, k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(col < q.S ? q.W_ih0[(int64_t)(k0 + e) * q.I + col] : 0.f, a, b); hi[e] = a; lo[e] = b; }
+        f16x8 *dst = q.frags + kMpBwdWx + (ks * 2) * 64 + lane;
+        dst[0] = hi; dst[64] = lo;
+    } else if (i < 3 * 1536 + 384 + 256) {            // out_proj^T: A[i = unit][k = emission row] (one k-step, rows >= NO zero)
+        const int r = i - 3 * 1536 - 384, lane = r & 63, w = r >> 6, unit = 16 * w + (lane & 15), k0 = 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(k0 + e < q.no ? q.out_W[(int64_t)(k0 + e) * 64 + unit] : 0.f, a, b); hi[e] = a; lo[e] = b; }
+        f16x8 *dst = q.frags + kMpBwdOut + (w * 2) * 64 + lane;
+        dst[0] = hi; dst[64] = lo;
+    }
+}
+
+// max |g| over the three upstream gradient tensors, as the bits of a non-negative float (order-independent: deterministic)
+__global__ void __launch_bounds__(256) mp_absmax_kernel(const float *a, int64_t na, const float *b, int64_t nb, const float *c, int64_t nc,
+                                                        unsigned *out) {
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += (int64_t)gridDim.x * 256) {
+        const float v = i < na ? a[i] : (i < na + nb ? b[i - na] : c[i - na - nb]);
+        const unsigned u = __float_as_uint(v) & 0x7fffffffu;
+        m = u > m ? u : m;     // NaN / inf bit patterns compare above every finite value: the scale saturates, the sweep stays NaN
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+        atomicMax(out, m);
+    }
+}
+
+struct MpBwdParams {
+    int B, T, P, C;
+    const float *g_paths, *g_means, *g_chol, *eps, *chol_raw, *acts;
+    const float *W_ih0;
+    const f16x8 *frags;
+    const unsigned *absmax;
+    float dt, sqdt, diag_min;
+    float *D4, *DO, *g_x0, *g_theta;
+};
+
+// R[r] = sum_k A[.][k] B[k][path] for the wave's 16 output units (lane: 4 of them), six k-steps, hi / lo' planes
+template <int NP>
+__device__ __forceinline__ void mp_matmul_t(const f16x8 (&af)[6][2], const f16x8 (&bf)[6], f32x4 &R) {
+    f32x4 A1 = {0.f, 0.f, 0.f, 0.f}, A2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        A1 = mp_mfma(af[ks][0], bf[ks], A1);
+        A2 = mp_mfma(af[ks][1], bf[ks], A2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[r] = fmaf(mp_row_shl<NP>(A1[r]) + A2[r], kMpLoInv, A1[r]);
+}
+
+template <int S, int NP>
+__global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
+    constexpr int L = 2, NTRIL = S * (S + 1) / 2, NO = S + NTRIL;
+    static_assert(S >= 1 && S <= 2 && (NP == 4 || NP == 8), "multi-path backward: two layers, state_dim <= 2, 4 or 8 paths per group");
+    // gate gradients in B-fragment order: [step parity][layer][block dr / du / dn / dc_n][k-step][lane group][column] x 8 f16
+    __shared__ __attribute__((aligned(16))) f16x8 dbuf[2][L][4][2][4][16];
+    __shared__ __attribute__((aligned(16))) f16x8 obuf[4][4][16];         // per layer-1 wave: dO as a one-k-step B operand
+    const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
+    const int b_raw = blockIdx.x * NP + (pp & (NP - 1));
+    const bool owner = pp < NP, live = owner && b_raw < p.B;
+    const int b = b_raw < p.B ? b_raw : p.B - 1;
+    const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+    for (int e = tid; e < 2 * L * 4 * 2 * 4 * 16; e += 512) (&dbuf[0][0][0][0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < 4 * 4 * 16; e += 512) (&obuf[0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    // scale of the sweep: Sg = 2^(E - 127 + 6), E the biased exponent of max |g| (0 -> everything is zero: any scale)
+    const unsigned am = *p.absmax;
+    int E = (int)(am >> 23);
+    E = E < 1 ? 121 : (E > 240 ? 240 : E);
+    const float Sg = __uint_as_float((unsigned)(E + 6) << 23), inv = __uint_as_float((unsigned)(248 - E) << 23);
+
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto load_t = [&](int m, f16x8 (&af)[6][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[ks][pl] = p.frags[(int64_t)m * kMpMatFrags + (((w * 6 + ks) * 2) + pl) * 64 + lane];
+    };
+    // gate gradients of the 4 owned units (backward.py:59-67) from d = dL/dh^l_t; returns the carried u * d
+    auto gate_grads = [&](const f32x4 &d, const f32x4 &r, const f32x4 &u, const f32x4 &n, const f32x4 &cn, const f32x4 &hp, f32x4 &dr,
+                          f32x4 &du, f32x4 &dn, f32x4 &dcn, f32x4 &carry) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dnn = (1.0f - u[e]) * d[e], duu = (hp[e] - n[e]) * d[e];
+            dn[e] = dnn * (1.0f - n[e] * n[e]);
+            du[e] = duu * (u[e] * (1.0f - u[e]));
+            dcn[e] = dn[e] * r[e];
+            dr[e] = (dn[e] * cn[e]) * (r[e] * (1.0f - r[e]));
+            carry[e] = u[e] * d[e];
+        }
+    };
+    auto publish = [&](const f32x4 &v, int par, int l, int blk) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(v[r], a, c); hi[r] = a; lo[r] = c; }
+        if (owner) {
+            *((f16x4 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
+            *((f16x4 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pp + NP] + (q & 1)) = lo;
+        }
+    };
+    auto read_d = [&](int par, int l, bool hh, f16x8 (&bf)[6]) {    // (dr, du, dn) or, hh, (dr, du, dc_n)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) bf[ks] = dbuf[par][l][(ks >> 1) == 2 ? (hh ? 3 : 2) : (ks >> 1)][ks & 1][q][pp];
+    };
+    auto store_d4 = [&](const f32x4 &dr, const f32x4 &du, const f32x4 &dn, const f32x4 &dcn, int t, int l) {
+        if (live) {   // D4[b][t][l][{dr, du, dn, dc_n}][64]
+            float *o = p.D4 + (((int64_t)b * T + t) * L + l) * 256 + j0;
+            *(f32x4 *)(o) = dr * Sg; *(f32x4 *)(o + 64) = du * Sg; *(f32x4 *)(o + 128) = dn * Sg; *(f32x4 *)(o + 192) = dcn * Sg;
+        }
+    };
+    // saved activations of (t, layer): r, u, n, n_hh, and h of step t - 1 (zero before the first step)
+    const float *ab = p.acts + (int64_t)b * T * L * 320 + j0;
+    auto load_acts = [&](int t, int l, f32x4 (&a)[5]) {
+        const int tc = t < 0 ? 0 : t;
+        const float *o = ab + ((int64_t)tc * L + l) * 320;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) a[k] = *(const f32x4 *)(o + 64 * k);
+        a[0] = tc > 0 ? *(const f32x4 *)(o - L * 320) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    if (role == 1) {
+        // =================================================================== layer-1 waves
+        f16x8 whh[6][2], wxs[6][2], wo[2];
+        load_t(2, whh);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wxs[ks][pl] = p.frags[kMpBwdWx + ((ks * 2) + pl) * 64 + lane];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo[pl] = p.frags[kMpBwdOut + ((w * 2) + pl) * 64 + lane];
+        float dx[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) dx[i] = 0.f;
+        f32x4 dh1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 act[5];
+        load_acts(T - 1, 1, act);
+        // upstream gradients / noise / raw Cholesky entries of the step, one step ahead
+        float gp[S], gm[S], gl[S][S], ee[S], raw[NTRIL];
+        auto load_up = [&](int t) {
+            const int tc = t < 0 ? 0 : t;
+            const int64_t bt = (int64_t)b * T + tc;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                gp[i] = p.g_paths[(bt + b + 1) * S + i]; gm[i] = p.g_means[bt * S + i]; ee[i] = p.eps[bt * S + i];
+#pragma unroll
+                for (int c = 0; c < S; ++c) gl[i][c] = p.g_chol[bt * S * S + i * S + c];
+            }
+#pragma unroll
+            for (int r = 0; r < NTRIL; ++r) raw[r] = p.chol_raw[bt * NTRIL + r];
+        };
+        load_up(T - 1);
+        for (int t = T - 1; t >= 0; --t) {
+            const int par = t & 1;
+            if (t < T - 1) {   // d z_{t+1} through layer 0's input of step t + 1: W_x^T pi0  (backward.py:494-509)
+                f16x8 bf[6];
+                read_d(par ^ 1, 0, false, bf);
+                f32x4 dxd;
+                mp_matmul_t<NP>(wxs, bf, dxd);
+#pragma unroll
+                for (int i = 0; i < S; ++i) dx[i] += dxd[i];
+            }
+            f32x4 a_r = act[1], a_u = act[2], a_n = act[3], a_cn = act[4], a_hp = act[0];
+            float cgp[S], cgm[S], cgl[S][S], ce[S], craw[NTRIL];
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                cgp[i] = gp[i]; cgm[i] = gm[i]; ce[i] = ee[i];
+#pragma unroll
+                for (int c = 0; c < S; ++c) cgl[i][c] = gl[i][c];
+            }
+#pragma unroll
+            for (int r = 0; r < NTRIL; ++r) craw[r] = raw[r];
+            load_acts(t - 1, 1, act);
+            load_up(t - 1);
+            // ---- dO_t  (backward.py:278-334)
+            float dO[NO];
+#pragma unroll
+            for (int i = 0; i < S; ++i) { dx[i] = fmaf(cgp[i], inv, dx[i]); dO[i] = fmaf(dx[i], p.dt, cgm[i] * inv); }
+            {
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int c = 0; c <= i; ++c, ++k) {
+                        float dL = fmaf(dx[i] * ce[c], p.sqdt, cgl[i][c] * inv);
+                        if (i == c && !(craw[k] >= p.diag_min || dL < 0.f)) dL = 0.f;    // bounds.py:20
+                        dO[S + k] = dL;
+                    }
+            }
+            if (w == 0 && q == 0 && live) {
+#pragma unroll
+                for (int r = 0; r < NO; ++r) p.DO[((int64_t)b * T + t) * NO + r] = dO[r] * Sg;
+            }
+            // dO as a B operand (k = emission row, in lane group 0), through this wave's private tile
+            if (q == 0 && owner) {
+                f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+#pragma unroll
+                for (int r = 0; r < NO; ++r) { _Float16 a, c; mp_split(dO[r], a, c); hi[r] = a; lo[r] = c; }
+                obuf[w][0][pp] = hi; obuf[w][0][pp + NP] = lo;
+            }
+            wave_lds_fence();
+            const f16x8 ob = obuf[w][q][pp];
+            f32x4 dcur;
+            {
+                f32x4 A1 = {0.f, 0.f, 0.f, 0.f}, A2 = A1;
+                A1 = mp_mfma(wo[0], ob, A1); A2 = mp_mfma(wo[1], ob, A2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dcur[r] = fmaf(mp_row_shl<NP>(A1[r]) + A2[r], kMpLoInv, A1[r]);   // out_proj^T dO  (:296-349)
+            }
+            f32x4 dr, du, dn, dcn, carry;
+            gate_grads(dcur + dh1, a_r, a_u, a_n, a_cn, a_hp, dr, du, dn, dcn, carry);
+            publish(dr, par, 1, 0); publish(du, par, 1, 1); publish(dn, par, 1, 2); publish(dcn, par, 1, 3);
+            barrier();                                 // 2: layer 1's gate gradients published
+            {
+                f16x8 bf[6];
+                read_d(par, 1, true, bf);
+                f32x4 rec;
+                mp_matmul_t<NP>(whh, bf, rec);         // W_hh_l1^T ph1  (:96-105)
+                dh1 = carry + rec;
+            }
+            store_d4(dr, du, dn, dcn, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            barrier();                                 // 3: layer 0's gate gradients published
+        }
+        {   // the step-0 term of d z_0, then grad x0  (:620-624)
+            f16x8 bf[6];
+            read_d(0, 0, false, bf);
+            f32x4 dxd;
+            mp_matmul_t<NP>(wxs, bf, dxd);
+            if (w == 0 && q == 0 && live) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) p.g_x0[(int64_t)b * S + i] = (dx[i] + dxd[i] + p.g_paths[(int64_t)b * (T + 1) * S + i] * inv) * Sg;
+            }
+        }
+        barrier();                                     // X: the gate-gradient tiles are free (layer 0 puts its theta sums there)
+        barrier();                                     // Y: pairs with the layer-0 waves' barrier in front of the grad-theta sums
+        return;
+    }
+
+    // ======================================================================= layer-0 waves
+    f16x8 wih1[6][2], whh0[6][2];
+    load_t(1, wih1);
+    load_t(0, whh0);
+    f32x4 dh0 = {0.f, 0.f, 0.f, 0.f}, ths[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) ths[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 act[5];
+    load_acts(T - 1, 0, act);
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        f32x4 a_r = act[1], a_u = act[2], a_n = act[3], a_cn = act[4], a_hp = act[0];
+        load_acts(t - 1, 0, act);
+        barrier();                                     // 2
+        f32x4 dcur;
+        {
+            f16x8 bf[6];
+            read_d(par, 1, false, bf);
+            mp_matmul_t<NP>(wih1, bf, dcur);           // W_ih_l1^T pi1: gradient of layer 0's output  (:83-94)
+        }
+        f32x4 dr, du, dn, dcn, carry;
+        gate_grads(dcur + dh0, a_r, a_u, a_n, a_cn, a_hp, dr, du, dn, dcn, carry);
+        publish(dr, par, 0, 0); publish(du, par, 0, 1); publish(dn, par, 0, 2); publish(dcn, par, 0, 3);
+        ths[0] += dr; ths[1] += du; ths[2] += dn;      // sum_t pi0: grad theta = W_theta^T of it (:511-548)
+        barrier();                                     // 3
+        {
+            f16x8 bf[6];
+            read_d(par, 0, true, bf);
+            f32x4 rec;
+            mp_matmul_t<NP>(whh0, bf, rec);            // W_hh_l0^T ph0  (:566-573)
+            dh0 = carry + rec;
+        }
+        store_d4(dr, du, dn, dcn, t, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // grad theta[b][e] = sum_rows W_ih_l0[row][S + C + e] * sum_t pi0[row]: the sums go through LDS (the gate-gradient tiles are free now)
+    float *tsum = (float *)&dbuf[0][0][0][0][0][0];    // [NP][192]
+    barrier();                                         // X: the layer-1 waves have read dbuf[0][0] (step 0) for grad x0
+    if (owner) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tsum[pp * 192 + g * 64 + j0 + r] = ths[g][r];
+    }
+    barrier();                                         // Y
+    for (int o = tid; o < NP * p.P; o += 256) {
+        const int path = o / p.P, e = o - path * p.P, bb = blockIdx.x * NP + path;
+        if (bb < p.B) {
+            float acc = 0.f;
+            for (int row = 0; row < 192; ++row) acc = fmaf(p.W_ih0[(int64_t)row * I + S + p.C + e], tsum[path * 192 + row], acc);
+            p.g_theta[(int64_t)bb * p.P + e] = acc * Sg;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 size_t mp_frag_bytes(int L, int S) {
     const int no = S + S * (S + 1) / 2, nto = (no + 3) / 4;
@@ -430,6 +764,37 @@ size_t mp_frag_bytes(int L, int S) {
 }
 
 bool mp_applicable(int H, int L, int S) { return H == 64 && L >= 1 && L <= 2 && S >= 1 && S <= 2; }
+bool mp_bwd_applicable(int H, int L, int S) { return H == 64 && L == 2 && S >= 1 && S <= 2; }
+size_t mp_bwd_frag_bytes(void) { return (size_t)kMpBwdTotal * sizeof(f16x8) + 256; }   // fragments + the absmax word
+
+int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t)) {
+    const int no = a.S + a.S * (a.S + 1) / 2;
+    f16x8 *frags = (f16x8 *)a.frags;
+    unsigned *absmax = (unsigned *)(frags + kMpBwdTotal);
+    MpBwdPrep q = {};
+    q.S = a.S; q.no = no; q.I = a.S + a.C + a.P;
+    q.W_hh0 = a.W_hh0; q.W_ih1 = a.W_ih_st; q.W_hh1 = a.W_hh_st; q.W_ih0 = a.W_ih0; q.out_W = a.out_W; q.frags = frags;
+    hipLaunchKernelGGL(mp_bwd_prep_kernel, dim3((3 * 1536 + 384 + 256 + 255) / 256), dim3(256), 0, s, q);
+    VSDE_CHECK_HIP(hipMemsetAsync(absmax, 0, sizeof(unsigned), s));
+    const int64_t n1 = (int64_t)a.B * (a.T + 1) * a.S, n2 = (int64_t)a.B * a.T * a.S, n3 = (int64_t)a.B * a.T * a.S * a.S;
+    int blocks = (int)((n1 + n2 + n3 + 1023) / 1024);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(mp_absmax_kernel, dim3(blocks), dim3(256), 0, s, a.g_paths, n1, a.g_means, n2, a.g_chol, n3, absmax);
+    MpBwdParams p = {};
+    p.B = a.B; p.T = a.T; p.P = a.P; p.C = a.C;
+    p.g_paths = a.g_paths; p.g_means = a.g_means; p.g_chol = a.g_chol; p.eps = a.eps; p.chol_raw = a.chol_raw; p.acts = a.acts;
+    p.W_ih0 = a.W_ih0; p.frags = frags; p.absmax = absmax;
+    p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
+    p.D4 = a.D4; p.DO = a.DO; p.g_x0 = a.g_x0; p.g_theta = a.g_theta;
+    int np = a.np == 4 || a.np == 8 ? a.np : (a.np == 16 ? 8 : (a.B <= 1024 ? 4 : 8));
+    const dim3 grid((a.B + np - 1) / np), block(512);
+    if (mark) mark(1, 0, s);
+    if (a.S == 1) { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<1, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<1, 8>), grid, block, 0, s, p); }
+    else { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<2, 8>), grid, block, 0, s, p); }
+    if (mark) mark(1, 1, s);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t)) {
     const int no = a.S + a.S * (a.S + 1) / 2, nto = (no + 3) / 4, nm = 2 * a.L - 1;
