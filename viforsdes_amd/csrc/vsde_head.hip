@@ -1571,9 +1571,10 @@ static bool use_mp(const vsde_head_dims *d, int save) {
     if (mode > 0) return true;
     return mp_auto(d, save);
 }
-// The reverse-time sweep on the matrix cores pays from ~700 paths on (profiles/r04_head_mp.txt: 512 paths 1055 us against 810 us for
-// the v2 kernel -- sixteen operand splits per unit and layer sit on the step's critical path -- 1024 paths 1083 against 1630 us,
-// 4096 paths 2670 against 6322 us).
+// The reverse-time sweep on the matrix cores pays from ~700 paths on (profiles/r04_head_mp.txt: 512 paths 993 us against 800 us for
+// the v2 kernel, 1024 paths 1017 against 1571 us, 4096 paths 2235 against 6253 us).  What holds it back at 512 paths is one CU's LDS
+// bandwidth: K = 192 products want six B fragments each and four published gradient vectors per layer
+// (profiles/r04_head_bwd_ablation.txt).
 static bool use_mp_bwd(const vsde_head_dims *d) {
     if (!mp_bwd_applicable(d->H, d->L, d->S)) return false;
     const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();

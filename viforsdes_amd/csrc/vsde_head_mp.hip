@@ -31,6 +31,8 @@
 //
 // Scope: hidden_dim 64, 1 or 2 layers, state_dim 1 or 2 (the OU and Lotka-Volterra heads); everything else keeps the v2 / v1 /
 // generic kernels.  Weights must fit f16 range after the exp2 scaling (|W| < 2.2e4; a GRU gate saturates long before).
+#include <stdlib.h>
+
 #include "vsde_common.h"
 
 namespace vsde {
@@ -41,6 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kMpLo = 2048.0f, kMpLoInv = 1.0f / 2048.0f;
 constexpr float kMpSr = -1.4426950408889634f, kMpSn = 2.8853900817779268f, kMpInvSn = 1.0f / 2.8853900817779268f;
+template <int V> struct MpSlot { static constexpr int value = V; };
 constexpr int kMpMatFrags = 4 * 3 * 2 * 2 * 64;   // f16x8 fragments of one recurrent matrix: [wave][gate][k-step][plane][lane]
 
 // x = hi + lo / 2048.  The matrix pipe flushes f16 DENORMAL inputs to zero (measured: rows of W holding an element below
@@ -50,6 +53,16 @@ __device__ __forceinline__ void mp_split(float v, _Float16 &hi, _Float16 &lo) {
     const float h = fabsf(v) < 6.103515625e-5f ? 0.0f : (float)(_Float16)v;
     hi = (_Float16)h;
     lo = (_Float16)((v - h) * kMpLo);
+}
+// The time loops run with the f16 denormal mode of the wave set to FLUSH (mp_flush_f16_denormals, MODE.fp_denorm[3:2] = 0): the
+// conversions then produce the zero the matrix pipe would see anyway, and the split needs no compare / select (7 -> 4.5 VALU
+// operations per value; the backward splits 16 values per lane and layer on its critical path).
+__device__ __forceinline__ void mp_flush_f16_denormals() {
+    __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);   // hwreg(HW_REG_MODE, offset 6, 2 bits): f16 / f64 denormals -> flush
+}
+__device__ __forceinline__ void mp_split_fast(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kMpLo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -158,6 +171,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     const bool live = owner && b_raw < p.B;
     const int b = b_raw < p.B ? b_raw : p.B - 1;   // lanes beyond the batch recompute the last path and store nothing
     const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+    mp_flush_f16_denormals();
     if (NP < 16) {
         for (int e = tid; e < 2 * L * PL * 2 * 4 * 16; e += 256 * L) (&hbuf[0][0][0][0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         __syncthreads();
@@ -168,7 +182,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     auto publish = [&](const float (&h)[4], int t, int l) {
         f16x4 hi, lo;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(h[r], a, c); hi[r] = a; lo[r] = c; }
+        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split_fast(h[r], a, c); hi[r] = a; lo[r] = c; }
         const int par = t & 1;
         if (NP == 16) {
             *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
@@ -435,9 +449,10 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 //   layer-0 waves (4): W_ih_l1^T, W_hh_l0^T.
 //       barrier 2 [W_ih_l1^T pi1 -> gradient of layer 0's output; layer-0 gate gradients] barrier 3 [W_hh_l0^T ph0 -> carried dh0]
 // Range: gradients have no natural scale (a GradScaler multiplies the loss by 65536), f16 does.  The sweep is linear in the
-// upstream gradients, so it runs on g / Sg with Sg = 2^(6 + exponent of max |g|) (mp_absmax_kernel; |g| / Sg <= 1/32: headroom of
-// 2^21 before an f16 operand overflows, values below 2^-14 keep 11 bits through the lo' plane alone) and every stored record is
-// multiplied by Sg -- a power of two, exact.
+// upstream gradients, so it runs on g / Sg with Sg = 2^(1 + exponent of max |g|) (mp_absmax_kernel; |g| / Sg in [1/2, 1): a gate
+// gradient may grow to 6e4 x the largest upstream gradient before an f16 operand overflows, values below 2^-14 of that scale keep 11
+// bits through the lo' plane alone -- with 2^5 more headroom a fifth of the gate gradients fell there and the gradients were 2e-5
+// .. 9e-5 off) and every stored record is multiplied by Sg -- a power of two, exact.
 struct MpBwdPrep {
     int S, no, I;
     const float *W_hh0, *W_ih1, *W_hh1, *W_ih0, *out_W;
@@ -502,11 +517,12 @@ struct MpBwdParams {
 };
 
 // R[r] = sum_k A[.][k] B[k][path] for the wave's 16 output units (lane: 4 of them), six k-steps, hi / lo' planes
-template <int NP>
+template <int NP, bool SKIP = false>
 __device__ __forceinline__ void mp_matmul_t(const f16x8 (&af)[6][2], const f16x8 (&bf)[6], f32x4 &R) {
     f32x4 A1 = {0.f, 0.f, 0.f, 0.f}, A2 = {0.f, 0.f, 0.f, 0.f};
+    if (SKIP) { A1[0] = (float)bf[0][0]; A2[1] = (float)af[1][0][0]; }
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
+    for (int ks = 0; ks < (SKIP ? 0 : 6); ++ks) {
         A1 = mp_mfma(af[ks][0], bf[ks], A1);
         A2 = mp_mfma(af[ks][1], bf[ks], A2);
     }
@@ -514,7 +530,9 @@ __device__ __forceinline__ void mp_matmul_t(const f16x8 (&af)[6][2], const f16x8
     for (int r = 0; r < 4; ++r) R[r] = fmaf(mp_row_shl<NP>(A1[r]) + A2[r], kMpLoInv, A1[r]);
 }
 
-template <int S, int NP>
+// ABL: timing-only ablations (wrong results; VSDE_MP_BWD_ABL, S = 2 / NP = 4 only): 1 = no D4 / DO stores, 2 = no activation / upstream
+// loads inside the loop, 4 = gate gradients published without the f16 split arithmetic, 8 = no matrix products
+template <int S, int NP, int ABL = 0>
 __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     constexpr int L = 2, NTRIL = S * (S + 1) / 2, NO = S + NTRIL;
     static_assert(S >= 1 && S <= 2 && (NP == 4 || NP == 8), "multi-path backward: two layers, state_dim <= 2, 4 or 8 paths per group");
@@ -526,14 +544,15 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     const bool owner = pp < NP, live = owner && b_raw < p.B;
     const int b = b_raw < p.B ? b_raw : p.B - 1;
     const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+    mp_flush_f16_denormals();
     for (int e = tid; e < 2 * L * 4 * 2 * 4 * 16; e += 512) (&dbuf[0][0][0][0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int e = tid; e < 4 * 4 * 16; e += 512) (&obuf[0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     __syncthreads();
-    // scale of the sweep: Sg = 2^(E - 127 + 6), E the biased exponent of max |g| (0 -> everything is zero: any scale)
+    // scale of the sweep: Sg = 2^(E - 127 + 1), E the biased exponent of max |g| (0 -> everything is zero: any scale)
     const unsigned am = *p.absmax;
     int E = (int)(am >> 23);
-    E = E < 1 ? 121 : (E > 240 ? 240 : E);
-    const float Sg = __uint_as_float((unsigned)(E + 6) << 23), inv = __uint_as_float((unsigned)(248 - E) << 23);
+    E = E < 1 ? 126 : (E > 250 ? 250 : E);
+    const float Sg = __uint_as_float((unsigned)(E + 1) << 23), inv = __uint_as_float((unsigned)(253 - E) << 23);
 
     auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto load_t = [&](int m, f16x8 (&af)[6][2]) {
@@ -558,7 +577,11 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     auto publish = [&](const f32x4 &v, int par, int l, int blk) {
         f16x4 hi, lo;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split(v[r], a, c); hi[r] = a; lo[r] = c; }
+        for (int r = 0; r < 4; ++r) {
+            _Float16 a, c;
+            if (ABL & 4) { a = (_Float16)v[r]; c = a; } else mp_split_fast(v[r], a, c);
+            hi[r] = a; lo[r] = c;
+        }
         if (owner) {
             *((f16x4 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
             *((f16x4 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pp + NP] + (q & 1)) = lo;
@@ -569,7 +592,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
         for (int ks = 0; ks < 6; ++ks) bf[ks] = dbuf[par][l][(ks >> 1) == 2 ? (hh ? 3 : 2) : (ks >> 1)][ks & 1][q][pp];
     };
     auto store_d4 = [&](const f32x4 &dr, const f32x4 &du, const f32x4 &dn, const f32x4 &dcn, int t, int l) {
-        if (live) {   // D4[b][t][l][{dr, du, dn, dc_n}][64]
+        if (live && !(ABL & 1)) {   // D4[b][t][l][{dr, du, dn, dc_n}][64]
             float *o = p.D4 + (((int64_t)b * T + t) * L + l) * 256 + j0;
             *(f32x4 *)(o) = dr * Sg; *(f32x4 *)(o + 64) = du * Sg; *(f32x4 *)(o + 128) = dn * Sg; *(f32x4 *)(o + 192) = dcn * Sg;
         }
@@ -577,6 +600,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     // saved activations of (t, layer): r, u, n, n_hh, and h of step t - 1 (zero before the first step)
     const float *ab = p.acts + (int64_t)b * T * L * 320 + j0;
     auto load_acts = [&](int t, int l, f32x4 (&a)[5]) {
+        if ((ABL & 2) && t < T - 2) return;
         const int tc = t < 0 ? 0 : t;
         const float *o = ab + ((int64_t)tc * L + l) * 320;
 #pragma unroll
@@ -598,45 +622,49 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
 #pragma unroll
         for (int i = 0; i < S; ++i) dx[i] = 0.f;
         f32x4 dh1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 act[5];
-        load_acts(T - 1, 1, act);
-        // upstream gradients / noise / raw Cholesky entries of the step, one step ahead
-        float gp[S], gm[S], gl[S][S], ee[S], raw[NTRIL];
-        auto load_up = [&](int t) {
+        // saved activations and the step's upstream gradients / noise / raw Cholesky entries travel TWO steps ahead in two register
+        // sets (the records were written by the forward launch long ago: HBM latency, more than one step of this loop)
+        f32x4 act[2][5];
+        float gp[2][S], gm[2][S], gl[2][S][S], ee[2][S], raw[2][NTRIL];
+        auto load_up = [&](int t, auto slot_c) {
+            constexpr int sl = decltype(slot_c)::value;
+            if ((ABL & 2) && t < T - 2) return;
             const int tc = t < 0 ? 0 : t;
             const int64_t bt = (int64_t)b * T + tc;
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                gp[i] = p.g_paths[(bt + b + 1) * S + i]; gm[i] = p.g_means[bt * S + i]; ee[i] = p.eps[bt * S + i];
+                gp[sl][i] = p.g_paths[(bt + b + 1) * S + i]; gm[sl][i] = p.g_means[bt * S + i]; ee[sl][i] = p.eps[bt * S + i];
 #pragma unroll
-                for (int c = 0; c < S; ++c) gl[i][c] = p.g_chol[bt * S * S + i * S + c];
+                for (int c = 0; c < S; ++c) gl[sl][i][c] = p.g_chol[bt * S * S + i * S + c];
             }
 #pragma unroll
-            for (int r = 0; r < NTRIL; ++r) raw[r] = p.chol_raw[bt * NTRIL + r];
+            for (int r = 0; r < NTRIL; ++r) raw[sl][r] = p.chol_raw[bt * NTRIL + r];
         };
-        load_up(T - 1);
-        for (int t = T - 1; t >= 0; --t) {
+        load_acts(T - 1, 1, act[0]); load_up(T - 1, MpSlot<0>{});
+        load_acts(T - 2, 1, act[1]); load_up(T - 2, MpSlot<1>{});
+        auto step = [&](int t, auto slot_c) {
+            constexpr int sl = decltype(slot_c)::value;
             const int par = t & 1;
             if (t < T - 1) {   // d z_{t+1} through layer 0's input of step t + 1: W_x^T pi0  (backward.py:494-509)
                 f16x8 bf[6];
                 read_d(par ^ 1, 0, false, bf);
                 f32x4 dxd;
-                mp_matmul_t<NP>(wxs, bf, dxd);
+                mp_matmul_t<NP, (ABL & 8) != 0>(wxs, bf, dxd);
 #pragma unroll
                 for (int i = 0; i < S; ++i) dx[i] += dxd[i];
             }
-            f32x4 a_r = act[1], a_u = act[2], a_n = act[3], a_cn = act[4], a_hp = act[0];
+            f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = act[sl][0];
             float cgp[S], cgm[S], cgl[S][S], ce[S], craw[NTRIL];
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                cgp[i] = gp[i]; cgm[i] = gm[i]; ce[i] = ee[i];
+                cgp[i] = gp[sl][i]; cgm[i] = gm[sl][i]; ce[i] = ee[sl][i];
 #pragma unroll
-                for (int c = 0; c < S; ++c) cgl[i][c] = gl[i][c];
+                for (int c = 0; c < S; ++c) cgl[i][c] = gl[sl][i][c];
             }
 #pragma unroll
-            for (int r = 0; r < NTRIL; ++r) craw[r] = raw[r];
-            load_acts(t - 1, 1, act);
-            load_up(t - 1);
+            for (int r = 0; r < NTRIL; ++r) craw[r] = raw[sl][r];
+            load_acts(t - 2, 1, act[sl]);
+            load_up(t - 2, slot_c);
             // ---- dO_t  (backward.py:278-334)
             float dO[NO];
 #pragma unroll
@@ -652,7 +680,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
                         dO[S + k] = dL;
                     }
             }
-            if (w == 0 && q == 0 && live) {
+            if (w == 0 && q == 0 && live && !(ABL & 1)) {
 #pragma unroll
                 for (int r = 0; r < NO; ++r) p.DO[((int64_t)b * T + t) * NO + r] = dO[r] * Sg;
             }
@@ -660,7 +688,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
             if (q == 0 && owner) {
                 f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
 #pragma unroll
-                for (int r = 0; r < NO; ++r) { _Float16 a, c; mp_split(dO[r], a, c); hi[r] = a; lo[r] = c; }
+                for (int r = 0; r < NO; ++r) { _Float16 a, c; mp_split_fast(dO[r], a, c); hi[r] = a; lo[r] = c; }
                 obuf[w][0][pp] = hi; obuf[w][0][pp + NP] = lo;
             }
             wave_lds_fence();
@@ -680,18 +708,22 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
                 f16x8 bf[6];
                 read_d(par, 1, true, bf);
                 f32x4 rec;
-                mp_matmul_t<NP>(whh, bf, rec);         // W_hh_l1^T ph1  (:96-105)
+                mp_matmul_t<NP, (ABL & 8) != 0>(whh, bf, rec);         // W_hh_l1^T ph1  (:96-105)
                 dh1 = carry + rec;
             }
             store_d4(dr, du, dn, dcn, t, 1);
             __builtin_amdgcn_sched_barrier(0);
             barrier();                                 // 3: layer 0's gate gradients published
+        };
+        for (int t = T - 1; t >= 0; t -= 2) {
+            step(t, MpSlot<0>{});
+            if (t >= 1) step(t - 1, MpSlot<1>{});
         }
         {   // the step-0 term of d z_0, then grad x0  (:620-624)
             f16x8 bf[6];
             read_d(0, 0, false, bf);
             f32x4 dxd;
-            mp_matmul_t<NP>(wxs, bf, dxd);
+            mp_matmul_t<NP, (ABL & 8) != 0>(wxs, bf, dxd);
             if (w == 0 && q == 0 && live) {
 #pragma unroll
                 for (int i = 0; i < S; ++i) p.g_x0[(int64_t)b * S + i] = (dx[i] + dxd[i] + p.g_paths[(int64_t)b * (T + 1) * S + i] * inv) * Sg;
@@ -709,18 +741,20 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     f32x4 dh0 = {0.f, 0.f, 0.f, 0.f}, ths[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) ths[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 act[5];
-    load_acts(T - 1, 0, act);
-    for (int t = T - 1; t >= 0; --t) {
+    f32x4 act[2][5];
+    load_acts(T - 1, 0, act[0]);
+    load_acts(T - 2, 0, act[1]);
+    auto step = [&](int t, auto slot_c) {
+        constexpr int sl = decltype(slot_c)::value;
         const int par = t & 1;
-        f32x4 a_r = act[1], a_u = act[2], a_n = act[3], a_cn = act[4], a_hp = act[0];
-        load_acts(t - 1, 0, act);
+        f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = act[sl][0];
+        load_acts(t - 2, 0, act[sl]);
         barrier();                                     // 2
         f32x4 dcur;
         {
             f16x8 bf[6];
             read_d(par, 1, false, bf);
-            mp_matmul_t<NP>(wih1, bf, dcur);           // W_ih_l1^T pi1: gradient of layer 0's output  (:83-94)
+            mp_matmul_t<NP, (ABL & 8) != 0>(wih1, bf, dcur);           // W_ih_l1^T pi1: gradient of layer 0's output  (:83-94)
         }
         f32x4 dr, du, dn, dcn, carry;
         gate_grads(dcur + dh0, a_r, a_u, a_n, a_cn, a_hp, dr, du, dn, dcn, carry);
@@ -731,11 +765,15 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
             f16x8 bf[6];
             read_d(par, 0, true, bf);
             f32x4 rec;
-            mp_matmul_t<NP>(whh0, bf, rec);            // W_hh_l0^T ph0  (:566-573)
+            mp_matmul_t<NP, (ABL & 8) != 0>(whh0, bf, rec);            // W_hh_l0^T ph0  (:566-573)
             dh0 = carry + rec;
         }
         store_d4(dr, du, dn, dcn, t, 0);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = T - 1; t >= 0; t -= 2) {
+        step(t, MpSlot<0>{});
+        if (t >= 1) step(t - 1, MpSlot<1>{});
     }
     // grad theta[b][e] = sum_rows W_ih_l0[row][S + C + e] * sum_t pi0[row]: the sums go through LDS (the gate-gradient tiles are free now)
     float *tsum = (float *)&dbuf[0][0][0][0][0][0];    // [NP][192]
@@ -789,6 +827,19 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     int np = a.np == 4 || a.np == 8 ? a.np : (a.np == 16 ? 8 : (a.B <= 1024 ? 4 : 8));
     const dim3 grid((a.B + np - 1) / np), block(512);
     if (mark) mark(1, 0, s);
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("VSDE_MP_BWD_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl && a.S == 2 && np == 4) {
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 1>), grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 2>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 3>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 4>), grid, block, 0, s, p); break;
+            case 8: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 8>), grid, block, 0, s, p); break;
+            case 7: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 7>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 15>), grid, block, 0, s, p); break;
+        }
+    } else
     if (a.S == 1) { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<1, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<1, 8>), grid, block, 0, s, p); }
     else { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<2, 8>), grid, block, 0, s, p); }
     if (mark) mark(1, 1, s);
