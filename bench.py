@@ -157,7 +157,7 @@ def cpu_baseline(lv, ou, lv_micro_batch, enc):
                    "sample": "OU T=100 S=1 full ELBO step, B=128 (the whole batch), median of 3 timed iterations, fp32"}}
 
 
-def parity_gate(problem, enc, device, batch=16, steps=3, name="LV"):
+def parity_gate(problem, enc, device, batch=16, steps=3, name="LV", force_mp=0):
     """ELBO per step and theta ``expected_value`` after ``steps`` optimizer steps: GPU (fp32 and bf16-autocast encoder) vs
     the CPU oracle path, same initial state, identical injected theta-eps and path noise.
     BASELINE config 2 asks for exactly this on OU at its full batch (B=128, T=100); LV runs a 16-path batch of the T=400
@@ -185,6 +185,14 @@ def parity_gate(problem, enc, device, batch=16, steps=3, name="LV"):
     res = {"workload": f"{name} T={T} batch {batch}, {steps} optimizer steps from one initial state, injected noise",
            "reference": "CPU oracle path (torch-CPU encoder + C oracle head/ELBO, fp32)",
            "elbo_cpu": e_cpu, "expected_value_cpu": ev_cpu}
+    # force_mp: the GPU legs run the multi-path MFMA time-stepping kernels (forward + reverse-time sweep, that many paths per workgroup) --
+    # the kernels the timed 512-path step takes; at this gate's batch size the dispatcher would pick the four-waves-per-path kernels
+    from viforsdes_amd import _hip
+    if force_mp:
+        _hip.debug_head_mp(force_mp)
+        res["head_kernels"] = f"multi-path MFMA forward + backward, {force_mp} paths per workgroup (forced: as in the timed step's forward)"
+    else:
+        res["head_kernels"] = "dispatcher default at this batch size (four waves per path)"
     rel = lambda a, b: max(abs(x - y) / max(abs(y), 1e-12) for x, y in zip(a, b))
     # bf16: measured 4e-4 / 4e-6 (LV) and 1.1e-3 / 2.6e-4 (OU); the round-3 stale-operand defect was 6.6e-3 on LV, 1.3e-1 on OU
     tols = {"fp32": (2e-3, 1e-3), "bf16": (5e-3, 2e-3)}
@@ -202,6 +210,7 @@ def parity_gate(problem, enc, device, batch=16, steps=3, name="LV"):
         res[f"tolerance_{tag}"] = {"elbo_rel": te, "expected_value_rel": tv}
         ok = ok and res[f"elbo_max_rel_diff_{tag}"] < te and res[f"expected_value_max_rel_diff_{tag}"] < tv
         del tr
+    _hip.debug_head_mp(-1)
     res["pass"] = bool(ok)
     return res
 
@@ -540,7 +549,7 @@ def main():
         ou_fields, _ = measure("ou", 128, args, device, distributed, world)
         out["ou"] = ou_fields
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "lv":
-        out["parity"] = parity_gate(problem, enc, device)
+        out["parity"] = parity_gate(problem, enc, device, force_mp=4 if batch > 256 else 0)
         # BASELINE config 2: OU (B=128, T=100) fused HIP GRU + ELBO, fp32 and bf16, vs the CPU path, with the tolerance
         out["parity"]["ou"] = parity_gate(ou_problem(), dict(enc_hidden=256, enc_depth=8), device, batch=128, steps=3, name="OU")
         out["parity"]["pass"] = bool(out["parity"]["pass"] and out["parity"]["ou"]["pass"])
