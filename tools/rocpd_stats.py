@@ -50,9 +50,10 @@ def categories(path):
         print(f"{k:<32} {v/1e6:>10.3f} ms {100*v/tot:>6.2f}%")
 
 
-def busy(path, marker="optim_update_kernel", first=8, last=28):
-    """GPU busy fraction between the `first`-th and `last`-th launch of the marker kernel (one per training step): sum of kernel
-    durations / wall span, plus the per-step wall time and the number of launches per step."""
+def busy(path, marker="optim_update_kernel", first=35, last=65):
+    """GPU busy fraction between the `first`-th and `last`-th launch of the marker kernel (one per training step; the defaults sit
+    inside the 50 timed steps of a default bench.py run: 3 + 4 probe steps, 3 capture warm-ups, 4 replays, 10 warm-up steps come first):
+    sum of kernel durations / wall span, plus the per-step wall time and the number of launches per step."""
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
