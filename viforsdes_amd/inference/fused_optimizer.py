@@ -13,6 +13,10 @@ told the outcome (``found_inf``) the way ``GradScaler.step`` would, so ``scaler.
 Used on CUDA for fp32, contiguous parameters with plain AdamW (no amsgrad / maximize); ``VSDE_FUSED_OPTIMIZER=0`` keeps the torch
 sequence.  Deterministic (fixed-order reductions), graph-capture safe (step count and outcome stay on the device).
 
+Gradients after the step: ``p.grad`` keeps what autograd wrote (loss-SCALED and unclipped) -- the kernel reads the gradients, it does
+not rewrite them the way ``unscale_`` / ``clip_grad_norm_`` do in place.  Code that inspects gradients after ``_optimizer_step`` must
+divide by ``scaler.get_scale()`` itself (nothing in the package does).
+
 EMA contract: the kernel applies this step's EMA lerp and sets ``ema.fused_step_done``; the ``ema.update()`` call that the
 trainer's loops (and the reference's) issue after every step then returns at once.  A caller that steps WITHOUT updating the EMA
 must construct the step with ``ema=None`` (``VariationalInferenceTrainer.fuse_ema = False``).
