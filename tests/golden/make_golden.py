@@ -736,6 +736,9 @@ if __name__ == "__main__":
         make_head_case("h80_l2", 2, 6, 2, 8, 2, 80, 2, seed=18, with_o2=False)
         make_head_case("h130_l1_s10", 2, 4, 10, 6, 2, 130, 1, seed=19, with_o2=False)
         make_head_case("h96_l3", 2, 5, 3, 8, 3, 96, 3, seed=20, with_o2=False)
+    if "head_mp" in which:  # hidden_dim 64 / two layers / state_dim <= 2 at batches where the dispatcher takes the multi-path MFMA kernels
+        make_head_case("mp_b300_s2", 300, 10, 2, 32, 3, 64, 2, seed=27, with_o2=False)      # forward multi-path, backward v2
+        make_head_case("mp_b700_s1", 700, 8, 1, 16, 3, 64, 2, seed=28, with_o2=False, clamp_stress=True)   # both multi-path
     if "head_mid" in which:  # 16 < S + S(S+1)/2 <= 64 with hidden_dim <= 64: emission rows spread over the waves
         make_head_case("s5_h32_l1", 3, 21, 5, 12, 2, 32, 1, seed=23, with_o2=False)
         make_head_case("s9_h64_l2", 2, 19, 9, 8, 4, 64, 2, seed=24, with_o2=False, clamp_stress=True)

@@ -7,6 +7,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 HEAD_CASES = ["tiny_l2", "tiny_l1_odd", "tiny_l4", "s8_h64", "clamp", "ou_dims", "lv_dims",
               "h80_l2", "h130_l1_s10", "h96_l3",  # these three: hidden_dim > 64 / state_dim > 9 (generic kernels)
               "s5_h32_l1", "s9_h64_l2"]           # 16 < emission rows <= 64: wide variant of the register-resident kernels
+# batches above the dispatcher's thresholds (forward > 256 paths, backward > 640): the multi-path MFMA kernels under DEFAULT dispatch
+MP_CASES = ["mp_b300_s2", "mp_b700_s1"]
 W_NAMES = ["W_ih_l0", "W_hh_l0", "b_ih_l0", "b_hh_l0", "W_ih_stack", "W_hh_stack",
            "b_ih_stack", "b_hh_stack", "out_weight", "out_bias"]
 G_NAMES = ["x0", "context", "sde_parameters"] + W_NAMES

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import G_NAMES, HEAD_CASES, W_NAMES, load_head_case, rel_err
+from helpers import G_NAMES, HEAD_CASES, MP_CASES, W_NAMES, load_head_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,13 @@ def test_forward_backward_vs_golden(name):
             assert g.numel() == 0
             continue
         assert rel_err(g.cpu().numpy(), ref) < BWD_TOL, gname
+
+
+@pytest.mark.parametrize("name", MP_CASES)
+def test_default_dispatch_above_the_batch_thresholds_vs_golden(name):
+    """Reference-generated cases (eager head definition looped, f64) with 300 / 700 paths: under the DEFAULT dispatch the forward
+    (both cases) and the reverse-time sweep (700 paths) run the multi-path MFMA kernels; same tolerances as every other case."""
+    test_forward_backward_vs_golden(name)
 
 
 @pytest.mark.parametrize("np_group", [4, 8, 16])

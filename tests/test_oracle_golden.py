@@ -4,7 +4,7 @@ f32 vs f32 to rounding."""
 import numpy as np
 import pytest
 
-from helpers import G_NAMES, GOLDEN, HEAD_CASES, W_NAMES, load_head_case, rel_err
+from helpers import G_NAMES, GOLDEN, HEAD_CASES, MP_CASES, W_NAMES, load_head_case, rel_err
 from oracle import vsde_oracle as vo
 
 
@@ -12,7 +12,7 @@ def _weights(d):
     return vo.HeadWeights(*[d["w_" + n] for n in W_NAMES])
 
 
-@pytest.mark.parametrize("name", HEAD_CASES)
+@pytest.mark.parametrize("name", HEAD_CASES + MP_CASES)
 @pytest.mark.parametrize("dtype,tag,ftol,btol", [(np.float32, "o1f32", 5e-6, 2e-5), (np.float64, "o1f64", 1e-12, 1e-12)])
 def test_head_forward_backward(name, dtype, tag, ftol, btol):
     d = load_head_case(name)
