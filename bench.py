@@ -544,7 +544,7 @@ def main():
                              "weight-gradient reductions, large-batch sampler) with fp32-equivalent results",
     }
     out.update(fields)
-    if args.workload == "lv" and not args.no_ou:
+    if args.workload == "lv" and not args.no_ou and world == 1:   # (the multi-GPU runs measure the headline workload only)
         # BASELINE configs 1/2 (north_star's second target): OU S=1, T=100, B=128 in the same run, same measurements
         ou_fields, _ = measure("ou", 128, args, device, distributed, world)
         out["ou"] = ou_fields

@@ -199,6 +199,38 @@ def test_two_graph_data_parallel_step_replays():
     assert moved > len(before) // 2 and np.isfinite(float(r.grad_norm))
 
 
+def test_captured_step_with_the_multi_path_kernels_replays_like_eager_steps():
+    """704 paths (OU, small encoder): forward AND reverse-time sweep take the multi-path MFMA kernels under the default dispatch; their
+    launch sequence (fragment prep kernels, the max-abs pre-pass with its memset, the sweeps) must survive HIP-graph capture: a
+    replayed trainer and an eagerly stepped twin from the same seed and the same injected noise reach the same parameters."""
+    B = 704
+    g = torch.Generator().manual_seed(3)
+    tr_e, tr_g = _small_ou_trainer(seed=11, batch=B), _small_ou_trainer(seed=11, batch=B)
+    T, P = 100, 3
+    teps = [torch.randn(B, P, generator=g).to(DEV) for _ in range(5)]
+    noise = [torch.randn(B, T, 1, generator=g).to(DEV) for _ in range(5)]
+    for k in range(5):   # eager twin
+        tr_e._train_step(tr_e.ctx.model, theta_eps=teps[k], path_noise=noise[k]); tr_e.ctx.ema.update()
+    # graph twin: static input buffers refilled before every replay
+    s_te, s_no = teps[0].clone(), noise[0].clone()
+    model = tr_g.ctx.model
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tr_g._train_step(model, theta_eps=s_te, path_noise=s_no); tr_g.ctx.ema.update()      # step 0 eagerly (optimizer state, caches)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tr_g._train_step(model, theta_eps=s_te, path_noise=s_no); tr_g.ctx.ema.update()
+    for k in range(1, 5):
+        s_te.copy_(teps[k]); s_no.copy_(noise[k])
+        graph.replay()
+    torch.cuda.synchronize()
+    for (n, a), b_ in zip(tr_e.ctx.model.named_parameters(), tr_g.ctx.model.parameters()):
+        assert torch.isfinite(b_).all(), n
+        assert float((a.detach() - b_.detach()).abs().max()) <= 1e-5 * float(a.detach().abs().max()) + 1e-8, n
+
+
 def test_resume_reproduces_the_run_on_gpu():
     """training_state_dict -> 3 steps -> reload -> the same 3 steps: the same draws and the same trajectory.  The head / ELBO
     / fused-encoder kernels are deterministic (no atomics); the library GEMMs the small encoder still uses may pick
