@@ -298,3 +298,34 @@ def test_ragged_step_counts_with_staggered_chunks(S, L, T):
     for name, a, b_ in zip(G_NAMES, grads, gref):
         if b_.size:
             assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, name
+
+
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("forward_kernel", [4, 8, 16], indirect=True, ids=["mfma4", "mfma8", "mfma16"])
+def test_multi_path_kernels_on_very_short_grids(forward_kernel, T):
+    """One, two and three Euler steps (the kernels prefetch one / two steps ahead, store outputs one step late and walk the reverse sweep
+    two steps per loop trip): forward and all 13 gradients against the float64 oracle, 5 paths = one partly filled group, one emission
+    diagonal below the floor (the clamp and its gradient rule fire)."""
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(40 + T)
+    B, S, C, P, H, L = 5, 2, 16, 3, 64, 2
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    ws = [rn(3 * H, S + C + P, sc=0.2), rn(3 * H, H, sc=0.2), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1), rn(L - 1, 3 * H, H, sc=0.2),
+          rn(L - 1, 3 * H, H, sc=0.2), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1), rn(S + 3, H, sc=0.2),
+          torch.tensor([0.0, 0.0, 0.7, 0.1, 0.005])]      # second diagonal below DIAG_MIN: the clamp and its gradient rule fire
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C), rn(B, P).abs(), rn(B, T, S)
+    gp, gm, gl = rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+    d_ = lambda t: t.to(dev)
+    out = _hip.head_forward(d_(x0), d_(ctx)[:, :-1], d_(theta), d_(eps), [d_(w) for w in ws], 0.05, True)
+    grads = _hip.head_backward(d_(gp), d_(gm), d_(gl), d_(ctx)[:, :-1], d_(theta), d_(eps), out[0], out[3], out[4],
+                               [d_(w) for w in ws], 0.05)
+    w = vo.HeadWeights(*[t.numpy() for t in ws])
+    f = vo.head_forward(x0.numpy(), ctx.numpy()[:, :-1], theta.numpy(), eps.numpy(), w, 0.05, True, np.float64)
+    gref = vo.head_backward(gp.numpy(), gm.numpy(), gl.numpy(), ctx.numpy()[:, :-1], theta.numpy(), eps.numpy(), f, w, 0.05, np.float64)
+    for a, b_, n in zip(out, (f.paths, f.means, f.chol, f.chol_raw, f.acts), ("paths", "means", "chol", "chol_raw", "acts")):
+        assert rel_err(a.cpu().numpy(), b_) < FWD_TOL, n
+    for a, b_, n in zip(grads, gref, G_NAMES):
+        if b_.size:
+            assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, n
