@@ -465,7 +465,7 @@ def measure(workload, batch, args, device, distributed, world):
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, "
-                                       "separate --pmc runs of tools/pmc_head.sh), not measured in this run",
+                                       "separate --pmc runs: tools/pmc.sh vsde::head tools/head_probe.py 3), not measured in this run",
                      "avg_ms": fwd_ms, "algorithmic_bytes": fwd_bytes_step * steps_per_launch,
                      "bytes_per_path_step": fwd_bytes_step, "path_steps_per_launch": steps_per_launch,
                      # the context read is done by the hoisted projection GEMM: the whole forward path priced with the same bytes
