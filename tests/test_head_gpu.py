@@ -329,3 +329,32 @@ def test_multi_path_kernels_on_very_short_grids(forward_kernel, T):
     for a, b_, n in zip(grads, gref, G_NAMES):
         if b_.size:
             assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, n
+
+
+@pytest.mark.parametrize("forward_kernel", [4, 8, 16], indirect=True, ids=["mfma4", "mfma8", "mfma16"])
+def test_a_non_finite_path_does_not_contaminate_its_group(forward_kernel):
+    """The multi-path forward puts 4 / 8 / 16 paths into the columns of one MFMA operand.  A path whose noise turns NaN / inf at some step
+    must turn NaN / inf itself from there on (the emission floor propagates NaN like ``torch.maximum``, reference primitives/bounds.py:10-31)
+    and must not touch the other paths of its group: they reproduce a clean run bit for bit, saved activations included."""
+    from viforsdes_amd import _hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    B, T, S, C, P, H, L = 21, 12, 2, 32, 3, 64, 2
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    ws = [rn(3 * H, S + C + P, sc=0.1), rn(3 * H, H, sc=0.15), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1), rn(L - 1, 3 * H, H, sc=0.15),
+          rn(L - 1, 3 * H, H, sc=0.15), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1), rn(S + 3, H, sc=0.1),
+          torch.tensor([0.0, 0.0, 1.0, 0.0, 1.0]).to(dev)]
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C), rn(B, P).abs(), rn(B, T, S)
+    clean = _hip.head_forward(x0, ctx[:, :-1], theta, eps, ws, 0.1, True)
+    bad = eps.clone()
+    bad[6, 4, 1] = float("nan")          # path 6 from step 4 on
+    bad[13, 7, 0] = float("inf")         # path 13 from step 7 on
+    out = _hip.head_forward(x0, ctx[:, :-1], theta, bad, ws, 0.1, True)
+    torch.cuda.synchronize()
+    others = [i for i in range(B) if i not in (6, 13)]
+    for a, b_ in zip(out, clean):
+        assert torch.equal(a[others], b_[others])
+    # path 6: eps[4, 1] only enters the second state component (L is lower triangular): z_5 = (finite, NaN), everything after is NaN
+    assert torch.equal(out[0][6, :5], clean[0][6, :5]) and torch.isnan(out[0][6, 5, 1]) and torch.isnan(out[0][6, 6:]).all()
+    assert torch.isnan(out[1][6, 5:]).all()              # the NaN state feeds the next step's GRU input: means are NaN from step 5 on
+    assert torch.equal(out[0][13, :8], clean[0][13, :8]) and not torch.isfinite(out[0][13, 8:]).any()
