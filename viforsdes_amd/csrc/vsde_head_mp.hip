@@ -113,6 +113,7 @@ struct MpParams {
     const f16x8 *frags;
     float dt, sqdt, diag_min;
     float *paths, *means, *chol, *chol_raw, *acts;
+    int abl;   // timing-only ablation (VSDE_MP_FWD_ABL; wrong results): 1 = layer 0 does not store its activations, 2 = layer 1 does not, 4 = no output stores
 };
 
 __device__ __forceinline__ f32x4 mp_mfma(const f16x8 &a, const f16x8 &b, const f32x4 &c) {
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // publishes the state -- in the slack where this role waits for the other one, not on the step's critical path
     auto save_acts = [&](const float (&h)[4], const float (&rg)[4], const float (&ug)[4], const float (&ng)[4], const float (&cn)[4],
                          int t, int l) {
-        if (SAVE && live) {
+        if (SAVE && live && !(p.abl & (1 << l))) {
             float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
             *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
             *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
@@ -267,9 +268,9 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 for (int r = 0; r < 4; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
                 gates(ar, au, an, c1, bn1, h1, rg, ug, ng, cn, t, L - 1);
                 barrier();                             // B: h^1_t published
+                save_acts(h1, rg, ug, ng, cn, t, L - 1);   // first thing in the slack: the vector-memory pipe drains them behind the product
                 read_state(t, L - 1, hb);
                 mp_matmul<NP>(wh, hb, c1);             // W_hh^1 h^1_t: consumed by step t + 1
-                save_acts(h1, rg, ug, ng, cn, t, L - 1);
             }
         }
         return;
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // cannot count), and a store issued just before it would put a full store round trip on every step.
     float pz[S], pmu[S], pL[S][S], praw[NTRIL];
     auto store_outputs = [&](int t) {     // paths[b, t + 1], means[b, t], chol[b, t], chol_raw[b, t]: one wave each
-        if (q == 0 && live) {
+        if (q == 0 && live && !(p.abl & 4)) {
             const int64_t bt = (int64_t)b * T + t;
             if (w == 0) {
 #pragma unroll
@@ -862,6 +863,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     p.frags = (const f16x8 *)a.frags;
     p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
     p.paths = a.paths; p.means = a.means; p.chol = a.chol; p.chol_raw = a.chol_raw; p.acts = a.acts;
+    { static int abl = -1; if (abl < 0) { const char *e = getenv("VSDE_MP_FWD_ABL"); abl = e ? atoi(e) : 0; } p.abl = abl; }
     // paths per workgroup: 16 fills the matrix pipe (large batches); a small batch takes 4 or 8 so that its groups spread over more CUs --
     // the time of a launch is T x one step's latency whatever the group size, and ONE CU's vector-memory pipe would have to carry the
     // saved activations of all its paths (41 KB per step for 16 paths: +30 % at 512 paths, profiles/r04_head_mp.txt)
