@@ -349,6 +349,15 @@ struct AttnBwdParams {
     float scale, scale_log2e;
     QkBwd f;                               // FUSED kernels only
     int park_off;                          // FUSED dk/dv: byte offset of the LDS area where first-round tiles wait (0 = no room: direct epilogue)
+    // FUSED, ntile = 13 (N = 401): the ragged 13th block is not a second round of wave 0 -- a lone wave on an otherwise idle CU --
+    // but shared by waves 0..3 (one per SIMD), a quarter of the tile loop each, in front of their own block; the four partial
+    // tiles (valid rows only, fp32, the staged row layout) wait in spare LDS at these byte offsets and are summed in a fixed
+    // order by the wave(s) that finish the block after the workgroup barrier.  0 = off (does not fit / other tile counts).
+    // While a sharing wave works on the ragged block its OWN block's fragments (requested before the staging, like everybody's)
+    // wait in its partial-tile space -- two fragment sets and a tile loop do not fit the register file.
+    int split_dq, split_dkv;
+    int split_pitch_dq, split_pitch_dkv;   // bytes of LDS per sharing wave (>= 8 KB: the kept fragments)
+    int nragged;                           // valid rows of the ragged block
 };
 
 __device__ __forceinline__ f32x16 tile_product(const uint16_t *arow, const bf16x8 (&bfrag)[4]) {
@@ -528,6 +537,52 @@ __device__ __forceinline__ void stage_acc_tile(float *slice, const f32x16 &a0, c
     }
 }
 
+// ... of the lane's own row only if `ok` (a partial tile of the shared ragged block: rows past the sequence are not kept)
+__device__ __forceinline__ void stage_acc_rows(float *tile, const f32x16 &a0, const f32x16 &a1, float mul, int lane, bool ok) {
+    float *row = tile + (lane & 31) * AT_ELD + 4 * (lane >> 5);
+    if (ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4 *)(row + 8 * g) = make_float4(a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul);
+            *(float4 *)(row + 32 + 8 * g) = make_float4(a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul);
+        }
+    }
+}
+
+// two fragment sets of a wave <-> its private LDS space (lane-interleaved 16-byte pieces: conflict-free); the pointer is made
+// opaque in between so that the values are not simply kept in registers
+__device__ __forceinline__ void keep_frags(uint4 *keep, const bf16x8 (&a)[4], const bf16x8 (&b2)[4], int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { keep[ks * 64 + lane] = *(const uint4 *)&a[ks]; keep[(4 + ks) * 64 + lane] = *(const uint4 *)&b2[ks]; }
+}
+__device__ __forceinline__ void restore_frags(const uint4 *keep, bf16x8 (&a)[4], bf16x8 (&b2)[4], int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 x = keep[ks * 64 + lane], y = keep[(4 + ks) * 64 + lane];
+        a[ks] = *(const bf16x8 *)&x; b2[ks] = *(const bf16x8 *)&y;
+    }
+}
+
+// slice [32][AT_ELD] = part[0] + part[1] + part[2] + part[3] (tiles of `rows` rows, `pitch` floats apart; fixed order: deterministic),
+// zero rows past `rows`; lane (row = lane / 8 + 8 pass, c = lane % 8) as in the staged epilogues below
+__device__ __forceinline__ void sum_partial_tiles(float *slice, const float *part, int pitch, int rows, int lane) {
+    const int c = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + (lane >> 3);
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (row < rows) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float4 a = *(const float4 *)(part + w * pitch + row * AT_ELD + 8 * c), b2 = *(const float4 *)(part + w * pitch + row * AT_ELD + 8 * c + 4);
+                lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w; hi.x += b2.x; hi.y += b2.y; hi.z += b2.z; hi.w += b2.w;
+            }
+        }
+        *(float4 *)(slice + row * AT_ELD + 8 * c) = lo;
+        *(float4 *)(slice + row * AT_ELD + 8 * c + 4) = hi;
+    }
+}
+
 __device__ __forceinline__ void unpack8(const uint4 &w, float (&x)[8]) {
     x[0] = bfl(w.x); x[1] = bfh(w.x); x[2] = bfl(w.y); x[3] = bfh(w.y); x[4] = bfl(w.z); x[5] = bfh(w.z); x[6] = bfl(w.w); x[7] = bfh(w.w);
 }
@@ -566,6 +621,25 @@ __device__ __forceinline__ void value_rows_request(const QkBwd &f, ValueRowsIn &
         in.df[pass] = mix ? *(const uint4 *)(f.vdiff + vo) : make_uint4(0u, 0u, 0u, 0u);
         in.ya[pass] = acc ? *(const uint4 *)(f.dv0 + vo) : make_uint4(0u, 0u, 0u, 0u);
     }
+}
+
+// The wave that finishes the shared ragged block asks for that block's rows only after its own epilogue (two row sets do not fit
+// the register file next to an epilogue); before the workgroup barrier -- where it waits for the sharing waves anyway -- it
+// touches one dword of every 64-byte half row so that the later request is served by the cache.
+template <int KIND>
+__device__ __forceinline__ void norm_rows_touch(const QkBwd &f, const uint16_t *yrows, int64_t ts, int64_t m0, int tok0, int N, int hh, int H, int lane) {
+    const int tok = tok0 + (lane & 31), tc = tok < N ? tok : N - 1;
+    const uint32_t a = *(const uint32_t *)(yrows + tc * ts + (lane >> 5) * 32);
+    const float r = f.rinv[(m0 + tc) * (2 * H) + KIND * H + hh];
+    asm volatile("" ::"v"(a), "v"(r));
+}
+__device__ __forceinline__ void value_rows_touch(const QkBwd &f, int64_t m0, int tok0, int N, int hh, int H, int lane) {
+    const int tok = tok0 + (lane & 31);
+    const int64_t vo = (m0 + (tok < N ? tok : N - 1)) * ((int64_t)H * 64) + hh * 64 + (lane >> 5) * 32;
+    const bool mix = f.vdiff != nullptr, acc = mix && f.dv0_accumulate, ext = f.dv_extra != nullptr;
+    const uint32_t a = ext ? *(const uint32_t *)(f.dv_extra + vo) : 0u, b2 = mix ? *(const uint32_t *)(f.vdiff + vo) : 0u;
+    const uint32_t c = acc ? *(const uint32_t *)(f.dv0 + vo) : 0u;
+    asm volatile("" ::"v"(a), "v"(b2), "v"(c));
 }
 
 // slice: gradient of the rotated, normalised rows y^ of the tile's 32 tokens (first token tok0 of batch row block m0 = b N)
@@ -638,6 +712,7 @@ __device__ __forceinline__ float staged_value_bwd(const QkBwd &f, const float *s
         if (ok)
             *(uint4 *)(f.dy + (m0 + tok) * f.ldy + (2 * H + hh) * 64 + 8 * c) =
                 make_uint4(pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3]), pack_bf16(g[4], g[5]), pack_bf16(g[6], g[7]));
+        __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaved, the four passes' unpacked rows need ~100 more registers
     }
     return dl;
 }
@@ -674,7 +749,10 @@ __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2,
 // dq: one workgroup per (batch, head); K and V resident in LDS, a wavefront owns 32 queries at a time.
 // FUSED: delta = <dO, O> is given (the gate backward computes it from the gated output), o is not read, and the result leaves
 // through norm_rope_bwd_store as the q columns of dy.
-template <bool FUSED>
+// ONE (FUSED only): no wave has a second block (ntile <= 12, or the ragged 13th block is shared) and no ablation switch is set:
+// the in-loop epilogue variants are not compiled -- their hoisted addresses would be spilled around the tile loop, and a kernel
+// that uses scratch at all pays for it at every workgroup launch (the dk/dv kernel: 375 -> 442 us with 100 more spilled registers).
+template <bool FUSED, bool ONE = false>
 __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
@@ -694,13 +772,62 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
         lsen = ok ? p.lse[srow + query] : INFINITY;  // padded queries: P = 0
     };
     request(wave);
+    constexpr int NWV = AT_BT / 64;
+    const bool split = FUSED && p.split_dq != 0;          // the ragged block NWV is shared by waves 0..3 (AttnBwdParams)
+    const bool sharer = split && wave < 4;
+    bf16x8 qx[4], dox[4];                                  // ... its fragments, requested with the wave's own before the staging
+    float lsex = INFINITY, delx = 0.f;
+    if constexpr (FUSED) {
+        if (sharer) {
+            const int query = NWV * 32 + fr;
+            const bool ok = query < N;
+            load_bfrag(p.q + base, ts, query, ok, h2, qx);
+            load_bfrag(p.dout + base, ts, query, ok, h2, dox);
+            delx = ok ? p.delta[srow + query] : 0.f;
+            lsex = ok ? p.lse[srow + query] : INFINITY;
+        }
+    }
     stage_two(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
     __syncthreads();
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
     f32x16 acc0, acc1;
+    // acc += (K^T dS^T) over the key tiles [kt0, kt1) for the 32 queries whose fragments are qf / dof
+    auto sweep = [&](const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], float lse2, float dsum, int kt0, int kt1) {
+#pragma unroll 1
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const uint16_t *kt_ = Ks + kt * 32 * AT_KLD, *vt_ = Vs + kt * 32 * AT_KLD;
+            const f32x16 stl = tile_product(kt_ + fr * AT_KLD + h2 * 8, qf);    // S^T  [key][query]
+            const f32x16 dpt = tile_product(vt_ + fr * AT_KLD + h2 * 8, dof);   // dP^T [key][query]
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
+            if (ragged && kt == p.ntile - 1) {  // keys beyond N (zero rows of K: their P is not 0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;
+            }
+            bf16x8 b0, b1;
+            pack_tile(ds, b0, b1);
+            accumulate_transposed(kt_, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
+        }
+    };
+    if constexpr (FUSED) {
+        if (sharer) {   // this wave's quarter of the ragged block's key tiles -> a partial tile in spare LDS
+            char *mine = (char *)asmem + p.split_dq + wave * p.split_pitch_dq;
+            keep_frags((uint4 *)mine, qn, don, lane);
+            asm volatile("" : "+v"(mine));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+            sweep(qx, dox, lsex * 1.4426950408889634f, delx, (p.ntile * wave) >> 2, (p.ntile * (wave + 1)) >> 2);
+            restore_frags((const uint4 *)mine, qn, don, lane);
+            asm volatile("" : "+v"(mine));
+            stage_acc_rows((float *)mine, acc0, acc1, p.scale, lane, NWV * 32 + fr < N);
+        }
+    }
+    const int nblk = split ? NWV : p.ntile;
     int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
-    for (int qblk = wave; qblk < p.ntile; qblk += AT_BT / 64) {
+    for (int qblk = wave; qblk < nblk; qblk += NWV) {
         if (qblk != wave) request(qblk);  // later rounds are rare with 12 waves (N <= 384 needs none): fetch on demand
         const int query = qblk * 32 + fr;
         const bool qok = query < N;
@@ -721,26 +848,11 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
         if constexpr (!FUSED) { if (qok && h2 == 0) p.delta[srow + query] = dsum; }
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-#pragma unroll 1
-        for (int kt = 0; kt < p.ntile; ++kt) {
-            const uint16_t *kt_ = Ks + kt * 32 * AT_KLD, *vt_ = Vs + kt * 32 * AT_KLD;
-            const f32x16 stl = tile_product(kt_ + fr * AT_KLD + h2 * 8, qf);    // S^T  [key][query]
-            const f32x16 dpt = tile_product(vt_ + fr * AT_KLD + h2 * 8, dof);   // dP^T [key][query]
-            float ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2)) * (dpt[r] - dsum);
-            if (ragged && kt == p.ntile - 1) {  // keys beyond N (zero rows of K: their P is not 0)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;
-            }
-            bf16x8 b0, b1;
-            pack_tile(ds, b0, b1);
-            accumulate_transposed(kt_, lane, b0, b1, acc0, acc1);  // dQ^T += K^T dS^T
-        }
+        sweep(qf, dof, lse2, dsum, 0, p.ntile);
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (loop-invariant: hoisted, they spill)
-            if (qblk + AT_BT / 64 >= p.ntile && !(p.f.dbg & 8)) last = qblk;
+            if constexpr (ONE) last = qblk;
+            else if (qblk + NWV >= nblk && !(p.f.dbg & 8)) last = qblk;
             else if (p.f.dbg & 4) { if (qok) store_transposed(p.f.dy + ((int64_t)b * N + query) * p.f.ldy + hh * 64, h2, acc0, acc1, p.scale); }
             else norm_rope_bwd_store<0>(p.f, acc0, acc1, p.scale, qf, (int64_t)b * N + query, query, hh, p.H, lane, qok);
         }
@@ -748,20 +860,29 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
     }
     if constexpr (FUSED) {
         NormRowsIn in;
-        if (p.f.dbg & 64) last = -1;
+        const bool finisher = split && wave == 4;   // sums the ragged block's partial tiles and runs its epilogue (waves 0..3 had the extra tiles)
+        if constexpr (!ONE) { if (p.f.dbg & 64) last = -1; }
         if (last >= 0) norm_rows_request<0>(p.f, in, p.q + base, ts, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        if (finisher) norm_rows_touch<0>(p.f, p.q + base, ts, (int64_t)b * N, NWV * 32, N, hh, p.H, lane);
         __syncthreads();   // every wave is done with K / V: their space becomes the waves' staging slices
+        float *slice = (float *)asmem + wave * AT_ESLICE;
         if (last >= 0) {
-            float *slice = (float *)asmem + wave * AT_ESLICE;
             stage_acc_tile(slice, acc0, acc1, p.scale, lane);
             wave_lds_fence();
             staged_norm_rope_bwd<0>(p.f, slice, in, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        }
+        if (finisher) {
+            norm_rows_request<0>(p.f, in, p.q + base, ts, (int64_t)b * N, NWV * 32, N, hh, p.H, lane);
+            wave_lds_fence();
+            sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dq), p.split_pitch_dq / 4, p.nragged, lane);
+            wave_lds_fence();
+            staged_norm_rope_bwd<0>(p.f, slice, in, (int64_t)b * N, NWV * 32, N, hh, p.H, lane);
         }
     }
 }
 
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
-template <bool FUSED>
+template <bool FUSED, bool ONE = false>
 __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
@@ -778,6 +899,17 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         load_bfrag(p.v + base, ts, key, ok, h2, vn);
     };
     request(wave);
+    constexpr int NWV = AT_BT / 64;
+    const bool split = FUSED && p.split_dkv != 0;         // the ragged block NWV is shared by waves 0..3 (AttnBwdParams)
+    const bool sharer = split && wave < 4;
+    bf16x8 kx[4], vx[4];                                   // ... its fragments, requested with the wave's own before the staging
+    if constexpr (FUSED) {
+        if (sharer) {
+            const int key = NWV * 32 + fr;
+            load_bfrag(p.k + base, ts, key, key < N, h2, kx);
+            load_bfrag(p.v + base, ts, key, key < N, h2, vx);
+        }
+    }
     stage_two(p.q + base, p.dout + base, ts, N, npad, tid, Qs, Os);
     for (int i = tid; i < npad; i += AT_BT) {  // padded queries: lse = +inf -> P = 0
         lse2s[i] = i < N ? p.lse[srow + i] * 1.4426950408889634f : INFINITY;
@@ -786,19 +918,10 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
     __syncthreads();
     const float c2 = p.scale_log2e;
     f32x16 dk0, dk1, dv0, dv1;
-    int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
-    int parked = -1; // FUSED: the wave's first round when a second one follows and spare LDS can hold its tiles
-    for (int kblk = wave; kblk < p.ntile; kblk += AT_BT / 64) {
-        if (kblk != wave) request(kblk);
-        const int key = kblk * 32 + fr;
-        const bool kok = key < N;
-        bf16x8 kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dk0[e] = 0.f; dk1[e] = 0.f; dv0[e] = 0.f; dv1[e] = 0.f; }
+    // dV^T += dO^T P, dK^T += Q^T dS over the query tiles [qt0, qt1) for the 32 keys whose fragments are kf / vf
+    auto sweep = [&](const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int qt0, int qt1) {
 #pragma unroll 1
-        for (int qt = 0; qt < p.ntile; ++qt) {
+        for (int qt = qt0; qt < qt1; ++qt) {
             const uint16_t *qt_ = Qs + qt * 32 * AT_KLD, *dot_ = Os + qt * 32 * AT_KLD;
             const f32x16 sc = tile_product(qt_ + fr * AT_KLD + h2 * 8, kf);     // S  [query][key]
             const f32x16 dp = tile_product(dot_ + fr * AT_KLD + h2 * 8, vf);    // dP [query][key]
@@ -821,9 +944,39 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
             accumulate_transposed(dot_, lane, p0, p1, dv0, dv1);  // dV^T += dO^T P
             accumulate_transposed(qt_, lane, s0, s1, dk0, dk1);   // dK^T += Q^T dS
         }
+    };
+    if constexpr (FUSED) {
+        if (sharer) {   // this wave's quarter of the ragged block's query tiles -> partial dV / dK tiles in spare LDS
+            char *mine = (char *)asmem + p.split_dkv + wave * p.split_pitch_dkv;
+            keep_frags((uint4 *)mine, kn, vn, lane);
+            asm volatile("" : "+v"(mine));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dk0[e] = 0.f; dk1[e] = 0.f; dv0[e] = 0.f; dv1[e] = 0.f; }
+            sweep(kx, vx, (p.ntile * wave) >> 2, (p.ntile * (wave + 1)) >> 2);
+            restore_frags((const uint4 *)mine, kn, vn, lane);
+            asm volatile("" : "+v"(mine));
+            const bool ok = NWV * 32 + fr < N;
+            stage_acc_rows((float *)mine, dv0, dv1, 1.0f, lane, ok);
+            stage_acc_rows((float *)mine + p.nragged * AT_ELD, dk0, dk1, p.scale, lane, ok);
+        }
+    }
+    const int nblk = split ? NWV : p.ntile;
+    int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
+    int parked = -1; // FUSED: the wave's first round when a second one follows and spare LDS can hold its tiles
+    for (int kblk = wave; kblk < nblk; kblk += NWV) {
+        if (kblk != wave) request(kblk);
+        const int key = kblk * 32 + fr;
+        const bool kok = key < N;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk0[e] = 0.f; dk1[e] = 0.f; dv0[e] = 0.f; dv1[e] = 0.f; }
+        sweep(kf, vf, 0, p.ntile);
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
-            if (kblk + AT_BT / 64 >= p.ntile && !(p.f.dbg & 8)) { last = kblk; continue; }
+            if constexpr (ONE) { last = kblk; continue; }
+            if (kblk + NWV >= nblk && !(p.f.dbg & 8)) { last = kblk; continue; }
             if (p.park_off != 0 && kblk < AT_BT / 64 && !(p.f.dbg & 8)) {
                 // a wave with one more round to go (the 13th block at N = 401): its epilogue would sit between its two rounds,
                 // i.e. on the workgroup's critical path with nothing to hide its loads.  The tile waits in spare LDS instead
@@ -850,39 +1003,68 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         }
     }
     if constexpr (FUSED) {
+        // opaque copies of the lane coordinates: the epilogue's addresses are then computed HERE -- hoisted above the tile loops
+        // they would be spilled around them (and a kernel that uses scratch at all pays for it at every workgroup launch)
+        int lane_e = lane, wave_e = wave;
+        asm volatile("" : "+v"(lane_e), "+v"(wave_e));
         const int64_t m0 = (int64_t)b * N;
         NormRowsIn kin; ValueRowsIn vin;
-        if (p.f.dbg & 64) last = -1;
+        if constexpr (!ONE) { if (p.f.dbg & 64) last = -1; }
         if (last >= 0) {
-            value_rows_request(p.f, vin, m0, last * 32, N, hh, p.H, lane);
-            norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane);
+            value_rows_request(p.f, vin, m0, last * 32, N, hh, p.H, lane_e);
+            // the key rows are only touched here (cache) and requested once the value epilogue has freed its registers: four
+            // accumulator tiles + both row sets + an epilogue's temporaries do not fit the register file
+            if constexpr (ONE) norm_rows_touch<1>(p.f, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
+            else norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
         }
+        // the ragged block is finished by two waves that had no extra tiles: wave 4 its values, wave 5 its keys
+        if (split && wave_e == 4) value_rows_touch(p.f, m0, NWV * 32, N, hh, p.H, lane_e);
+        if (split && wave_e == 5) norm_rows_touch<1>(p.f, p.k + base, ts, m0, NWV * 32, N, hh, p.H, lane_e);
         __syncthreads();   // every wave is done with Q / dO / lse / delta: their space becomes the waves' staging slices
         if (last >= 0) {
-            float *slice = (float *)asmem + wave * AT_ESLICE;
-            stage_acc_tile(slice, dv0, dv1, 1.0f, lane);
-            wave_lds_fence();
-            float dl = (p.f.dbg & 32) ? 0.f : staged_value_bwd(p.f, slice, vin, m0, last * 32, N, hh, p.H, lane);
-            if (p.f.dlam_partial != nullptr) {
-                dl = wave_sum(dl);
-                if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + last] = dl;
+            float *slice = (float *)asmem + wave_e * AT_ESLICE;
+            // values: the own tile, then (wave 4 of a sharing workgroup) the ragged block's summed partial tiles -- one loop, so
+            // that the value epilogue exists once (a second inlined copy costs ~150 spilled registers)
+            const int vreps = (split && wave_e == 4) ? 2 : 1;
+            stage_acc_tile(slice, dv0, dv1, 1.0f, lane_e);
+#pragma unroll 1
+            for (int rep = 0; rep < vreps; ++rep) {
+                const int blk = rep == 0 ? last : NWV;
+                if (rep != 0) {
+                    value_rows_request(p.f, vin, m0, blk * 32, N, hh, p.H, lane_e);
+                    sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dkv), p.split_pitch_dkv / 4, p.nragged, lane_e);
+                }
+                wave_lds_fence();
+                float dl = (!ONE && (p.f.dbg & 32)) ? 0.f : staged_value_bwd(p.f, slice, vin, m0, blk * 32, N, hh, p.H, lane_e);
+                if (p.f.dlam_partial != nullptr) {
+                    dl = wave_sum(dl);
+                    if (lane_e == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + blk] = dl;
+                }
+                wave_lds_fence();
             }
+            stage_acc_tile(slice, dk0, dk1, p.scale, lane_e);
+            if constexpr (ONE) norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
             wave_lds_fence();
-            stage_acc_tile(slice, dk0, dk1, p.scale, lane);
-            wave_lds_fence();
-            if (!(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane);
+            if (ONE || !(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane_e);
+            if (split && wave_e == 5) {   // keys of the ragged block
+                norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, NWV * 32, N, hh, p.H, lane_e);
+                wave_lds_fence();
+                sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dkv) + p.nragged * AT_ELD, p.split_pitch_dkv / 4, p.nragged, lane_e);
+                wave_lds_fence();
+                staged_norm_rope_bwd<1>(p.f, slice, kin, m0, NWV * 32, N, hh, p.H, lane_e);
+            }
         }
-        if (parked >= 0) {   // wave-uniform; the parked tiles were written by this wave: in-order LDS, no barrier needed
-            const float *park = (const float *)((char *)asmem + p.park_off) + wave * (2 * AT_ESLICE);
-            value_rows_request(p.f, vin, m0, parked * 32, N, hh, p.H, lane);
-            norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, parked * 32, N, hh, p.H, lane);
+        if (!ONE && parked >= 0) {   // wave-uniform; the parked tiles were written by this wave: in-order LDS, no barrier needed
+            const float *park = (const float *)((char *)asmem + p.park_off) + wave_e * (2 * AT_ESLICE);
+            value_rows_request(p.f, vin, m0, parked * 32, N, hh, p.H, lane_e);
+            norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, parked * 32, N, hh, p.H, lane_e);
             wave_lds_fence();
-            float dl = staged_value_bwd(p.f, park, vin, m0, parked * 32, N, hh, p.H, lane);
+            float dl = staged_value_bwd(p.f, park, vin, m0, parked * 32, N, hh, p.H, lane_e);
             if (p.f.dlam_partial != nullptr) {
                 dl = wave_sum(dl);
-                if (lane == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + parked] = dl;
+                if (lane_e == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + parked] = dl;
             }
-            staged_norm_rope_bwd<1>(p.f, park + AT_ESLICE, kin, m0, parked * 32, N, hh, p.H, lane);
+            staged_norm_rope_bwd<1>(p.f, park + AT_ESLICE, kin, m0, parked * 32, N, hh, p.H, lane_e);
         }
     }
 }
@@ -1089,11 +1271,38 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
         const size_t park = (size_t)two_round * 2 * AT_ESLICE * sizeof(float);
         if (two_round > 0 && p.ntile <= 2 * waves && lds_dkv + park <= 160 * 1024) { p.park_off = (int)lds_dkv; lds_dkv += park; }
     }
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+    {   // exactly one block more than waves (N = 385 .. 416): share it among four waves instead of a lone second round, if the
+        // partial tiles fit behind the operands (VSDE_ATTN_SPLIT=0: the second round as before)
+        static int on = -1;
+        if (on < 0) { const char *e = getenv("VSDE_ATTN_SPLIT"); on = e ? atoi(e) : 1; }
+        const int waves = AT_BT / 64;
+        if (on && p.f.dbg == 0 && p.ntile == waves + 1) {
+            p.nragged = N - waves * 32;
+            const size_t tile = (size_t)p.nragged * AT_ELD * sizeof(float), keep = 8 * 64 * 16;   // a partial tile; two kept fragment sets
+            const size_t pitch_dq = tile > keep ? tile : keep, pitch_dkv = 2 * tile > keep ? 2 * tile : keep;
+            if (lds_dq + 4 * pitch_dq <= 160 * 1024) { p.split_dq = (int)lds_dq; p.split_pitch_dq = (int)pitch_dq; lds_dq += 4 * pitch_dq; }
+            const size_t operands = lds_dkv - (p.park_off ? (size_t)2 * AT_ESLICE * sizeof(float) : 0);
+            if (operands + 4 * pitch_dkv <= 160 * 1024) {
+                p.split_dkv = (int)operands; p.split_pitch_dkv = (int)pitch_dkv; p.park_off = 0; lds_dkv = operands + 4 * pitch_dkv;
+            }
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
+    const int nwv = AT_BT / 64;
+    if (p.f.dbg == 0 && (p.ntile <= nwv || p.split_dq != 0)) {   // one block per wave: the lean instantiation
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
+    }
+    if (p.f.dbg == 0 && (p.ntile <= nwv || p.split_dkv != 0)) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
+    }
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
