@@ -12,11 +12,13 @@ for m in re.finditer(r"^(_Z\w*" + re.escape(pat) + r"\w*):", s, re.M):
     name = m.group(1)
     body = s[m.end():s.index(".Lfunc_end", m.end())].split("\n")
     print(name, len(body), "lines")
-    blk, stats, order = "entry", {}, []
+    blk, stats, order, depth = "entry", {}, [], {}
     for ln in body:
-        lm = re.match(r"^(\.LBB\d+_\d+):", ln)
+        lm = re.match(r"^(\.LBB\d+_\d+):(.*)", ln)
         if lm:
             blk = lm.group(1)
+            dm = re.search(r"Depth=(\d+)", lm.group(2))
+            depth[blk] = int(dm.group(1)) if dm else 0
         if blk not in stats:
             stats[blk] = [0, 0, 0, 0]; order.append(blk)
         st = stats[blk]
@@ -24,4 +26,4 @@ for m in re.finditer(r"^(_Z\w*" + re.escape(pat) + r"\w*):", s, re.M):
     for b in order:
         st = stats[b]
         if st[0] or st[1] or st[2]:
-            print(f"  {b:12s} lines {st[3]:5d} mfma {st[2]:3d} scratch_store {st[0]:3d} scratch_load {st[1]:3d}")
+            print(f"  {b:12s} loop depth {depth.get(b, 0)} lines {st[3]:5d} mfma {st[2]:3d} scratch_store {st[0]:3d} scratch_load {st[1]:3d}")

@@ -1035,23 +1035,27 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
                     sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dkv), p.split_pitch_dkv / 4, p.nragged, lane_e);
                 }
                 wave_lds_fence();
-                float dl = (!ONE && (p.f.dbg & 32)) ? 0.f : staged_value_bwd(p.f, slice, vin, m0, blk * 32, N, hh, p.H, lane_e);
+                int lane_v = lane_e;   // opaque: the store addresses are recomputed here, not kept (spilled) from the request above
+                asm volatile("" : "+v"(lane_v));
+                float dl = (!ONE && (p.f.dbg & 32)) ? 0.f : staged_value_bwd(p.f, slice, vin, m0, blk * 32, N, hh, p.H, lane_v);
                 if (p.f.dlam_partial != nullptr) {
                     dl = wave_sum(dl);
                     if (lane_e == 0) p.f.dlam_partial[(int64_t)blockIdx.x * p.ntile + blk] = dl;
                 }
                 wave_lds_fence();
             }
-            stage_acc_tile(slice, dk0, dk1, p.scale, lane_e);
-            if constexpr (ONE) norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
+            int lane_k = lane_e;   // opaque: the key epilogue's addresses are computed after the value loop, not spilled around it
+            asm volatile("" : "+v"(lane_k));
+            stage_acc_tile(slice, dk0, dk1, p.scale, lane_k);
+            if constexpr (ONE) norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_k);
             wave_lds_fence();
-            if (ONE || !(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane_e);
+            if (ONE || !(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane_k);
             if (split && wave_e == 5) {   // keys of the ragged block
-                norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, NWV * 32, N, hh, p.H, lane_e);
+                norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, NWV * 32, N, hh, p.H, lane_k);
                 wave_lds_fence();
-                sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dkv) + p.nragged * AT_ELD, p.split_pitch_dkv / 4, p.nragged, lane_e);
+                sum_partial_tiles(slice, (const float *)((const char *)asmem + p.split_dkv) + p.nragged * AT_ELD, p.split_pitch_dkv / 4, p.nragged, lane_k);
                 wave_lds_fence();
-                staged_norm_rope_bwd<1>(p.f, slice, kin, m0, NWV * 32, N, hh, p.H, lane_e);
+                staged_norm_rope_bwd<1>(p.f, slice, kin, m0, NWV * 32, N, hh, p.H, lane_k);
             }
         }
         if (!ONE && parked >= 0) {   // wave-uniform; the parked tiles were written by this wave: in-order LDS, no barrier needed
