@@ -152,3 +152,21 @@ def test_packed_operands_follow_a_fused_optimizer_step():
     PackedWeight.refresh_all(force=True)       # what the trainer does: one pass over every live pack
     assert not pack.stale()
     assert torch.equal(pack.transposed(), w.detach().to(torch.bfloat16).t()) and tr is pack.transposed()
+
+
+def test_forced_refresh_is_scoped_to_the_callers_parameters():
+    """A trainer's forced refresh (and a HIP graph captured from its step, which replays with raw addresses) must only touch
+    the packs built from ITS parameters: the registry of live packs is process-wide, and a pack of another model that happens
+    to be alive may be freed later.  Packs outside the scope stay covered by their own staleness check."""
+    from viforsdes_amd.primitives.fused import PackedWeight, plain_pack
+    torch.manual_seed(1)
+    wa, wb_ = torch.nn.Parameter(torch.randn(16, 8)), torch.nn.Parameter(torch.randn(16, 8))
+    pa, pb = plain_pack(wa, None), plain_pack(wb_, None)
+    a0, b0 = pa.operands()[0].clone(), pb.operands()[0].clone()
+    wa.data.add_(1.0); wb_.data.add_(1.0)      # in place through .data: no version bump, no optimizer hook -- only `force` sees it
+    assert not pa.stale() and not pb.stale()
+    PackedWeight.refresh_all(force=True, params={id(wa)})
+    assert torch.equal(pa.weight, wa.detach().to(torch.bfloat16)) and not torch.equal(pa.weight, a0)
+    assert torch.equal(pb.weight, b0), "a pack outside the caller's parameters was rewritten"
+    PackedWeight.refresh_all(force=True)       # unscoped: every live pack
+    assert torch.equal(pb.weight, wb_.detach().to(torch.bfloat16))

@@ -80,6 +80,14 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // sum over the 64 lanes; result valid in every lane
+// v(lane) + v(lane ^ 32) without the lane index (__shfl_xor builds its ds_bpermute address from v_mbcnt; hoisted out of a loop that
+// uses every VGPR that index is spilled and reloaded per trip): v_permlane32_swap of two copies gives [lo, lo] and [hi, hi]
+__device__ __forceinline__ float sum_xor32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -1034,6 +1034,10 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     auto chunk_t0 = [&](int c) { return max(0, c * CH - phase); };
     auto chunk_n = [&](int c) { return min(T, (c + 1) * CH - phase) - max(0, c * CH - phase); };
     const int ABUF = (CH + 1) * REC;  // floats of one activation buffer
+    // the per-chunk loads below address global memory with tid_c / lane_c, opaque copies renewed once per chunk: their per-thread
+    // base addresses are loop-invariant, and hoisted out of the chunk loop (all 256 VGPRs are in use) they are spilled and every
+    // reload is followed by a full vmcnt(0) drain
+    int tid_c = tid, lane_c = lane;
     // activation records t0-1 .. t0+n-1 (record -1 of the path is all zero)
     auto load_acts_sync = [&](int t0, int n, float *dst) {
         const int nrec = (n + 1) * REC;
@@ -1048,8 +1052,8 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
         const int nbytes = ((n + 1) * REC - skip) * 4;
 #pragma unroll 1
         for (int off = wave * 1024; off < nbytes; off += 4096) {  // one instruction: 64 lanes x 16 B -> 1 KB of LDS
-            if (off + lane * 16 < nbytes)
-                __builtin_amdgcn_global_load_lds((const void *)(src + off + lane * 16),
+            if (off + lane_c * 16 < nbytes)
+                __builtin_amdgcn_global_load_lds((const void *)(src + off + lane_c * 16),
                                                  (__attribute__((address_space(3))) void *)((char *)(dst + skip) + off), 16, 0, 0);
         }
     };
@@ -1062,7 +1066,7 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     auto small_issue = [&](int t0, int n) {
 #pragma unroll
         for (int q = 0; q < NSV; ++q) {
-            const int e = tid + 256 * q;
+            const int e = tid_c + 256 * q;
             float v = 0.f;
             if (e < n * small_per_step) {
                 int r = e;
@@ -1102,6 +1106,7 @@ __global__ void __launch_bounds__(256, 2) head_bwd_v2_kernel(BwdParams p) {
     for (int c = nchunks - 1; c >= 0; --c) {
         const int t0 = chunk_t0(c), nsteps = chunk_n(c);
         const int tprev = c > 0 ? chunk_t0(c - 1) : 0, nprev = c > 0 ? chunk_n(c - 1) : 0;
+        asm volatile("" : "+v"(tid_c), "+v"(lane_c));
         if (c > 0) {  // the next (earlier) chunk: its loads fly during this chunk's time steps
             if (DMA) load_acts_dma(tprev, nprev, acts_buf0 + ((c - 1) & 1) * ABUF);
             small_issue(tprev, nprev);

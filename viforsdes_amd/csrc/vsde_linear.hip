@@ -174,7 +174,7 @@ __device__ __forceinline__ void qknorm_head(const LinParams &p, uint16_t *stage,
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) ss = fmaf(xl[e], xl[e], fmaf(xh[e], xh[e], ss));
-        ss += __shfl_xor(ss, 32, 64);
+        ss = sum_xor32(ss);
         const float rq = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
         if (p.Rinv != nullptr && h == 0 && row0 + r < p.M) p.Rinv[(row0 + r) * (2 * p.heads) + kind * p.heads + hh] = rq;
         const float *w = wlds + 64 * kind;   // [wq | wk] staged in LDS by the kernel prologue
@@ -272,7 +272,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 }
                 *(u32x4 *)(px + (part >> 1) * 32 + (part & 1) * 8) = o4;
             }
-            dsum += __shfl_xor(dsum, 32, 64);
+            dsum = sum_xor32(dsum);
             if (h == 0 && row0 + r < p.M) {
                 const int64_t bb = (row0 + r) / p.tokens, nn = (row0 + r) - bb * p.tokens;
                 p.Delta[(bb * p.heads + hh) * p.tokens + nn] = dsum;
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinP
     do {                                                                                                      \
         const int tile_ = tile0 + ((q_) / NKH + rot) % ntiles;                                                \
         wtile_load<NLD, KC, THREADS>(breg, p.W + (int64_t)tile_ * 32 * KT + ((q_) % NKH) * KC, KT, tid);      \
-        if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * tid) : 0u;             \
+        if (tid < 16) biasreg = p.bias ? *(const uint32_t *)(p.bias + tile_ * 32 + 2 * (lane_t & 15)) : 0u;   \
     } while (0)
 #define VSDE_TILE_STORE(Bs_)                                                                                  \
     do {                                                                                                      \
@@ -534,8 +534,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinP
         if constexpr (EPI == EPI_QKNORM) {   /* residual values of a v head: requested when its tile pair begins */ \
             const int tl_ = tile0 + ((t_) + rot) % ntiles, pp_ = tl_ >> 1, kind_ = pp_ / p.heads;              \
             if (p.V0 != nullptr && (tl_ & 1) == 0 && kind_ == 2) {                                            \
-                const int64_t m_ = row0 + r < p.M ? row0 + r : p.M - 1;                                       \
-                const uint16_t *v_ = p.V0 + m_ * ((int64_t)p.heads * 64) + (pp_ - 2 * p.heads) * 64 + 16 * h; \
+                const int64_t m_ = row0 + (lane_t & 31) < p.M ? row0 + (lane_t & 31) : p.M - 1;               \
+                const uint16_t *v_ = p.V0 + m_ * ((int64_t)p.heads * 64) + (pp_ - 2 * p.heads) * 64 + 16 * (lane_t >> 5); \
                 ureg[0] = *(const u32x4 *)v_; ureg[1] = *(const u32x4 *)(v_ + 8);                             \
                 ureg[2] = *(const u32x4 *)(v_ + 32); ureg[3] = *(const u32x4 *)(v_ + 40);                     \
             }                                                                                                 \
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinP
             const int tl_ = tile0 + ((t_) + rot) % ntiles;                                                    \
             if ((tl_ & 1) == 0) {                                                                             \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-                    const int row = (lane >> 3) + 8 * i, c = lane & 7;                                        \
+                    const int row = (lane_t >> 3) + 8 * i, c = lane_t & 7;                                    \
                     const int64_t m_ = row0 + row < p.M ? row0 + row : p.M - 1;                               \
                     ureg[i] = *(const u32x4 *)(p.Og + m_ * (int64_t)p.N + (tl_ >> 1) * 64 + c * 8);           \
                 }                                                                                             \
@@ -565,15 +565,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) lin_rows_kernel(LinP
     do {                                                                                                      \
         constexpr int q_par = (NKH * (TPAR_) + (KH_)) & 1;                                                    \
         const int q_ = NKH * (t_) + (KH_);                                                                    \
+        if constexpr (EPI == EPI_QKNORM || EPI == EPI_GATE_BWD) asm volatile("" : "+v"(lane_t));              \
         const uint16_t *Bs = lsm + q_par * TILE;                                                              \
         rows_tile_mfma<KC, RB, KS, (KH_) * (KC / 16), (KH_) == 0>(acc, afr, Bs + r * LDB + 8 * h);            \
         if constexpr ((KH_) == NKH - 1)                                                                       \
-            rows_epilogue<EPI, TPAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane, cs, sn, wlds, (t_) + 1 == ntiles); \
+            rows_epilogue<EPI, TPAR_, RB>(p, acc, Bs + 32 * LDB, stage, ureg, row0, (tile0 + ((t_) + rot) % ntiles) * 32, lane_t, cs, sn, wlds, (t_) + 1 == ntiles); \
         if (q_ + 1 < NKH * ntiles) VSDE_TILE_STORE(lsm + (1 - q_par) * TILE);                                 \
         lds_barrier();                                                                                        \
         if (q_ + 2 < NKH * ntiles) VSDE_TILE_LOAD(q_ + 2);                                                    \
         if constexpr ((KH_) == NKH - 1) { if ((t_) + 1 < ntiles) VSDE_U_LOAD((t_) + 1); }                     \
     } while (0)
+    // The fused epilogues' global addresses (rows of V0 / og / rinv / the outputs) are loop-invariant per lane: hoisted out of the
+    // tile loop they are spilled (256 VGPRs are in use), and every reload of a spilled address is followed by a full vmcnt(0) drain of
+    // the weight-tile loads in flight.  An opaque copy of the lane index per tile makes them cheap recomputations instead.
+    int lane_t = lane;
     VSDE_TILE_LOAD(0);
     VSDE_U_LOAD(0);
     VSDE_TILE_STORE(lsm);

@@ -7,6 +7,8 @@ not change results: the ELBO scalars stay on the device and are copied to the ho
 actually averaged across ranks (see data_parallel.py)."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import TYPE_CHECKING, Callable, Optional
 
@@ -121,7 +123,10 @@ class VariationalInferenceTrainer:
             # bf16 GEMM operands of the encoder follow the updated parameters: ONE kernel over all packs now, instead of a
             # staleness check + copies per pack inside the next forward (the check alone is sufficient since round 4: the
             # optimizer step advances fused._param_epoch and the parameters' version counters)
-            fused.PackedWeight.refresh_all(force=True)
+            ids = getattr(self, "_param_ids", None)
+            if ids is None:
+                ids = self._param_ids = {id(q) for q in ctx.model.parameters()}
+            fused.PackedWeight.refresh_all(force=True, params=ids)
         return grad_norm.detach()
 
     def _train_step(self, model: VariationalSDEPosterior, theta_eps: Optional[Tensor] = None,
@@ -180,6 +185,9 @@ class VariationalInferenceTrainer:
                 static = TrainStepResult(elbo_result=elbo, grad_norm=gnorm)
                 graphs = (g_fb, g_opt)
         except Exception as err:  # capture is an optimisation, never a requirement
+            if os.environ.get("VSDE_DEBUG_CAPTURE"):   # where it failed (the console only shows the message)
+                import traceback
+                traceback.print_exc()
             torch.cuda.synchronize(ctx.device)
             self.console.config_panel(f"HIP graph capture unavailable ({type(err).__name__}: {err}); running eagerly")
             return None

@@ -547,13 +547,19 @@ class PackedWeight:
 
     @staticmethod
     @torch.no_grad()
-    def refresh_all(force: bool = False) -> None:
+    def refresh_all(force: bool = False, params: Optional[set] = None) -> None:
         """Re-fill every live pack whose sources changed.  ``force``: re-fill all of them regardless of the version counters --
         what the trainer does right after the optimizer step: the fused (multi-tensor) AdamW kernel updates the parameters
         WITHOUT bumping ``Tensor._version``, so a version check alone would keep the first step's operands forever.
+        ``params`` (ids of parameters): only the packs built from these -- a trainer passes its own model's, so that its step
+        (and a HIP graph captured from it, which replays with raw addresses) never touches the packs of another model that
+        happens to be alive; those stay covered by their staleness check.
         On the GPU a forced refresh is ONE kernel over a cached table of tiles (fp32 parameters -> bf16 packs and their
-        transposes, csrc/vsde_pack.hip); otherwise one multi-tensor copy."""
+        transposes, csrc/vsde_pack.hip); otherwise one multi-tensor copy.  The table is built (a host -> device copy) on first
+        use; during a stream capture, where that copy is illegal, a missing table means the multi-tensor copy is captured instead."""
         live = sorted(PackedWeight._live, key=id)
+        if params is not None:
+            live = [pk for pk in live if any(id(q) in params for q in pk.params)]
         if force and live and all(pk.weight.is_cuda for pk in live):
             by_dev: dict = {}
             for pk in live:
@@ -563,6 +569,9 @@ class PackedWeight:
                 key = (dev, tuple((id(pk), pk.weight.data_ptr(), 0 if pk.weight_t is None else pk.weight_t.data_ptr(),
                                    tuple(q.data_ptr() for q in pk.params)) for pk in packs))
                 table = PackedWeight._tables.get(key)
+                if table is None and torch.cuda.is_current_stream_capturing():
+                    ok = False
+                    break
                 if table is None:
                     rows = []
                     for pk in packs:
