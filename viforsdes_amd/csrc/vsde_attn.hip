@@ -100,11 +100,15 @@ __device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vre
             const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
             ss = fmaf(lo, lo, fmaf(hi, hi, ss));
         }
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        ss += xor_lane<1>(ss); ss += xor_lane<2>(ss); ss += xor_lane<4>(ss);
         kss_max = fmaxf(kss_max, ss);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) kss_max = fmaxf(kss_max, __shfl_xor(kss_max, off, 64));
+    kss_max = fmaxf(kss_max, xor_lane<8>(kss_max)); kss_max = fmaxf(kss_max, xor_lane<16>(kss_max));   // (8 adjacent lanes already agree)
+    {   // lanes l and l ^ 32 without a lane index (a __shfl_xor's index registers, set up once, are spilled across the tile loop)
+        const uint32_t u = __float_as_uint(kss_max);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        kss_max = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     if (lane == 0) kred[wave] = kss_max;
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
@@ -141,14 +145,27 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
     // only inside VSDE_FWD_STAGE (a loop-carried register set is spilled across the tile loop by hipcc)
     constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (AT_MAXN * 8 + NT - 1) / NT, VIT = PERSIST ? 1 : (AT_MAXN + NT - 1) / NT;
     __shared__ float kred[NW];
+    // the wave's first query block of a pair: one dword of each of its 64-byte half rows is touched together with the pair's K / V
+    // requests, so that the fragment loads after the barrier are served by the cache (the fragments themselves, requested here,
+    // are spilled: 16 more registers do not fit beside the staging's)
+    uint32_t qtouch = 0u;
+    auto touch_q = [&](int64_t head_) {
+        int ln = tid & 63;
+        asm volatile("" : "+v"(ln));
+        const int pq = wave * 32 + (ln & 31);
+        const int64_t hb = head_ / p.H, base_ = (hb * N * p.H + (head_ - hb * p.H)) * AT_D;
+        qtouch = *(const uint32_t *)(p.q + base_ + (pq < N ? pq : N - 1) * ts + (ln >> 5) * 32);
+    };
 #define VSDE_FWD_STAGE(head_, first_)                                                                          \
     do {                                                                                                       \
         uint4 kreg[KIT], vreg[VIT][8];                                                                         \
         asm volatile("" : "+v"(pt));   /* staging addresses are recomputed per pair, not kept across the tile loop */ \
+        touch_q(head_);                                                                                        \
         fwd_request<KIT, VIT>(kreg, vreg, p, (head_), pt, PT, stager, N, npad, ts);                            \
         if (!(first_)) __syncthreads();   /* everyone is done with the previous pair's K / V */               \
         fwd_commit<KIT, VIT>(kreg, vreg, Ks, Vt, kred, pt, PT, stager, npad, vld, lane, wave);                 \
         __syncthreads();                                                                                       \
+        asm volatile("" ::"v"(qtouch));                                                                        \
     } while (0)
     const int64_t nheads = p.pairs;              // total (batch, head) pairs
     int64_t head = blockIdx.x;
@@ -191,7 +208,7 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
                 qss = fmaf(lo, lo, fmaf(hi, hi, qss));
             }
         }
-        qss += __shfl_xor(qss, 32, 64);
+        qss = sum_xor32(qss);
         // shift of the softmax: |q| max|k| >= every score of this query (x 1.0001 against rounding of the norms)
         float mx = sqrtf(qss) * kmax * 1.0001f;
         const bool exact = !__all(mx * p.scale_log2e <= 40.0f);  // wave-uniform
@@ -210,7 +227,11 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         }
-        if (exact) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other half-wave holds the other 16 keys of every tile
+        if (exact) {
+            const uint32_t u = __float_as_uint(mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }  // the other half-wave holds the other 16 keys of every tile
         // ---- pass 2: P^T = exp2(c (S^T - max)), O^T += V^T P^T -------------------------------------------
         const float c2 = p.scale_log2e, mc = mx * c2;
         float lsum = 0.f, lsum2 = 0.f;
@@ -273,7 +294,7 @@ __global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
             if (kt + 1 < nkt) step(sb, sa, kt + 1);
         }
         lsum += lsum2;
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = sum_xor32(lsum);
         if (qok) {
             const float inv = 1.0f / lsum;
             uint16_t *orow = p.o + base + query * ts;
@@ -450,7 +471,7 @@ __device__ __forceinline__ void norm_rope_bwd_store(const QkBwd &f, const f32x16
     float c = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c = fmaf(a0[r], yl[r], fmaf(a1[r], yh[r], c));
-    c += __shfl_xor(c, 32, 64);
+    c = sum_xor32(c);
     c *= mul * (1.0f / 64.0f);
     if (!ok) return;
     const float rr = f.rinv[m * (2 * H) + KIND * H + hh];
@@ -666,7 +687,7 @@ __device__ __forceinline__ void staged_norm_rope_bwd(const QkBwd &f, const float
         float cc = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) cc = fmaf(g[j], y[j], cc);
-        cc += __shfl_xor(cc, 1, 64); cc += __shfl_xor(cc, 2, 64); cc += __shfl_xor(cc, 4, 64);
+        cc += xor_lane<1>(cc); cc += xor_lane<2>(cc); cc += xor_lane<4>(cc);
         cc *= 1.0f / 64.0f;
         float o[8];
 #pragma unroll
@@ -843,7 +864,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
             }
         }
         if constexpr (FUSED) dsum = deln;
-        else dsum += __shfl_xor(dsum, 32, 64);
+        else dsum = sum_xor32(dsum);
         const float lse2 = lsen * 1.4426950408889634f;
         if constexpr (!FUSED) { if (qok && h2 == 0) p.delta[srow + query] = dsum; }
 #pragma unroll

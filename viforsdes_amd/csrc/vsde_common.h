@@ -88,6 +88,18 @@ __device__ __forceinline__ float sum_xor32(float v) {
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// v(lane ^ 32) the same way, and v(lane ^ K) for K < 32 as a ds_swizzle bit-mode pattern (an immediate): neither needs a lane index
+__device__ __forceinline__ float xor32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? s[0] : s[1]);
+}
+template <int K>
+__device__ __forceinline__ float xor_lane(float v) {
+    static_assert(K > 0 && K < 32, "ds_swizzle bit mode reaches the 32 lanes of a half wave");
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (K << 10) | 0x1f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
