@@ -68,6 +68,9 @@ def _run(att, x, rot, v0, go, gv, mode):
 @pytest.mark.parametrize("B,N,wscale", [(112, 37, None), (12, 401, None), (40, 130, 0.3), (10, 430, None),   # 430: two-round waves without spare LDS (direct epilogues)
                                         # 70,576 rows: the QK-norm projection's last round of workgroups in finer column chunks, the
                                         # gate-backward GEMM on eight-wave workgroups (M >= 65,536)
+                                        # 13 blocks: the ragged one shared by four waves (1, 18 valid rows); 19 and 32 rows: its partial
+                                        # tiles no longer fit beside the dk / dv operands (dq shared, dk / dv second round)
+                                        (12, 385, None), (12, 402, None), (12, 403, None), (12, 416, None),
                                         (176, 401, None),
                                         (512, 401, None)])   # the LV benchmark's own shape (205,312 rows)
 def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
@@ -98,7 +101,9 @@ def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, v
             assert _l2(g_c[n], g_s[n]) < 1.5e-2 and rel_err(g_c[n], g_s[n]) < 6e-2, (n, worst[n], rel_err(g_c[n], g_s[n]))
         assert rel_err(g_c[n], g_f[n]) < (0.3 if scalar else 8e-2), (n, worst[n])
         # the fused route must not be further from the fp32 specification than the separate passes are (+ slack for noise)
-        assert rel_err(g_c[n], g_f[n]) < 1.5 * rel_err(g_s[n], g_f[n]) + 1e-2, (n, rel_err(g_c[n], g_f[n]), rel_err(g_s[n], g_f[n]))
+        # (the one scalar, d lambda = <dv, v_raw - v0>, is a cancelling sum of ~1e6 bf16-rounded products: both routes scatter by a
+        # few per cent around the fp32 value; tools/attn_split_check.py pins the kernel variants against each other to 3e-7)
+        assert rel_err(g_c[n], g_f[n]) < 1.5 * rel_err(g_s[n], g_f[n]) + (5e-2 if scalar else 1e-2), (n, rel_err(g_c[n], g_f[n]), rel_err(g_s[n], g_f[n]))
     print("\nworst (L2 vs separate passes, max-norm vs fp32):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()})
 
 

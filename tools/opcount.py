@@ -6,8 +6,9 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_trainer
-from viforsdes_amd.examples.sdes import lv_problem
-tr = build_trainer(lv_problem(), 512, torch.device("cuda:0"), True, seed=1, enc_hidden=256, enc_depth=8)
+from viforsdes_amd.examples.sdes import lv_problem, ou_problem
+wl = sys.argv[1] if len(sys.argv) > 1 else "lv"
+tr = build_trainer(lv_problem() if wl == "lv" else ou_problem(), 512 if wl == "lv" else 128, torch.device("cuda:0"), True, seed=1, enc_hidden=256, enc_depth=8)
 for _ in range(3):
     tr._train_step(tr.ctx.model); tr.ctx.ema.update()
 torch.cuda.synchronize()
@@ -22,12 +23,15 @@ for e in ev:
     if e.self_device_time_total <= 0 or e.self_device_time_total > 60:
         continue
     byop[e.name][0] += 1; byop[e.name][1] += e.self_device_time_total
-    frame = next((s for s in (e.stack or []) if "viforsdes_amd" in s or "bench.py" in s), "?")
-    byframe[frame.split("/root/repo/")[-1][:110]][0] += 1; byframe[frame.split("/root/repo/")[-1][:110]][1] += e.self_device_time_total
+    frame = next((s for s in (e.stack or []) if ("viforsdes_amd/" in s or "bench.py" in s) and "torch/" not in s), "?")
+    frame = frame.split("viforsdes_amd/")[-1][:110] if "viforsdes_amd/" in frame else frame[-110:]
+    byframe[frame][0] += 1; byframe[frame][1] += e.self_device_time_total
 print("== by op (kernels <= 60 us) ==")
 for k, (n, t) in sorted(byop.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{k:45s} {n / 2:7.1f} calls/step {t / 2:8.1f} us/step")
 print("total:", sum(v[0] for v in byop.values()) / 2, "calls/step,", sum(v[1] for v in byop.values()) / 2, "us/step")
+if all(k == "?" for k in byframe):
+    print("no python frames in the events; sample stack:", next((e.stack for e in ev if e.stack), None))
 print("== by frame ==")
 for k, (n, t) in sorted(byframe.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{n / 2:6.1f} {t / 2:8.1f} us  {k}")
