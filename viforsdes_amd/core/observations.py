@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional, Protocol, runtime_checkable
 
 import torch
@@ -32,6 +33,26 @@ class Observations(BaseModel):
 
     def to(self, device: torch.device | str) -> "Observations":
         return Observations(times=self.times.to(device), values=self.values.to(device))
+
+
+_GRID_INDEX_CACHE: dict = {}
+
+
+def grid_index(times: Tensor, time_step: float, max_index: int) -> Tensor:
+    """``round(times / time_step).long().clamp(max=max_index)``: the grid rows of the observation times (reference:
+    evidence_lower_bound.py:45, encoder.py:74).  The observation times do not change during a run, so the index tensor is built
+    once per (tensor, version, step, bound) instead of four small kernels at each of its two uses in every step."""
+    key = (id(times), times._version, float(time_step), int(max_index))
+    hit = _GRID_INDEX_CACHE.get(key)
+    if hit is not None and hit[0]() is times:     # the id of a dead tensor can be reused: the weak reference pins the identity
+        return hit[1]
+    idx = torch.round(times / time_step).long().clamp(max=max_index)
+    if times.is_cuda and torch.cuda.is_current_stream_capturing():
+        return idx   # memory of a capturing graph's private pool: valid for that graph only
+    if len(_GRID_INDEX_CACHE) >= 16:
+        _GRID_INDEX_CACHE.clear()
+    _GRID_INDEX_CACHE[key] = (weakref.ref(times), idx)
+    return idx
 
 
 @runtime_checkable

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 from torch.autograd.function import once_differentiable
 
-from ..core.observations import ObservationLikelihood, Observations
+from ..core.observations import ObservationLikelihood, Observations, grid_index
 from ..core.priors import Prior
 from ..core.sde import SDE, builtin_sde_kind
 from ..kernels.backend import get_backend
@@ -149,7 +149,7 @@ def compute_evidence_lower_bound(sde: SDE, observations: Observations, observati
     sde_lp, gen_lp, jac = _PathTerms.apply(z, x, sample.transition_means, sample.transition_cholesky, drift,
                                            diffusion, sample.state_space.positive_dims, time_step)
 
-    obs_idx = torch.round(observations.times / time_step).long().clamp(max=n_steps)
+    obs_idx = grid_index(observations.times, time_step, n_steps)
     cfg = _fused_tail_config(observations, observation_likelihood, prior, sde_parameter_posterior, x, sde_parameters)
     if cfg is not None:
         out = _ElboTail.apply(x[:, obs_idx], sde_parameters, sde_parameter_posterior.mean, sde_parameter_posterior.log_std,

@@ -13,6 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from ..config import EncoderConfig
+from ..core.observations import grid_index
 from ..primitives.embeddings import RotarySpec, SinusoidalEmbedding, precompute_freq_cis
 from ..primitives.sit import SiT, SiTConfig
 
@@ -40,7 +41,7 @@ class ObservationContextEncoder(nn.Module):
                     dtype: torch.dtype) -> Tensor:
         """``[T+1, C]`` tokens shared by all batch rows (reference: encoder.py:70-81)."""
         n = int(round(time_horizon / time_step)) + 1
-        idx = torch.round(obs_times / time_step).long().clamp(max=n - 1)
+        idx = grid_index(obs_times, time_step, n - 1)
         tokens = self.bridge_token.to(dtype).expand(n, -1).index_put((idx,), self.obs_proj(obs_values).to(dtype))
         return tokens + self._grid_embedding(n, float(time_horizon), obs_values.device, dtype)
 
