@@ -199,6 +199,38 @@ def test_two_graph_data_parallel_step_replays():
     assert moved > len(before) // 2 and np.isfinite(float(r.grad_norm))
 
 
+def test_captured_step_ignores_the_packs_of_other_models():
+    """The registry of packed bf16 operands is process-wide.  A trainer's forced refresh -- and the graph captured from its step,
+    which replays with raw addresses -- must cover only the packs of ITS model: a pack of another model that is alive during the
+    warm-up and dies before the capture used to change the refresh table's key inside the capture (a host -> device copy there is
+    illegal: the capture failed), and a pack alive at capture time would be written by every replay after it was freed."""
+    import gc
+    from viforsdes_amd.primitives.fused import PackedWeight, plain_pack
+    foreign_w = torch.nn.Parameter(torch.randn(64, 32, device=DEV))
+    foreign = plain_pack(foreign_w, None)
+    image = foreign.weight.clone()
+    tr = _small_ou_trainer(batch=256)                # 256 x 101 rows: the packed routes are taken (>= 4096 rows)
+    for _ in range(2):
+        tr._train_step(tr.ctx.model); tr.ctx.ema.update()
+    assert any(pk is not foreign for pk in PackedWeight._live), "the encoder did not build packs: the test would be vacuous"
+    foreign_w.data.add_(1.0)                         # no version bump, no optimizer hook: only an unscoped forced refresh would see it
+    tr._train_step(tr.ctx.model); tr.ctx.ema.update()
+    torch.cuda.synchronize()
+    assert torch.equal(foreign.weight, image), "the trainer's step rewrote a pack of another model"
+    second = plain_pack(torch.nn.Parameter(torch.randn(64, 32, device=DEV)), None)   # alive during the warm-up ...
+    warm = []
+    tr2 = _small_ou_trainer(batch=256, seed=7)
+    tr2._train_step(tr2.ctx.model); tr2.ctx.ema.update()
+    del second
+    gc.collect()                                      # ... gone before the capture
+    replay = tr2.capture_step_graph(warmup=1, warm_results=warm)
+    assert replay is not None, "capture failed"
+    r = replay()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(r.elbo_result.evidence_lower_bound))
+    assert torch.equal(foreign.weight, image)
+
+
 def test_captured_step_with_the_multi_path_kernels_replays_like_eager_steps():
     """704 paths (OU, small encoder): forward AND reverse-time sweep take the multi-path MFMA kernels under the default dispatch; their
     launch sequence (fragment prep kernels, the max-abs pre-pass with its memset, the sweeps) must survive HIP-graph capture: a
