@@ -219,3 +219,22 @@ def test_zero_norm_weight_takes_the_separate_passes():
         out, _ = att.forward_fused(x, rotary=rot, v0=None)
     assert not fused.attention_core_usable(x, att._proj_pack, 4, 64, att.q_norm.weight, att.k_norm.weight, cos)
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("B,N,gated", [(130, 401, True), (130, 385, False), (140, 300, True), (150, 257, False)])
+def test_ring_forward_is_bit_identical_to_the_resident_forward(B, N, gated, monkeypatch):
+    """The opt-in forward that streams K / V through an LDS ring (a producer wave + global_load_lds, swizzled unpadded tiles,
+    ds_read_b64_tr_b16 for V^T; VSDE_ATTN_RING=1, 8 .. 13 key tiles, >= 2 pairs per CU) does the resident kernel's arithmetic in the
+    resident kernel's order: outputs and log-sum-exp must agree bit for bit."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(B + N)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV, torch.bfloat16)
+    q, k, v = R(B, N, 4, 64), R(B, N, 4, 64), R(B, N, 4, 64)
+    gate = torch.sigmoid(R(B * N, 64).float()).to(torch.bfloat16)
+    run = (lambda: _hip.attention_fwd_gated(q, k, v, gate, 0.125)) if gated else (lambda: _hip.attention_fwd(q, k, v, 0.125))
+    monkeypatch.delenv("VSDE_ATTN_RING", raising=False)
+    o0, l0 = run()
+    monkeypatch.setenv("VSDE_ATTN_RING", "1")
+    o1, l1 = run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1.float()).all() and torch.equal(o0, o1) and torch.equal(l0, l1)

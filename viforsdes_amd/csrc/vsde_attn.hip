@@ -43,6 +43,8 @@ struct AttnParams {
     const uint16_t *gate;       // optional output gate [B*N][ldg] (64 factors per token, shared by the heads, = rnd(sigmoid(logit))): o *= gate
     int64_t ldg;
     int64_t pairs;              // B * H (the persistent kernel's loop bound)
+    int dbg;                    // ring kernel, timing-only ablations (VSDE_ATTN_RING_DBG): 1 = the producer loads only the first pair, 2 = no tile-step
+                                // barriers, 4 = the consumers skip their tile steps, 8 = no epilogue stores
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -415,6 +417,305 @@ __device__ __forceinline__ void accumulate_transposed(const uint16_t *tile, int 
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w0, b0, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&w1, b1, acc1, 0, 0, 0);
         }
+    }
+}
+
+// ===================================================================================== forward, K / V streamed through an LDS ring
+// The LDS-resident forward above is a chain per (batch, head) pair: stage K / V (HBM) -> barrier -> tile loop -> barrier, one
+// workgroup per CU, so the HBM phases add to the tile loop (56 us of tile loop in 188).  Here the operands never stop streaming:
+//   * 8 waves: 7 consumers + 1 PRODUCER.  The producer copies the key tiles of the NEXT pair global -> LDS with
+//     global_load_lds_dwordx4 (no registers, no transposition, nothing in any consumer's LDS queue) while the consumers work on the
+//     current pair, and computes the next pair's max |k|^2 (the softmax shift) from the rows it has just pulled through L2;
+//   * a ring of 18 tile slots (32 keys x 128 bytes of K and of V each, 144 KB): the 13 tiles of the current pair + 5 of the next;
+//     the next pair's tile t >= 5 takes the slot of the current tile t - 5 once every consumer has passed it in its LAST sweep;
+//   * a consumer owns query block w, then block w + 7 (two sweeps over the pair's tiles per pair; 13 blocks: 4 / 4 / 3 / 2 per
+//     SIMD as in the resident kernel), one workgroup barrier per tile step -- the barrier is what tells the producer a slot is free;
+//   * rows are unpadded, 16-byte chunk c of row r sits at chunk c ^ f(r): conflict-free for the K row fragments (ds_read_b128)
+//     AND for the V^T fragments, which come out of the row-major V tile through ds_read_b64_tr_b16 (no V^T staging);
+//   * the next sweep's Q fragments are requested a sweep ahead.
+// Same arithmetic in the same order as attn_fwd_kernel: the results are bit-identical.
+constexpr int RG_SLOTS = 18, RG_TILE = 32 * AT_D, RG_NW = 8, RG_NC = 7;
+
+__device__ __forceinline__ int rg_f(int row) { const int a = row >> 1; return ((a & 1) << 2) | ((a >> 1) & 3); }
+__device__ __forceinline__ void rg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+typedef __attribute__((address_space(3))) void *rg_lds_ptr;
+
+__device__ __forceinline__ uint2 rg_read_tr(const uint16_t *ptr) {
+    bf16x4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4s *)ptr);
+    return *(uint2 *)&r;
+}
+
+__global__ void __launch_bounds__(64 * RG_NW) attn_fwd_ring_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
+    uint16_t *Kr = asmem, *Vr = asmem + RG_SLOTS * RG_TILE;
+    __shared__ float kmax_s[2][RG_NC];   // per pair parity: the consumers' shares of max_j |k_j|^2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N, nkt = p.npad >> 5;
+    const int64_t ts = (int64_t)p.H * AT_D;
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    const int npairs = (int)((p.pairs - first + stride - 1) / stride);   // >= 1 (grid <= pairs)
+    constexpr int STEPS = 2 * 13;   // tile steps per pair: two sweeps of up to 13 tiles (shorter sequences idle through the rest)
+
+    if (wave == RG_NC) {
+        // ------------------------------------------------------------------------------------------------ producer
+        auto issue_tile = [&](int64_t head, int t, int slot) {
+            if (t >= nkt) return;
+            const int64_t hb = head / p.H, base_ = (hb * N * p.H + (head - hb * p.H)) * AT_D;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // 8 rows per instruction: lane = (row, physical chunk), 64 x 16 bytes land back to back
+                const int row = i * 8 + (lane >> 3), c = (lane & 7) ^ rg_f(row);
+                int key = t * 32 + row;
+                key = key < N ? key : N - 1;   // rows past the sequence repeat the last one (masked in the softmax, finite for P = 0)
+                const int64_t off = base_ + (int64_t)key * ts + c * 8;
+                __builtin_amdgcn_global_load_lds((const void *)(p.k + off), (rg_lds_ptr)(Kr + slot * RG_TILE + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void *)(p.v + off), (rg_lds_ptr)(Vr + slot * RG_TILE + i * 512), 16, 0, 0);
+            }
+        };
+        for (int t = 0; t < nkt; ++t) issue_tile(first, t, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rg_barrier();
+        int pbase = 0;   // ring slot of the current pair's tile 0
+        for (int pi = 0; pi < npairs; ++pi) {
+            const int64_t next = first + (int64_t)(pi + 1) * stride;
+            const bool has_next = pi + 1 < npairs;
+            int nbase = pbase + 13; nbase -= nbase >= RG_SLOTS ? RG_SLOTS : 0;
+            rg_barrier();   // (the consumers exchange their shares of max |k|^2 here)
+#pragma unroll 1
+            for (int s = 0; s < STEPS; ++s) {
+                if (has_next) {
+                    // tiles 0..4 of the next pair go into the 5 slots the current pair does not use; tile t >= 5 into the slot of the
+                    // current tile t - 5, free once every consumer is past barrier 13 + (t - 5) (its second sweep)
+                    int t = -1;
+                    if (s < 5) t = s;
+                    else if (s >= 14 && s <= 21) t = s - 9;
+                    if (t >= 0 && !(p.dbg & 1)) { int slot = nbase + t; slot -= slot >= RG_SLOTS ? RG_SLOTS : 0; issue_tile(next, t, slot); }
+                }
+                if (s == STEPS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next pair is complete at the pair boundary
+                if (!(p.dbg & 2) || s == STEPS - 1) rg_barrier();
+            }
+            pbase = nbase;
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- consumers
+    const int fr = lane & 31, h2 = lane >> 5, m = lane & 15, l4 = (lane >> 4) & 1;
+    int kofs[4], vofs[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kofs[ks] = fr * AT_D + (((2 * ks + h2) ^ rg_f(fr)) * 8);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const int m3 = (m >> 3) & 1, m1 = (m >> 1) & 1;
+            const int pc = 4 * (dt ^ m3) + 2 * (l4 ^ jp) + (m1 ^ h2);
+            vofs[dt][jp] = (4 * h2 + (m >> 2)) * AT_D + pc * 8 + (m & 1) * 4;
+        }
+    const bool ragged = (N & 31) != 0;
+    uint4 qn[4];   // fragments of the next sweep's query block
+    auto request_q = [&](int64_t head, int qblk) {
+        const int query = qblk * 32 + fr;
+        const int64_t hb = head / p.H, base_ = (hb * N * p.H + (head - hb * p.H)) * AT_D;
+        const uint16_t *row = p.q + base_ + (int64_t)(query < N ? query : N - 1) * ts + h2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const uint4 *)(row + ks * 16);
+    };
+    request_q(first, wave);
+    // qn is waited for at the END of a sweep's tile loop, before that sweep's output stores are issued: a wait at the next sweep's
+    // start would sit behind those stores (the counter is in order and the stores are conditional: the compiler drains to zero)
+    uint4 qcur[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qcur[ks] = qn[ks];
+    rg_barrier();
+    int pbase = 0;
+    for (int pi = 0; pi < npairs; ++pi) {
+        const int64_t head = first + (int64_t)pi * stride;
+        const int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
+        const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
+        // max_j |k_j|^2 from the resident tiles (wave w: tiles w and w + 7), in the arithmetic order of the resident kernel's staging
+        // (8 adjacent lanes = one row, chunk by chunk), so that the shift -- and with it every result -- is bit-identical
+        {
+            float mxk = 0.f;
+            for (int t = wave; t < nkt; t += RG_NC) {
+                int sl = pbase + t; sl -= sl >= RG_SLOTS ? RG_SLOTS : 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3), pc = (lane & 7) ^ rg_f(row);
+                    const uint4 kv = *(const uint4 *)(Kr + sl * RG_TILE + row * AT_D + pc * 8);
+                    const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+                    float ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                        ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+                    }
+                    ss += xor_lane<1>(ss); ss += xor_lane<2>(ss); ss += xor_lane<4>(ss);
+                    if (t * 32 + row < N) mxk = fmaxf(mxk, ss);
+                }
+            }
+            mxk = fmaxf(mxk, xor_lane<8>(mxk)); mxk = fmaxf(mxk, xor_lane<16>(mxk));
+            const uint32_t u = __float_as_uint(mxk);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mxk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            if (lane == 0) kmax_s[pi & 1][wave] = mxk;
+        }
+        rg_barrier();
+        float kss_max = 0.f;
+#pragma unroll
+        for (int w = 0; w < RG_NC; ++w) kss_max = fmaxf(kss_max, kmax_s[pi & 1][w]);
+        const float kmax = sqrtf(kss_max);
+#pragma unroll 1
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            const int qblk = wave + RG_NC * sweep;
+            if (qblk >= nkt) {   // no block in this sweep: keep the barrier count (and the next pair's first block on its way)
+                if (sweep == 1 && pi + 1 < npairs) request_q(head + stride, wave);
+#pragma unroll 1
+                for (int s = 0; s < 13; ++s) if (!(p.dbg & 2) || s == 12) rg_barrier();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qcur[ks] = qn[ks];
+                continue;
+            }
+            const int query = qblk * 32 + fr;
+            const bool qok = query < N;
+            uint2 gr[8];   // the lane's share of the token's gate row (index 2 g: channels 8 g + 4 h2 .., 2 g + 1: + 32), requested two tile steps before the epilogue
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gr[j] = make_uint2(0u, 0u);
+            bf16x8 qf[4];
+            float qss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 t = qok ? qcur[ks] : make_uint4(0, 0, 0, 0);
+                qf[ks] = *(bf16x8 *)&t;
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    qss = fmaf(lo, lo, fmaf(hi, hi, qss));
+                }
+            }
+            // the next sweep's block: this pair's second, or the next pair's first
+            if (sweep == 0) { if (wave + RG_NC < nkt) request_q(head, wave + RG_NC); }
+            else if (pi + 1 < npairs) request_q(head + stride, wave);
+            qss = sum_xor32(qss);
+            const float mx = sqrtf(qss) * kmax * 1.0001f;
+            const float c2 = p.scale_log2e, mc = mx * c2;
+            float lsum = 0.f, lsum2 = 0.f;
+            f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0;
+            auto slot_of = [&](int kt) { int sl = pbase + kt; return sl - (sl >= RG_SLOTS ? RG_SLOTS : 0); };
+            // One tile step = phase A (LDS reads of K tile kt + 1 and V tile kt, softmax of score tile kt on the VALU) + phase B (the
+            // score product of tile kt + 1 and the PV product of tile kt on the matrix pipe, registers only).  The per-step barrier
+            // keeps the two consumers of a SIMD in lock step -- both on the VALU, then both on the matrix pipe -- so the second wave
+            // of every SIMD (waves 4..6) runs half a step out of phase: B of the previous tile, then A, between two barriers.  All
+            // LDS reads of a step still happen before its barrier: the producer's slot rule does not change.
+            bf16x8 kf[4], pb0, pb1;
+            uint2 va[2][4];
+            auto phase_a = [&](f32x16 &scur, int kt) {
+                const int ktn = min(kt + 1, nkt - 1);
+                const uint16_t *kn_ = Kr + slot_of(ktn) * RG_TILE, *vt_ = Vr + slot_of(kt) * RG_TILE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8 *)(kn_ + kofs[ks]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) va[dt][j] = rg_read_tr(vt_ + vofs[dt][j & 1] + j * 8 * AT_D);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ragged && kt == nkt - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) scur[r] = -INFINITY;
+                }
+                float pr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    pr[r] = fast_exp2(fmaf(scur[r], c2, -mc)); pr[r + 1] = fast_exp2(fmaf(scur[r + 1], c2, -mc));
+                    lsum += pr[r]; lsum2 += pr[r + 1];
+                }
+                uint4 pw0 = make_uint4(pack_bf16(pr[0], pr[1]), pack_bf16(pr[2], pr[3]), pack_bf16(pr[4], pr[5]), pack_bf16(pr[6], pr[7]));
+                uint4 pw1 = make_uint4(pack_bf16(pr[8], pr[9]), pack_bf16(pr[10], pr[11]), pack_bf16(pr[12], pr[13]), pack_bf16(pr[14], pr[15]));
+                pb0 = *(bf16x8 *)&pw0; pb1 = *(bf16x8 *)&pw1;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto phase_b = [&](f32x16 &snxt) {
+                f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], t, 0, 0, 0);
+                snxt = t;
+                uint4 aw;
+                aw = make_uint4(va[0][0].x, va[0][0].y, va[0][1].x, va[0][1].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o0, 0, 0, 0);
+                aw = make_uint4(va[1][0].x, va[1][0].y, va[1][1].x, va[1][1].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o1, 0, 0, 0);
+                aw = make_uint4(va[0][2].x, va[0][2].y, va[0][3].x, va[0][3].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o0, 0, 0, 0);
+                aw = make_uint4(va[1][2].x, va[1][2].y, va[1][3].x, va[1][3].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            f32x16 sa = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = sa;
+            {
+                const uint16_t *k0_ = Kr + slot_of(0) * RG_TILE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(k0_ + kofs[ks]), qf[ks], sa, 0, 0, 0);
+            }
+            const bool late = wave >= 4;   // the second consumer of its SIMD
+            const bool nobar = (p.dbg & 2) != 0, nostep = (p.dbg & 4) != 0;
+            auto tile_barrier = [&](int kt) { if (!nobar || kt == 12) rg_barrier(); };
+            auto gate_request = [&](int kt) {
+                if (kt == 10 && p.gate != nullptr) {
+                    const uint16_t *grow = p.gate + ((int64_t)b * N + (qok ? query : N - 1)) * p.ldg + 4 * h2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gr[j] = *(const uint2 *)(grow + 8 * (j >> 1) + 32 * (j & 1));
+                }
+            };
+            if (!late) {
+#pragma unroll 1
+                for (int kt = 0; kt < 13; kt += 2) {
+                    gate_request(kt);
+                    if (kt < nkt && !nostep) { phase_a(sa, kt); phase_b(sb); }
+                    tile_barrier(kt);
+                    if (kt + 1 < 13) {
+                        if (kt + 1 < nkt && !nostep) { phase_a(sb, kt + 1); phase_b(sa); }
+                        tile_barrier(kt + 1);
+                    }
+                }
+            } else {
+                // score tiles alternate sa (even) / sb (odd): B of tile kt - 1 writes the tile A of tile kt reads
+#pragma unroll 1
+                for (int kt = 0; kt < 13; kt += 2) {
+                    gate_request(kt);
+                    if (kt < nkt && !nostep) { if (kt > 0) phase_b(sa); phase_a(sa, kt); }
+                    tile_barrier(kt);
+                    if (kt + 1 < 13) {
+                        if (kt + 1 < nkt && !nostep) { phase_b(sb); phase_a(sb, kt + 1); }
+                        tile_barrier(kt + 1);
+                    }
+                }
+                f32x16 unused;
+                phase_b(unused);   // the last tile's PV product (its score product recomputes the last tile: not used)
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qcur[ks] = qn[ks];   // (requested a sweep ago)
+            asm volatile("" : "+v"(qcur[0].x), "+v"(qcur[1].x), "+v"(qcur[2].x), "+v"(qcur[3].x));   // keep the copy (and its wait) here
+            lsum += lsum2;
+            lsum = sum_xor32(lsum);
+            if (qok && !(p.dbg & 8)) {
+                const float inv = 1.0f / lsum;
+                uint16_t *orow = p.o + base + query * ts;
+                if (p.gate != nullptr) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint2 ga = gr[2 * g], gb = gr[2 * g + 1];
+                        const float ga4[4] = {bfl(ga.x), bfh(ga.x), bfl(ga.y), bfh(ga.y)};
+                        const float gb4[4] = {bfl(gb.x), bfh(gb.x), bfl(gb.y), bfh(gb.y)};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { o0[4 * g + i] *= ga4[i]; o1[4 * g + i] *= gb4[i]; }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 8 * g + 4 * h2;
+                    *(uint2 *)(orow + d0) = make_uint2(pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+                    *(uint2 *)(orow + 32 + d0) = make_uint2(pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+                }
+                if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = mx * p.scale + __logf(lsum);
+            }
+        }
+        pbase += 13; pbase -= pbase >= RG_SLOTS ? RG_SLOTS : 0;
     }
 }
 
@@ -1154,6 +1455,13 @@ static bool persist_enabled() {
     if (f < 0) { const char *e = getenv("VSDE_ATTN_PERSIST"); f = e ? atoi(e) : 1; }
     return f != 0;
 }
+// VSDE_ATTN_RING=1: forward with K / V streamed through the LDS ring by a producer wave (attn_fwd_ring_kernel) where it applies.
+// Opt-in (it is correct -- bit-identical to the resident kernel -- but slower: profiles/r04_attn_ring.txt); read at every launch so
+// that a test can switch it inside one process.
+static bool ring_enabled() {
+    const char *e = getenv("VSDE_ATTN_RING");
+    return e != nullptr && atoi(e) != 0;
+}
 static int attn_cus() {
     static int cus = 0;
     if (!cus) {
@@ -1170,6 +1478,7 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
     const int cus = attn_cus();
     AttnParams q = p;
     q.pairs = pairs;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_ATTN_RING_DBG"); dbg = e ? atoi(e) : 0; } q.dbg = dbg; }
     static int abl = -1;
     if (abl < 0) { const char *e = getenv("VSDE_ATTN_FWD_ABL"); abl = e ? atoi(e) : 0; }
     if (abl && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // timing-only variants (wrong results)
@@ -1180,6 +1489,11 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
     } while (0)
         if (abl == 1) VSDE_ABL_LAUNCH(1); else if (abl == 2) VSDE_ABL_LAUNCH(2); else if (abl == 3) VSDE_ABL_LAUNCH(3); else VSDE_ABL_LAUNCH(7);
 #undef VSDE_ABL_LAUNCH
+    } else if (ring_enabled() && p.npad >= 256 && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
+        // 8 .. 13 key tiles and query blocks (two sweeps of the seven consumer waves), at least two pairs per CU
+        const size_t ring = (size_t)2 * RG_SLOTS * RG_TILE * sizeof(uint16_t);
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring));
+        hipLaunchKernelGGL(attn_fwd_ring_kernel, dim3((unsigned)cus), dim3(64 * RG_NW), ring, stream, q);
     } else if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds, stream, q);
