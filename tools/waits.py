@@ -13,7 +13,7 @@ for m in re.finditer(r"^(_Z\w*" + re.escape(pat) + r"\w*):", s, re.M):
     print(m.group(1))
     blk, depth, info, order = "entry", {"entry": 0}, {}, []
     for ln in body:
-        lm = re.match(r"^(\.LBB\d+_\d+):(.*)", ln)
+        lm = re.match(r"^(\.LBB\d+_\d+):(.*)", ln) or re.match(r"^; (%bb\.\d+):(.*)", ln)   # (fall-through blocks carry no label)
         if lm:
             blk = lm.group(1)
             dm = re.search(r"Depth=(\d+)", lm.group(2))
