@@ -881,7 +881,17 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
     const int64_t stripes = (p.M + rows - 1) / rows;
     const int pairs = p.N / 64;
     int chunks = 1;
-    while (stripes * chunks < resident && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
+    if ((EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM) && stripes < resident && pairs >= 2) {
+        // these epilogues work pair by pair, so a stripe's chunks need not be equal (the kernel gives the last one what is left):
+        // about one round of resident workgroups whatever the pair count (N = 1408 / 832 / 704: 22 / 13 / 11 pairs -- the
+        // doubling rule below stops at 2 / 1 / 1 chunks, i.e. ~100 workgroups on 256 CUs at the OU example's 12.9 k tokens)
+        int64_t c = (resident + stripes - 1) / stripes;
+        if (c > pairs) c = pairs;
+        const int64_t ppc = (pairs + c - 1) / c;
+        chunks = (int)((pairs + ppc - 1) / ppc);   // no empty trailing chunk
+    } else {
+        while (stripes * chunks < resident && chunks * 2 <= pairs && pairs % (chunks * 2) == 0) chunks *= 2;
+    }
     {
         static int big = -1;   // VSDE_ROWS_CHUNKS: chunks at large M (A/B runs; 0 = the default below)
         if (big < 0) { const char *e = getenv("VSDE_ROWS_CHUNKS"); big = e ? atoi(e) : 0; }
@@ -914,7 +924,7 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
         if (on < 0) { const char *e = getenv("VSDE_ROWS_TAIL"); on = e ? atoi(e) : 1; }
         const int64_t full = wg_main / resident * resident, rest = wg_main - full;   // workgroups of the partly filled last round
         const bool can_chunk = EPI != EPI_GATE_BWD && (EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || EPI == EPI_PLAIN);
-        if (on && can_chunk && full > 0 && rest > 0 && rest * 2 <= resident) {
+        if (on && can_chunk && full > 0 && rest >= 8 * (int64_t)chunks && rest * 2 <= resident) {   // (at least one stripe group in the last round)
             const int64_t tg = (rest / chunks + 7) / 8;                 // stripe groups in the last round
             int tc = (int)(resident / (tg * 8));                         // chunks that fill the chip once
             if (tc > pairs) tc = pairs;
