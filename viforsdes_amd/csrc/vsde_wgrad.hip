@@ -18,6 +18,7 @@
 //   * The workgroups of one split (same rows, different output tiles) sit on one XCD, so the shared X rows are served by that
 //     XCD's L2.  TN = 128: 4 waves, two workgroups per CU; TN = 256: 8 waves, one workgroup per CU, half the X re-reads.
 //   * The column sums of dY (bias gradient) are accumulated from the staging registers on the way to LDS.
+#include <math.h>
 #include <stdlib.h>
 
 #include "vsde_common.h"
@@ -280,6 +281,20 @@ static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
             if (cost < best * 0.98) { best = cost; pick = ns; }
         }
         nsplit = pick;
+    }
+    {
+        // Few rows (the OU example: 12.9 k tokens = 404 row blocks): with the split count of a full round every workgroup has a handful of
+        // steps and the partial tiles (tiles x nsplit x 263 KB) outweigh the operands -- the fixed-order reduction then costs as much as
+        // the product (17 us each).  Product time ~ a + b chunks / nsplit, reduction ~ c nsplit: nsplit ~ sqrt(2.5 chunks), measured
+        // on the OU step: 8 | 16 | 24 | 32 | 48 | 64 splits = 5.16 | 4.59 | 4.44 | 4.40 | 4.54 | 4.59 ms.  (At LV sizes the cap is above 64.)
+        int64_t cap = ((int64_t)sqrt(2.5 * (double)chunks) + 4) & ~(int64_t)7;
+        if (cap < 8) cap = 8;
+        if (nsplit > cap) nsplit = cap;
+    }
+    {
+        static int force_ns = -1;   // VSDE_WGRAD_NSPLIT: split count for every problem (A/B runs)
+        if (force_ns < 0) { const char *e = getenv("VSDE_WGRAD_NSPLIT"); force_ns = e ? atoi(e) : 0; }
+        if (force_ns > 0) { nsplit = force_ns; if (nsplit > chunks) nsplit = chunks; }
     }
     p.nsplit = (int)nsplit; p.chunks = chunks;
 }
