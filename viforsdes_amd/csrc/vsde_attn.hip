@@ -130,22 +130,24 @@ __device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vre
 
 // ABL: timing-only ablations of the tile loop's VALU work (results are wrong): 1 = exponentials of the raw scores (no scale / shift
 // fma), 2 = no row-sum adds, 4 = no exponentials at all (tools/attn_core_bench.py with VSDE_ATTN_FWD_ABL)
-template <bool PERSIST, int ABL = 0>
-__global__ void __launch_bounds__(768) attn_fwd_kernel(AttnParams p) {
+// NT = 256 (non-persistent, N <= 128): four-wave workgroups, three per CU (see AT_BT_SMALL)
+template <bool PERSIST, int ABL = 0, int NT = 768>
+__global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     uint16_t *Ks = asmem;                      // [npad][AT_KLD]
     uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, npad = p.npad, vld = p.vld;
     const int64_t ts = (int64_t)p.H * AT_D;    // token stride in elements
-    constexpr int NT = 768, NW = NT / 64;
+    constexpr int NW = NT / 64, MAXN = NT == 768 ? AT_MAXN : 128;
+    static_assert(NT == 768 || !PERSIST, "the persistent form is built for 12-wave workgroups");
     const int two_round = PERSIST ? ((npad >> 5) > NW ? (npad >> 5) - NW : 0) : 0;   // waves 0 .. two_round - 1 own two query blocks
     int pt = tid - 64 * two_round;                                                    // staging thread index ...
     const int PT = NT - 64 * two_round;                                               // ... and count
     const bool stager = pt >= 0;
     // ---- staging of K [key][d] and V^T [d][key]: every global load is issued before the first use; the staging registers live
     // only inside VSDE_FWD_STAGE (a loop-carried register set is spilled across the tile loop by hipcc)
-    constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (AT_MAXN * 8 + NT - 1) / NT, VIT = PERSIST ? 1 : (AT_MAXN + NT - 1) / NT;
+    constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (MAXN * 8 + NT - 1) / NT, VIT = PERSIST ? 1 : (MAXN + NT - 1) / NT;
     __shared__ float kred[NW];
     // the wave's first query block of a pair: one dword of each of its 64-byte half rows is touched together with the pair's K / V
     // requests, so that the fragment loads after the barrier are served by the cache (the fragments themselves, requested here,
@@ -1041,21 +1043,26 @@ __device__ __forceinline__ float staged_value_bwd(const QkBwd &f, const float *s
 
 // ---- staging of whole row-major operands [npad][64] -> LDS [npad][AT_KLD]; all global loads issued before first use ---
 constexpr int AT_BT = 768;                                 // threads of a backward workgroup (12 waves: 3 per SIMD)
-constexpr int AT_SIT = (AT_MAXN * 8 + AT_BT - 1) / AT_BT;  // 16-byte chunks per thread and operand
+// Short sequences (N <= 128: at most four 32-token blocks, the OU example's 101 tokens): workgroups of FOUR waves (BT = 256).  Eight
+// idle waves of a 12-wave workgroup still hold their registers, so a CU had room for one workgroup = one (batch, head) pair at a time;
+// three four-wave workgroups per CU overlap each other's HBM phases and tile loops.
+constexpr int AT_BT_SMALL = 256, AT_MAXN_SMALL = 128;
 
+template <int BT, int MAXN>
 __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2, int64_t ts, int N, int npad, int tid,
                                           uint16_t *sa, uint16_t *sb) {
+    constexpr int AT_SIT = (MAXN * 8 + BT - 1) / BT;   // 16-byte chunks per thread and operand
     uint4 ra[AT_SIT], rb[AT_SIT];
 #pragma unroll
     for (int it = 0; it < AT_SIT; ++it) {
-        const int i = tid + it * AT_BT, n = i >> 3, c = i & 7;
+        const int i = tid + it * BT, n = i >> 3, c = i & 7;
         const bool ok = i < npad * 8 && n < N;
         ra[it] = ok ? *(const uint4 *)(a + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
         rb[it] = ok ? *(const uint4 *)(b2 + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < AT_SIT; ++it) {
-        const int i = tid + it * AT_BT, n = i >> 3, c = i & 7;
+        const int i = tid + it * BT, n = i >> 3, c = i & 7;
         if (i < npad * 8) {
             *(uint4 *)(sa + n * AT_KLD + c * 8) = ra[it];
             *(uint4 *)(sb + n * AT_KLD + c * 8) = rb[it];
@@ -1074,8 +1081,8 @@ __device__ __forceinline__ void stage_two(const uint16_t *a, const uint16_t *b2,
 // ONE (FUSED only): no wave has a second block (ntile <= 12, or the ragged 13th block is shared) and no ablation switch is set:
 // the in-loop epilogue variants are not compiled -- their hoisted addresses would be spilled around the tile loop, and a kernel
 // that uses scratch at all pays for it at every workgroup launch (the dk/dv kernel: 375 -> 442 us with 100 more spilled registers).
-template <bool FUSED, bool ONE = false>
-__global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
+template <bool FUSED, bool ONE = false, int BT = AT_BT>
+__global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
@@ -1094,7 +1101,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
         lsen = ok ? p.lse[srow + query] : INFINITY;  // padded queries: P = 0
     };
     request(wave);
-    constexpr int NWV = AT_BT / 64;
+    constexpr int NWV = BT / 64;
     const bool split = FUSED && p.split_dq != 0;          // the ragged block NWV is shared by waves 0..3 (AttnBwdParams)
     const bool sharer = split && wave < 4;
     bf16x8 qx[4], dox[4];                                  // ... its fragments, requested with the wave's own before the staging
@@ -1109,7 +1116,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
             lsex = ok ? p.lse[srow + query] : INFINITY;
         }
     }
-    stage_two(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
+    stage_two<BT, (BT == AT_BT ? AT_MAXN : AT_MAXN_SMALL)>(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
     __syncthreads();
     const float c2 = p.scale_log2e;
     const bool ragged = (N & 31) != 0;
@@ -1204,8 +1211,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dq_kernel(AttnBwdParams p) {
 }
 
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
-template <bool FUSED, bool ONE = false>
-__global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
+template <bool FUSED, bool ONE = false, int BT = AT_BT>
+__global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
     const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
@@ -1221,7 +1228,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
         load_bfrag(p.v + base, ts, key, ok, h2, vn);
     };
     request(wave);
-    constexpr int NWV = AT_BT / 64;
+    constexpr int NWV = BT / 64;
     const bool split = FUSED && p.split_dkv != 0;         // the ragged block NWV is shared by waves 0..3 (AttnBwdParams)
     const bool sharer = split && wave < 4;
     bf16x8 kx[4], vx[4];                                   // ... its fragments, requested with the wave's own before the staging
@@ -1232,8 +1239,8 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
             load_bfrag(p.v + base, ts, key, key < N, h2, vx);
         }
     }
-    stage_two(p.q + base, p.dout + base, ts, N, npad, tid, Qs, Os);
-    for (int i = tid; i < npad; i += AT_BT) {  // padded queries: lse = +inf -> P = 0
+    stage_two<BT, (BT == AT_BT ? AT_MAXN : AT_MAXN_SMALL)>(p.q + base, p.dout + base, ts, N, npad, tid, Qs, Os);
+    for (int i = tid; i < npad; i += BT) {  // padded queries: lse = +inf -> P = 0
         lse2s[i] = i < N ? p.lse[srow + i] * 1.4426950408889634f : INFINITY;
         dels[i] = i < N ? p.delta[srow + i] : 0.f;
     }
@@ -1299,7 +1306,7 @@ __global__ void __launch_bounds__(768) attn_bwd_dkv_kernel(AttnBwdParams p) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
             if constexpr (ONE) { last = kblk; continue; }
             if (kblk + NWV >= nblk && !(p.f.dbg & 8)) { last = kblk; continue; }
-            if (p.park_off != 0 && kblk < AT_BT / 64 && !(p.f.dbg & 8)) {
+            if (p.park_off != 0 && kblk < NWV && !(p.f.dbg & 8)) {
                 // a wave with one more round to go (the 13th block at N = 401): its epilogue would sit between its two rounds,
                 // i.e. on the workgroup's critical path with nothing to hide its loads.  The tile waits in spare LDS instead
                 // (already in the staged row layout) and is finished after the barrier below.
@@ -1462,6 +1469,12 @@ static bool ring_enabled() {
     const char *e = getenv("VSDE_ATTN_RING");
     return e != nullptr && atoi(e) != 0;
 }
+// VSDE_ATTN_SMALL_WG=0: short sequences (N <= 128) on the 12-wave workgroups as before (A/B runs)
+static bool small_wg_enabled() {
+    static int f = -1;
+    if (f < 0) { const char *e = getenv("VSDE_ATTN_SMALL_WG"); f = e ? atoi(e) : 1; }
+    return f != 0;
+}
 static int attn_cus() {
     static int cus = 0;
     if (!cus) {
@@ -1489,6 +1502,9 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
     } while (0)
         if (abl == 1) VSDE_ABL_LAUNCH(1); else if (abl == 2) VSDE_ABL_LAUNCH(2); else if (abl == 3) VSDE_ABL_LAUNCH(3); else VSDE_ABL_LAUNCH(7);
 #undef VSDE_ABL_LAUNCH
+    } else if (small_wg_enabled() && p.npad <= 128) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<false, 0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((attn_fwd_kernel<false, 0, 256>), dim3((unsigned)pairs), dim3(256), lds, stream, q);
     } else if (ring_enabled() && p.npad >= 256 && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         // 8 .. 13 key tiles and query blocks (two sweeps of the seven consumer waves), at least two pairs per CU
         const size_t ring = (size_t)2 * RG_SLOTS * RG_TILE * sizeof(uint16_t);
@@ -1628,6 +1644,18 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
     }
     hipStream_t s = (hipStream_t)stream;
     const int nwv = AT_BT / 64;
+    if (p.f.dbg == 0 && small_wg_enabled() && p.ntile <= AT_BT_SMALL / 64) {   // N <= 128: four-wave workgroups, three per CU
+        const size_t stage_s = (size_t)(AT_BT_SMALL / 64) * AT_ESLICE * sizeof(float);
+        size_t l_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), l_dkv = l_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
+        l_dq = l_dq > stage_s ? l_dq : stage_s; l_dkv = l_dkv > stage_s ? l_dkv : stage_s;
+        p.park_off = 0; p.split_dq = 0; p.split_dkv = 0;
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true, true, AT_BT_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_dq));
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<true, true, AT_BT_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_dkv));
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true, AT_BT_SMALL>), dim3((unsigned)(B * H)), dim3(AT_BT_SMALL), l_dq, s, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true, AT_BT_SMALL>), dim3((unsigned)(B * H)), dim3(AT_BT_SMALL), l_dkv, s, p);
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (p.f.dbg == 0 && (p.ntile <= nwv || p.split_dq != 0)) {   // one block per wave: the lean instantiation
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
