@@ -158,3 +158,35 @@ def test_persistent_deep_reduction_kernel():
         "print('deep ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), DEEP_SHAPES)
     res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VSDE_DEEP_GEMM="1"), capture_output=True, text=True)
     assert res.returncode == 0 and "deep ok" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradients_are_bit_identical_to_single_launches():
+    """``vsde_linear_wgrad_group_bf16`` plans every problem exactly as ``vsde_linear_wgrad_bf16_rows`` does and sums its partial
+    tiles in the same fixed order: the results of a mixed group (both tile widths, with and without bias, a row map, few and many
+    rows, more problems than one launch takes) must be bit-identical to one call per problem."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(7)
+    R = lambda *s: torch.randn(*s, generator=g).to("cuda", torch.bfloat16)
+    shapes = [(12928, 832, 256, True), (12928, 256, 704, True), (12928, 1408, 256, True), (12928, 256, 256, False),
+              (4096, 128, 128, True), (700, 64, 256, False), (33, 8, 64, True), (205312, 256, 256, True)]
+    shapes = shapes + [(3000 + 64 * i, 256, 256, bool(i & 1)) for i in range(24)]      # 32 problems: more than one group holds
+    problems, expect = [], []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dy, x = R(M, N), R(M, K)
+        row_map, rows = None, None
+        if i == 2:   # the interleaved SwiGLU pack: rows permuted, a few dropped
+            perm = torch.randperm(N, generator=g)
+            row_map = torch.where(perm < N - 26, perm, torch.full_like(perm, -1)).to("cuda", torch.int32)
+            rows = N - 26
+        problems.append((dy, x, bias, row_map, rows))
+        expect.append(_hip.linear_wgrad(dy, x, bias, row_map, rows))
+    got = _hip.linear_wgrad_group(problems)
+    torch.cuda.synchronize()
+    for i, ((dW, db), (eW, eb)) in enumerate(zip(got, expect)):
+        if problems[i][3] is not None:   # dropped rows are not written by either path: compare the mapped rows only
+            keep = problems[i][3][problems[i][3] >= 0].long()
+            assert torch.equal(dW[keep], eW[keep]) and torch.equal(db[keep], eb[keep]), i
+        else:
+            assert torch.equal(dW, eW), (i, shapes[i])
+            assert (db is None) == (eb is None) and (db is None or torch.equal(db, eb)), (i, shapes[i])

@@ -56,7 +56,7 @@ EXPORTS = (
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
-    "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows",
+    "vsde_residual_ln_fwd", "vsde_residual_ln_bwd", "vsde_colsum_workspace_bytes", "vsde_linear_wgrad_workspace_bytes", "vsde_linear_wgrad_bf16", "vsde_linear_wgrad_bf16_rows", "vsde_linear_wgrad_group_workspace_bytes", "vsde_linear_wgrad_group_bf16",
     "vsde_attention_max_tokens", "vsde_attention_fwd_bf16", "vsde_attention_bwd_bf16",
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
@@ -95,6 +95,7 @@ def load() -> ctypes.CDLL:
     lib.vsde_qk_norm_rope_bwd_partials.restype = ctypes.c_int64
     lib.vsde_attention_bwd_fused_partials.restype = ctypes.c_int64
     lib.vsde_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsde_linear_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
     lib.vsde_colsum_workspace_bytes.restype = ctypes.c_size_t
     _lib = lib
     return lib
@@ -718,6 +719,35 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool, row_map: Op
         _call(lib.vsde_linear_wgrad_bf16_rows, _ptr(dy), _ptr(x), _i64(M), ctypes.c_int(N), ctypes.c_int(K), _ptr(dW), _ptr(db),
               _ptr(row_map), _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
     return dW, db
+
+
+class _WgradItem(ctypes.Structure):
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("row_map", ctypes.c_void_p)]
+
+
+def linear_wgrad_group(problems):
+    """``[(dy, x, want_bias, row_map, out_rows), ...]`` -> ``[(dW, db), ...]``: every problem exactly as ``linear_wgrad`` computes it
+    (bit-identical), all of them in a handful of launches (csrc/vsde_wgrad.hip, ``vsde_linear_wgrad_group_bf16``)."""
+    lib = load()
+    dev = _require_hip(*[t for pr in problems for t in pr[:2]])
+    n = len(problems)
+    items = (_WgradItem * n)()
+    outs = []
+    for i, (dy, x, want_bias, row_map, out_rows) in enumerate(problems):
+        M, N = dy.shape
+        K = x.shape[1]
+        rows = N if row_map is None else int(out_rows)
+        dW = torch.empty(rows, K, device=dev, dtype=torch.float32)
+        db = torch.empty(rows, device=dev, dtype=torch.float32) if want_bias else None
+        items[i] = _WgradItem(dy.data_ptr(), x.data_ptr(), M, N, K, dW.data_ptr(), None if db is None else db.data_ptr(),
+                              None if row_map is None else row_map.data_ptr())
+        outs.append((dW, db))
+    nbytes = lib.vsde_linear_wgrad_group_workspace_bytes(ctypes.c_int(n), ctypes.byref(items))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_wgrad_group_bf16, ctypes.c_int(n), ctypes.byref(items), _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
+    return outs
 
 
 EPI_PLAIN, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2

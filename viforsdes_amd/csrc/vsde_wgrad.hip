@@ -69,14 +69,24 @@ __device__ __forceinline__ bf16x8 w2_frag(const uint16_t *tile, int ld, int c0, 
     return *(bf16x8 *)&w;
 }
 
+// Several problems in ONE launch (the OU example's 12.9 k tokens: every weight gradient of the step is a ~20 us kernel + a ~10 us
+// reduction, 25 of each per step; grouped, the small problems fill the chip together).  Workgroup ids [first[g], first[g + 1]) belong
+// to problem g (counts are multiples of 8: the XCD of a workgroup id is unchanged), tiles [tile0[g], tile0[g + 1]) in the reduction.
+constexpr int W2_MAXG = 24;
+struct Wgrad2Group {
+    Wgrad2Params g[W2_MAXG];
+    int first[W2_MAXG + 1], tile0[W2_MAXG + 1];
+    int n;
+};
+
 template <int TN>
-__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) {
+__device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int bid) {
     using C = W2<TN>;
     extern __shared__ __attribute__((aligned(16))) uint16_t w2s[];
     __shared__ float bred[C::YR][TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // consecutive workgroup ids go round-robin over the 8 XCDs, so id = 8 * local + xcd
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int xcd = bid & 7, local = bid >> 3;
     const int tile = local % p.tiles, split = (local / p.tiles) * 8 + xcd;
     if (split >= p.nsplit) return;
     const int n_blk = (tile / p.tiles_k) * TN, k_blk = (tile % p.tiles_k) * W2_TK;
@@ -187,16 +197,26 @@ __global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgr
     }
 }
 
+template <int TN>
+__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) { wgrad_tr_body<TN>(p, (int)blockIdx.x); }
+
+template <int TN>
+__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_group_kernel(Wgrad2Group G) {
+    int g = 0;
+    while (g + 1 < G.n && (int)blockIdx.x >= G.first[g + 1]) ++g;   // workgroup-uniform
+    wgrad_tr_body<TN>(G.g[g], (int)blockIdx.x - G.first[g]);
+}
+
+
 // Fixed-order sum of the split partials.  grid (TN * 256 / 4 / 64 + 1, tiles), 256 threads = 64 float4 columns x 4 groups of
 // splits: group g adds splits g, g + 4, ... with four loads in flight, the four group sums are combined through LDS in order.  (One
 // thread per float4 walking all splits leaves ~64 workgroups on the chip for a two-tile problem and is latency-bound: 57 us against
 // 50 us for the product itself.)  The extra block (last blockIdx.x) sums the tile's bias row.
 template <int TN>
-__global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) {
+__device__ __forceinline__ void wgrad_tr_reduce_body(const Wgrad2Params &p, const int tile) {
     constexpr int PART = W2<TN>::PART;
     __shared__ float4 comb[3][64];
     __shared__ float bcomb[256];
-    const int tile = blockIdx.y;
     const int n_blk = (tile / p.tiles_k) * TN, k_blk = (tile % p.tiles_k) * W2_TK;
     const float *src = p.partial + (int64_t)tile * p.nsplit * PART;
     if (blockIdx.x == gridDim.x - 1) {
@@ -251,6 +271,17 @@ __global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) {
         }
     }
 }
+
+template <int TN>
+__global__ void __launch_bounds__(256) wgrad_tr_reduce_kernel(Wgrad2Params p) { wgrad_tr_reduce_body<TN>(p, (int)blockIdx.y); }
+
+template <int TN>
+__global__ void __launch_bounds__(256) wgrad_tr_reduce_group_kernel(Wgrad2Group G) {
+    int g = 0;
+    while (g + 1 < G.n && (int)blockIdx.y >= G.tile0[g + 1]) ++g;
+    wgrad_tr_reduce_body<TN>(G.g[g], (int)blockIdx.y - G.tile0[g]);
+}
+
 
 // TN = 256 when the output has at least three 256 x 256 tiles (half the re-reads of X; measured 155 | 227 | 126 us against
 // 172 | 264 | 136 us for dW[832,256] | [1536,256] | [256,768] at M = 205k, and 94 against 77 us for the one-tile [256,256]:
@@ -314,6 +345,81 @@ template <int TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s)
 }
 
 }  // namespace vsde
+
+template <int TN> static int wgrad2_launch_group(const vsde::Wgrad2Group &G, int wgs, hipStream_t s) {
+    using namespace vsde;
+    using C = W2<TN>;
+    const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_tr_group_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wgrad_tr_group_kernel<TN>, dim3((unsigned)wgs), dim3(C::THREADS), lds, s, G);
+    VSDE_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_tr_reduce_group_kernel<TN>, dim3(TN * W2_TK / 4 / 64 + 1, (unsigned)G.tile0[G.n]), dim3(256), 0, s, G);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// One item of a grouped weight-gradient launch (include/vsde_hip.h: VsdeWgradItem)
+struct VsdeWgradItemC {
+    const void *dy, *x;
+    int64_t M;
+    int32_t N, K;
+    float *dW, *db;
+    const int32_t *row_map;
+};
+
+extern "C" size_t vsde_linear_wgrad_group_workspace_bytes(int n, const void *items_) {
+    const VsdeWgradItemC *items = (const VsdeWgradItemC *)items_;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].M <= 0 || items[i].N <= 0 || items[i].K <= 0) return 0;
+        vsde::Wgrad2Params p;
+        vsde::wgrad2_plan(items[i].M, items[i].N, items[i].K, p);
+        total += (vsde::wgrad2_workspace(p) + 255) & ~(size_t)255;
+    }
+    return total;
+}
+
+// dW_i = dy_i^T x_i, db_i = colsum(dy_i) for n problems in (at most) two launches per tile width (+ their reductions) instead of n;
+// same arithmetic as vsde_linear_wgrad_bf16_rows problem by problem (same plan, same fixed-order sums: identical results)
+extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace vsde;
+    const VsdeWgradItemC *items = (const VsdeWgradItemC *)items_;
+    VSDE_CHECK_ARG(n > 0 && items && workspace, VSDE_E_BADARG, "bad linear_wgrad_group arguments");
+    VSDE_CHECK_ARG(workspace_bytes >= vsde_linear_wgrad_group_workspace_bytes(n, items_), VSDE_E_WORKSPACE, "linear_wgrad_group workspace too small");
+    char *ws = (char *)workspace;
+    for (int tn = 128; tn <= 256; tn += 128) {
+        Wgrad2Group G;
+        G.n = 0; G.first[0] = 0; G.tile0[0] = 0;
+        char *w = ws;
+        for (int i = 0; i <= n; ++i) {
+            bool flush = i == n;
+            Wgrad2Params p;
+            size_t bytes = 0;
+            if (i < n) {
+                const VsdeWgradItemC &it = items[i];
+                VSDE_CHECK_ARG(it.dy && it.x && it.dW && it.M > 0 && it.N % 8 == 0 && it.K % 8 == 0 && ((uintptr_t)it.dy % 16) == 0 &&
+                               ((uintptr_t)it.x % 16) == 0, VSDE_E_BADARG, "bad item %d of linear_wgrad_group", i);
+                wgrad2_plan(it.M, it.N, it.K, p);
+                bytes = (wgrad2_workspace(p) + 255) & ~(size_t)255;
+                if (p.tn == tn) {
+                    p.dy = (const uint16_t *)it.dy; p.x = (const uint16_t *)it.x; p.partial = (float *)w; p.dW = it.dW; p.db = it.db; p.row_map = it.row_map;
+                    G.g[G.n] = p;
+                    G.first[G.n + 1] = G.first[G.n] + ((p.nsplit + 7) / 8) * 8 * p.tiles;
+                    G.tile0[G.n + 1] = G.tile0[G.n] + p.tiles;
+                    ++G.n;
+                    flush = flush || G.n == W2_MAXG;
+                }
+                w += bytes;
+            }
+            if (flush && G.n > 0) {
+                const int rc = tn == 256 ? wgrad2_launch_group<256>(G, G.first[G.n], (hipStream_t)stream) : wgrad2_launch_group<128>(G, G.first[G.n], (hipStream_t)stream);
+                if (rc != 0) return rc;
+                G.n = 0; G.first[0] = 0; G.tile0[0] = 0;
+            }
+        }
+    }
+    return 0;
+}
 
 extern "C" size_t vsde_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -91,7 +91,9 @@ class VariationalInferenceTrainer:
                                             self.time_horizon, cfg.time_step, self.state_space, noise=path_noise)
             result = compute_evidence_lower_bound(self.sde, ctx.observations, self.observation_likelihood, self.prior,
                                                   model.sde_parameter_posterior, sde_parameters, sample, cfg.time_step)
-        ctx.scaler.scale(-result.evidence_lower_bound).backward()
+        # the encoder's small weight-gradient products are collected over the backward pass and issued together (primitives/fused.py)
+        with fused.deferred_weight_grads():
+            ctx.scaler.scale(-result.evidence_lower_bound).backward()
         # hand out detached scalars: nothing the caller keeps may hold this step's autograd graph (and its AccumulateGrad
         # nodes) alive across steps or across a HIP-graph capture; the reference returns host floats (trainer.py:199-206)
         c = result.components

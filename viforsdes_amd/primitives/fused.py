@@ -643,6 +643,57 @@ def _mm_nt(x2: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
     return torch.nn.functional.linear(x2, w, bias)
 
 
+# ---- weight gradients of the packed Linears: immediately, or collected over one backward pass -----------------------------------
+# At a few thousand rows (the OU example: 12.9 k tokens) every weight gradient is a ~20 us kernel + a ~10 us reduction that cannot
+# fill the chip alone, 25 of each per step.  Inside ``deferred_weight_grads()`` (the trainer wraps its backward pass in it) the
+# backward functions below queue (dy, x) instead, return no gradient for the pack's parameters, and the context's exit issues all of
+# them in a handful of launches (``_hip.linear_wgrad_group``: problem by problem the same arithmetic, bit-identical) and accumulates
+# into ``p.grad`` the way autograd would have.  Large problems (>= WGRAD_DEFER_MAX_ROWS rows) fill the chip by themselves and read
+# their dy while it is still warm in the cache: they stay immediate.
+WGRAD_DEFER_MAX_ROWS = int(os.environ.get("VSDE_WGRAD_DEFER_MAX_ROWS", "65536"))   # 0: never defer
+_wgrad_queue: Optional[list] = None
+
+
+class deferred_weight_grads:
+    def __enter__(self):
+        global _wgrad_queue
+        self.outer, _wgrad_queue = _wgrad_queue, []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _wgrad_queue
+        queue, _wgrad_queue = _wgrad_queue, self.outer
+        if exc_type is None and queue:
+            _flush_weight_grads(queue)
+        return False
+
+
+@torch.no_grad()
+def _flush_weight_grads(queue: list) -> None:
+    results = _hip.linear_wgrad_group([q[:5] for q in queue])
+    for (dy, x, want_bias, row_map, out_rows, pack, mapped), (dW, db) in zip(queue, results):
+        for prm, g in zip(pack.params, pack.split_grads(dW, db, mapped=mapped)):
+            if g is None or not prm.requires_grad:
+                continue
+            if g.dtype != prm.dtype:
+                g = g.to(prm.dtype)
+            if prm.grad is None:
+                prm.grad = g if g.is_contiguous() else g.contiguous()   # (autograd copies a strided gradient the same way)
+            else:
+                prm.grad.add_(g)
+
+
+def _pack_weight_grads(dy: Tensor, x: Tensor, pack: "PackedWeight", row_map: Optional[Tensor] = None, out_rows: Optional[int] = None) -> list:
+    """Gradients of ``pack.params`` for y = x W^T + b with W = the pack: a list for the backward's return value (all ``None`` when
+    the product was queued for the end of the backward pass)."""
+    want_bias, mapped = pack.bias is not None, row_map is not None
+    if _wgrad_queue is not None and 0 < dy.shape[0] < WGRAD_DEFER_MAX_ROWS:
+        _wgrad_queue.append((dy, x, want_bias, row_map, out_rows, pack, mapped))
+        return [None] * len(pack.params)
+    dW, db = _hip.linear_wgrad(dy, x, want_bias, row_map, out_rows)
+    return pack.split_grads(dW, db, mapped=mapped)
+
+
 class _PackedLinear(torch.autograd.Function):
     """y = x W^T + b with a ``PackedWeight``: forward and input gradient on the MFMA GEMM kernels of csrc/vsde_linear.hip
     where the shape is covered (hipBLASLt otherwise), HIP weight-gradient kernel, gradients returned per parameter piece."""
@@ -667,8 +718,7 @@ class _PackedLinear(torch.autograd.Function):
             dx = _hip.linear_bf16(dy2, pack.transposed(), None).reshape(x.shape)   # dx = dy W as an x W^T product with W^T
         else:
             dx = (dy2 @ wb).reshape(x.shape)
-        dW, db = _hip.linear_wgrad(dy2, x2, pack.bias is not None)
-        return (dx, None, *pack.split_grads(dW, db))
+        return (dx, None, *_pack_weight_grads(dy2, x2, pack))
 
 
 def packed_linear_usable(x: Tensor, rows: int, cols: int) -> bool:
@@ -764,10 +814,9 @@ class _SwiGLUMLP(torch.autograd.Function):
             dx = _hip.linear_bf16(du, pin.transposed(), None)
         else:
             dx = du @ w1
-        dW1, db1 = _hip.linear_wgrad(du, x2, pin.bias is not None, pin.grad_row_map,
-                                     None if pin.grad_rows is None else pin.grad_rows.numel())
-        dW2, db2 = _hip.linear_wgrad(dy2, s_, pout.bias is not None)
-        return (dx.reshape(ctx.xshape), None, None, None, *pin.split_grads(dW1, db1, mapped=pin.grad_row_map is not None), *pout.split_grads(dW2, db2))
+        g1 = _pack_weight_grads(du, x2, pin, pin.grad_row_map, None if pin.grad_rows is None else pin.grad_rows.numel())
+        g2 = _pack_weight_grads(dy2, s_, pout)
+        return (dx.reshape(ctx.xshape), None, None, None, *g1, *g2)
 
 
 def swiglu_mlp_usable(x: Tensor, width: int) -> bool:
@@ -853,8 +902,7 @@ class _AttentionCore(torch.autograd.Function):
                 dattn, delta = _hip.linear_gate_bwd(do2, opack.transposed(), og, glog, dy[:, C3:], N)
             else:
                 dattn, delta = _hip.gate_bwd_delta((do2 @ wo).view(shape), og, glog, dy[:, C3:])
-            dWo, dbo = _hip.linear_wgrad(do2, og.view(M, C), opack.bias is not None)
-            ograds = tuple(opack.split_grads(dWo, dbo))
+            ograds = tuple(_pack_weight_grads(do2, og.view(M, C), opack))
         acc = v0link.value if (v0link is not None and mix) else None
         extra = v0link.take() if (v0link is not None and not mix) else None
         if dv_out is not None:   # the values were consumed outside the link protocol (a direct use of the returned tensor)
@@ -870,8 +918,7 @@ class _AttentionCore(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (_hip.linear_bf16(dy, pack.transposed(), None) if own_gemm(M, wb.shape[1], wb.shape[0]) else dy @ wb).view(B, N, K)
-        dW, db = _hip.linear_wgrad(dy, x2.contiguous(), pack.bias is not None)
-        return (dx, None, None, None, None, None, None, dv0, dlam, None, None, None, None, *pack.split_grads(dW, db), *ograds)
+        return (dx, None, None, None, None, None, None, dv0, dlam, None, None, None, None, *_pack_weight_grads(dy, x2.contiguous(), pack), *ograds)
 
 
 def attention_core_usable(x: Tensor, pack: "PackedWeight", heads: int, d: int, wq: Tensor, wk: Tensor, cos: Tensor) -> bool:
