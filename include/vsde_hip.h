@@ -255,7 +255,7 @@ int vsde_linear_wgrad_bf16(const void *dy, const void *x, int64_t M, int N, int 
 int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_t M, int N, int K, float *dW, float *db,
                                 const int32_t *row_map, void *workspace, size_t workspace_bytes, void *stream);
 /* Several weight gradients in (at most) two launches per tile width plus their reductions instead of one pair per problem:
- * item i is exactly one vsde_linear_wgrad_bf16_rows call (same plan, same fixed-order sums: bit-identical results).  At a few
+ * item i is exactly one vsde_linear_wgrad_bf16_rows call (with group_plan = 0: same plan, same fixed-order sums, bit-identical).  At a few
  * thousand rows every such problem is a ~20 us kernel that cannot fill the chip alone (the OU example: 25 per optimizer step);
  * the trainer collects the encoder's weight gradients of one backward pass and issues them together. */
 typedef struct VsdeWgradItem {
@@ -266,7 +266,9 @@ typedef struct VsdeWgradItem {
     const int32_t *row_map;  /* device int32 [N] or NULL (identity) */
 } VsdeWgradItem;
 size_t vsde_linear_wgrad_group_workspace_bytes(int n, const void *items /* VsdeWgradItem[n], host */);
-int vsde_linear_wgrad_group_bf16(int n, const void *items, void *workspace, size_t workspace_bytes, void *stream);
+/* group_plan != 0: split counts chosen for the group as a whole (fewer, longer workgroups per problem: less partial-tile traffic);
+ * the fixed-order sums then differ in order from a single launch's -- deterministic, but not bit-identical to it. */
+int vsde_linear_wgrad_group_bf16(int n, const void *items, int group_plan, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Dense contractions of the encoder on bf16 MFMA ----------------------------------------------------------------
  * y[M][N] = x[M][K] w[N][K]^T + bias[N]   (x, w, bias, y bf16; fp32 accumulation).  Replaces the hipBLASLt GEMMs behind

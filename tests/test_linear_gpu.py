@@ -182,7 +182,14 @@ def test_grouped_weight_gradients_are_bit_identical_to_single_launches():
         problems.append((dy, x, bias, row_map, rows))
         expect.append(_hip.linear_wgrad(dy, x, bias, row_map, rows))
     got = _hip.linear_wgrad_group(problems)
+    planned = _hip.linear_wgrad_group(problems, group_plan=True)   # split counts chosen for the group: another summation order
     torch.cuda.synchronize()
+    for i, ((dW, db), (eW, eb)) in enumerate(zip(planned, expect)):
+        sel = slice(None) if problems[i][3] is None else problems[i][3][problems[i][3] >= 0].long()
+        scale = float(eW[sel].abs().max()) + 1e-30
+        assert float((dW[sel] - eW[sel]).abs().max()) <= 2e-5 * scale, (i, shapes[i])
+        if eb is not None:
+            assert float((db[sel] - eb[sel]).abs().max()) <= 2e-5 * (float(eb[sel].abs().max()) + 1e-30), (i, shapes[i])
     for i, ((dW, db), (eW, eb)) in enumerate(zip(got, expect)):
         if problems[i][3] is not None:   # dropped rows are not written by either path: compare the mapped rows only
             keep = problems[i][3][problems[i][3] >= 0].long()

@@ -726,9 +726,10 @@ class _WgradItem(ctypes.Structure):
                 ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("row_map", ctypes.c_void_p)]
 
 
-def linear_wgrad_group(problems):
-    """``[(dy, x, want_bias, row_map, out_rows), ...]`` -> ``[(dW, db), ...]``: every problem exactly as ``linear_wgrad`` computes it
-    (bit-identical), all of them in a handful of launches (csrc/vsde_wgrad.hip, ``vsde_linear_wgrad_group_bf16``)."""
+def linear_wgrad_group(problems, group_plan: bool = False):
+    """``[(dy, x, want_bias, row_map, out_rows), ...]`` -> ``[(dW, db), ...]``: every problem as ``linear_wgrad`` computes it, all of
+    them in a handful of launches (csrc/vsde_wgrad.hip, ``vsde_linear_wgrad_group_bf16``).  ``group_plan=False``: bit-identical to
+    one call per problem; ``True``: split counts chosen for the group as a whole (other summation order, less partial traffic)."""
     lib = load()
     dev = _require_hip(*[t for pr in problems for t in pr[:2]])
     n = len(problems)
@@ -746,7 +747,8 @@ def linear_wgrad_group(problems):
     nbytes = lib.vsde_linear_wgrad_group_workspace_bytes(ctypes.c_int(n), ctypes.byref(items))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
-        _call(lib.vsde_linear_wgrad_group_bf16, ctypes.c_int(n), ctypes.byref(items), _ptr(ws), ctypes.c_size_t(nbytes), _stream(dev))
+        _call(lib.vsde_linear_wgrad_group_bf16, ctypes.c_int(n), ctypes.byref(items), ctypes.c_int(1 if group_plan else 0), _ptr(ws),
+              ctypes.c_size_t(nbytes), _stream(dev))
     return outs
 
 

@@ -381,13 +381,30 @@ extern "C" size_t vsde_linear_wgrad_group_workspace_bytes(int n, const void *ite
 
 // dW_i = dy_i^T x_i, db_i = colsum(dy_i) for n problems in (at most) two launches per tile width (+ their reductions) instead of n;
 // same arithmetic as vsde_linear_wgrad_bf16_rows problem by problem (same plan, same fixed-order sums: identical results)
-extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, int group_plan, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace vsde;
     const VsdeWgradItemC *items = (const VsdeWgradItemC *)items_;
     VSDE_CHECK_ARG(n > 0 && items && workspace, VSDE_E_BADARG, "bad linear_wgrad_group arguments");
     VSDE_CHECK_ARG(workspace_bytes >= vsde_linear_wgrad_group_workspace_bytes(n, items_), VSDE_E_WORKSPACE, "linear_wgrad_group workspace too small");
     char *ws = (char *)workspace;
+    // group_plan: a problem's split count only has to fill the chip TOGETHER with the others -- about 3.5 rounds of resident
+    // workgroups over all tiles of its tile-width class (every workgroup costs ~8 us of prologue / partial-tile write whatever its
+    // share of the rows, and the reduction reads tiles x splits x 263 KB).  Never more splits than the problem's own plan (the
+    // workspace is sized for that).  The sums are then taken in a different order than a single launch takes them.
+    int64_t class_tiles[2] = {0, 0};
+    if (group_plan)
+        for (int i = 0; i < n; ++i) {
+            Wgrad2Params p;
+            wgrad2_plan(items[i].M, items[i].N, items[i].K, p);
+            class_tiles[p.tn == 256] += p.tiles;
+        }
     for (int tn = 128; tn <= 256; tn += 128) {
+        int64_t cap = 1 << 30;
+        if (group_plan && class_tiles[tn == 256] > 0) {
+            const int resident = tn == 256 ? 256 : 512;
+            cap = ((int64_t)(3.5 * resident / (double)class_tiles[tn == 256]) + 4) & ~(int64_t)7;
+            if (cap < 8) cap = 8;
+        }
         Wgrad2Group G;
         G.n = 0; G.first[0] = 0; G.tile0[0] = 0;
         char *w = ws;
@@ -402,6 +419,7 @@ extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, void *wor
                 wgrad2_plan(it.M, it.N, it.K, p);
                 bytes = (wgrad2_workspace(p) + 255) & ~(size_t)255;
                 if (p.tn == tn) {
+                    if (p.nsplit > cap) p.nsplit = (int)cap;
                     p.dy = (const uint16_t *)it.dy; p.x = (const uint16_t *)it.x; p.partial = (float *)w; p.dW = it.dW; p.db = it.db; p.row_map = it.row_map;
                     G.g[G.n] = p;
                     G.first[G.n + 1] = G.first[G.n] + ((p.nsplit + 7) / 8) * 8 * p.tiles;

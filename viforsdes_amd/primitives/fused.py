@@ -670,7 +670,7 @@ class deferred_weight_grads:
 
 @torch.no_grad()
 def _flush_weight_grads(queue: list) -> None:
-    results = _hip.linear_wgrad_group([q[:5] for q in queue])
+    results = _hip.linear_wgrad_group([q[:5] for q in queue], group_plan=True)
     for (dy, x, want_bias, row_map, out_rows, pack, mapped), (dW, db) in zip(queue, results):
         for prm, g in zip(pack.params, pack.split_grads(dW, db, mapped=mapped)):
             if g is None or not prm.requires_grad:
