@@ -109,17 +109,34 @@ __global__ void __launch_bounds__(OPT_THREADS) optim_update_kernel(OptParams q) 
     const float step_size = (float)(lr / (double)bc1);
     const float inv = q.scale ? (float)(1.0 / (double)q.scale[0]) : 1.0f;
     const float *g = q.grads[c.param] + c.goff;
-    for (int i = threadIdx.x; i < c.n; i += OPT_THREADS) {
-        float grad = g[i] * inv;     // unscale_ ...
+    auto adam = [&](float grad, float &p, float &m, float &v, float &sh) {
+        grad *= inv;                 // unscale_ ...
         grad *= clip;                // ... clip_grad_norm_ (always multiplies, by 1 when the norm is small)
-        float p = c.p[i], m = c.m[i], v = c.v[i];
         p = (float)((double)p - lr * wd * (double)p);
         m = (float)((double)m + (1.0 - beta1) * (double)(grad - m));          // lerp(exp_avg, grad, 1 - beta1), weight < 0.5
         v = (float)(beta2 * (double)v + (1.0 - beta2) * (double)grad * (double)grad);
         const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + eps);
         p -= step_size * m / denom;
+        if (ema) sh = sh + q.ema_weight * (p - sh);                            // torch.lerp, scalar weight < 0.5
+    };
+    // four elements per thread and trip (16-byte accesses, all of a trip's loads in flight together); parameter / moment / shadow
+    // chunks start on 16-byte boundaries, a gradient may be an arbitrary view: scalar trips then
+    const bool vec = ((((uintptr_t)g) | ((uintptr_t)c.p) | ((uintptr_t)c.m) | ((uintptr_t)c.v) | (ema ? (uintptr_t)c.ema : 0)) & 15) == 0;
+    const int nvec = vec ? (c.n & ~3) : 0;
+    for (int i = threadIdx.x * 4; i < nvec; i += OPT_THREADS * 4) {
+        const float4 g4 = *(const float4 *)(g + i);
+        float4 p4 = *(const float4 *)(c.p + i), m4 = *(const float4 *)(c.m + i), v4 = *(const float4 *)(c.v + i);
+        float4 s4 = ema ? *(const float4 *)(c.ema + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam(g4.x, p4.x, m4.x, v4.x, s4.x); adam(g4.y, p4.y, m4.y, v4.y, s4.y);
+        adam(g4.z, p4.z, m4.z, v4.z, s4.z); adam(g4.w, p4.w, m4.w, v4.w, s4.w);
+        *(float4 *)(c.p + i) = p4; *(float4 *)(c.m + i) = m4; *(float4 *)(c.v + i) = v4;
+        if (ema) *(float4 *)(c.ema + i) = s4;
+    }
+    for (int i = nvec + threadIdx.x; i < c.n; i += OPT_THREADS) {
+        float p = c.p[i], m = c.m[i], v = c.v[i], sh = ema ? c.ema[i] : 0.f;
+        adam(g[i], p, m, v, sh);
         c.p[i] = p; c.m[i] = m; c.v[i] = v;
-        if (ema) { const float sh = c.ema[i]; c.ema[i] = sh + q.ema_weight * (p - sh); }   // torch.lerp, scalar weight < 0.5
+        if (ema) c.ema[i] = sh;
     }
 }
 

@@ -694,6 +694,20 @@ def _pack_weight_grads(dy: Tensor, x: Tensor, pack: "PackedWeight", row_map: Opt
     return pack.split_grads(dW, db, mapped=mapped)
 
 
+class _LinearParams:
+    """What ``_flush_weight_grads`` needs of a plain (unpacked) Linear: its parameters and how the product maps to them."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor]):
+        self.params = [weight] if bias is None else [weight, bias]
+        self.bias = bias
+
+    def leaf(self) -> bool:   # gradients can only be written to ``.grad`` of leaves: anything else takes the immediate path
+        return all(q.is_leaf and q.requires_grad for q in self.params)
+
+    def split_grads(self, dW: Tensor, db: Optional[Tensor], mapped: bool = False) -> list:
+        return [dW] if self.bias is None else [dW, db]
+
+
 class _PackedLinear(torch.autograd.Function):
     """y = x W^T + b with a ``PackedWeight``: forward and input gradient on the MFMA GEMM kernels of csrc/vsde_linear.hip
     where the shape is covered (hipBLASLt otherwise), HIP weight-gradient kernel, gradients returned per parameter piece."""
@@ -741,6 +755,7 @@ class _Linear(torch.autograd.Function):
         y = torch.nn.functional.linear(x, wb, None if bias is None else bias.to(torch.bfloat16))
         ctx.save_for_backward(x, wb)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        ctx.owner = _LinearParams(weight, bias)
         return y
 
     @staticmethod
@@ -751,6 +766,10 @@ class _Linear(torch.autograd.Function):
         dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         dx = (dy2 @ wb).reshape(x.shape)
+        own = ctx.owner
+        if (_wgrad_queue is not None and 0 < dy2.shape[0] < WGRAD_DEFER_MAX_ROWS and own.leaf()):
+            _wgrad_queue.append((dy2, x2, bdtype is not None, None, None, own, False))   # issued with the others at the end of the pass
+            return dx, None, None
         dW, db = _hip.linear_wgrad(dy2, x2, bdtype is not None)
         return dx, dW.to(wdtype), None if db is None else db.to(bdtype)
 
