@@ -167,10 +167,13 @@ __global__ void __launch_bounds__(256) ln_mod_fwd_kernel(const T *__restrict__ x
 // the channel sums in registers; the token slots are combined through LDS and each block stores one fp32 partial
 // row part[k][b][chunk][C].  colsum_finish_kernel adds the nchunk partials in a fixed order (deterministic).
 constexpr int kColsumChunksMax = 64;
-// token chunks per batch row: ~2048 workgroups in total (per-workgroup prologue/epilogue is the overhead that grows
+// token chunks per batch row: ~768 workgroups in total, at least four per row (per-workgroup prologue/epilogue is the overhead that grows
 // with the chunk count: 4 chunks beat 8 by 5 % and 32 by 2x at B = 512), at least 8 tokens per chunk
 static int colsum_chunks(int64_t B, int N) {
-    int64_t c = (2048 + B - 1) / B;
+    static int force = -1;   // VSDE_COLSUM_CHUNKS: token chunks per batch row (A/B runs)
+    if (force < 0) { const char *e = getenv("VSDE_COLSUM_CHUNKS"); force = e ? atoi(e) : 0; }
+    if (force > 0) return force > kColsumChunksMax ? kColsumChunksMax : (force > N ? (N > 0 ? N : 1) : force);
+    int64_t c = (768 + B - 1) / B;   // ~768 workgroups (B = 128, 101 tokens: 12 | 8 | 6 | 4 | 2 chunks = 3.73 | 3.59 | 3.57 | 3.58 | 3.62 ms per OU step)
     if (c < 4) c = 4;
     if (c > kColsumChunksMax) c = kColsumChunksMax;
     if (c > N / 8) c = N / 8 > 0 ? N / 8 : 1;
