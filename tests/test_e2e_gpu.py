@@ -405,3 +405,35 @@ def test_full_depth_synthetic_step_properties():
     torch.cuda.empty_cache()
     _, elbos2 = run()
     assert elbos == elbos2, (elbos, elbos2)
+
+
+def test_deferred_weight_gradients_match_the_immediate_ones(monkeypatch):
+    """The trainer collects the encoder's small weight-gradient products over its backward pass and issues them in grouped launches
+    (primitives/fused.py::deferred_weight_grads).  One forward / backward from identical seeds and noise with the deferral switched
+    off: every parameter gradient must agree (the grouped launch takes its fixed-order sums with other split counts: ~1e-6
+    relative), nothing may be missing, and gradients of a second pass without zeroing must accumulate."""
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(5)
+    B, T, P = 256, 100, 3
+    teps, noise = torch.randn(B, P, generator=g).to(DEV), torch.randn(B, T, 1, generator=g).to(DEV)
+
+    def grads(defer_rows, twice=False):
+        monkeypatch.setattr(fused, "WGRAD_DEFER_MAX_ROWS", defer_rows)
+        tr = _small_ou_trainer(seed=21, batch=B)
+        tr._forward_backward(tr.ctx.model, theta_eps=teps, path_noise=noise)
+        if twice:   # a second pass on top (no zero_grad): the flush has to add to the existing gradients
+            keep = {n: p.grad.clone() for n, p in tr.ctx.model.named_parameters() if p.grad is not None}
+            tr.ctx.grad_sync.zero_grad = lambda: None
+            tr._forward_backward(tr.ctx.model, theta_eps=teps, path_noise=noise)
+            return {n: (p.grad.float().cpu().numpy(), keep[n].float().cpu().numpy()) for n, p in tr.ctx.model.named_parameters() if p.grad is not None}
+        return {n: p.grad.float().cpu().numpy() for n, p in tr.ctx.model.named_parameters() if p.grad is not None}
+
+    now, later = grads(0), grads(65536)
+    assert set(now) == set(later) and len(now) > 20
+    for n in now:
+        scale = np.abs(now[n]).max() + 1e-30
+        assert np.abs(later[n] - now[n]).max() <= 2e-3 * scale, (n, np.abs(later[n] - now[n]).max() / scale)   # bf16 activations upstream: identical inputs, fp32 sums
+    both = grads(65536, twice=True)
+    for n, (total, first) in both.items():
+        scale = np.abs(first).max() + 1e-30
+        assert np.abs(total - 2.0 * first).max() <= 2e-3 * 2 * scale, n
