@@ -335,7 +335,13 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
         if (!outs[k]) continue;
         const float *p = part + ((int64_t)k * (BC / C) + b) * nchunk * C + c;
         float t = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) t += p[(int64_t)ch * C];
+        for (int ch0 = 0; ch0 < nchunk; ch0 += 8) {   // eight loads in flight, added in the fixed order (a serial chain of loads took ~0.5 us each)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ch0 + j < nchunk ? p[(int64_t)(ch0 + j) * C] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (ch0 + j < nchunk) t += v[j];
+        }
         outs[k][b * mp + c] = from_f32<T>(t);
     }
 }
