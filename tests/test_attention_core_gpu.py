@@ -71,6 +71,8 @@ def _run(att, x, rot, v0, go, gv, mode):
                                         # 13 blocks: the ragged one shared by four waves (1, 18 valid rows); 19 and 32 rows: its partial
                                         # tiles no longer fit beside the dk / dv operands (dq shared, dk / dv second round)
                                         (12, 385, None), (12, 402, None), (12, 403, None), (12, 416, None),
+                                        # N <= 128: four-wave attention workgroups (the limit, one block, and the first 12-wave size)
+                                        (40, 128, None), (140, 31, None), (36, 129, None),
                                         (176, 401, None),
                                         (512, 401, None)])   # the LV benchmark's own shape (205,312 rows)
 def test_fused_core_matches_the_separate_passes_and_the_fp32_chain(residual_v, value_grad, B, N, wscale):
