@@ -934,6 +934,32 @@ __device__ __forceinline__ void norm_rows_request(const QkBwd &f, NormRowsIn &in
     }
 }
 
+// The y^ rows of a wave's OWN block are the B-operand fragments it has held since before the tile loop (lane (fr, h2): channels
+// 16 ks + 8 h2 .. of token fr): through 4 KB of the wave's staging slice into the row layout of the staged epilogue -- instead of
+// reading the rows from global memory once more (105 MB per launch, and in the dk/dv kernel a latency in front of the key epilogue).
+// Only the inverse RMS still comes from memory (requested before the workgroup barrier).
+template <int KIND>
+__device__ __forceinline__ void norm_rinv_request(const QkBwd &f, NormRowsIn &in, int64_t m0, int tok0, int N, int hh, int H, int lane) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int tok = tok0 + pass * 8 + (lane >> 3), tc = tok < N ? tok : N - 1;
+        in.rr[pass] = f.rinv[(m0 + tc) * (2 * H) + KIND * H + hh];
+    }
+}
+__device__ __forceinline__ void norm_rows_from_frags(NormRowsIn &in, uint16_t *rows, const bf16x8 (&yf)[4], int lane) {
+    const int fr = lane & 31, h2 = lane >> 5, c = lane & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) *(uint4 *)(rows + fr * AT_D + (2 * ks + h2) * 8) = *(const uint4 *)&yf[ks];
+    wave_lds_fence();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const uint16_t *row = rows + (pass * 8 + (lane >> 3)) * AT_D;
+        in.y[pass] = *(const uint4 *)(row + 8 * c);
+        in.yp[pass] = *(const uint4 *)(row + 8 * (c ^ 4));
+    }
+    wave_lds_fence();   // (read before the slice is overwritten with the gradient tile)
+}
+
 __device__ __forceinline__ void value_rows_request(const QkBwd &f, ValueRowsIn &in, int64_t m0, int tok0, int N, int hh, int H, int lane) {
     const int c = lane & 7;
     const bool mix = f.vdiff != nullptr, acc = mix && f.dv0_accumulate, ext = f.dv_extra != nullptr;
@@ -1156,6 +1182,9 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdPara
     }
     const int nblk = split ? NWV : p.ntile;
     int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
+    bf16x8 ykeep[4];   // ONE: the q^ fragments of that block (the epilogue's y^ rows)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ykeep[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int qblk = wave; qblk < nblk; qblk += NWV) {
         if (qblk != wave) request(qblk);  // later rounds are rare with 12 waves (N <= 384 needs none): fetch on demand
         const int query = qblk * 32 + fr;
@@ -1180,8 +1209,11 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdPara
         sweep(qf, dof, lse2, dsum, 0, p.ntile);
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (loop-invariant: hoisted, they spill)
-            if constexpr (ONE) last = qblk;
-            else if (qblk + NWV >= nblk && !(p.f.dbg & 8)) last = qblk;
+            if constexpr (ONE) {
+                last = qblk;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ykeep[ks] = qf[ks];
+            } else if (qblk + NWV >= nblk && !(p.f.dbg & 8)) last = qblk;
             else if (p.f.dbg & 4) { if (qok) store_transposed(p.f.dy + ((int64_t)b * N + query) * p.f.ldy + hh * 64, h2, acc0, acc1, p.scale); }
             else norm_rope_bwd_store<0>(p.f, acc0, acc1, p.scale, qf, (int64_t)b * N + query, query, hh, p.H, lane, qok);
         }
@@ -1191,11 +1223,15 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdPara
         NormRowsIn in;
         const bool finisher = split && wave == 4;   // sums the ragged block's partial tiles and runs its epilogue (waves 0..3 had the extra tiles)
         if constexpr (!ONE) { if (p.f.dbg & 64) last = -1; }
-        if (last >= 0) norm_rows_request<0>(p.f, in, p.q + base, ts, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        if (last >= 0) {
+            if constexpr (ONE) norm_rinv_request<0>(p.f, in, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+            else norm_rows_request<0>(p.f, in, p.q + base, ts, (int64_t)b * N, last * 32, N, hh, p.H, lane);
+        }
         if (finisher) norm_rows_touch<0>(p.f, p.q + base, ts, (int64_t)b * N, NWV * 32, N, hh, p.H, lane);
         __syncthreads();   // every wave is done with K / V: their space becomes the waves' staging slices
         float *slice = (float *)asmem + wave * AT_ESLICE;
         if (last >= 0) {
+            if constexpr (ONE) norm_rows_from_frags(in, (uint16_t *)slice, ykeep, lane);
             stage_acc_tile(slice, acc0, acc1, p.scale, lane);
             wave_lds_fence();
             staged_norm_rope_bwd<0>(p.f, slice, in, (int64_t)b * N, last * 32, N, hh, p.H, lane);
@@ -1292,6 +1328,9 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdPar
     const int nblk = split ? NWV : p.ntile;
     int last = -1;   // FUSED: the wave's last round, whose epilogue goes through LDS after the workgroup barrier below
     int parked = -1; // FUSED: the wave's first round when a second one follows and spare LDS can hold its tiles
+    bf16x8 ykeep[4];   // ONE: the k^ fragments of the wave's block (the key epilogue's y^ rows)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ykeep[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int kblk = wave; kblk < nblk; kblk += NWV) {
         if (kblk != wave) request(kblk);
         const int key = kblk * 32 + fr;
@@ -1304,7 +1343,12 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdPar
         sweep(kf, vf, 0, p.ntile);
         if constexpr (FUSED) {
             asm volatile("" ::: "memory");   // keep the epilogue's table loads out of the tile loop (they are loop-invariant: hoisted, they spill)
-            if constexpr (ONE) { last = kblk; continue; }
+            if constexpr (ONE) {
+                last = kblk;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ykeep[ks] = kf[ks];
+                continue;
+            }
             if (kblk + NWV >= nblk && !(p.f.dbg & 8)) { last = kblk; continue; }
             if (p.park_off != 0 && kblk < NWV && !(p.f.dbg & 8)) {
                 // a wave with one more round to go (the 13th block at N = 401): its epilogue would sit between its two rounds,
@@ -1343,7 +1387,7 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdPar
             value_rows_request(p.f, vin, m0, last * 32, N, hh, p.H, lane_e);
             // the key rows are only touched here (cache) and requested once the value epilogue has freed its registers: four
             // accumulator tiles + both row sets + an epilogue's temporaries do not fit the register file
-            if constexpr (ONE) norm_rows_touch<1>(p.f, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
+            if constexpr (ONE) norm_rinv_request<1>(p.f, kin, m0, last * 32, N, hh, p.H, lane_e);   // (the rows come from the fragments)
             else norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_e);
         }
         // the ragged block is finished by two waves that had no extra tiles: wave 4 its values, wave 5 its keys
@@ -1375,8 +1419,8 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdPar
             }
             int lane_k = lane_e;   // opaque: the key epilogue's addresses are computed after the value loop, not spilled around it
             asm volatile("" : "+v"(lane_k));
+            if constexpr (ONE) norm_rows_from_frags(kin, (uint16_t *)slice, ykeep, lane_k);
             stage_acc_tile(slice, dk0, dk1, p.scale, lane_k);
-            if constexpr (ONE) norm_rows_request<1>(p.f, kin, p.k + base, ts, m0, last * 32, N, hh, p.H, lane_k);
             wave_lds_fence();
             if (ONE || !(p.f.dbg & 16)) staged_norm_rope_bwd<1>(p.f, slice, kin, m0, last * 32, N, hh, p.H, lane_k);
             if (split && wave_e == 5) {   // keys of the ragged block
