@@ -182,7 +182,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = wn + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * fh, col = wk + 32 * b + fr;
-                out[row * W2_TK + col] = acc[a][b][e];
+                if (n_blk + wn + 32 * a < p.N) out[row * W2_TK + col] = acc[a][b][e];   // (whole 32-row blocks past N: never read back)
             }
     if (want_bias) {   // YR threads share a column chunk
 #pragma unroll
@@ -242,6 +242,7 @@ __device__ __forceinline__ void wgrad_tr_reduce_body(const Wgrad2Params &p, cons
     const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = (blockIdx.x * 64 + col) * 4;
     const int n = n_blk + e / W2_TK, k = k_blk + e % W2_TK;
+    if (n >= p.N) return;   // a workgroup is one output row (64 columns x 4 = W2_TK): rows past N of the last tile are not summed at all
     float4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
