@@ -166,6 +166,13 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // hidden state in B-fragment order: [step parity][layer][plane][k-step][lane group][column] x 8 f16 (NP < 16: one plane, the hi parts
     // in columns [0, NP), the lo' parts in [NP, 2 NP), the rest zero)
     __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][PL][2][4][16];
+    // Training launch, two layers: the layer-1 role does not store its saved-activation records itself -- five 16-byte stores per lane
+    // and step cost ~250 issue cycles in its short slack (VSDE_MP_FWD_ABL=2: 30 us of 510).  It leaves them in LDS ([step parity]
+    // [path][5][64] fp32: five ds_write_b128) and the layer-0 waves, which have the longer slack, copy the previous step's record out
+    // as whole 16-byte lanes of consecutive addresses (one or two instructions per wave) behind their barrier A.
+    constexpr bool STASH = SAVE && L > 1;
+    constexpr int SREC = STASH ? NP * 320 : 4;            // floats per record (all paths of the group)
+    __shared__ __attribute__((aligned(16))) float srec[2][SREC];
     const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
     const int b_raw = blockIdx.x * NP + (pp & (NP - 1));
     const bool owner = pp < NP;                    // NP < 16: lanes of the other columns run along and store nothing
@@ -268,10 +275,18 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 for (int r = 0; r < 4; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
                 gates(ar, au, an, c1, bn1, h1, rg, ug, ng, cn, t, L - 1);
                 barrier();                             // B: h^1_t published
-                save_acts(h1, rg, ug, ng, cn, t, L - 1);   // first thing in the slack: the vector-memory pipe drains them behind the product
+                if (STASH && owner && !(p.abl & 2)) {      // the record of step t for the layer-0 waves (copied out behind barrier A of step t + 1)
+                    float *rec = &srec[t & 1][0] + pp * 320 + j0;
+                    *(f32x4 *)(rec) = f32x4{h1[0], h1[1], h1[2], h1[3]};
+                    *(f32x4 *)(rec + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
+                    *(f32x4 *)(rec + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
+                    *(f32x4 *)(rec + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
+                    *(f32x4 *)(rec + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
+                }
                 read_state(t, L - 1, hb);
                 mp_matmul<NP>(wh, hb, c1);             // W_hh^1 h^1_t: consumed by step t + 1
             }
+            if (STASH) barrier();                      // the last record is complete: the layer-0 waves copy it out
         }
         return;
     }
@@ -356,6 +371,20 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         }
     };
 
+    // layer 1's record of step t: NP x 80 float4, lane = consecutive addresses (path f / 80, offset f % 80)
+    auto copy_l1_record = [&](int t) {
+        if (STASH && !(p.abl & 2)) {
+            constexpr int NF = NP * 80;
+            const f32x4 *src = (const f32x4 *)&srec[t & 1][0];
+#pragma unroll
+            for (int k = 0; k < (NF + 255) / 256; ++k) {
+                const int f = k * 256 + w * 64 + lane;
+                const int path = f / 80, off = f - path * 80;
+                const int bb = blockIdx.x * NP + path;
+                if (f < NF && bb < p.B) *(f32x4 *)(p.acts + (((int64_t)bb * T + t) * L + (L - 1)) * 320 + off * 4) = src[f];
+            }
+        }
+    };
     for (int t = 0; t < T; ++t) {
         f32x4 g0 = gq[0], g1 = gq[1], g2 = gq[2];
         float e[S];
@@ -379,7 +408,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         if (L > 1) {
             mp_matmul<NP>(wf, hb, c0);                 // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
             save_acts(h0, rg, ug, ng, cn, t, 0);
-            if (t > 0) store_outputs(t - 1);
+            if (t > 0) { store_outputs(t - 1); copy_l1_record(t - 1); }
             __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs are not ordered by the barrier's "memory" clobber)
             barrier();                                 // B: h^1_t published
             read_state(t, L - 1, hb);
@@ -435,6 +464,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 #pragma unroll
         for (int r = 0; r < NTRIL; ++r) praw[r] = o[S + r];
     }
+    if (STASH) { barrier(); copy_l1_record(T - 1); }
     store_outputs(T - 1);
 }
 
