@@ -192,7 +192,8 @@ def parity_gate(problem, enc, device, batch=16, steps=3, name="LV", force_mp=0):
         _hip.debug_head_mp(force_mp)
         res["head_kernels"] = f"multi-path MFMA forward + backward, {force_mp} paths per workgroup (forced: as in the timed step's forward)"
     else:
-        res["head_kernels"] = "dispatcher default at this batch size (four waves per path)"
+        res["head_kernels"] = ("dispatcher default at this batch size (training forward: multi-path MFMA kernel from 96 paths on, "
+                               "four waves per path below; reverse-time sweep: four waves per path)")
     rel = lambda a, b: max(abs(x - y) / max(abs(y), 1e-12) for x, y in zip(a, b))
     # bf16: measured 4e-4 / 4e-6 (LV) and 1.1e-3 / 2.6e-4 (OU); the round-3 stale-operand defect was 6.6e-3 on LV, 1.3e-1 on OU
     tols = {"fp32": (2e-3, 1e-3), "bf16": (5e-3, 2e-3)}

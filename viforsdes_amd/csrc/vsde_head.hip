@@ -1563,11 +1563,11 @@ static int mp_env() {
     return mode;
 }
 static bool mp_auto(const vsde_head_dims *d, int save) {
-    // Measured at the LV head dims (profiles/r04_head_mp.txt; us, training / no-grad launch): up to 256 paths the v2 kernel has one
-    // path per CU and wins (502 / 425 vs 550 / 466); from 2 paths per CU on the multi-path kernel does (512 paths: 663 / 548 vs
-    // 550 / 464; 4096 paths: 4705 / 3793 vs 1366 / 583).
-    (void)save;
-    return d->B > 256;
+    // Measured at the LV head dims (profiles/r04_head_mp.txt; us, training / no-grad launch, v2 vs multi-path): 128 paths 508 / 426 vs
+    // 461 / 441, 256 paths 535 / 440 vs 462 / 441, 512 paths 676 / 549 vs 492 / 445, 4096 paths 4709 / 3967 vs 1104 / 591.  The
+    // no-grad launch of the v2 kernel (one path per CU up to 256 paths) keeps its edge there; the training launch does not since the
+    // layer-1 role's records leave through LDS.
+    return save ? d->B >= 96 : d->B > 256;
 }
 static bool use_mp(const vsde_head_dims *d, int save) {
     if (!mp_applicable(d->H, d->L, d->S)) return false;
