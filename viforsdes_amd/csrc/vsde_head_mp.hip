@@ -171,7 +171,9 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // [path][5][64] fp32: five ds_write_b128) and the layer-0 waves, which have the longer slack, copy the previous step's record out
     // as whole 16-byte lanes of consecutive addresses (one or two instructions per wave) behind their barrier A.
     constexpr bool STASH = SAVE && L > 1;
-    constexpr int SREC = STASH ? NP * 320 : 4;            // floats per record (all paths of the group)
+    constexpr int SPITCH = 324;                           // floats per path: 320 + 4, so that the 8-lane groups of a ds_write_b128 (paths
+                                                          // 0..7 of one row group) fall on different banks (320 = 0 mod 32: 4-way conflicts)
+    constexpr int SREC = STASH ? NP * SPITCH : 4;         // floats per record (all paths of the group)
     __shared__ __attribute__((aligned(16))) float srec[2][SREC];
     const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
     const int b_raw = blockIdx.x * NP + (pp & (NP - 1));
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 gates(ar, au, an, c1, bn1, h1, rg, ug, ng, cn, t, L - 1);
                 barrier();                             // B: h^1_t published
                 if (STASH && owner && !(p.abl & 2)) {      // the record of step t for the layer-0 waves (copied out behind barrier A of step t + 1)
-                    float *rec = &srec[t & 1][0] + pp * 320 + j0;
+                    float *rec = &srec[t & 1][0] + pp * SPITCH + j0;
                     *(f32x4 *)(rec) = f32x4{h1[0], h1[1], h1[2], h1[3]};
                     *(f32x4 *)(rec + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
                     *(f32x4 *)(rec + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 const int f = k * 256 + w * 64 + lane;
                 const int path = f / 80, off = f - path * 80;
                 const int bb = blockIdx.x * NP + path;
-                if (f < NF && bb < p.B) *(f32x4 *)(p.acts + (((int64_t)bb * T + t) * L + (L - 1)) * 320 + off * 4) = src[f];
+                if (f < NF && bb < p.B) *(f32x4 *)(p.acts + (((int64_t)bb * T + t) * L + (L - 1)) * 320 + off * 4) = src[path * (SPITCH / 4) + off];
             }
         }
     };
