@@ -11,6 +11,7 @@ Both were made by ``tests/golden/make_golden.py posterior_sample pretrain`` (imp
 replacing ``torch.randn`` with a feeder that hands out persistent buffers per shape: a HIP-graph replay reads the same buffers,
 so the graph-replayed pre-training loop on the GPU sees exactly the recorded draws too."""
 from contextlib import contextmanager
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -219,3 +220,80 @@ def test_pretraining_graph_replay_matches_reference_on_gpu(name):
     iteration undone from the graph's own snapshot) against the reference's eager CPU loop on the same draws."""
     tr = _check_pretrain(name, "cuda", 5e-4)
     assert getattr(tr, "_pretrain_graph", None) is not None, "the pre-training loop did not replay from a HIP graph"
+
+
+# ---------------------------------------------------------------------------------------------- captured sampling call (GPU)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lv", "ou"])
+def test_repeated_sample_replays_a_graph_and_matches_the_eager_call(name):
+    """``sample(n)`` with a repeated ``n`` replays the call as one HIP graph from the second occurrence on: with the generator
+    seeded alike the replay must give what the eager call gives (same kernels, same Philox offsets), the EMA swap must still be
+    undone, new EMA weights must reach the replay (it reads the parameters in place), and two replays must differ (fresh draws)."""
+    from viforsdes_amd.inference import diffusion_path_sampler as dps
+    c = _case(dict(np.load(f"{GOLDEN}/posterior_sample.npz")), name)
+    vp, n, _ = _posterior(c, name, "cuda")
+    live = {k: v.clone() for k, v in vp.model.state_dict().items()}
+    vp.sample(n)                                    # first call of this size: eager
+    vp.sample(n)                                    # second: captured
+    assert vp._captured.get(n) is not None, "capture failed: sample() fell back to the eager call"
+
+    def eager(seed):
+        dps.SAMPLE_GRAPH = False
+        try:
+            torch.manual_seed(seed)
+            return vp.sample(n)
+        finally:
+            dps.SAMPLE_GRAPH = True
+
+    def replay(seed):
+        torch.manual_seed(seed)
+        return vp.sample(n)
+    a, b = eager(11), replay(11)
+    assert torch.allclose(a.sde_parameters, b.sde_parameters, rtol=1e-6, atol=1e-7)
+    assert rel_err(b.diffusion_paths.cpu().numpy(), a.diffusion_paths.cpu().numpy()) < 1e-5
+    b2 = vp.sample(n)                               # no reseed: the next draws
+    assert not torch.equal(b2.diffusion_paths, b.diffusion_paths)
+    for k, v in vp.model.state_dict().items():      # swap undone after a replay as well
+        assert torch.equal(v, live[k]), k
+    # new shadow weights (here: the live ones) must be what the next replay samples with
+    vp.exponential_moving_average.load_state_dict({n_: p.detach().clone() for n_, p in vp.model.named_parameters()})
+    a3, b3 = eager(5), replay(5)
+    assert rel_err(b3.diffusion_paths.cpu().numpy(), a3.diffusion_paths.cpu().numpy()) < 1e-5
+    assert rel_err(b3.diffusion_paths.cpu().numpy(), replay(5).diffusion_paths.cpu().numpy()) < 1e-7
+
+
+@pytest.mark.gpu
+def test_captured_sampler_under_autocast_follows_parameter_changes():
+    """The bench's sampling leg: ``CapturedPathSampler`` under bf16 autocast at the OU benchmark's size (encoder 256 wide: own
+    GEMM kernels reading bf16 operand packs).  A parameter changed between two replays must reach the second one -- the packs
+    are refreshed outside the graph, before the replay."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench import build_trainer
+    from viforsdes_amd.examples.sdes import ou_problem
+    from viforsdes_amd.inference.diffusion_path_sampler import CapturedPathSampler, sample_diffusion_paths
+    problem = ou_problem()
+    horizon, dt = problem[4], problem[5]
+    n = 128
+    tr = build_trainer(problem, n, torch.device("cuda:0"), True, seed=5, enc_hidden=256, enc_depth=2)
+    model, ctx = tr.ctx.model.eval(), tr.ctx
+    smp = CapturedPathSampler(model, ctx.observations, horizon, dt, tr.state_space, n, autocast_dtype=torch.bfloat16)
+
+    @torch.no_grad()
+    def eager(seed):
+        torch.manual_seed(seed)
+        theta = model.sde_parameter_posterior.rsample(n)
+        x0 = ctx.observations.values[0].unsqueeze(0).expand(n, -1)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            return sample_diffusion_paths(model.encoder, model.head, ctx.observations, theta, x0, horizon, dt, tr.state_space).x
+
+    def replay(seed):
+        torch.manual_seed(seed)
+        return smp()[1].clone()
+    assert rel_err(replay(3).cpu().numpy(), eager(3).cpu().numpy()) < 1e-5
+    with torch.no_grad():
+        for p in model.encoder.parameters():
+            p.mul_(1.05)
+    changed = eager(3)
+    assert rel_err(changed.cpu().numpy(), eager(3).cpu().numpy()) == 0.0
+    assert rel_err(replay(3).cpu().numpy(), changed.cpu().numpy()) < 1e-5

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from pathlib import Path
+from typing import Optional
 
 import torch
 from pydantic import BaseModel, ConfigDict
@@ -15,7 +16,8 @@ from torch import Tensor
 
 from ..core.observations import Observations
 from ..core.priors import Prior
-from ..inference.diffusion_path_sampler import sample_diffusion_paths
+from ..inference import diffusion_path_sampler as _sampler
+from ..inference.diffusion_path_sampler import CapturedPathSampler, sample_diffusion_paths
 from ..inference.exponential_moving_average import ExponentialMovingAverage
 from ..inference.state_space import StateSpace
 from ..models.variational_sde_posterior import VariationalSDEPosterior
@@ -74,17 +76,43 @@ class VariationalPosterior:
         self.time_horizon, self.time_step, self.state_space = time_horizon, time_step, state_space
         self.evidence_lower_bound_history = evidence_lower_bound_history
         self.device = device
+        self._calls: dict[int, int] = {}                                  # sample(n) calls seen per n
+        self._captured: dict[int, Optional[CapturedPathSampler]] = {}     # n -> replayable call (None: capture failed, stay eager)
 
     @torch.no_grad()
     def sample(self, n: int) -> VariationalPosteriorSamples:
-        """n joint draws (theta, path) from the variational posterior using the EMA weights."""
+        """n joint draws (theta, path) from the variational posterior using the EMA weights.
+
+        On the GPU a repeated ``sample(n)`` with the same ``n`` (a serving loop) replays the call as ONE HIP graph from its
+        second occurrence on (``CapturedPathSampler``: same kernels, same RNG stream order -- theta draw, then the path noise --
+        fresh draws per call; ``VSDE_SAMPLE_GRAPH=0`` keeps every call eager).  The first call of a size runs eagerly."""
         self.model.eval()
         with self.exponential_moving_average.apply():
+            replay = self._replayable(n)
+            if replay is not None:
+                theta, x, _ = replay()
+                return VariationalPosteriorSamples(sde_parameters=theta.clone(), diffusion_paths=x.clone())
             theta = self.model.sde_parameter_posterior.rsample(n)
             x0 = self.observations.values[0].unsqueeze(0).expand(n, -1)
             drawn = sample_diffusion_paths(self.model.encoder, self.model.head, self.observations, theta, x0,
                                            self.time_horizon, self.time_step, self.state_space)
         return VariationalPosteriorSamples(sde_parameters=theta, diffusion_paths=drawn.x)
+
+    def _replayable(self, n: int) -> Optional[CapturedPathSampler]:
+        if self.device.type != "cuda" or not _sampler.SAMPLE_GRAPH:
+            return None
+        self._calls[n] = self._calls.get(n, 0) + 1
+        if self._calls[n] < 2:
+            return None
+        if n not in self._captured:
+            if len(self._captured) >= 4:   # each graph keeps a private memory pool: a handful of sizes at most
+                self._captured.pop(next(iter(self._captured)))
+            try:
+                self._captured[n] = CapturedPathSampler(self.model, self.observations, self.time_horizon, self.time_step,
+                                                        self.state_space, n, warmup=1)
+            except Exception:   # capture is an optimisation, never a requirement
+                self._captured[n] = None
+        return self._captured[n]
 
     def summary(self, n_samples: int = 1000) -> VariationalPosteriorSummary:
         s = self.sample(n_samples)
