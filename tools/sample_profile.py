@@ -1,21 +1,24 @@
-"""Kernels of one no-grad posterior-sampling call (theta ~ q -> encoder -> head, eval kernels) at the LV size (GPU only)."""
+"""Kernels of one no-grad posterior-sampling call (theta ~ q -> encoder -> head, eval kernels) at the LV / OU size (GPU only):
+    python tools/sample_profile.py [lv|ou]"""
 import os, sys
 from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
-from viforsdes_amd.examples.sdes import lv_problem
+from viforsdes_amd.examples.sdes import lv_problem, ou_problem
 from viforsdes_amd.inference.diffusion_path_sampler import sample_diffusion_paths
 
 dev = torch.device("cuda:0")
-tr = bench.build_trainer(lv_problem(), 512, dev, True, seed=1234)
+wl = sys.argv[1] if len(sys.argv) > 1 else "lv"
+B = 512 if wl == "lv" else 128
+tr = bench.build_trainer(lv_problem() if wl == "lv" else ou_problem(), B, dev, True, seed=1234)
 model, ctx, cfg = tr.ctx.model, tr.ctx, tr.config
 model.eval()
 
 @torch.no_grad()
 def step():
-    theta = model.sde_parameter_posterior.rsample(512)
+    theta = model.sde_parameter_posterior.rsample(B)
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         sample_diffusion_paths(model.encoder, model.head, ctx.observations, theta, ctx.x0_buffer, tr.time_horizon, cfg.time_step, tr.state_space)
 
@@ -29,5 +32,5 @@ for ev in prof.events():
     if ev.device_type == torch.autograd.DeviceType.CUDA:
         k = kern[ev.name[:100]]; k[0] += 1; k[1] += ev.device_time
 print(f"kernels {sum(v[0] for v in kern.values())}, device time {sum(v[1] for v in kern.values()) / 1e3:.2f} ms")
-for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:22]:
+for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{v[0]:4d} {v[1]:9.1f} us  {k}")
