@@ -93,6 +93,51 @@ def pmc_traffic_bytes(workload, batch):
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
+LIVE_TRAFFIC = None   # (bytes per launch, source text) measured by this run's own rocprofv3 --pmc passes (measure_pmc_traffic)
+
+
+def measure_pmc_traffic(batch, timeout_s=240):
+    """HBM bytes per launch of the serial forward kernel (training variant), measured NOW: two child processes -- one
+    ``rocprofv3 --pmc`` pass per counter (FETCH_SIZE, WRITE_SIZE; never combined with each other or with the hip / hsa trace
+    domains, MI355X_MICROARCH.md) over ``tools/head_probe.py 3 <batch>`` (the head alone at the benchmark's dims) -- started
+    before this process touches the GPU.  KiB summed over the XCDs, mean over the dispatches; 4-byte loads: no FETCH_SIZE
+    correction (as for the committed passes).  None when rocprofv3 is missing or a pass fails: the committed figure stands."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if exe is None or profiled:   # no profiler, or this process itself runs under one (no nested passes)
+        return None
+    total = 0.0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="vsde_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "head_probe.py"), "3", str(batch)], cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None
+            acc, seen = 0.0, set()
+            for name, disp, cname, val in sqlite3.connect(dbs[0]).execute(
+                    "select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+                if cname == ctr and ("head_fwd_mp_kernel<2, true" in name or "head_fwd_v2_kernel<2, true" in name):
+                    acc += val
+                    seen.add(disp)
+            if not seen:
+                return None
+            total += acc / len(seen)
+        except Exception as err:
+            print(f"[bench] live PMC pass {ctr} failed ({type(err).__name__}); using the committed figure", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return total * 1024.0
+
+
 def sync(device):
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -470,6 +515,12 @@ def measure(workload, batch, args, device, distributed, world):
         p.grad = None
 
     traffic = pmc_traffic_bytes(workload, batch)
+    traffic_source = (None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, separate --pmc runs: "
+                      "tools/pmc.sh vsde::head tools/head_probe.py 3), not measured in this run")
+    if LIVE_TRAFFIC is not None and workload == "lv" and batch == 512:
+        traffic_source = ("measured by this run: one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE) over tools/head_probe.py 3 512 in "
+                          f"child processes before the timed region; the committed passes ({PMC_FILE}) give {traffic}")
+        traffic = LIVE_TRAFFIC
     fwd_kernel = ("multi-path MFMA kernel (csrc/vsde_head_mp.hip), " + ("4" if batch <= 1024 else "8" if batch <= 2048 else "16") + " paths per workgroup"
                   if (batch > 256 and H == 64 and L <= 2 and S <= 2) else "four-waves-per-path VALU kernel (csrc/vsde_head.hip)")
     out = {
@@ -489,8 +540,7 @@ def measure(workload, batch, args, device, distributed, world):
         "roofline": {"kernel": f"vsde head forward, GRU time-stepping kernel (training variant, L={L}): {fwd_kernel}",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, "
-                                       "separate --pmc runs: tools/pmc.sh vsde::head tools/head_probe.py 3), not measured in this run",
+                     "traffic_source": traffic_source,
                      "avg_ms": fwd_ms, "algorithmic_bytes": fwd_bytes_step * steps_per_launch,
                      "bytes_per_path_step": fwd_bytes_step, "path_steps_per_launch": steps_per_launch,
                      # the context read is done by the hoisted projection GEMM: the whole forward path priced with the same bytes
@@ -534,6 +584,8 @@ def main():
     ap.add_argument("--hip-graph", action="store_true", help="always replay the captured HIP graph (default: whichever of "
                     "eager / replay is faster in a 3-step probe before the warm-up; same kernels and work either way)")
     ap.add_argument("--cpu-micro-batch", type=int, default=64)
+    ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic from the committed PMC passes instead of two live "
+                    "rocprofv3 --pmc passes (child processes, ~30 s) before the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -544,6 +596,10 @@ def main():
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    global LIVE_TRAFFIC
+    if (world == 1 and args.gpus == 1 and not args.no_pmc and args.workload == "lv" and (args.batch or 512) == 512
+            and torch.cuda.device_count() > 0):   # device_count() does not initialise the GPU: the children get it to themselves
+        LIVE_TRAFFIC = measure_pmc_traffic(512)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the fused kernels have no CPU fallback)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -16,7 +16,7 @@ for w in $WL; do
     synthetic) args="--workload synthetic --steps 5 --warmup 2" ;;
   esac
   rm -rf /tmp/prof_$w
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o b -- python3 $R/bench.py $args --no-cpu-baseline --no-ou > $O/bench_prof_${w}_$TAG.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o b -- python3 $R/bench.py $args --no-cpu-baseline --no-ou --no-pmc > $O/bench_prof_${w}_$TAG.log 2>&1
   python3 $R/tools/rocpd_stats.py $(find /tmp/prof_$w -name '*.db' | head -1) > $O/${ROUND}_bench_${w}_kernels_$TAG.txt 2>&1
   python3 $R/tools/rocpd_stats.py $(find /tmp/prof_$w -name '*.db' | head -1) busy >> $O/${ROUND}_bench_${w}_kernels_$TAG.txt 2>&1
   (cd $R && python3 bench.py $args --no-cpu-baseline --no-ou > $O/bench_${ROUND}_${w}_$TAG.json 2> $O/bench_${ROUND}_${w}_$TAG.err)
