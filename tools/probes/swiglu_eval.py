@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from viforsdes_amd import _hip
 M, K, H = 205312, 256, 704
 dev = "cuda:0"
