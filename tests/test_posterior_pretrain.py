@@ -235,7 +235,7 @@ def test_repeated_sample_replays_a_graph_and_matches_the_eager_call(name):
     live = {k: v.clone() for k, v in vp.model.state_dict().items()}
     vp.sample(n)                                    # first call of this size: eager
     vp.sample(n)                                    # second: captured
-    assert vp._captured.get(n) is not None, "capture failed: sample() fell back to the eager call"
+    assert vp._captured.get((n, None)) is not None, "capture failed: sample() fell back to the eager call"
 
     def eager(seed):
         dps.SAMPLE_GRAPH = False
@@ -297,3 +297,33 @@ def test_captured_sampler_under_autocast_follows_parameter_changes():
     changed = eager(3)
     assert rel_err(changed.cpu().numpy(), eager(3).cpu().numpy()) == 0.0
     assert rel_err(replay(3).cpu().numpy(), changed.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_mixed_precision_sample_is_the_fp32_sample_within_bf16_accuracy():
+    """``sample(n, mixed_precision=True)``: encoder under bf16 autocast (the fused encoder kernels), same draws -- the paths agree
+    with the fp32 call to bf16 accuracy, eagerly (first call) and replayed (third call), and the live weights come back."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from bench import build_trainer
+    from viforsdes_amd.examples.sdes import ou_problem
+    problem = ou_problem()
+    n = 128
+    tr = build_trainer(problem, n, torch.device("cuda:0"), True, seed=9, enc_hidden=256, enc_depth=2)
+    vp = VariationalPosterior(model=tr.ctx.model, exponential_moving_average=tr.ctx.ema, prior=problem[3], observations=problem[1],
+                              time_horizon=problem[4], time_step=problem[5], state_space=tr.state_space,
+                              evidence_lower_bound_history=[], device=torch.device("cuda:0"))
+    live = {k: v.clone() for k, v in vp.model.state_dict().items()}
+
+    def draw(mixed):
+        torch.manual_seed(21)
+        return vp.sample(n, mixed_precision=mixed)
+    ref = draw(False)
+    for call in range(3):                          # eager, capture + replay, replay
+        got = draw(True)
+        assert torch.equal(got.sde_parameters, ref.sde_parameters)
+        err = rel_err(got.diffusion_paths.cpu().numpy(), ref.diffusion_paths.cpu().numpy())
+        assert 0.0 < err < 3e-2, (call, err)
+    assert vp._captured.get((n, torch.bfloat16)) is not None
+    for k, v in vp.model.state_dict().items():
+        assert torch.equal(v, live[k]), k

@@ -75,6 +75,7 @@ class CapturedPathSampler:
                                            state_space)
             return theta, s.x, s
 
+        rng = torch.cuda.get_rng_state(dev)   # warm-up draws must not show: the first replay continues the caller's stream
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -90,6 +91,8 @@ class CapturedPathSampler:
             except Exception:
                 torch.cuda.synchronize(dev)
                 raise
+            finally:
+                torch.cuda.set_rng_state(rng, dev)
         self.n = n
 
     def __call__(self) -> tuple[Tensor, Tensor, DiffusionPathSample]:

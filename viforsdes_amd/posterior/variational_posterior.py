@@ -76,46 +76,52 @@ class VariationalPosterior:
         self.time_horizon, self.time_step, self.state_space = time_horizon, time_step, state_space
         self.evidence_lower_bound_history = evidence_lower_bound_history
         self.device = device
-        self._calls: dict[int, int] = {}                                  # sample(n) calls seen per n
-        self._captured: dict[int, Optional[CapturedPathSampler]] = {}     # n -> replayable call (None: capture failed, stay eager)
+        self._calls: dict[tuple, int] = {}                                  # sample() calls seen per (n, autocast dtype)
+        self._captured: dict[tuple, Optional[CapturedPathSampler]] = {}     # -> replayable call (None: capture failed, stay eager)
 
     @torch.no_grad()
-    def sample(self, n: int) -> VariationalPosteriorSamples:
+    def sample(self, n: int, mixed_precision: bool = False) -> VariationalPosteriorSamples:
         """n joint draws (theta, path) from the variational posterior using the EMA weights.
 
         On the GPU a repeated ``sample(n)`` with the same ``n`` (a serving loop) replays the call as ONE HIP graph from its
         second occurrence on (``CapturedPathSampler``: same kernels, same RNG stream order -- theta draw, then the path noise --
-        fresh draws per call; ``VSDE_SAMPLE_GRAPH=0`` keeps every call eager).  The first call of a size runs eagerly."""
+        fresh draws per call; ``VSDE_SAMPLE_GRAPH=0`` keeps every call eager).  The first call of a size runs eagerly.
+        ``mixed_precision`` (not in the reference, whose ``sample`` always runs in the parameters' precision): run the encoder
+        under bf16 autocast, i.e. in the precision a ``mixed_precision`` training run optimised it in -- the fused encoder
+        kernels instead of fp32 library GEMMs (~5 x faster at the Lotka-Volterra size); the head stays fp32."""
         self.model.eval()
+        amp = torch.bfloat16 if (mixed_precision and self.device.type == "cuda") else None
         with self.exponential_moving_average.apply():
-            replay = self._replayable(n)
+            replay = self._replayable(n, amp)
             if replay is not None:
                 theta, x, _ = replay()
                 return VariationalPosteriorSamples(sde_parameters=theta.clone(), diffusion_paths=x.clone())
             theta = self.model.sde_parameter_posterior.rsample(n)
             x0 = self.observations.values[0].unsqueeze(0).expand(n, -1)
-            drawn = sample_diffusion_paths(self.model.encoder, self.model.head, self.observations, theta, x0,
-                                           self.time_horizon, self.time_step, self.state_space)
-        return VariationalPosteriorSamples(sde_parameters=theta, diffusion_paths=drawn.x)
+            with torch.autocast(device_type=self.device.type, dtype=amp, enabled=amp is not None):
+                drawn = sample_diffusion_paths(self.model.encoder, self.model.head, self.observations, theta, x0,
+                                               self.time_horizon, self.time_step, self.state_space)
+            return VariationalPosteriorSamples(sde_parameters=theta, diffusion_paths=drawn.x)
 
-    def _replayable(self, n: int) -> Optional[CapturedPathSampler]:
+    def _replayable(self, n: int, amp: Optional[torch.dtype] = None) -> Optional[CapturedPathSampler]:
         if self.device.type != "cuda" or not _sampler.SAMPLE_GRAPH:
             return None
-        self._calls[n] = self._calls.get(n, 0) + 1
-        if self._calls[n] < 2:
+        key = (n, amp)
+        self._calls[key] = self._calls.get(key, 0) + 1
+        if self._calls[key] < 2:
             return None
-        if n not in self._captured:
+        if key not in self._captured:
             if len(self._captured) >= 4:   # each graph keeps a private memory pool: a handful of sizes at most
                 self._captured.pop(next(iter(self._captured)))
             try:
-                self._captured[n] = CapturedPathSampler(self.model, self.observations, self.time_horizon, self.time_step,
-                                                        self.state_space, n, warmup=1)
+                self._captured[key] = CapturedPathSampler(self.model, self.observations, self.time_horizon, self.time_step,
+                                                          self.state_space, n, autocast_dtype=amp, warmup=1)
             except Exception:   # capture is an optimisation, never a requirement
-                self._captured[n] = None
-        return self._captured[n]
+                self._captured[key] = None
+        return self._captured[key]
 
-    def summary(self, n_samples: int = 1000) -> VariationalPosteriorSummary:
-        s = self.sample(n_samples)
+    def summary(self, n_samples: int = 1000, mixed_precision: bool = False) -> VariationalPosteriorSummary:
+        s = self.sample(n_samples, mixed_precision)
         levels = torch.tensor(QUANTILE_LEVELS, device=self.device, dtype=s.sde_parameters.dtype)
         q = torch.quantile(s.sde_parameters, levels, dim=0)
         return VariationalPosteriorSummary(
