@@ -157,6 +157,28 @@ __device__ __forceinline__ void swiglu_quads(const f32x16 &acc, const uint16_t *
     }
 }
 
+// EPI_SWIGLU: swiglu_quads and stage_block of the same tile in one pass.  The unfused chain computes s from the bf16 u, so the
+// packed words that go to the staging row ARE the rounded a / b: unpacking them replaces a second conversion per value (the
+// epilogue is the longer phase of this kernel, profiles/r04_pmc_linear_swiglu.txt: 4.5 -> 2 v_cvt_pk_bf16_f32 and 4 -> 3 adds per pair).
+__device__ __forceinline__ void swiglu_stage(const f32x16 &acc, const uint16_t *bias32, uint16_t *dst_row, int h, uint32_t (&out)[4]) {
+    uint32_t uw[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+        uw[g][0] = pack_bf16x2(acc[4 * g + 0] + bf_lo(bb.x), acc[4 * g + 1] + bf_hi(bb.x));
+        uw[g][1] = pack_bf16x2(acc[4 * g + 2] + bf_lo(bb.y), acc[4 * g + 3] + bf_hi(bb.y));
+        *(uint2 *)(dst_row + 8 * g + 4 * h) = make_uint2(uw[g][0], uw[g][1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float a0 = bf_lo(uw[g][w]), a1 = bf_hi(uw[g][w]), b0 = bf_lo(uw[g + 2][w]), b1 = bf_hi(uw[g + 2][w]);
+            const uint32_t t = pack_bf16x2(a0 * sigm_f(a0), a1 * sigm_f(a1));
+            out[2 * g + w] = pack_bf16x2(bf_lo(t) * b0, bf_hi(t) * b1);
+        }
+}
+
 // EPI_QKNORM on the staged head (R = 32 rows x 64 columns of bf16 = the projection output after bias and rounding, exactly what
 // the unfused chain hands to qk_norm_rope): lane (r, h) owns the rotary pairs i in [16 h, 16 h + 16) of row r, i.e. columns i
 // and i + 32.  kind 0 / 1: x -> rnd(x rms w) rotated by the row's (cos, sin); kind 2 with residual values: lam v + (1 - lam) v0.
@@ -220,14 +242,17 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
     const int r = lane & 31, h = lane >> 5;
     constexpr int SLD = R2_SLD, R = 32 * RB;
     if constexpr (EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_QKNORM || EPI == EPI_GATE_BWD) {
+        uint32_t sq[RB][4];   // EPI_SWIGLU: this tile's s (second tile of a pair: kept until the pair's u has left the staging rows)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
-            if constexpr (EPI == EPI_SWIGLU && PAR == 0) {   // the first tile's s waits in columns 64..79 of the staging row
-                uint32_t s0[4];
-                swiglu_quads(acc[rb], bias32, h, s0);
+            if constexpr (EPI == EPI_SWIGLU) {
+                swiglu_stage(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h, sq[rb]);
+                if constexpr (PAR == 0) {   // the first tile's s waits in columns 64..79 of the staging row
 #pragma unroll
-                for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 64 + 8 * g + 4 * h) = make_uint2(s0[2 * g], s0[2 * g + 1]);
+                    for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 64 + 8 * g + 4 * h) = make_uint2(sq[rb][2 * g], sq[rb][2 * g + 1]);
+                }
+            } else {
+                stage_block(acc[rb], bias32, stage + (rb * 32 + r) * SLD + PAR * 32, h);
             }
         }
         if constexpr (EPI == EPI_GATE_BWD && PAR == 1) {
@@ -323,14 +348,12 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
         if constexpr (PAR == 1) {
             wave_lds_fence();
             if (EPI == EPI_PLAIN || p.C != nullptr) flush_rows64<SLD, R>(stage, p.C + (n0 - 32), p.ldc, row0, p.M, lane);
-            if constexpr (EPI == EPI_SWIGLU) {   // second tile's s (acc is still live) into columns 0..15, then 32 columns of s per row
+            if constexpr (EPI == EPI_SWIGLU) {   // second tile's s into columns 0..15, then 32 columns of s per row
                 wave_lds_fence();
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    uint32_t s1[4];
-                    swiglu_quads(acc[rb], bias32, h, s1);
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 8 * g + 4 * h) = make_uint2(s1[2 * g], s1[2 * g + 1]);
+                    for (int g = 0; g < 2; ++g) *(uint2 *)(stage + (rb * 32 + r) * SLD + 8 * g + 4 * h) = make_uint2(sq[rb][2 * g], sq[rb][2 * g + 1]);
                 }
                 wave_lds_fence();
 #pragma unroll
