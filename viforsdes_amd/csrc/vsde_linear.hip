@@ -977,7 +977,12 @@ static int launch_rows(const LinParams &p, hipStream_t s) {
     // K = 512 (two k-halves, 32-row waves for every epilogue): synthetic step 146.0 -> 145.1 ms with eight waves; the SwiGLU backward
     // at K = 256 (172 registers, two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step with them, the plain /
     // SwiGLU-forward epilogues (64-row waves, 512-row workgroups) 0.1-0.25 ms.
-    if constexpr ((EPI == EPI_GATE_BWD && NKH == 1) || (NKH > 1 && EPI != EPI_QKNORM)) {
+    // Round 4: with the epilogue's per-lane addresses no longer spilled (opaque lane copy per tile) the gate-backward epilogue at
+    // K = 256 is faster on two four-wave workgroups as well: 85 vs 96 us stand-alone, LV step 26.74 / 26.89 -> 26.60 / 26.67 ms.  (Its
+    // eight waves in anti-phase -- waves 4..7 one phase behind waves 0..3, two barriers per tile, three tile buffers -- were tried
+    // for every epilogue and lose 15-20 % to lockstep: waves released by one barrier skew by themselves, the first wave of a SIMD to
+    // win the matrix pipe finishes its MFMAs early and runs its epilogue under the other one's.)
+    if constexpr (NKH > 1 && EPI != EPI_QKNORM) {
         if (rows_wide_wg() == 8 && p.M >= 256 * 256) return launch_rows_nw<KC, EPI, NKH, 8>(p, s);
     }
     return launch_rows_nw<KC, EPI, NKH, 4>(p, s);
