@@ -971,12 +971,11 @@ static int rows_wide_wg() {   // VSDE_ROWS_NW=4: four-wave workgroups for every 
 }
 template <int KC, int EPI, int NKH = 1>
 static int launch_rows(const LinParams &p, hipStream_t s) {
-    // eight waves (one 256-row workgroup per CU) for the gate-backward epilogue, whose registers only allow 32-row waves, when M fills
-    // the chip: 109.5 -> 95 us at the LV shape.  The QK-norm epilogue (also 32-row waves) loses with it: 242 -> 260 us (training) /
-    // 205 -> 221 (no grad), whatever the column-chunk count -- its long epilogues want a second workgroup on the CU to hide behind.
-    // K = 512 (two k-halves, 32-row waves for every epilogue): synthetic step 146.0 -> 145.1 ms with eight waves; the SwiGLU backward
-    // at K = 256 (172 registers, two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step with them, the plain /
-    // SwiGLU-forward epilogues (64-row waves, 512-row workgroups) 0.1-0.25 ms.
+    // Eight waves (one 256-row workgroup per CU) at K = 512 (two k-halves, 32-row waves for every epilogue) when M fills the chip:
+    // synthetic step 146.0 -> 145.1 ms.  The QK-norm epilogue loses with them (242 -> 260 us training / 205 -> 221 no grad, whatever
+    // the column-chunk count: its long epilogues want a second workgroup on the CU to hide behind), the SwiGLU backward at K = 256
+    // (two four-wave workgroups per CU overlap better) loses 0.08 ms per LV step, the plain / SwiGLU-forward epilogues (64-row
+    // waves, 512-row workgroups) 0.1-0.25 ms.  Until round 3 the gate-backward epilogue at K = 256 gained from them (109.5 -> 95 us).
     // Round 4: with the epilogue's per-lane addresses no longer spilled (opaque lane copy per tile) the gate-backward epilogue at
     // K = 256 is faster on two four-wave workgroups as well: 85 vs 96 us stand-alone, LV step 26.74 / 26.89 -> 26.60 / 26.67 ms.  (Its
     // eight waves in anti-phase -- waves 4..7 one phase behind waves 0..3, two barriers per tile, three tile buffers -- were tried
