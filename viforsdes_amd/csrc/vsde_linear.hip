@@ -929,7 +929,9 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
             double best = 0.0;
             for (int c = 2; c <= 4; ++c) {
                 if (pairs < 2 * c) break;
-                const double rounds = (double)stripes * c / resident, eff = rounds / (double)(int64_t)(rounds + 0.999999) - 0.02 * c;
+                // (0.05 per chunk since round 4: the SwiGLU backward's 1,604 stripes of 128 rows took 4 chunks with 0.02 -- 302 us against
+                //  284 / 293 / 307 us for 2 / 3 / 4 chunks stand-alone; the forward keeps 3)
+                const double rounds = (double)stripes * c / resident, eff = rounds / (double)(int64_t)(rounds + 0.999999) - 0.05 * c;
                 if (eff > best) { best = eff; want = c; }
             }
         }
