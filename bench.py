@@ -96,7 +96,7 @@ def pmc_traffic_bytes(workload, batch):
 LIVE_TRAFFIC = None   # (bytes per launch, source text) measured by this run's own rocprofv3 --pmc passes (measure_pmc_traffic)
 
 
-def measure_pmc_traffic(batch, timeout_s=240):
+def measure_pmc_traffic(batch, timeout_s=120):
     """HBM bytes per launch of the serial forward kernel (training variant), measured NOW: two child processes -- one
     ``rocprofv3 --pmc`` pass per counter (FETCH_SIZE, WRITE_SIZE; never combined with each other or with the hip / hsa trace
     domains, MI355X_MICROARCH.md) over ``tools/head_probe.py 3 <batch>`` (the head alone at the benchmark's dims) -- started
