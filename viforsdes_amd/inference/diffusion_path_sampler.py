@@ -96,7 +96,10 @@ class CapturedPathSampler:
         self.n = n
 
     def __call__(self) -> tuple[Tensor, Tensor, DiffusionPathSample]:
-        self._packs.refresh_all(params=self._ids)   # a no-op unless a parameter changed since the last call
+        # nothing unless a parameter changed since the last call; then ONE kernel over all packs of this model (an EMA swap makes
+        # every pack stale: the per-pack copies of the unforced refresh would be ~50 launches)
+        if any(pk.stale() for pk in self._packs._live if any(id(q) in self._ids for q in pk.params)):
+            self._packs.refresh_all(force=True, params=self._ids)
         self.graph.replay()
         return self._static
 
