@@ -521,8 +521,9 @@ def measure(workload, batch, args, device, distributed, world):
         traffic_source = ("measured by this run: one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE) over tools/head_probe.py 3 512 in "
                           f"child processes before the timed region; the committed passes ({PMC_FILE}) give {traffic}")
         traffic = LIVE_TRAFFIC
+    # mirrors csrc/vsde_head.hip::mp_auto (training launch: multi-path from 96 paths on) and vsde_head_mp.hip's group size
     fwd_kernel = ("multi-path MFMA kernel (csrc/vsde_head_mp.hip), " + ("4" if batch <= 1024 else "8" if batch <= 2048 else "16") + " paths per workgroup"
-                  if (batch > 256 and H == 64 and L <= 2 and S <= 2) else "four-waves-per-path VALU kernel (csrc/vsde_head.hip)")
+                  if (batch >= 96 and H == 64 and L <= 2 and S <= 2) else "four-waves-per-path VALU kernel (csrc/vsde_head.hip)")
     out = {
         "value": global_batch * iters_per_sec, "unit": "paths/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "config": {"workload": f"{workload}: state_dim={S}, T={T} Euler steps (dt={dt}), batch={batch}/GPU, "
