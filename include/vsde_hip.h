@@ -316,6 +316,20 @@ int vsde_linear_gated_bf16(const void *attn, int64_t ldx, const void *gate, int6
 int vsde_linear_gate_bwd_bf16(const void *dy, int64_t ldy, const void *w_t, const void *og, const void *s, int64_t lds, void *dattn,
                               void *dgate, int64_t ldd, float *delta, int64_t M, int K, int heads, int tokens, void *stream);
 
+/* ---- The SwiGLU feed-forward of a SiT block as one kernel per direction (csrc/vsde_mlp.hip, round 5) -------------------------
+ * Replaces primitives/mlp.py:50-54 under autocast:  y = W_out (silu(a) * b) + b_out,  [a | b] = W_in x + b_in,  x [M][C] bf16,
+ * hidden size H (a multiple of 64, zero-padded), C in {128, 256}.  The weights are handed over as tile IMAGES (T = H / 16 tiles;
+ * sizes per tile from vsde_mlp_image_bytes; layouts in csrc/vsde_mlp.hip, built by primitives/fused.py::MlpImages):
+ *   w1_img [T][32 rows][C + 8] bf16 (+ padding to whole KB): row 8 g + 4 h + i of tile t = (g < 2 ? a : b) unit 16 t + 8 h + 4 (g & 1) + i
+ *   w2_img [T][2][C][8] bf16: W_out[n][16 t + 8 h + 0..7];   b1_img [T][64] fp32: b_in in w1_img's row order (32 used)
+ * s_out (training only, else NULL): silu(a) * b [M][lds] bf16 in natural unit order, what the weight gradient of W_out needs; the
+ * pre-activations are never written (the backward recomputes them). */
+/* debugging aid (VSDE_MLP_DEBUG=16): device buffer that receives workgroup 0's per-phase cycle stamps */
+int vsde_mlp_debug_trace(void *buf);
+int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile);
+int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img, const void *w2_img, const float *b1_img, const void *b2, void *y,
+                      int64_t ldy, void *s_out, int64_t lds, int64_t M, int C, int H, void *stream);
+
 /* ---- The optimizer step as two launches over all parameters -----------------------------------------------------------
  * Replaces, per training step (inference/trainer.py:197-204, inference/exponential_moving_average.py:27-32):
  * scaler.unscale_ (non-finite check + g *= 1/scale), clip_grad_norm_ (norms + g *= clip coefficient), the multi-tensor AdamW

@@ -1,0 +1,80 @@
+"""GPU: the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) against the unfused chain of primitives/mlp.py:50-54 under autocast,
+evaluated in fp32 from the same bf16-rounded intermediates: u = bf16(x W_in^T + b_in), s = bf16(bf16(silu(a)) * b),
+y = bf16(s W_out^T + b_out).  Tolerances: s 1e-2 of its max (one bf16 rounding of u flips the last bit of some s), y 1e-2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(torch.bfloat16)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+
+def _packs(C, H, hreal, seed=0, interleave=False):
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(seed)
+    w_in = torch.nn.Parameter((torch.randn(2 * hreal, C, generator=g) * C ** -0.5).to(DEV))
+    b_in = torch.nn.Parameter((torch.randn(2 * hreal, generator=g)).to(DEV))
+    w_out = torch.nn.Parameter((torch.randn(C, hreal, generator=g) * hreal ** -0.5).to(DEV))
+    b_out = torch.nn.Parameter((torch.randn(C, generator=g)).to(DEV))
+    pin, pout = fused.swiglu_packs(w_in, b_in, w_out, b_out, H, interleave=interleave)
+    return (w_in, b_in, w_out, b_out), pin, pout, fused.MlpImages(pin, pout, H)
+
+
+def _reference(x, w_in, b_in, w_out, b_out):
+    bf = lambda t: t.to(torch.bfloat16).float()
+    h = w_out.shape[1]
+    u = bf(x.float() @ bf(w_in).t() + bf(b_in))
+    a, b = u[:, :h], u[:, h:]
+    s = bf(bf(a * torch.sigmoid(a)) * b)
+    return s, s @ bf(w_out).t() + bf(b_out)
+
+
+# (M, C, H padded, H real): the LV encoder's MLP (682 -> 704), the C = 128 fixture width, ragged M, a single partial stripe,
+# more than one round of workgroups, the benchmark's own shape
+@pytest.mark.parametrize("M,C,H,hreal", [(20000, 256, 704, 682), (4264, 128, 384, 341), (300, 128, 64, 64), (77, 256, 128, 100),
+                                         (133000 + 5, 256, 704, 682), (205312, 256, 704, 682)])
+@pytest.mark.parametrize("interleave", [False, True])
+def test_fused_mlp_forward(M, C, H, hreal, interleave):
+    from viforsdes_amd import _hip
+    params, pin, pout, img = _packs(C, H, hreal, interleave=interleave)
+    x = _rand(M, C, seed=5)
+    s_ref, y_ref = _reference(x, *[q.detach() for q in params])
+    w1, w2, b1 = img.operands()
+    y, s = _hip.mlp_fwd(x, w1, w2, b1, pout.bias, H, want_s=True)
+    assert _rel(s[:, :hreal], s_ref) < 1e-2 and (hreal == H or float(s[:, hreal:].abs().max()) == 0.0)
+    assert _rel(y, y_ref) < 1e-2
+    # y from the kernel's own s isolates the second product from the rounding of u
+    y_own = s.float() @ pout.weight.float().t() + pout.bias.float()
+    assert _rel(y, y_own) < 6e-3
+    y2, none = _hip.mlp_fwd(x, w1, w2, b1, pout.bias, H, want_s=False)
+    assert none is None and torch.equal(y2, y)
+    # a row-pitched input (column range of a wider buffer)
+    wide = _rand(M, C + 64, seed=6)
+    y3, _ = _hip.mlp_fwd(wide[:, 32:32 + C], w1, w2, b1, pout.bias, H)
+    y3c, _ = _hip.mlp_fwd(wide[:, 32:32 + C].contiguous(), w1, w2, b1, pout.bias, H)
+    assert torch.equal(y3, y3c)
+
+
+def test_images_follow_a_pack_refresh():
+    from viforsdes_amd import _hip
+    from viforsdes_amd.primitives import fused
+    params, pin, pout, img = _packs(256, 704, 682)
+    x = _rand(5000, 256, seed=7)
+    w1, w2, b1 = img.operands()
+    y0, _ = _hip.mlp_fwd(x, w1, w2, b1, pout.bias, 704)
+    with torch.no_grad():
+        for q in params:
+            q.mul_(0.5)
+    fused.note_parameters_changed()
+    fused.PackedWeight.refresh_all(force=True, params={id(q) for q in params})
+    y1, _ = _hip.mlp_fwd(x, img.w1, img.w2, img.b1, pout.bias, 704)   # no operands() call: what a captured step replays
+    _, y_ref = _reference(x, *[q.detach() for q in params])
+    assert _rel(y1, y_ref) < 1e-2 and _rel(y0, y_ref) > 0.1

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Times the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) against the two-launch chain they replace, at the LV encoder's shape.
+    python tools/mlp_bench.py [--m 205312]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viforsdes_amd import _hip  # noqa: E402
+from viforsdes_amd.accelerate import enable_tuned_gemms  # noqa: E402
+from viforsdes_amd.primitives import fused  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=205312)
+ap.add_argument("--c", type=int, default=256)
+ap.add_argument("--h", type=int, default=682)
+a = ap.parse_args()
+enable_tuned_gemms()
+dev = "cuda:0"
+M, C, hreal = a.m, a.c, a.h
+H = -(-hreal // 64) * 64
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+P = lambda *s, sc=1.0: torch.nn.Parameter(torch.randn(*s, device=dev) * sc)
+w_in, b_in, w_out, b_out = P(2 * hreal, C, sc=C ** -0.5), P(2 * hreal), P(C, hreal, sc=hreal ** -0.5), P(C)
+x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+pin_i, pout_i = fused.swiglu_packs(w_in, b_in, w_out, b_out, H, interleave=True)
+img = fused.MlpImages(pin_i, pout_i, H)
+w1, w2, b1 = img.operands()
+w1i, b1i = pin_i.operands(); w2o, b2o = pout_i.operands()
+print(f"M = {M}, C = {C}, H = {H} ({hreal})")
+fl = 2.0 * M * (2 * H * C + H * C)
+for name, fn, by in (
+        ("old no-grad: rows+SwiGLU | hipBLASLt", lambda: torch.nn.functional.linear(_hip.linear_swiglu_bf16(x, w1i, b1i, want_u=False)[1], w2o, b2o), 0),
+        ("old train  : rows+SwiGLU | hipBLASLt", lambda: torch.nn.functional.linear(_hip.linear_swiglu_bf16(x, w1i, b1i, want_u=True)[1], w2o, b2o), 0),
+        ("fused no-grad", lambda: _hip.mlp_fwd(x, w1, w2, b1, b2o, H, want_s=False), 2.0 * M * 2 * C),
+        ("fused train (writes s)", lambda: _hip.mlp_fwd(x, w1, w2, b1, b2o, H, want_s=True), 2.0 * M * (2 * C + H))):
+    t = timeit(fn)
+    print(f"{name:40s} {t:8.1f} us   {fl / t / 1e6:6.0f} TF/s" + (f"   {by / t / 1e3:6.0f} GB/s algorithmic" if by else ""))

@@ -61,6 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_debug_trace",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -859,6 +860,29 @@ def gate_bwd_delta(dout: torch.Tensor, og: torch.Tensor, gate: torch.Tensor, dga
         _call(lib.vsde_gate_bwd_delta, _ptr(dout), _ptr(og), _ptr(gate), _i64(ldg), _ptr(dattn), _ptr(dgate), _i64(ldd), _ptr(delta),
               _i64(B), ctypes.c_int(N), ctypes.c_int(H), _stream(dev))
     return dattn, delta
+
+
+def mlp_image_bytes(C: int) -> tuple[int, int, int]:
+    """Bytes per 16-unit tile of the fused SwiGLU MLP's weight images (W1, W2, b1) for width C."""
+    a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = load().vsde_mlp_image_bytes(ctypes.c_int(C), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    if rc != 0:
+        _raise(rc)
+    return int(a.value), int(b.value), int(c.value)
+
+
+def mlp_fwd(x: torch.Tensor, w1_img: torch.Tensor, w2_img: torch.Tensor, b1_img: torch.Tensor, b2: Optional[torch.Tensor], H: int,
+            want_s: bool = False):
+    """Fused SwiGLU MLP forward (csrc/vsde_mlp.hip): x [M,C] bf16 (row-pitched) -> (y [M,C] bf16, s [M,H] bf16 or None)."""
+    lib = load(); dev = _require_hip(x, w1_img, w2_img, b1_img)
+    x, ldx = _rows2d(x)
+    M, C = x.shape
+    y = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    s = torch.empty(M, H, device=dev, dtype=torch.bfloat16) if want_s else None
+    with torch.cuda.device(dev):
+        _call(lib.vsde_mlp_fwd_bf16, _ptr(x), _i64(ldx), _ptr(w1_img), _ptr(w2_img), _ptr(b1_img), _ptr(b2), _ptr(y), _i64(C), _ptr(s),
+              _i64(H), _i64(M), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
+    return y, s
 
 
 def linear_gate_bwd(dy: torch.Tensor, w_t: torch.Tensor, og: torch.Tensor, s: torch.Tensor, dgate: torch.Tensor, tokens: int):

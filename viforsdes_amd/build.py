@@ -12,7 +12,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libvsde_hip.so")
-SOURCES = ["vsde_gemm.hip", "vsde_head.hip", "vsde_elbo.hip", "vsde_encoder.hip", "vsde_wgrad.hip", "vsde_attn.hip", "vsde_sde.hip", "vsde_linear.hip", "vsde_attn_stream.hip", "vsde_tn_wide.hip", "vsde_proj.hip", "vsde_pack.hip", "vsde_optim.hip", "vsde_head_mp.hip"]
+SOURCES = ["vsde_gemm.hip", "vsde_head.hip", "vsde_elbo.hip", "vsde_encoder.hip", "vsde_wgrad.hip", "vsde_attn.hip", "vsde_sde.hip", "vsde_linear.hip", "vsde_attn_stream.hip", "vsde_tn_wide.hip", "vsde_proj.hip", "vsde_pack.hip", "vsde_optim.hip", "vsde_head_mp.hip", "vsde_mlp.hip"]
 HEADERS = ["vsde_common.h", os.path.join("..", "..", "include", "vsde_hip.h")]
 ARCH = "gfx950"
 

@@ -593,6 +593,7 @@ class PackedWeight:
                     pk.mark_fresh()
                     if pk.weight_t is not None:
                         pk._t_versions = list(pk._versions)
+                PackedWeight._refresh_derived(live)
                 return
         dst, src, packs = [], [], []
         for pk in live:
@@ -606,6 +607,19 @@ class PackedWeight:
                 if pk.weight_t is not None:
                     pk.weight_t.copy_(pk.weight.t())
                     pk._t_versions = list(pk._versions)
+        PackedWeight._refresh_derived(live)
+
+    # operands derived from packs (tile images of the fused MLP kernels): objects with ``packs`` and ``refresh_if_stale()``; they
+    # follow every refresh of their packs, so that a captured training step (whose forward never checks staleness) replays with
+    # images of the parameters its captured optimizer step has just written
+    _derived = weakref.WeakSet()
+
+    @staticmethod
+    def _refresh_derived(live) -> None:
+        ids = {id(pk) for pk in live}
+        for d in sorted(PackedWeight._derived, key=id):
+            if any(id(pk) in ids for pk in d.packs):
+                d.refresh_if_stale()
 
 
 # the MFMA GEMM kernels of csrc/vsde_linear.hip for the shapes they cover (VSDE_OWN_GEMM=0: library GEMMs everywhere, for A/B runs)
@@ -800,6 +814,49 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
             and weight.shape[1] % 8 == 0 and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
         return _Linear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class MlpImages:
+    """Weight operands of the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) as tile images, one tile = 16 hidden units:
+    ``w1`` [T, 32 rows, C + 8] (row 8 g + 4 h + i = (a if g < 2 else b) unit 16 t + 8 h + 4 (g & 1) + i: the MFMA result layout then
+    hands every lane a_j, b_j for the 8 units it feeds into the next product), ``w2`` [T, 2, C, 8] (W_out[n, 16 t + 8 h + 0..7]) and
+    ``b1`` [T, 64] fp32 (b_in in w1's row order).  Built from the bf16 packs ``pin`` ([2 width, C]; halves interleaved in blocks of
+    16 rows, or at rows 0 / width) and ``pout`` ([C, width]) and rebuilt whenever those are refreshed."""
+
+    def __init__(self, pin: PackedWeight, pout: PackedWeight, width: int) -> None:
+        C, T, dev = pin.weight.shape[1], width // 16, pin.weight.device
+        w1b, w2b, b1b = _hip.mlp_image_bytes(C)
+        self.w1 = torch.zeros(T, w1b // 2, device=dev, dtype=torch.bfloat16)
+        self.w2 = torch.zeros(T, w2b // 2, device=dev, dtype=torch.bfloat16)
+        self.b1 = torch.zeros(T, b1b // 4, device=dev, dtype=torch.float32)
+        rho = torch.arange(32)
+        g, h, i = rho >> 3, (rho >> 2) & 1, rho & 3
+        ab, j = g >> 1, 8 * h + 4 * (g & 1) + i
+        t = torch.arange(T)[:, None]
+        rows = (32 * t + 16 * ab + j) if pin.grad_rows is not None else (ab * width + 16 * t + j)
+        self.rows = rows.reshape(-1).to(dev)
+        self.packs, self.width, self.C, self.T = (pin, pout), width, C, T
+        self._key = None
+        PackedWeight._derived.add(self)
+
+    @torch.no_grad()
+    def refresh_if_stale(self) -> None:
+        pin, pout = self.packs
+        key = (tuple(pin._versions or ()), tuple(pout._versions or ()))
+        if key == self._key:
+            return
+        C, T = self.C, self.T
+        self.w1[:, :32 * (C + 8)].view(T, 32, C + 8)[:, :, :C].copy_(pin.weight.index_select(0, self.rows).view(T, 32, C))
+        if pin.bias is not None:
+            self.b1[:, :32].copy_(pin.bias.index_select(0, self.rows).view(T, 32))
+        self.w2.view(T, 2, C, 8).copy_(pout.weight.view(C, T, 2, 8).permute(1, 2, 0, 3))
+        self._key = key
+
+    def operands(self):
+        for pk in self.packs:
+            pk.operands()
+        self.refresh_if_stale()
+        return self.w1, self.w2, self.b1
 
 
 class _SwiGLUMLP(torch.autograd.Function):
