@@ -324,6 +324,14 @@ int vsde_linear_gate_bwd_bf16(const void *dy, int64_t ldy, const void *w_t, cons
  *   w2_img [T][2][C][8] bf16: W_out[n][16 t + 8 h + 0..7];   b1_img [T][64] fp32: b_in in w1_img's row order (32 used)
  * s_out (training only, else NULL): silu(a) * b [M][lds] bf16 in natural unit order, what the weight gradient of W_out needs; the
  * pre-activations are never written (the backward recomputes them). */
+/* Block form (no-grad sampling): the gated residuals and modulated LayerNorms on either side of the MLP are the kernel's prologue
+ * and epilogue (reference primitives/sit.py:112-128 under autocast, bf16 roundings where the unfused chain has them):
+ *   x1 = x + ga * yin;  tok = x1 + gm * mlp(LN(x1) (1 + sc) + sh);  hnext = LN(tok) (1 + sn) + hs   (sn / hs / hnext NULL: last block)
+ * x, yin, tok, hnext [M][C] bf16 contiguous; ga .. hs per-batch-row vectors [B][mp] bf16, batch row of row m = m / tokens. */
+int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const void *ga, const void *sc, const void *sh, const void *gm,
+                            const void *sn, const void *hs, int64_t mp, int tokens, double eps, double eps_next, const void *w1_img,
+                            const void *w2_img, const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H,
+                            void *stream);
 /* debugging aid (VSDE_MLP_DEBUG=16): device buffer that receives workgroup 0's per-phase cycle stamps */
 int vsde_mlp_debug_trace(void *buf);
 int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile);

@@ -78,3 +78,29 @@ def test_images_follow_a_pack_refresh():
     y1, _ = _hip.mlp_fwd(x, img.w1, img.w2, img.b1, pout.bias, 704)   # no operands() call: what a captured step replays
     _, y_ref = _reference(x, *[q.detach() for q in params])
     assert _rel(y1, y_ref) < 1e-2 and _rel(y0, y_ref) > 0.1
+
+
+@pytest.mark.parametrize("B,N,C,H,hreal,last", [(40, 401, 256, 704, 682, False), (40, 401, 256, 704, 682, True), (33, 129, 128, 384, 341, False),
+                                               (512, 401, 256, 704, 682, False)])
+def test_block_form_matches_the_unfused_chain(B, N, C, H, hreal, last):
+    """vsde_mlp_block_fwd_bf16 against the kernels it replaces: residual_ln_fwd -> fused MLP -> residual_ln_fwd / gated_residual_fwd
+    (same rounding points; the row statistics are summed in another order: one bf16 ulp of the outputs, |out| <= ~8 here)."""
+    from viforsdes_amd import _hip
+    params, pin, pout, img = _packs(C, H, hreal)
+    w1, w2, b1 = img.operands()
+    x, yin = _rand(B, N, C, seed=11), _rand(B, N, C, seed=12)
+    allm = _rand(B, 8 * C + 64, scale=0.5, seed=13)   # one buffer, six column ranges: the row pitch is shared
+    ga, sc, sh, gm, sn, hs = [allm[:, i * C:(i + 1) * C] for i in range(6)]
+    eps = 1e-5
+    x1, h2, _, _ = _hip.residual_ln_fwd(x, yin, ga, sc, sh, eps)
+    m, _ = _hip.mlp_fwd(h2.reshape(B * N, C), w1, w2, b1, pout.bias, H)
+    m = m.reshape(B, N, C)
+    if last:
+        tok_ref, h_ref = _hip.gated_residual_fwd(x1, m, gm), None
+    else:
+        tok_ref, h_ref, _, _ = _hip.residual_ln_fwd(x1, m, gm, sn, hs, eps)
+    tok, hn = _hip.mlp_block_fwd(x, yin, ga, sc, sh, gm, None if last else sn, None if last else hs, eps, eps, w1, w2, b1, pout.bias, H)
+    assert _rel(tok, tok_ref) < 1e-2
+    assert (hn is None) == last
+    if not last:
+        assert _rel(hn, h_ref) < 1.5e-2

@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
-    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_debug_trace",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_debug_trace",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -883,6 +883,23 @@ def mlp_fwd(x: torch.Tensor, w1_img: torch.Tensor, w2_img: torch.Tensor, b1_img:
         _call(lib.vsde_mlp_fwd_bf16, _ptr(x), _i64(ldx), _ptr(w1_img), _ptr(w2_img), _ptr(b1_img), _ptr(b2), _ptr(y), _i64(C), _ptr(s),
               _i64(H), _i64(M), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
     return y, s
+
+
+def mlp_block_fwd(x, yin, ga, sc, sh, gm, sn, hs, eps: float, eps_next: float, w1_img, w2_img, b1_img, b2, H: int):
+    """Block form of the fused SwiGLU MLP (no-grad): x, yin [B,N,C] bf16 contiguous, modulation vectors [B,C] views of one
+    [B,pitch] buffer -> (tok [B,N,C], hnext [B,N,C] or None when sn / hs are None).  See include/vsde_hip.h."""
+    lib = load(); dev = _require_hip(x, yin, ga, sc, sh, gm, w1_img, w2_img, b1_img)
+    B, N, C = x.shape
+    if not (x.is_contiguous() and yin.is_contiguous() and x.dtype == torch.bfloat16 and yin.dtype == torch.bfloat16 and yin.shape == x.shape):
+        raise ValueError("mlp_block_fwd: x and yin must be contiguous bf16 tensors of one shape")
+    mp = _mod_pitch(C, ga, sc, sh, gm, sn, hs)
+    tok = torch.empty_like(x)
+    hnext = torch.empty_like(x) if sn is not None else None
+    with torch.cuda.device(dev):
+        _call(lib.vsde_mlp_block_fwd_bf16, _ptr(x), _ptr(yin), _ptr(ga), _ptr(sc), _ptr(sh), _ptr(gm), _ptr(sn), _ptr(hs), _i64(mp),
+              ctypes.c_int(N), ctypes.c_double(eps), ctypes.c_double(eps_next), _ptr(w1_img), _ptr(w2_img), _ptr(b1_img), _ptr(b2),
+              _ptr(tok), _ptr(hnext), _i64(B * N), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
+    return tok, hnext
 
 
 def linear_gate_bwd(dy: torch.Tensor, w_t: torch.Tensor, og: torch.Tensor, s: torch.Tensor, dgate: torch.Tensor, tokens: int):

@@ -47,6 +47,7 @@ __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-
 
 constexpr int NW = 8;     // waves per workgroup
 constexpr int SLD = 72;   // staging row pitch (bf16): 64 columns + 16 bytes
+constexpr int MODB = 3;   // block form: batch rows a 256-row stripe may touch (sequences of >= 128 tokens)
 template <int C> struct Geo {
     static constexpr int W1_PITCH = 2 * C + 16;                                   // bytes per row of the W1 image
     static constexpr int W1_BYTES = (32 * W1_PITCH + 1023) / 1024 * 1024;         // padded to whole 1 KB DMA pieces
@@ -68,8 +69,17 @@ struct FwdParams {
     uint16_t *S; int64_t lds_;          // training: s [M][lds_] (16 T columns), else nullptr
     int64_t M; int T;                   // T = tiles of 16 hidden units (a multiple of 4, >= 4)
     long long *trace;                   // DBG & 16: per-wave cycle stamps of workgroup 0, [8 waves][2 T + 2][2] (before / after each barrier)
+    // BLOCK form (no-grad sampling, template flag BLK): the gated residual and modulated LayerNorm on either side of the MLP are
+    // the kernel's prologue and epilogue (reference primitives/sit.py:112-128):
+    //     x1 = x + ga * yin;   h = LN(x1) (1 + sc) + sh  -> the MLP input (X is unused);   out = x1 + gm * mlp(h)  -> TOK
+    //     hn = LN(out) (1 + sn) + hn_shift -> HOUT   (SN == nullptr: last block, no next norm)
+    // per-batch-row vectors [B][mp] bf16 (batch row of row m: m / tokens); roundings to bf16 where the unfused chain has them
+    const uint16_t *R0, *R1, *GA, *SC, *SH, *GM, *SN, *HS;
+    uint16_t *TOK, *HOUT;
+    int64_t mp; int tokens; float eps, eps_next;
     int rotate;                         // 1: per-workgroup rotated tile order (default)
-    int antiphase;                      // 1: waves 4..7 run one phase behind waves 0..3 (default); 0: lockstep (A/B runs)
+    int antiphase;                      // 2: lockstep, one barrier per tile (default); 1: waves 4..7 run one phase behind waves 0..3 (two barriers
+                                        // per tile); 0: lockstep with two barriers (VSDE_MLP_ANTIPHASE, A/B runs)
 };
 
 // LDS-DMA of tile t = { W1 image, bias row, W2 image } into the slot at `buf`: 1 KB pieces round-robin over the 8 waves, EVERY wave
@@ -217,7 +227,7 @@ __device__ __forceinline__ void end_phase(const FwdParams &p, int n, bool g1, bo
 }
 
 // SAVE: 1 = also write s (training).  DBG: timing ablations (wrong results): 2 no SwiGLU arithmetic, 4 no y product, 8 no u product
-template <int C, int SAVE, int DBG = 0>
+template <int C, int SAVE, int DBG = 0, int BLK = 0>
 __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     using G = Geo<C>;
     extern __shared__ __attribute__((aligned(16))) char lsm[];
@@ -228,6 +238,26 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * 32;
     if ((int64_t)blockIdx.x * NW * 32 >= p.M) return;
     // tiles 0 and 1 are on their way while the activations load (T >= 4: the host checks)
+    // block form: this lane's 4 rows of the row-segment layout; their x / yin chunks are requested before anything else (the only
+    // HBM latency of the prologue that nothing can hide: one workgroup per CU)
+    int64_t mrow[4]; int brow[4];
+    u32x4 xr[BLK ? C / 64 : 1][4], yr[BLK ? C / 64 : 1][4];
+    if constexpr (BLK != 0) {
+        const int64_t b0 = ((int64_t)blockIdx.x * NW * 32) / p.tokens;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = row0 + (lane >> 3) + 8 * i;
+            mrow[i] = m < p.M ? m : p.M - 1;
+            brow[i] = (int)(mrow[i] / p.tokens - b0);
+        }
+#pragma unroll
+        for (int q = 0; q < C / 64; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xr[q][i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 64 * q + 8 * (lane & 7));
+                yr[q][i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 64 * q + 8 * (lane & 7));
+            }
+    }
     // Tiles are visited in an order rotated per workgroup (in whole groups of 4 tiles = 64 columns of s): the 256 workgroups of a
     // round pull different lines of the images out of L2 at any moment instead of all queueing for the same ones.
     const int rot = p.rotate ? 4 * (int)((blockIdx.x * 5u) % (unsigned)(p.T / 4)) : 0;
@@ -235,11 +265,83 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     issue_tile<C>(p, (1 + rot) % p.T, lsm + G::BUF, wave, lane);
     if (tid < C / 8) *(u32x4 *)(b2row + 8 * tid) = p.b2 ? *(const u32x4 *)(p.b2 + 8 * tid) : (u32x4){0u, 0u, 0u, 0u};
     bf16x8 xfr[G::KS];
-    {
+    // block form: the modulation vectors of the (at most MODB) batch rows this workgroup's 256 rows belong to, [MODB][6][C] bf16 in LDS
+    // (ga, sc, sh, gm, sn, hs); per lane: the 4 rows of the row-segment layout and their batch-row slots
+    const uint16_t *mods = (const uint16_t *)(lsm + G::NSLOT * G::BUF + NW * 32 * SLD * 2 + C * 2);
+    if constexpr (BLK != 0) {
+        const int64_t wg0 = (int64_t)blockIdx.x * NW * 32, b0 = wg0 / p.tokens;
+        const uint16_t *const vecs[6] = {p.GA, p.SC, p.SH, p.GM, p.SN, p.HS};
+        for (int idx = tid; idx < MODB * 6 * (C / 8); idx += 64 * NW) {
+            const int ch = idx % (C / 8), v = (idx / (C / 8)) % 6, bb = idx / (6 * (C / 8));
+            int64_t b = b0 + bb;
+            const int64_t blast = (p.M - 1) / p.tokens;
+            b = b < blast ? b : blast;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (vecs[v] != nullptr) val = *(const u32x4 *)(vecs[v] + b * p.mp + ch * 8);
+            *(u32x4 *)(const_cast<uint16_t *>(mods) + (bb * 6 + v) * C + ch * 8) = val;
+        }
+        __syncthreads();   // (before any DMA wait is counted: the tile DMAs above stay in flight -- __syncthreads drains vmcnt, which only costs the prologue some overlap)
+    }
+    if constexpr (BLK == 0) {
         const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const uint16_t *src = p.X + m * p.ldx + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) xfr[ks] = *(const bf16x8 *)(src + ks * 16);
+    } else {
+        // Prologue of the block form, in the layout of full row segments: lane -> rows (lane >> 3) + 8 i, columns 64 q + 8 c .. + 7
+        // (128 bytes of a row per 8 lanes).  x1 = x + ga * yin stays in registers (packed), the row statistics are sums over the
+        // lane's 4 chunks and the 8 lanes of a row; h = LN(x1) (1 + sc) + sh then goes through the wave's staging rows into the
+        // MFMA fragment layout (lane (r, h): columns 16 ks + 8 h .. + 7 of row r).
+        constexpr int NQ = C / 64;
+        const int c = lane & 7;
+        u32x4 x1[NQ][4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 64 * q + 8 * c;
+                const u32x4 xv = xr[q][i], yv = yr[q][i];
+                const u32x4 gv = *(const u32x4 *)(mods + (brow[i] * 6 + 0) * C + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t t = pack2(bf_lo(gv[e]) * bf_lo(yv[e]), bf_hi(gv[e]) * bf_hi(yv[e]));
+                    x1[q][i][e] = pack2(bf_lo(xv[e]) + bf_lo(t), bf_hi(xv[e]) + bf_hi(t));
+                    s1[i] += bf_lo(x1[q][i][e]) + bf_hi(x1[q][i][e]);
+                }
+            }
+        float mu[4], rs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = s1[i];
+            t += xor_lane<1>(t); t += xor_lane<2>(t); t += xor_lane<4>(t);
+            mu[i] = t * (1.0f / C);
+            float qq = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d0 = bf_lo(x1[q][i][e]) - mu[i], d1 = bf_hi(x1[q][i][e]) - mu[i]; qq += d0 * d0 + d1 * d1; }
+            qq += xor_lane<1>(qq); qq += xor_lane<2>(qq); qq += xor_lane<4>(qq);
+            rs[i] = rsqrtf(qq * (1.0f / C) + p.eps);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 64 * q + 8 * c;
+                const u32x4 cv = *(const u32x4 *)(mods + (brow[i] * 6 + 1) * C + col), hv = *(const u32x4 *)(mods + (brow[i] * 6 + 2) * C + col);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack2((bf_lo(x1[q][i][e]) - mu[i]) * rs[i] * (1.0f + bf_lo(cv[e])) + bf_lo(hv[e]),
+                                 (bf_hi(x1[q][i][e]) - mu[i]) * rs[i] * (1.0f + bf_hi(cv[e])) + bf_hi(hv[e]));
+                *(u32x4 *)(stage + ((lane >> 3) + 8 * i) * SLD + c * 8) = o;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xfr[4 * q + j] = *(const bf16x8 *)(stage + r * SLD + 16 * j + 8 * h);
+            wave_lds_fence();
+        }
     }
     f32x16 yacc[G::CB];
 #pragma unroll
@@ -248,7 +350,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
     // tile 0 has landed once at most tile 1's instructions are in flight (the x loads above are older still)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::PER) : "memory");
-    const int off = p.antiphase ? wave >> 2 : 0;   // phase offset of this wave
+    const int off = p.antiphase == 1 ? wave >> 2 : 0;   // phase offset of this wave
     int n = 0;
     if (off) { end_phase<C, DBG>(p, n, false, false, wave, lane); ++n; }
     f32x16 u;
@@ -256,7 +358,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         char *slot = lsm + (t % G::NSLOT) * G::BUF, *nslot = lsm + ((t + 2) % G::NSLOT) * G::BUF;
         const int tn = t + 2 < p.T ? (t + 2 + rot) % p.T : -1;   // the tile this wave helps fetch during step t
         if (!(DBG & 8)) gemm1<C>(u, xfr, slot, lane, p, tn, nslot, wave);
-        end_phase<C, DBG>(p, n, true, t + 2 >= p.T, wave, lane); ++n;
+        if (p.antiphase != 2) { end_phase<C, DBG>(p, n, true, t + 2 >= p.T, wave, lane); ++n; }
         bf16x8 sfr, w2a[G::CB / 2];
         if (!(DBG & 4)) gemm2_prefetch<C>(w2a, slot, lane);
         if (!(DBG & 2)) sfr = swiglu8(u);
@@ -269,40 +371,128 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
             }
         }
         if (!(DBG & 4)) gemm2<C>(yacc, sfr, w2a, slot, lane, p, tn, nslot, wave);
-        if (t + 1 < p.T || !off) { end_phase<C, DBG>(p, n, false, false, wave, lane); ++n; }   // (2 T barriers per wave either way)
+        if (p.antiphase == 2) {   // lockstep, ONE barrier per tile: the next tile has landed, everyone is done with this one
+            if (t + 2 < p.T) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if (t + 1 < p.T || !off) { end_phase<C, DBG>(p, n, false, false, wave, lane); ++n; }   // (2 T barriers per wave either way)
     }
     // y = acc + b_out, 64 columns at a time through the wave's staging rows
+    if constexpr (BLK == 0) {
 #pragma unroll
-    for (int q = 0; q < G::CB / 2; ++q) {
+        for (int q = 0; q < G::CB / 2; ++q) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x16 &a = yacc[2 * q + half];
-            const uint16_t *bias32 = b2row + 64 * q + 32 * half;
-            uint16_t *dst = stage + r * SLD + 32 * half;
+            for (int half = 0; half < 2; ++half) {
+                const f32x16 &a = yacc[2 * q + half];
+                const uint16_t *bias32 = b2row + 64 * q + 32 * half;
+                uint16_t *dst = stage + r * SLD + 32 * half;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
-                *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
-                                                             pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+                    *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                                 pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                }
             }
+            wave_lds_fence();
+            flush64(stage, p.Y + 64 * q, p.ldy, row0, p.M, lane);
+            wave_lds_fence();
         }
-        wave_lds_fence();
-        flush64(stage, p.Y + 64 * q, p.ldy, row0, p.M, lane);
-        wave_lds_fence();
+    } else {
+        // epilogue of the block form, in the layout of the row-segment stores: lane -> rows (lane >> 3) + 8 i, columns 64 q + 8 c .. + 7;
+        // x and yin of chunk q + 1 are requested before chunk q is worked on
+        constexpr int NQ = G::CB / 2;
+        const int c = lane & 7;
+        u32x4 tk[NQ][4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f};
+        u32x4 xn[4], yn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 8 * c); yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 8 * c); }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x16 &a = yacc[2 * q + half];
+                const uint16_t *bias32 = b2row + 64 * q + 32 * half;
+                uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+                    *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                                 pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                }
+            }
+            u32x4 xv[4], yv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; yv[i] = yn[i]; }
+            if (q + 1 < NQ) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 64 * (q + 1) + 8 * c);
+                    yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 64 * (q + 1) + 8 * c);
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 64 * q + 8 * c;
+                const u32x4 ml = *(const u32x4 *)(stage + ((lane >> 3) + 8 * i) * SLD + c * 8);
+                const u32x4 gv = *(const u32x4 *)(mods + (brow[i] * 6 + 0) * C + col), mv = *(const u32x4 *)(mods + (brow[i] * 6 + 3) * C + col);
+                u32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t gy = pack2(bf_lo(gv[e]) * bf_lo(yv[i][e]), bf_hi(gv[e]) * bf_hi(yv[i][e]));
+                    const uint32_t x1 = pack2(bf_lo(xv[i][e]) + bf_lo(gy), bf_hi(xv[i][e]) + bf_hi(gy));
+                    const uint32_t gm = pack2(bf_lo(mv[e]) * bf_lo(ml[e]), bf_hi(mv[e]) * bf_hi(ml[e]));
+                    t[e] = pack2(bf_lo(x1) + bf_lo(gm), bf_hi(x1) + bf_hi(gm));
+                    s1[i] += bf_lo(t[e]) + bf_hi(t[e]);
+                }
+                tk[q][i] = t;
+                if (row0 + (lane >> 3) + 8 * i < p.M) *(u32x4 *)(p.TOK + mrow[i] * C + col) = t;
+            }
+            wave_lds_fence();
+        }
+        if (p.SN != nullptr) {   // workgroup-uniform: the next block's modulated LayerNorm of the rows just written
+            float mu[4], rs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = s1[i];
+                t += xor_lane<1>(t); t += xor_lane<2>(t); t += xor_lane<4>(t);
+                mu[i] = t * (1.0f / C);
+                float qq = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d0 = bf_lo(tk[q][i][e]) - mu[i], d1 = bf_hi(tk[q][i][e]) - mu[i]; qq += d0 * d0 + d1 * d1; }
+                qq += xor_lane<1>(qq); qq += xor_lane<2>(qq); qq += xor_lane<4>(qq);
+                rs[i] = rsqrtf(qq * (1.0f / C) + p.eps_next);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 64 * q + 8 * c;
+                    const u32x4 cv = *(const u32x4 *)(mods + (brow[i] * 6 + 4) * C + col), hv = *(const u32x4 *)(mods + (brow[i] * 6 + 5) * C + col);
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = pack2((bf_lo(tk[q][i][e]) - mu[i]) * rs[i] * (1.0f + bf_lo(cv[e])) + bf_lo(hv[e]),
+                                     (bf_hi(tk[q][i][e]) - mu[i]) * rs[i] * (1.0f + bf_hi(cv[e])) + bf_hi(hv[e]));
+                    if (row0 + (lane >> 3) + 8 * i < p.M) *(u32x4 *)(p.HOUT + mrow[i] * C + col) = o;
+                }
+        }
     }
 }
 
 template <int C> static size_t fwd_lds_bytes() {
     using G = Geo<C>;
-    return (size_t)G::NSLOT * G::BUF + (size_t)NW * 32 * SLD * 2 + (size_t)C * 2;
+    return (size_t)G::NSLOT * G::BUF + (size_t)NW * 32 * SLD * 2 + (size_t)C * 2 + (size_t)MODB * 6 * C * 2;
 }
 
-template <int C, int SAVE, int DBG = 0>
+template <int C, int SAVE, int DBG = 0, int BLK = 0>
 static int launch_fwd(const FwdParams &p, hipStream_t s) {
     const size_t lds = fwd_lds_bytes<C>();
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<C, SAVE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<C, SAVE, DBG, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t stripes = (p.M + NW * 32 - 1) / (NW * 32);
-    hipLaunchKernelGGL((mlp_fwd_kernel<C, SAVE, DBG>), dim3((unsigned)stripes), dim3(64 * NW), lds, s, p);
+    hipLaunchKernelGGL((mlp_fwd_kernel<C, SAVE, DBG, BLK>), dim3((unsigned)stripes), dim3(64 * NW), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -324,10 +514,41 @@ extern "C" int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, i
     return 0;
 }
 
+static void mlp_env(mlp::FwdParams &p) {
+    static int anti = -1, rot = -1;   // VSDE_MLP_ANTIPHASE (see FwdParams), VSDE_MLP_ROTATE=0: every workgroup walks the tiles in the same order
+    if (anti < 0) { const char *e = getenv("VSDE_MLP_ANTIPHASE"); anti = e ? atoi(e) : 2; }
+    if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; }
+    p.antiphase = anti; p.rotate = rot; p.trace = g_mlp_trace;
+}
+
+// The block form (no-grad): tokens x, attention branch output yin, per-batch-row modulation vectors (row pitch mp, batch row of
+// row m = m / tokens) -> tok = x1 + gm * mlp(LN(x1) (1 + sc) + sh) with x1 = x + ga * yin, and hnext = LN(tok) (1 + sn) + hs (sn, hs,
+// hnext may be NULL: last block).  Replaces residual_ln_fwd + the MLP + residual_ln_fwd of primitives/sit.py's fused chain.
+extern "C" int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const void *ga, const void *sc, const void *sh, const void *gm,
+                                       const void *sn, const void *hs, int64_t mp, int tokens, double eps, double eps_next,
+                                       const void *w1_img, const void *w2_img, const float *b1_img, const void *b2, void *tok, void *hnext,
+                                       int64_t M, int C, int H, void *stream) {
+    VSDE_CHECK_ARG(x && yin && ga && sc && sh && gm && w1_img && w2_img && b1_img && tok && M > 0 && tokens > 0, VSDE_E_BADARG, "bad mlp_block_fwd arguments");
+    VSDE_CHECK_ARG((C == 128 || C == 256) && H >= 64 && H % 64 == 0, VSDE_E_BADARG,
+                   "fused SwiGLU MLP is built for widths 128 / 256 and a hidden size that is a multiple of 64 (got %d, %d)", C, H);
+    VSDE_CHECK_ARG((!sn) == (!hs) && (!sn) == (!hnext), VSDE_E_BADARG, "next-norm scale, shift and output go together");
+    const void *ptrs[] = {x, yin, ga, sc, sh, gm, sn, hs, w1_img, w2_img, b1_img, b2, tok, hnext};
+    for (const void *q : ptrs) VSDE_CHECK_ARG(((uintptr_t)q % 16) == 0, VSDE_E_BADARG, "mlp_block_fwd operands must be 16-byte aligned");
+    VSDE_CHECK_ARG(mp >= C && mp % 8 == 0, VSDE_E_BADARG, "bad modulation row pitch");
+    VSDE_CHECK_ARG(tokens >= 128, VSDE_E_BADARG, "mlp_block_fwd keeps the modulation vectors of %d batch rows per 256-row stripe: sequences of >= 128 tokens", mlp::MODB);
+    mlp::FwdParams p = {};
+    p.R0 = (const uint16_t *)x; p.R1 = (const uint16_t *)yin; p.GA = (const uint16_t *)ga; p.SC = (const uint16_t *)sc; p.SH = (const uint16_t *)sh;
+    p.GM = (const uint16_t *)gm; p.SN = (const uint16_t *)sn; p.HS = (const uint16_t *)hs; p.TOK = (uint16_t *)tok; p.HOUT = (uint16_t *)hnext;
+    p.mp = mp; p.tokens = tokens; p.eps = (float)eps; p.eps_next = (float)eps_next;
+    p.W1I = (const uint16_t *)w1_img; p.W2I = (const uint16_t *)w2_img; p.B1I = b1_img; p.b2 = (const uint16_t *)b2; p.M = M; p.T = H / 16;
+    mlp_env(p);
+    return C == 256 ? mlp::launch_fwd<256, 0, 0, 1>(p, (hipStream_t)stream) : mlp::launch_fwd<128, 0, 0, 1>(p, (hipStream_t)stream);
+}
+
 extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img, const void *w2_img, const float *b1_img, const void *b2,
                                  void *y, int64_t ldy, void *s_out, int64_t lds, int64_t M, int C, int H, void *stream) {
     VSDE_CHECK_ARG(x && w1_img && w2_img && b1_img && y && M > 0, VSDE_E_BADARG, "bad mlp_fwd arguments");
-    VSDE_CHECK_ARG((C == 128 || C == 256) && H > 0 && H % 64 == 0, VSDE_E_BADARG,
+    VSDE_CHECK_ARG((C == 128 || C == 256) && H >= 64 && H % 64 == 0, VSDE_E_BADARG,
                    "fused SwiGLU MLP is built for widths 128 / 256 and a hidden size that is a multiple of 64 (got %d, %d)", C, H);
     VSDE_CHECK_ARG(ldx >= C && ldx % 8 == 0 && ldy >= C && ldy % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                    ((uintptr_t)w1_img % 16) == 0 && ((uintptr_t)w2_img % 16) == 0 && ((uintptr_t)b1_img % 16) == 0 &&
@@ -337,12 +558,9 @@ extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img,
     mlp::FwdParams p = {};
     p.X = (const uint16_t *)x; p.ldx = ldx; p.W1I = (const uint16_t *)w1_img; p.W2I = (const uint16_t *)w2_img; p.B1I = b1_img;
     p.b2 = (const uint16_t *)b2; p.Y = (uint16_t *)y; p.ldy = ldy; p.S = (uint16_t *)s_out; p.lds_ = lds; p.M = M; p.T = H / 16;
-    static int dbg = -1, anti = -1;   // VSDE_MLP_DEBUG: timing ablations (wrong results); VSDE_MLP_ANTIPHASE=0: all waves in lockstep
+    static int dbg = -1;   // VSDE_MLP_DEBUG: timing ablations (wrong results)
     if (dbg < 0) { const char *e = getenv("VSDE_MLP_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (anti < 0) { const char *e = getenv("VSDE_MLP_ANTIPHASE"); anti = e ? atoi(e) : 1; }
-    p.antiphase = anti;
-    { static int rot = -1; if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; } p.rotate = rot; }
-    p.trace = g_mlp_trace;
+    mlp_env(p);
     hipStream_t st = (hipStream_t)stream;
     if (C == 256 && dbg && !s_out) {
         switch (dbg) {

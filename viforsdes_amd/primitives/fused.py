@@ -816,6 +816,12 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     return torch.nn.functional.linear(x, weight, bias)
 
 
+# VSDE_FUSED_MLP=0: the two-launch SwiGLU MLP everywhere (A/B runs)
+FUSED_MLP = os.environ.get("VSDE_FUSED_MLP", "1") != "0"
+# VSDE_BLOCK_MLP=0: residual / LayerNorm passes stay separate kernels in the no-grad chain (A/B runs)
+BLOCK_MLP = os.environ.get("VSDE_BLOCK_MLP", "1") != "0"
+
+
 class MlpImages:
     """Weight operands of the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) as tile images, one tile = 16 hidden units:
     ``w1`` [T, 32 rows, C + 8] (row 8 g + 4 h + i = (a if g < 2 else b) unit 16 t + 8 h + 4 (g & 1) + i: the MFMA result layout then
@@ -859,6 +865,30 @@ class MlpImages:
         return self.w1, self.w2, self.b1
 
 
+def mlp_block_nograd_usable(x: Tensor, mods: Optional["Modulations"], width: int) -> bool:
+    """Whether [gated residual + modulated LayerNorm + SwiGLU MLP + gated residual + next LayerNorm] runs as ONE kernel
+    (``mlp_block_nograd``): no-grad calls on bf16 [B, N, C] streams with C in (128, 256) and packed modulations."""
+    return (ENABLED and OWN_GEMM and FUSED_MLP and BLOCK_MLP and not torch.is_grad_enabled() and mods is not None and x.is_cuda
+            and x.dtype == torch.bfloat16 and x.ndim == 3 and x.shape[-1] in (128, 256) and width % 64 == 0 and width >= 64
+            and x.numel() // x.shape[-1] >= OWN_GEMM_MIN_ROWS and mods.allm.dtype == torch.bfloat16)
+
+
+@torch.no_grad()
+def mlp_block_nograd(x: Tensor, attn_out: Tensor, mods: "Modulations", block: int, nxt: Optional[int], eps: float, eps_next: float,
+                     pin: PackedWeight, pout: PackedWeight):
+    """(tokens_new, h_next) of one SiT block's second half (reference primitives/sit.py:112-128) from the stream ``x`` and the
+    attention branch's output: csrc/vsde_mlp.hip in its block form.  ``nxt``: index of the block whose first norm follows (None:
+    last block, ``h_next`` is None).  Chunk order of a block's modulations: (sa, ha, ga, sm, hm, gm)."""
+    img = getattr(pin, "_mlp_images", None)
+    if img is None:
+        img = pin._mlp_images = MlpImages(pin, pout, pout.weight.shape[1])
+    w1i, w2i, b1i = img.operands()
+    sn = None if nxt is None else mods.vec(nxt, 0)
+    hs = None if nxt is None else mods.vec(nxt, 1)
+    return _hip.mlp_block_fwd(x.contiguous(), attn_out.to(x.dtype).contiguous(), mods.vec(block, 2), mods.vec(block, 3), mods.vec(block, 4),
+                              mods.vec(block, 5), sn, hs, eps, eps_next, w1i, w2i, b1i, pout.bias, pout.weight.shape[1])
+
+
 class _SwiGLUMLP(torch.autograd.Function):
     """SwiGLU feed-forward ``W_out (silu(a) * b) + b_out`` with ``[a | b] = W_in x + b_in`` (mlp.py:50-54) around two GEMM
     kernels with fused epilogues: the input projection writes u (for the backward) and s = silu(a) * b in one pass, the
@@ -870,6 +900,14 @@ class _SwiGLUMLP(torch.autograd.Function):
         w1, b1 = pin.operands()
         w2, b2 = pout.operands()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        if not train and FUSED_MLP and x2.shape[1] in (128, 256) and w2.shape[1] % 64 == 0:
+            # no-grad call (posterior sampling): ONE kernel, neither u nor s is materialised (csrc/vsde_mlp.hip)
+            img = getattr(pin, "_mlp_images", None)
+            if img is None:
+                img = pin._mlp_images = MlpImages(pin, pout, w2.shape[1])
+            w1i, w2i, b1i = img.operands()
+            y, _ = _hip.mlp_fwd(x2, w1i, w2i, b1i, b2, w2.shape[1])
+            return y.reshape(*x.shape[:-1], w2.shape[0])
         # the pre-activation u is only kept for the backward: a no-grad call (posterior sampling) skips its [M, 2*width] write
         u, s_ = _hip.linear_swiglu_bf16(x2, w1, b1, want_u=train)
         y = _mm_nt(s_, w2, b2)

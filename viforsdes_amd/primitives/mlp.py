@@ -27,18 +27,27 @@ class SwiGLU(nn.Module):
         b1 = None if self.input_proj.bias is None else F.pad(self.input_proj.bias.view(2, h), (0, pad)).reshape(2 * width)
         return w1, b1, F.pad(self.output_proj.weight, (0, pad))
 
+    def padded_width(self) -> int:
+        return -(-self.hidden_dim // _PAD) * _PAD   # 682 -> 704 (a multiple of the 64-column tile pairs; 768 wasted 9 % more)
+
+    def packs(self, x: Tensor, fused_mlp: bool):
+        """The (cached) bf16 operand packs of both projections, padded to ``padded_width()``."""
+        width = self.padded_width()
+        packs = getattr(self, "_packs", None)
+        if (packs is None or packs[0].weight.device != x.device or packs[0].weight.shape[0] != 2 * width
+                or (packs[0].grad_rows is not None) != fused_mlp):
+            packs = fused.swiglu_packs(self.input_proj.weight, self.input_proj.bias, self.output_proj.weight,
+                                       self.output_proj.bias, width, interleave=fused_mlp)
+            object.__setattr__(self, "_packs", packs)
+        return packs
+
     def forward(self, x: Tensor) -> Tensor:
         if fused.ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
-            width = -(-self.hidden_dim // _PAD) * _PAD   # 682 -> 704 (a multiple of the 64-column tile pairs; 768 wasted 9 % more)
+            width = self.padded_width()
             if fused.packed_linear_usable(x, 2 * width, self.in_dim):
                 # bf16 operands of both projections (padded to `width`) live in a cache refreshed once per optimizer step
                 fused_mlp = fused.swiglu_mlp_usable(x, width)   # both GEMMs with the SwiGLU math in their epilogues
-                packs = getattr(self, "_packs", None)
-                if (packs is None or packs[0].weight.device != x.device or packs[0].weight.shape[0] != 2 * width
-                        or (packs[0].grad_rows is not None) != fused_mlp):
-                    packs = fused.swiglu_packs(self.input_proj.weight, self.input_proj.bias, self.output_proj.weight,
-                                               self.output_proj.bias, width, interleave=fused_mlp)
-                    object.__setattr__(self, "_packs", packs)
+                packs = self.packs(x, fused_mlp)
                 if fused_mlp:
                     return fused.swiglu_mlp(x, packs[0], packs[1])
                 return fused.packed_linear(fused.swiglu(fused.packed_linear(x, packs[0])), packs[1])

@@ -142,6 +142,14 @@ class SiT(nn.Module):
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
             lk = link0 if k == 0 else None
+            if (isinstance(blk.mlp, SwiGLU) and blk.mlp.input_proj.bias is not None
+                    and fused.mlp_block_nograd_usable(tokens, mods, blk.mlp.padded_width())
+                    and fused.swiglu_mlp_usable(tokens, blk.mlp.padded_width())):
+                # no-grad call: [res1 + LN2 | MLP | res2 + next LN1] is ONE kernel (csrc/vsde_mlp.hip, block form)
+                pin, pout = blk.mlp.packs(tokens, True)
+                tokens, h1 = fused.mlp_block_nograd(tokens, attn_out, mods, k, k + 1 if k + 1 < nb else None, blk.mlp_norm.eps,
+                                                    blocks[k + 1].attn_norm.eps if k + 1 < nb else blk.mlp_norm.eps, pin, pout)
+                continue
             if mods is None:
                 x1, h2 = fused.residual_norm(tokens, attn_out, ml[k][GA], ml[k][SM], ml[k][HM], blk.mlp_norm.eps, lk)
             else:
