@@ -73,35 +73,58 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
 PMC_FILE = "profiles/r04_pmc_head_lv.txt"
 
 
+FWD_KERNELS = ("head_fwd_mp_kernel<2, true", "head_fwd_v2_kernel<2, true")
+BWD_KERNELS = ("head_bwd_v2_kernel<2", "head_bwd_mp_kernel<")
+
+
+def _fetch_factor(kernel_name):
+    """MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports HALF the bytes of wide coalesced streaming reads (16 bytes
+    per lane).  The multi-path forward kernel streams its one large input -- the projected context G, fp32 -- as f32x4 per lane
+    (csrc/vsde_head_mp.hip): its FETCH_SIZE is doubled.  The four-waves-per-path kernels (forward v2, reverse sweep v2) read with
+    4-byte lanes, for which the guide gives no correction: raw counter."""
+    return 2.0 if "head_fwd_mp_kernel" in kernel_name else 1.0
+
+
+def _traffic_from_counters(vals):
+    """{(kernel, counter): KiB per dispatch} -> (forward bytes, backward bytes or None) per launch."""
+    def total(kinds):
+        for k in kinds:
+            f, w = vals.get((k, "FETCH_SIZE")), vals.get((k, "WRITE_SIZE"))
+            if f is not None and w is not None:
+                return (_fetch_factor(k) * f + w) * 1024.0
+        return None
+    return total(FWD_KERNELS), total(BWD_KERNELS)
+
+
 def pmc_traffic_bytes(workload, batch):
-    """HBM bytes per launch of the serial forward kernel (training variant) from the committed rocprofv3 --pmc passes
-    (PMC_FILE: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed over the XCDs).  The kernel reads with 4-byte loads, for which the guide gives no FETCH_SIZE correction, so the raw
-    counter is used; null for other workloads."""
+    """(forward, backward) HBM bytes per launch of the serial time-stepping kernels (training variant) from the committed
+    rocprofv3 --pmc passes (PMC_FILE: FETCH_SIZE and WRITE_SIZE in KiB, separate passes, LV B=512, per-dispatch means summed over
+    the XCDs; FETCH_SIZE corrected per ``_fetch_factor``); (None, None) for other workloads."""
     path = os.path.join(ROOT, PMC_FILE)
     if workload != "lv" or batch != 512 or not os.path.exists(path):
-        return None
+        return None, None
     vals, kernel = {}, ""
     for line in open(path):
         if not line.startswith(" ") and "dispatches=" in line:
             kernel = line
-        elif ("head_fwd_mp_kernel<2, true" in kernel or "head_fwd_v2_kernel<2, true" in kernel) and "mean=" in line:
+        elif "mean=" in line:
             name = line.split()[0]
             if name in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[name] = float(line.split("mean=")[1])
-    if len(vals) != 2:
-        return None
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                for k in FWD_KERNELS + BWD_KERNELS:
+                    if k in kernel:
+                        vals[(k, name)] = float(line.split("mean=")[1])
+    return _traffic_from_counters(vals)
 
 
-LIVE_TRAFFIC = None   # (bytes per launch, source text) measured by this run's own rocprofv3 --pmc passes (measure_pmc_traffic)
+LIVE_TRAFFIC = None   # (forward bytes, backward bytes) per launch measured by this run's own rocprofv3 --pmc passes (measure_pmc_traffic)
 
 
 def measure_pmc_traffic(batch, timeout_s=120):
-    """HBM bytes per launch of the serial forward kernel (training variant), measured NOW: two child processes -- one
-    ``rocprofv3 --pmc`` pass per counter (FETCH_SIZE, WRITE_SIZE; never combined with each other or with the hip / hsa trace
-    domains, MI355X_MICROARCH.md) over ``tools/head_probe.py 3 <batch>`` (the head alone at the benchmark's dims) -- started
-    before this process touches the GPU.  KiB summed over the XCDs, mean over the dispatches; 4-byte loads: no FETCH_SIZE
-    correction (as for the committed passes).  None when rocprofv3 is missing or a pass fails: the committed figure stands."""
+    """(forward, backward) HBM bytes per launch of the serial time-stepping kernels (training variant), measured NOW: two child
+    processes -- one ``rocprofv3 --pmc`` pass per counter (FETCH_SIZE, WRITE_SIZE; never combined with each other or with the hip /
+    hsa trace domains, MI355X_MICROARCH.md) over ``tools/head_probe.py 3 <batch>`` (the head alone at the benchmark's dims) --
+    started before this process touches the GPU.  KiB summed over the XCDs, mean over the dispatches, FETCH_SIZE corrected per
+    ``_fetch_factor``.  None when rocprofv3 is missing or a pass fails: the committed figure stands."""
     import glob
     import shutil
     import sqlite3
@@ -110,7 +133,7 @@ def measure_pmc_traffic(batch, timeout_s=120):
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
     if exe is None or profiled:   # no profiler, or this process itself runs under one (no nested passes)
         return None
-    total = 0.0
+    vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="vsde_pmc_", dir="/tmp")
         try:
@@ -121,21 +144,24 @@ def measure_pmc_traffic(batch, timeout_s=120):
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if not dbs:
                 return None
-            acc, seen = 0.0, set()
+            acc, seen = {}, {}
             for name, disp, cname, val in sqlite3.connect(dbs[0]).execute(
                     "select kernel_name, dispatch_id, counter_name, value from counters_collection"):
-                if cname == ctr and ("head_fwd_mp_kernel<2, true" in name or "head_fwd_v2_kernel<2, true" in name):
-                    acc += val
-                    seen.add(disp)
-            if not seen:
-                return None
-            total += acc / len(seen)
+                if cname != ctr:
+                    continue
+                for k in FWD_KERNELS + BWD_KERNELS:
+                    if k in name:
+                        acc[k] = acc.get(k, 0.0) + val
+                        seen.setdefault(k, set()).add(disp)
+            for k in acc:
+                vals[(k, ctr)] = acc[k] / len(seen[k])
         except Exception as err:
             print(f"[bench] live PMC pass {ctr} failed ({type(err).__name__}); using the committed figure", file=sys.stderr)
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return total * 1024.0
+    fwd, bwd = _traffic_from_counters(vals)
+    return None if fwd is None else (fwd, bwd)
 
 
 def sync(device):
@@ -311,6 +337,68 @@ def encoder_flops_per_step(B, N, C, depth, heads, mlp_hidden, cond_dim):
     return 3.0 * fwd
 
 
+FAMILIES = (   # kernel-name fragments -> family of the step's kernel table
+    ("attention", ("attn_",)),
+    ("own_gemm", ("lin_rows_kernel", "lin_cols_kernel", "lin_deep_kernel", "mlp_fwd_kernel", "mlp_bwd_kernel")),
+    ("library_gemm", ("Cijk_",)),
+    ("ln_residual", ("ln_mod_", "gated_residual", "residual_ln", "swiglu_fwd_kernel", "swiglu_bwd_kernel", "gate_merge", "qk_norm_rope")),
+    ("weight_grad", ("wgrad_", "colsum_")),
+    ("head_elbo", ("head_", "tn_wide", "tn_grouped", "proj_fwd", "proj_bwd", "gemm_nt", "elbo_", "coef_", "em_fwd", "em_bwd", "mp_prep", "split_planes")),
+    ("optimizer", ("optim_", "pack_refresh", "pack_weights")),
+)
+
+
+def encoder_families(step_fn, device, B, N, C, depth, heads, mlp_hidden, mlp_padded):
+    """Kernel time of ONE eager training step by family (torch.profiler kernel records = the HIP activity timestamps of every
+    launch, outside the timed region), with the algorithmic FLOPs / bytes of the families that have a roof:
+      attention    4 B heads N^2 d forward (QK^T, PV) + 2.5 x that backward                              -> fraction of the bf16 MFMA peak
+      gemm (own + library together: which shapes run where is a dispatch decision, see the two time entries)
+                   forward projections + their input gradients (2 x forward)                            -> fraction of the MFMA peak
+      weight_grad  the same products once more (dW = dy^T x)                                             -> fraction of the MFMA peak
+      ln_residual  every pass reads and writes [M, C] bf16 streams: 4 per fused residual+norm forward (x, y in; xnew, h out),
+                   5 backward (xnew, y, dh, dxnew in ... counted as 4 in + 2 out), 2 LN per block        -> fraction of the HBM peak
+    Returns None when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        step_fn(); sync(device)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step_fn(); sync(device)
+        fam = {name: 0.0 for name, _ in FAMILIES}
+        fam["other"], launches = 0.0, 0
+        for ev in prof.events():
+            if ev.device_type != torch.autograd.DeviceType.CUDA:
+                continue
+            launches += 1
+            for name, frags in FAMILIES:
+                if any(f in ev.name for f in frags):
+                    fam[name] += ev.device_time
+                    break
+            else:
+                fam["other"] += ev.device_time
+    except Exception as err:   # the table is a report, never a requirement
+        print(f"[bench] encoder_families unavailable ({type(err).__name__}: {err})", file=sys.stderr)
+        return None
+    M, d = B * N, C // heads
+    attn_fl = depth * 4.0 * B * heads * N * N * d * 3.5
+    proj_fl = depth * 2.0 * M * (C * (3 * C + d) + C * C + C * 2 * mlp_padded + mlp_padded * C) + 2.0 * M * C * C
+    stream = 2.0 * M * C   # one bf16 [M, C] stream
+    ln_bytes = depth * 2 * (4 + 6) * stream
+    total = sum(fam.values())
+    tf = lambda fl, us: fl / (us * 1e-6) / 1e12 if us > 0 else None
+    out = {"launches_per_step": launches, "kernel_us_per_step": total, "us": {k: round(v, 1) for k, v in fam.items()},
+           "share": {k: round(v / total, 4) for k, v in fam.items()} if total > 0 else None}
+    gemm_us = fam["own_gemm"] + fam["library_gemm"]
+    out["attention"] = {"flops": attn_fl, "tflops": tf(attn_fl, fam["attention"]),
+                        "frac_mfma": (tf(attn_fl, fam["attention"]) or 0.0) / MFMA_BF16_PEAK_TFLOPS}
+    out["gemm"] = {"flops": 2.0 * proj_fl, "tflops": tf(2.0 * proj_fl, gemm_us), "frac_mfma": (tf(2.0 * proj_fl, gemm_us) or 0.0) / MFMA_BF16_PEAK_TFLOPS,
+                   "note": "forward + input-gradient products; padded SwiGLU width; own and library kernels together"}
+    out["weight_grad"] = {"flops": proj_fl, "tflops": tf(proj_fl, fam["weight_grad"]),
+                          "frac_mfma": (tf(proj_fl, fam["weight_grad"]) or 0.0) / MFMA_BF16_PEAK_TFLOPS}
+    out["ln_residual"] = {"bytes": ln_bytes, "gbs": ln_bytes / (fam["ln_residual"] * 1e-6) / 1e9 if fam["ln_residual"] > 0 else None,
+                          "frac_hbm": (ln_bytes / (fam["ln_residual"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if fam["ln_residual"] > 0 else None}
+    return out
+
+
 def measure(workload, batch, args, device, distributed, world):
     """Everything the JSON line says about ONE workload on this rank's GPU: the timed full ELBO step (K steps after W warm-up,
     barrier + synchronize on both sides, MAX over ranks), the no-grad sampling calls, HIP-event timings of the head kernels
@@ -443,6 +531,31 @@ def measure(workload, batch, args, device, distributed, world):
         gs.pack()
     e1.record(); sync(device)
     dp_pack_ms = e0.elapsed_time(e1) / 10
+    dp_payload_bytes = int(gs.flat.numel()) * 4
+    # The collective itself on ONE rank (N > 1 is not available to this run): a 1-rank RCCL group's all-reduce of the same flat
+    # buffer in the same two buckets = the launch + local pass a step pays before any xGMI traffic; the xGMI part is priced in
+    # DESIGN.md section 6 (ring all-reduce: 2 (N - 1) / N x payload over 7 links per GPU).
+    allreduce_1rank_ms = None
+    if not distributed and not dist.is_initialized():
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            for b in gs.buckets:
+                dist.all_reduce(b)
+            sync(device); e0.record()
+            for _ in range(10):
+                hs = [dist.all_reduce(b, async_op=True) for b in gs.buckets]
+                for h in hs:
+                    h.wait()
+            e1.record(); sync(device)
+            allreduce_1rank_ms = e0.elapsed_time(e1) / 10
+        except Exception as err:
+            print(f"[bench] 1-rank RCCL probe unavailable ({type(err).__name__}: {err})", file=sys.stderr)
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
     del gs
     for p in model.parameters():
         p.grad = None
@@ -513,14 +626,31 @@ def measure(workload, batch, args, device, distributed, world):
     enc_flops = encoder_flops_per_step(batch, T + 1, C, depth, heads, mlp_hidden, cond_dim)
     for p in model.parameters():
         p.grad = None
+    families = None
+    if not distributed and not getattr(args, "no_families", False):
+        # the step's kernel table by family (one profiled EAGER step outside the timed region): the encoder is 93 % of the step
+        was_training = model.training
+        model.train()
 
-    traffic = pmc_traffic_bytes(workload, batch)
+        def eager_step():
+            tr._train_step(model)
+            ctx.ema.update()
+        mlp0 = enc_mod.sit.blocks[0].mlp
+        families = encoder_families(eager_step, device, batch, T + 1, C, depth, heads, mlp_hidden,
+                                    mlp0.padded_width() if hasattr(mlp0, "padded_width") else mlp_hidden)
+        model.train(was_training)
+        for p in model.parameters():
+            p.grad = None
+
+    traffic, traffic_bwd = pmc_traffic_bytes(workload, batch)
+    correction = ("FETCH_SIZE x 2 for the multi-path forward kernel (16-byte lanes: the gfx950 counter reports half, MI355X_MICROARCH.md), "
+                  "raw for the 4-byte-lane reverse sweep")
     traffic_source = (None if traffic is None else f"committed PMC passes ({PMC_FILE}: FETCH_SIZE + WRITE_SIZE, separate --pmc runs: "
-                      "tools/pmc.sh vsde::head tools/head_probe.py 3), not measured in this run")
+                      f"tools/pmc.sh vsde::head tools/head_probe.py 3; {correction}), not measured in this run")
     if LIVE_TRAFFIC is not None and workload == "lv" and batch == 512:
         traffic_source = ("measured by this run: one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE) over tools/head_probe.py 3 512 in "
-                          f"child processes before the timed region; the committed passes ({PMC_FILE}) give {traffic}")
-        traffic = LIVE_TRAFFIC
+                          f"child processes before the timed region; {correction}; the committed passes ({PMC_FILE}) give {traffic}")
+        traffic, traffic_bwd = LIVE_TRAFFIC
     # mirrors csrc/vsde_head.hip::mp_auto (training launch: multi-path from 96 paths on) and vsde_head_mp.hip's group size
     fwd_kernel = ("multi-path MFMA kernel (csrc/vsde_head_mp.hip), " + ("4" if batch <= 1024 else "8" if batch <= 2048 else "16") + " paths per workgroup"
                   if (batch >= 96 and H == 64 and L <= 2 and S <= 2) else "four-waves-per-path VALU kernel (csrc/vsde_head.hip)")
@@ -538,6 +668,8 @@ def measure(workload, batch, args, device, distributed, world):
         "rccl_ranks": dist.get_world_size() if distributed else 1,
         "allreduce_ms_per_step": allreduce_ms,
         "dp_pack_ms": dp_pack_ms,
+        "dp_payload_bytes": dp_payload_bytes,
+        "allreduce_1rank_ms": allreduce_1rank_ms,
         "roofline": {"kernel": f"vsde head forward, GRU time-stepping kernel (training variant, L={L}): {fwd_kernel}",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -552,6 +684,7 @@ def measure(workload, batch, args, device, distributed, world):
                      "frac_incl_projection": gbs(fwd_bytes_step, avg[2]) / HBM_PEAK_GBS,
                      "backward": {"serial_kernel_ms": bwd_ms, "grad_context_gemm_ms": avg[5], "weight_grad_reduction_ms": avg[6],
                                   "backward_path_ms": avg[3], "bytes_per_path_step": bwd_bytes_step,
+                                  "algorithmic_bytes": bwd_bytes_step * steps_per_launch, "traffic": traffic_bwd,
                                   "achieved": gbs(bwd_bytes_step, bwd_ms), "frac": gbs(bwd_bytes_step, bwd_ms) / HBM_PEAK_GBS,
                                   "frac_whole_path": gbs(bwd_bytes_step, avg[3]) / HBM_PEAK_GBS}},
         "roofline_eval": {"kernel": f"vsde head forward, GRU time-stepping kernel (no-grad sampling variant, L={L})",
@@ -560,6 +693,7 @@ def measure(workload, batch, args, device, distributed, world):
                           "algorithmic_bytes": eval_bytes_step * steps_per_launch, "bytes_per_path_step": eval_bytes_step,
                           "path_steps_per_launch": steps_per_launch, "valu_floor_ms": valu_floor_ms,
                           "frac_of_valu_floor": valu_floor_ms / eval_ms},
+        "encoder_families": families,
         "mfma_util": {"encoder_flops_per_step": enc_flops, "encoder_fwd_bwd_ms": enc_ms,
                       "achieved_tflops": enc_flops / (enc_ms * 1e-3) / 1e12, "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
                       "frac": enc_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -585,6 +719,7 @@ def main():
     ap.add_argument("--hip-graph", action="store_true", help="always replay the captured HIP graph (default: whichever of "
                     "eager / replay is faster in a 3-step probe before the warm-up; same kernels and work either way)")
     ap.add_argument("--cpu-micro-batch", type=int, default=64)
+    ap.add_argument("--no-families", dest="no_families", action="store_true", help="skip the encoder_families kernel table (one profiled eager step)")
     ap.add_argument("--no-pmc", action="store_true", help="roofline.traffic from the committed PMC passes instead of two live "
                     "rocprofv3 --pmc passes (child processes, ~30 s) before the timed region")
     args = ap.parse_args()

@@ -72,7 +72,25 @@ def _worker(rank, world, port, out_dir):
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     dist.all_gather(gathered, flat)
     assert all(torch.equal(gathered[0], g) for g in gathered), "parameters diverged across ranks"
+    torch.save({"final": flat, "early_launches": ctx.grad_sync.early_launches}, os.path.join(out_dir, f"final{rank}.pt"))
     ctx.cleanup()
+
+
+@pytest.mark.timeout(600)
+def test_early_bucket_overlap_is_bit_identical(tmp_path, monkeypatch):
+    """The early gradient bucket (sent from inside the backward pass from the second step on) against the plain path (everything
+    after the backward): the same three optimizer steps on two ranks must end in bit-identical parameters, and the overlapped run
+    must really have launched early (steps 2 and 3)."""
+    finals = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VSDE_DP_OVERLAP", mode)
+        monkeypatch.setenv("VSDE_DP_OVERLAP_MIN", "0")
+        d = tmp_path / f"overlap{mode}"
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(d)), nprocs=2, join=True)
+        finals[mode] = torch.load(d / "final0.pt")
+    assert finals["1"]["early_launches"] == 2 and finals["0"]["early_launches"] == 0
+    assert torch.equal(finals["1"]["final"], finals["0"]["final"])
 
 
 @pytest.mark.timeout(600)

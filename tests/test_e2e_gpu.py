@@ -231,6 +231,41 @@ def test_captured_step_ignores_the_packs_of_other_models():
     assert torch.equal(foreign.weight, image)
 
 
+def test_captured_step_refills_packs_that_an_ema_swap_rewrote():
+    """the captured forward holds no operand refresh, so a replay right after something else re-filled the
+    packs -- here a no-grad forward under ``ema.apply()``, what ``VariationalPosterior.sample()`` does from a ``train()`` callback --
+    used to run its forward and backward on the EMA weights.  Two identical trainers replay the same two steps (same seeds); one of
+    them samples under the EMA swap in between (its RNG state restored afterwards): their parameters must stay bit-identical, and
+    the packs must hold the live weights when the second replay starts."""
+    from viforsdes_amd.inference.diffusion_path_sampler import sample_diffusion_paths
+    from viforsdes_amd.primitives.fused import PackedWeight
+
+    def run(interleave):
+        tr = _small_ou_trainer(batch=256, seed=11)       # 256 x 101 rows: the packed routes are taken
+        ctx = tr.ctx
+        replay = tr.capture_step_graph(warmup=2)
+        assert replay is not None
+        torch.manual_seed(123); torch.cuda.manual_seed(123)
+        replay()
+        if interleave:
+            ids = {id(q) for q in ctx.model.parameters()}
+            rng = torch.cuda.get_rng_state(torch.device(DEV))
+            with torch.no_grad(), ctx.ema.apply():
+                theta = ctx.model.sde_parameter_posterior.rsample(256)
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    sample_diffusion_paths(ctx.model.encoder, ctx.model.head, ctx.observations, theta, ctx.x0_buffer[:256],
+                                           tr.time_horizon, tr.config.time_step, tr.state_space)
+            torch.cuda.set_rng_state(rng, torch.device(DEV))
+            mine = [pk for pk in PackedWeight._live if any(id(q) in ids for q in pk.params)]
+            assert mine and any(pk.stale() for pk in mine), "the swap did not touch the packs: the test would be vacuous"
+        replay()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in ctx.model.parameters()]
+
+    plain, swapped = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(plain, swapped))
+
+
 def test_captured_step_with_the_multi_path_kernels_replays_like_eager_steps():
     """704 paths (OU, small encoder): forward AND reverse-time sweep take the multi-path MFMA kernels under the default dispatch; their
     launch sequence (fragment prep kernels, the max-abs pre-pass with its memset, the sweeps) must survive HIP-graph capture: a
@@ -344,6 +379,61 @@ def test_bf16_fused_trajectory_tracks_the_bf16_torch_chain():
     print("\nbf16 fused vs bf16 torch chain: ELBO", e_f, e_t, "max rel", rel, "E[theta] rel", rel_err(ev_f, ev_t), "stale", stale)
     assert stale == 0.0, "a cached bf16 GEMM operand no longer matches its parameter after the optimizer step"
     assert rel < 5e-3 and rel_err(ev_f, ev_t) < 1e-3
+
+
+def test_fp16_amp_route_trains_and_tracks_fp32():
+    """``TrainingConfig(amp_dtype=AmpDtype.FLOAT16)`` (reference config.py:24-38, trainer.py:173: autocast in fp16 + GradScaler):
+    the fused encoder operators are bf16 / fp32 kernels, so under fp16 autocast the encoder runs as the torch autocast chain
+    (library GEMMs, SDPA) and hands the GRU head an fp16 context, which the HIP head kernels take as fp32.  Three optimizer steps
+    at the ``fused_dims`` size from one initial state on identical injected draws: finite ELBOs with a live loss scale, the fp16
+    trajectory within fp16 accuracy of the fp32 one (5e-3 relative, the bench's bf16 gate), and closer to it than bf16 must be."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from viforsdes_amd import AmpDtype, EncoderConfig, HeadConfig, TrainingConfig
+    from viforsdes_amd.console import Console
+    from viforsdes_amd.examples.sdes import ou_problem
+    from viforsdes_amd.inference.trainer import VariationalInferenceTrainer
+    sde, obs, like, prior, horizon, dt, state_pos, theta_pos = ou_problem()
+    B, T, steps = 128, 100, 3
+    g = torch.Generator().manual_seed(17)
+    teps = [torch.randn(B, 3, generator=g).to(DEV) for _ in range(steps)]
+    noise = [torch.randn(B, T, 1, generator=g).to(DEV) for _ in range(steps)]
+
+    def make(mixed, amp):
+        return VariationalInferenceTrainer(
+            sde=sde, observations=obs, observation_likelihood=like, prior=prior, time_horizon=horizon,
+            config=TrainingConfig(time_step=dt, batch_size=B, n_iterations=1, learning_rate=1e-4, sde_param_lr=1e-3, amp_dtype=amp),
+            encoder_config=EncoderConfig(hidden_dim=128, num_heads=2, depth=2), head_config=HeadConfig(hidden_dim=64, num_layers=2),
+            state_positive_dims=state_pos, sde_param_positive_dims=theta_pos, device=torch.device(DEV), mixed_precision=mixed,
+            console=Console(enabled=False), seed=23)
+
+    ref = make(False, AmpDtype.BFLOAT16)
+    gw = torch.Generator().manual_seed(3)
+    with torch.no_grad():   # the default init leaves the emission independent of the GRU state: give it something to propagate
+        w = ref.ctx.model.head.out_proj.weight
+        w.copy_((torch.randn(w.shape, generator=gw) * 0.1).to(w.device))
+    init = {k: v.clone() for k, v in ref.ctx.model.state_dict().items()}
+
+    def run(tr):
+        tr.ctx.model.load_state_dict(init)
+        tr.ctx.ema._init_shadow()
+        tr.ctx.model.train()
+        out = []
+        for k in range(steps):
+            r = tr._train_step(tr.ctx.model, theta_eps=teps[k], path_noise=noise[k])
+            out.append(float(r.elbo_result.evidence_lower_bound))
+            assert np.isfinite(float(r.grad_norm))
+        return out
+
+    e32 = run(ref)
+    tr16 = make(True, AmpDtype.FLOAT16)
+    e16 = run(tr16)
+    ebf = run(make(True, AmpDtype.BFLOAT16))
+    assert tr16.ctx.scaler.is_enabled() and float(tr16.ctx.scaler.get_scale()) >= 1.0
+    rel16 = max(abs(a - b) / abs(b) for a, b in zip(e16, e32))
+    relbf = max(abs(a - b) / abs(b) for a, b in zip(ebf, e32))
+    print("\nfp16 AMP: ELBO", e16, "fp32", e32, "bf16", ebf, "rel fp16", rel16, "rel bf16", relbf)
+    assert all(np.isfinite(e16)) and rel16 < 5e-3 and relbf < 1e-2
 
 
 def test_full_depth_synthetic_step_properties():

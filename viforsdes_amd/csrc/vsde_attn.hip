@@ -1535,9 +1535,9 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
     const int cus = attn_cus();
     AttnParams q = p;
     q.pairs = pairs;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_ATTN_RING_DBG"); dbg = e ? atoi(e) : 0; } q.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = ablation_env("VSDE_ATTN_RING_DBG"); q.dbg = dbg; }
     static int abl = -1;
-    if (abl < 0) { const char *e = getenv("VSDE_ATTN_FWD_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = ablation_env("VSDE_ATTN_FWD_ABL");
     if (abl && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // timing-only variants (wrong results)
 #define VSDE_ABL_LAUNCH(A_)                                                                                                      \
     do {                                                                                                                         \
@@ -1661,7 +1661,7 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
     p.f.dy = (uint16_t *)dy; p.f.ldy = ldy; p.f.rinv = rinv; p.f.cosT = cosT; p.f.sinT = sinT; p.f.wq = wq; p.f.wk = wk; p.f.lam = lam;
     p.f.vdiff = (const uint16_t *)vdiff; p.f.dv0 = (uint16_t *)dv0; p.f.dv0_accumulate = dv0_accumulate;
     p.f.dv_extra = (const uint16_t *)dv_extra; p.f.dlam_partial = dlam_partial;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; } p.f.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = ablation_env("VSDE_ATTN_DEBUG"); p.f.dbg = dbg; }
     const size_t stage = (size_t)(AT_BT / 64) * AT_ESLICE * sizeof(float);   // the waves' epilogue slices reuse the operand space
     size_t lds_dq = (size_t)2 * p.ntile * 32 * AT_KLD * sizeof(uint16_t), lds_dkv = lds_dq + (size_t)2 * p.ntile * 32 * sizeof(float);
     lds_dq = lds_dq > stage ? lds_dq : stage; lds_dkv = lds_dkv > stage ? lds_dkv : stage;

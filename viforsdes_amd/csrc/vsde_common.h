@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/vsde_hip.h"
 
@@ -14,6 +15,15 @@ constexpr int kChunks = 16;    // kHP / 4 (float4 chunks along the reduction ind
 constexpr int kMatF4 = kChunks * 3 * kHP;  // float4 elements of one packed 64x192 matrix
 
 void set_error(const char *fmt, ...);
+
+// Timing-only ablation switches (environment variables that make a kernel skip part of its work: RESULTS ARE WRONG) are read
+// through this: the first non-zero value is announced on stderr, so that a stray variable cannot corrupt a run silently.
+static inline int ablation_env(const char *name) {
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    if (v != 0) fprintf(stderr, "libvsde_hip: %s=%d is a TIMING-ONLY ablation switch -- results of the affected kernels are WRONG\n", name, v);
+    return v;
+}
 
 #define VSDE_CHECK_ARG(cond, code, ...)          \
     do {                                         \
@@ -180,6 +190,7 @@ struct MpLaunch {
     float *paths, *means, *chol, *chol_raw, *acts;
 };
 bool mp_applicable(int H, int L, int S);
+bool mp_weights_overflowed();   // sticky: a weight left the f16 range of the multi-path kernels (no device synchronisation)
 size_t mp_frag_bytes(int L, int S);
 // mark: the profile-event hook of vsde_head.hip (slot 0 = the time-stepping kernel), may be nullptr
 int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t));

@@ -1570,7 +1570,7 @@ static bool mp_auto(const vsde_head_dims *d, int save) {
     return save ? d->B >= 96 : d->B > 256;
 }
 static bool use_mp(const vsde_head_dims *d, int save) {
-    if (!mp_applicable(d->H, d->L, d->S)) return false;
+    if (!mp_applicable(d->H, d->L, d->S) || mp_weights_overflowed()) return false;
     const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
     if (mode == 0) return false;
     if (mode > 0) return true;
@@ -1581,7 +1581,7 @@ static bool use_mp(const vsde_head_dims *d, int save) {
 // bandwidth: K = 192 products want six B fragments each and four published gradient vectors per layer
 // (profiles/r04_head_bwd_ablation.txt).
 static bool use_mp_bwd(const vsde_head_dims *d) {
-    if (!mp_bwd_applicable(d->H, d->L, d->S)) return false;
+    if (!mp_bwd_applicable(d->H, d->L, d->S) || mp_weights_overflowed()) return false;
     const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
     if (mode == 0) return false;
     if (mode > 0) return true;

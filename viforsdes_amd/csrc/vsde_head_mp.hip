@@ -74,6 +74,7 @@ struct MpPrep {
     const float *W[3];     // W_hh_l0, W_ih_l1, W_hh_l1  ([192][64], nn.GRU layout)
     const float *out_W;    // [no][64]
     f16x8 *frags;
+    int *overflow;         // host-mapped sticky flag: a scaled weight left the f16 range (see mp_weights_overflowed)
 };
 
 __global__ void __launch_bounds__(256) mp_prep_kernel(MpPrep q) {
@@ -86,8 +87,10 @@ __global__ void __launch_bounds__(256) mp_prep_kernel(MpPrep q) {
         const float sc = g < 2 ? kMpSr : kMpSn;
         const float *W = q.W[m] + (int64_t)row * 64 + k0;
         f16x8 hi, lo;
+        bool big = false;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(sc * W[e], a, b); hi[e] = a; lo[e] = b; }
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; mp_split(sc * W[e], a, b); hi[e] = a; lo[e] = b; big = big || !(fabsf(sc * W[e]) < 65504.0f); }
+        if (big && q.overflow) *q.overflow = 1;
         f16x8 *dst = q.frags + (int64_t)m * kMpMatFrags + (((w * 3 + g) * 2 + ks) * 2) * 64 + lane;
         dst[0] = hi; dst[64] = lo;
     } else if (i - nmat < q.nto * 128) {
@@ -97,8 +100,10 @@ __global__ void __launch_bounds__(256) mp_prep_kernel(MpPrep q) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             _Float16 a, b;
-            mp_split(orow < q.no ? q.out_W[(int64_t)orow * 64 + k0 + e] : 0.0f, a, b);
+            const float wv = orow < q.no ? q.out_W[(int64_t)orow * 64 + k0 + e] : 0.0f;
+            mp_split(wv, a, b);
             hi[e] = a; lo[e] = b;
+            if (!(fabsf(wv) < 65504.0f) && q.overflow) *q.overflow = 1;
         }
         f16x8 *dst = q.frags + (int64_t)q.nm * kMpMatFrags + ((tl * 2 + ks) * 2) * 64 + lane;
         dst[0] = hi; dst[64] = lo;
@@ -861,7 +866,7 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     const dim3 grid((a.B + np - 1) / np), block(512);
     if (mark) mark(1, 0, s);
     static int abl = -1;
-    if (abl < 0) { const char *e = getenv("VSDE_MP_BWD_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = ablation_env("VSDE_MP_BWD_ABL");
     if (abl && a.S == 2 && np == 4) {
         switch (abl) {
             case 1: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 1>), grid, block, 0, s, p); break;
@@ -880,12 +885,37 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     return 0;
 }
 
+// The multi-path kernels hold the recurrent weights as split f16 fragments: a (scaled) weight beyond the f16 range -- |W| > 2.2e4
+// for gate rows, 6.5e4 for the emission rows; only a diverged run gets there -- would become inf in the products.  mp_prep_kernel
+// raises a sticky flag in host-mapped memory when it meets one; the dispatcher (vsde_head.hip::use_mp) reads it WITHOUT a device
+// synchronisation before every launch and routes to the fp32 four-waves-per-path kernels from then on (the launch that raised it
+// has already produced non-finite outputs, which the trainer's non-finite check / GradScaler skip as for any diverged step).
+static int *g_mp_overflow = nullptr;
+static int *mp_overflow_flag() {
+    if (!g_mp_overflow) {
+        if (hipHostMalloc((void **)&g_mp_overflow, sizeof(int), hipHostMallocMapped) != hipSuccess) { g_mp_overflow = nullptr; return nullptr; }
+        *g_mp_overflow = 0;
+    }
+    return g_mp_overflow;
+}
+bool mp_weights_overflowed() {
+    static bool told = false;
+    const bool o = g_mp_overflow != nullptr && *(volatile int *)g_mp_overflow != 0;
+    if (o && !told) {
+        told = true;
+        fprintf(stderr, "libvsde_hip: a GRU head weight left the f16 range of the multi-path MFMA kernels (|W| > 2.2e4): "
+                        "the fp32 four-waves-per-path kernels take over for the rest of the process\n");
+    }
+    return o;
+}
+
 int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t)) {
     const int no = a.S + a.S * (a.S + 1) / 2, nto = (no + 3) / 4, nm = 2 * a.L - 1;
     MpPrep q = {};
     q.nm = nm; q.no = no; q.nto = nto;
     q.W[0] = a.W_hh0; q.W[1] = a.W_ih_st; q.W[2] = a.W_hh_st; q.out_W = a.out_W;
     q.frags = (f16x8 *)a.frags;
+    q.overflow = mp_overflow_flag();
     const int nthr = nm * 1536 + nto * 128;
     hipLaunchKernelGGL(mp_prep_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, q);
     MpParams p = {};
@@ -895,7 +925,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     p.frags = (const f16x8 *)a.frags;
     p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
     p.paths = a.paths; p.means = a.means; p.chol = a.chol; p.chol_raw = a.chol_raw; p.acts = a.acts;
-    { static int abl = -1; if (abl < 0) { const char *e = getenv("VSDE_MP_FWD_ABL"); abl = e ? atoi(e) : 0; } p.abl = abl; }
+    { static int abl = -1; if (abl < 0) abl = ablation_env("VSDE_MP_FWD_ABL"); p.abl = abl; }
     // paths per workgroup: 16 fills the matrix pipe (large batches); a small batch takes 4 or 8 so that its groups spread over more CUs --
     // the time of a launch is T x one step's latency whatever the group size, and ONE CU's vector-memory pipe would have to carry the
     // saved activations of all its paths (41 KB per step for 16 paths: +30 % at 512 paths, profiles/r04_head_mp.txt)

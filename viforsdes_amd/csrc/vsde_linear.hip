@@ -1070,7 +1070,7 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
     p.A = (const uint16_t *)x; p.lda = ldx; p.W = (const uint16_t *)w; p.bias = (const uint16_t *)bias;
     p.C = (uint16_t *)y; p.ldc = ldy; p.M = M; p.N = N; p.K = K;
     p.S = (uint16_t *)s_out; p.lds_ = lds; p.U = (const uint16_t *)u_in; p.ldu = ldu;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("VSDE_LIN_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = ablation_env("VSDE_LIN_DEBUG"); p.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
     if (epilogue == EPI_PLAIN) {
         VSDE_CHECK_ARG(y && ldy >= N && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0, VSDE_E_BADARG, "bad linear output");

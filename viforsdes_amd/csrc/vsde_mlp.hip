@@ -47,7 +47,7 @@ __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-
 
 constexpr int NW = 8;     // waves per workgroup
 constexpr int SLD = 72;   // staging row pitch (bf16): 64 columns + 16 bytes
-constexpr int MODB = 3;   // block form: batch rows a 256-row stripe may touch (sequences of >= 128 tokens)
+constexpr int MODB = 4;   // block form: batch rows a 256-row stripe may touch (sequences of >= 86 tokens)
 template <int C> struct Geo {
     static constexpr int W1_PITCH = 2 * C + 16;                                   // bytes per row of the W1 image
     static constexpr int W1_BYTES = (32 * W1_PITCH + 1023) / 1024 * 1024;         // padded to whole 1 KB DMA pieces
@@ -535,7 +535,7 @@ extern "C" int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const voi
     const void *ptrs[] = {x, yin, ga, sc, sh, gm, sn, hs, w1_img, w2_img, b1_img, b2, tok, hnext};
     for (const void *q : ptrs) VSDE_CHECK_ARG(((uintptr_t)q % 16) == 0, VSDE_E_BADARG, "mlp_block_fwd operands must be 16-byte aligned");
     VSDE_CHECK_ARG(mp >= C && mp % 8 == 0, VSDE_E_BADARG, "bad modulation row pitch");
-    VSDE_CHECK_ARG(tokens >= 128, VSDE_E_BADARG, "mlp_block_fwd keeps the modulation vectors of %d batch rows per 256-row stripe: sequences of >= 128 tokens", mlp::MODB);
+    VSDE_CHECK_ARG(tokens >= 86, VSDE_E_BADARG, "mlp_block_fwd keeps the modulation vectors of %d batch rows per 256-row stripe: sequences of >= 86 tokens", mlp::MODB);
     mlp::FwdParams p = {};
     p.R0 = (const uint16_t *)x; p.R1 = (const uint16_t *)yin; p.GA = (const uint16_t *)ga; p.SC = (const uint16_t *)sc; p.SH = (const uint16_t *)sh;
     p.GM = (const uint16_t *)gm; p.SN = (const uint16_t *)sn; p.HS = (const uint16_t *)hs; p.TOK = (uint16_t *)tok; p.HOUT = (uint16_t *)hnext;
@@ -559,7 +559,7 @@ extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img,
     p.X = (const uint16_t *)x; p.ldx = ldx; p.W1I = (const uint16_t *)w1_img; p.W2I = (const uint16_t *)w2_img; p.B1I = b1_img;
     p.b2 = (const uint16_t *)b2; p.Y = (uint16_t *)y; p.ldy = ldy; p.S = (uint16_t *)s_out; p.lds_ = lds; p.M = M; p.T = H / 16;
     static int dbg = -1;   // VSDE_MLP_DEBUG: timing ablations (wrong results)
-    if (dbg < 0) { const char *e = getenv("VSDE_MLP_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = ablation_env("VSDE_MLP_DEBUG");
     mlp_env(p);
     hipStream_t st = (hipStream_t)stream;
     if (C == 256 && dbg && !s_out) {

@@ -54,7 +54,8 @@ class FlatGradientAllReduce:
     is all-reduced in at most ``max_buckets`` pieces and ``.grad`` is re-pointed at its views (what unscale / clip / the
     optimizer then read)."""
 
-    def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2, force_buffer: bool = False) -> None:
+    def __init__(self, params: Iterable[nn.Parameter], max_buckets: int = 2, force_buffer: bool = False,
+                 overlap: Optional[bool] = None) -> None:
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -64,21 +65,100 @@ class FlatGradientAllReduce:
         self._views: list[Tensor] = []
         self.buckets: list[Tensor] = []
         self.active = self.world_size > 1 or force_buffer  # force_buffer: exercise the packed path on one rank (tests)
+        # Overlap (round 5): the gradients that are finished EARLY in the backward pass (head, theta posterior, the last encoder
+        # blocks) travel while the rest of the backward still runs.  The arrival order is recorded by post-accumulate hooks during
+        # the first step; from the second step on the flat buffer is laid out [early | late] and the early bucket's all-reduce
+        # is issued from the hook of its last arrival.  Same sums, element by element: results are bit-identical to the plain
+        # path (tests/test_data_parallel.py).  VSDE_DP_OVERLAP=0 switches it off; VSDE_DP_OVERLAP_MIN: minimum payload (elements).
+        env = os.environ.get("VSDE_DP_OVERLAP")
+        self.overlap = (env != "0") if overlap is None else overlap
+        self.overlap_min = int(os.environ.get("VSDE_DP_OVERLAP_MIN", str(1 << 20)))
+        self.early_launches = 0                       # how many steps sent their early bucket from inside the backward
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._recording: Optional[list[int]] = None   # arrival order of the step being recorded
+        self._early: list[int] = []                   # parameter indices of the early bucket (empty: no overlap)
+        self._early_set: set[int] = set()
+        self._arrived = 0
+        self._early_handle = None
+        self._early_sent = False
+        self._laid_out = False
         if self.active:
             self._allocate()
+            if self.overlap:
+                for p in self.params:
+                    p.register_post_accumulate_grad_hook(self._on_grad)
 
-    def _allocate(self) -> None:
+    def _allocate(self, order: Optional[list[int]] = None, n_early: int = 0) -> None:
+        """Flat buffer and the per-parameter views in ``order`` (default: parameter order); with ``n_early`` > 0 the first
+        bucket is exactly the first ``n_early`` parameters of the order."""
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self._views = []
-        off = 0
-        for p in self.params:
-            self._views.append(self.flat[off:off + p.numel()].view_as(p))
+        if self.flat is None:
+            self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        order = list(range(len(self.params))) if order is None else order
+        views: list[Optional[Tensor]] = [None] * len(self.params)
+        off, early_end = 0, 0
+        for k, i in enumerate(order):
+            p = self.params[i]
+            views[i] = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        n = max(1, min(self.max_buckets, total // (1 << 20) or 1))
-        cuts = [round(i * total / n) for i in range(n + 1)]
-        self.buckets = [self.flat[cuts[i]:cuts[i + 1]] for i in range(n)]
+            if k + 1 == n_early:
+                early_end = off
+        self._views = views  # type: ignore[assignment]
+        if n_early > 0 and 0 < early_end < total:
+            self.buckets = [self.flat[:early_end], self.flat[early_end:]]
+        else:
+            n = max(1, min(self.max_buckets, total // (1 << 20) or 1))
+            cuts = [round(i * total / n) for i in range(n + 1)]
+            self.buckets = [self.flat[cuts[i]:cuts[i + 1]] for i in range(n)]
+
+    # ---- overlap of the early bucket with the rest of the backward pass
+    def _on_grad(self, p: Tensor) -> None:
+        i = self._index.get(id(p))
+        if i is None:
+            return
+        if self._recording is not None:
+            self._recording.append(i)
+            return
+        if not self._early or self._early_sent or i not in self._early_set:
+            return
+        self._arrived += 1
+        if self._arrived == len(self._early):
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                return   # a captured backward: the collective stays outside the graph (trainer.capture_step_graph)
+            self._send_early()
+
+    @torch.no_grad()
+    def _send_early(self) -> None:
+        have = [(self._views[i], self.params[i].grad) for i in self._early
+                if self.params[i].grad is not None and self.params[i].grad is not self._views[i]]
+        if len(have) + sum(1 for i in self._early if self.params[i].grad is self._views[i]) != len(self._early):
+            return   # a gradient of the early set is absent this step: the plain path handles everything after the backward
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self.world_size > 1:
+            self._early_handle = dist.all_reduce(self.buckets[0], op=dist.ReduceOp.SUM, async_op=True)
+        self._early_sent = True
+        self.early_launches += 1
+
+    def _finish_recording(self) -> None:
+        """First step done: lay the flat buffer out as [early | late] from the recorded arrival order."""
+        seen: set[int] = set()
+        arrived = [i for i in (self._recording or []) if not (i in seen or seen.add(i))]
+        self._recording = None
+        self._laid_out = True
+        total = sum(p.numel() for p in self.params)
+        if total < self.overlap_min or len(arrived) < 2:
+            return
+        early, acc = [], 0
+        for i in arrived[:-1]:              # at least one arrival stays late: the hook of the last early one fires mid-backward
+            early.append(i)
+            acc += self.params[i].numel()
+            if acc * 2 >= total:
+                break
+        rest = [i for i in range(len(self.params)) if i not in set(early)]
+        self._early, self._early_set = early, set(early)
+        self._allocate(order=early + rest, n_early=len(early))
 
     def flat_gradients(self) -> Tensor:
         """Copy of all gradients as one fp32 vector in parameter order (zeros where a gradient is absent)."""
@@ -89,12 +169,17 @@ class FlatGradientAllReduce:
         """Replaces ``optimizer.zero_grad(set_to_none=True)``."""
         for p in self.params:
             p.grad = None
+        self._arrived, self._early_sent, self._early_handle = 0, False, None
+        if self.active and self.overlap and not self._laid_out and self._recording is None:
+            self._recording = []
 
     @torch.no_grad()
     def pack(self) -> None:
         """Gather every ``p.grad`` into the flat buffer (one multi-tensor copy; absent gradients become zeros)."""
-        have = [(v, p.grad) for p, v in zip(self.params, self._views) if p.grad is not None and p.grad is not v]
-        missing = [v for p, v in zip(self.params, self._views) if p.grad is None]
+        skip = self._early_set if self._early_sent else ()
+        have = [(v, p.grad) for i, (p, v) in enumerate(zip(self.params, self._views))
+                if i not in skip and p.grad is not None and p.grad is not v]
+        missing = [v for i, (p, v) in enumerate(zip(self.params, self._views)) if i not in skip and p.grad is None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         for v in missing:
@@ -104,7 +189,11 @@ class FlatGradientAllReduce:
     def reduce(self) -> None:
         """Average the flat buffer over the ranks: at most ``max_buckets`` RCCL all-reduces, then one scale."""
         if self.world_size > 1:
-            handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+            todo = self.buckets[1:] if self._early_sent else self.buckets
+            handles = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in todo]
+            if self._early_handle is not None:
+                handles.insert(0, self._early_handle)
+                self._early_handle = None
             for h in handles:
                 h.wait()
             self.flat.mul_(1.0 / self.world_size)
@@ -120,6 +209,15 @@ class FlatGradientAllReduce:
             return
         self.pack()
         self.reduce()
+        if self._recording is not None:   # the first step's arrival order is known now: [early | late] layout from the next step on
+            grads = [p.grad for p in self.params]
+            vals = [None if g is None else v.clone() for g, v in zip(grads, self._views)]
+            self._finish_recording()
+            for v_new, val in zip(self._views, vals):   # (the reduced values move with their parameters)
+                if val is not None:
+                    v_new.copy_(val)
+                else:
+                    v_new.zero_()
         self.attach()
 
 

@@ -196,8 +196,8 @@ class FusedOptimizerStep:
         if self.has_ema:
             self.ema.fused_step_done = True
         # Tensor._version is what cached views of the parameters (primitives/fused.py::PackedWeight) compare: the kernel wrote
-        # the parameters behind autograd's back, so say so (host-side counters; under capture this runs once, and the captured
-        # forward re-fills its packs on every replay anyway)
+        # the parameters behind autograd's back, so say so (host-side counters; under capture this runs once -- a replayed step
+        # re-fills the packs in its own captured tail, and the trainer's replay() checks for packs someone else rewrote)
         torch.autograd.graph.increment_version(params)
         from ..primitives import fused
         fused.note_parameters_changed()

@@ -123,8 +123,9 @@ class VariationalInferenceTrainer:
         ctx.scaler.update()
         if ctx.device.type == "cuda":
             # bf16 GEMM operands of the encoder follow the updated parameters: ONE kernel over all packs now, instead of a
-            # staleness check + copies per pack inside the next forward (the check alone is sufficient since round 4: the
-            # optimizer step advances fused._param_epoch and the parameters' version counters)
+            # staleness check + copies per pack inside the next forward.  (An eager forward would also notice by itself: the optimizer
+            # step advances fused._param_epoch and the parameters' version counters.  A CAPTURED forward does not check anything --
+            # capture_step_graph's replay() looks for stale packs before every replay.)
             ids = getattr(self, "_param_ids", None)
             if ids is None:
                 ids = self._param_ids = {id(q) for q in ctx.model.parameters()}
@@ -195,12 +196,27 @@ class VariationalInferenceTrainer:
             return None
         self._graph = graphs  # keep alive
 
+        # The captured forward holds no operand refresh (the packs were fresh at capture, ``PackedWeight.operands()`` was a no-op);
+        # only the tail of the captured optimizer step re-fills them.  Anything that rewrites the packs BETWEEN replays -- an EMA
+        # swap around ``VariationalPosterior.sample()`` / ``summary()`` from a callback, another sampler's forced refresh -- would
+        # otherwise make the next replay run its forward on those weights.  Same check as ``CapturedPathSampler.__call__``: when a
+        # pack of this model is stale (versions / parameter epoch moved since it was filled), re-fill all of them from the live
+        # parameters with one kernel before replaying.
+        from ..primitives.fused import PackedWeight
+        ids = {id(q) for q in model.parameters()}
+
+        def refresh_if_stale() -> None:
+            if any(pk.stale() for pk in PackedWeight._live if any(id(q) in ids for q in pk.params)):
+                PackedWeight.refresh_all(force=True, params=ids)
+
         if not split:
             def replay() -> TrainStepResult:
+                refresh_if_stale()
                 graphs[0].replay()
                 return static
         else:
             def replay() -> TrainStepResult:
+                refresh_if_stale()
                 graphs[0].replay()
                 ctx.grad_sync.reduce()
                 graphs[1].replay()

@@ -6,6 +6,8 @@ the EMA weights, summaries, diagnostics and the on-disk checkpoint
 which is byte-compatible with the reference's ``torch.save`` layout (same keys, same tensors)."""
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional
@@ -78,6 +80,10 @@ class VariationalPosterior:
         self.device = device
         self._calls: dict[tuple, int] = {}                                  # sample() calls seen per (n, autocast dtype)
         self._captured: dict[tuple, Optional[CapturedPathSampler]] = {}     # -> replayable call (None: capture failed, stay eager)
+        self._capture_failure_logged = False
+        # sample(n) is replayed from a HIP graph from its second call on, for n up to this many samples (a graph pins the call's
+        # peak memory: ~0.5 GB at 512 Lotka-Volterra paths); 0 = always eager.  release_graphs() frees the pools.
+        self.graph_max_samples = int(os.environ.get("VSDE_SAMPLE_GRAPH_MAX", "1024"))
 
     @torch.no_grad()
     def sample(self, n: int, mixed_precision: bool = False) -> VariationalPosteriorSamples:
@@ -110,15 +116,29 @@ class VariationalPosterior:
         self._calls[key] = self._calls.get(key, 0) + 1
         if self._calls[key] < 2:
             return None
+        if n > self.graph_max_samples:     # a captured call pins the peak memory of one sampling call at this size for good
+            return None
         if key not in self._captured:
-            if len(self._captured) >= 4:   # each graph keeps a private memory pool: a handful of sizes at most
+            if len(self._captured) >= 2:   # each graph keeps a private memory pool: two sizes at most (oldest goes first)
                 self._captured.pop(next(iter(self._captured)))
             try:
                 self._captured[key] = CapturedPathSampler(self.model, self.observations, self.time_horizon, self.time_step,
                                                           self.state_space, n, autocast_dtype=amp, warmup=1)
-            except Exception:   # capture is an optimisation, never a requirement
+            except Exception as err:   # capture is an optimisation, never a requirement -- but a persistent fallback must be visible
                 self._captured[key] = None
+                if not self._capture_failure_logged:
+                    self._capture_failure_logged = True
+                    import logging
+                    logging.getLogger("viforsdes_amd").warning(
+                        "VariationalPosterior.sample(%d): HIP graph capture failed (%s: %s); sampling eagerly", n, type(err).__name__, err)
         return self._captured[key]
+
+    def release_graphs(self) -> None:
+        """Drop the captured sampling calls and their private memory pools (they are re-captured on demand)."""
+        self._captured.clear()
+        self._calls.clear()
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
 
     def summary(self, n_samples: int = 1000, mixed_precision: bool = False) -> VariationalPosteriorSummary:
         s = self.sample(n_samples, mixed_precision)

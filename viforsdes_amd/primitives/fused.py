@@ -664,19 +664,41 @@ def _mm_nt(x2: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
 # them in a handful of launches (``_hip.linear_wgrad_group``: problem by problem the same arithmetic, bit-identical) and accumulates
 # into ``p.grad`` the way autograd would have.  Large problems (>= WGRAD_DEFER_MAX_ROWS rows) fill the chip by themselves and read
 # their dy while it is still warm in the cache: they stay immediate.
+# Contract of the deferred path: the gradients are written to ``p.grad`` directly at the context's exit, NOT through autograd's
+# AccumulateGrad -- post-accumulate-grad hooks (and a DDP reducer, if someone wraps the model) do not fire for these parameters;
+# inference/data_parallel.py packs them after the backward (its early bucket only ever holds hook-announced gradients).  Only
+# leaves that require a gradient are deferred; several parameters of one pack may end up with ``.grad`` views of one buffer.
+# The queue keeps its (dy, x) operands alive until the flush: it is flushed early whenever it holds more than
+# WGRAD_DEFER_MAX_BYTES (VSDE_WGRAD_DEFER_MAX_BYTES, default 1 GiB).
 WGRAD_DEFER_MAX_ROWS = int(os.environ.get("VSDE_WGRAD_DEFER_MAX_ROWS", "65536"))   # 0: never defer
+WGRAD_DEFER_MAX_BYTES = int(os.environ.get("VSDE_WGRAD_DEFER_MAX_BYTES", str(1 << 30)))
 _wgrad_queue: Optional[list] = None
+_wgrad_queue_bytes = 0
+
+
+def _queue_weight_grads(item: tuple) -> None:
+    """Append one (dy, x, ...) problem to the open queue; flush the queue when its operands exceed the byte budget."""
+    global _wgrad_queue_bytes
+    _wgrad_queue.append(item)
+    _wgrad_queue_bytes += item[0].numel() * item[0].element_size() + item[1].numel() * item[1].element_size()
+    if _wgrad_queue_bytes > WGRAD_DEFER_MAX_BYTES:
+        queue = list(_wgrad_queue)
+        _wgrad_queue.clear()
+        _wgrad_queue_bytes = 0
+        _flush_weight_grads(queue)
 
 
 class deferred_weight_grads:
     def __enter__(self):
-        global _wgrad_queue
+        global _wgrad_queue, _wgrad_queue_bytes
         self.outer, _wgrad_queue = _wgrad_queue, []
+        self.outer_bytes, _wgrad_queue_bytes = _wgrad_queue_bytes, 0
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _wgrad_queue
+        global _wgrad_queue, _wgrad_queue_bytes
         queue, _wgrad_queue = _wgrad_queue, self.outer
+        _wgrad_queue_bytes = self.outer_bytes
         if exc_type is None and queue:
             _flush_weight_grads(queue)
         return False
@@ -701,8 +723,9 @@ def _pack_weight_grads(dy: Tensor, x: Tensor, pack: "PackedWeight", row_map: Opt
     """Gradients of ``pack.params`` for y = x W^T + b with W = the pack: a list for the backward's return value (all ``None`` when
     the product was queued for the end of the backward pass)."""
     want_bias, mapped = pack.bias is not None, row_map is not None
-    if _wgrad_queue is not None and 0 < dy.shape[0] < WGRAD_DEFER_MAX_ROWS:
-        _wgrad_queue.append((dy, x, want_bias, row_map, out_rows, pack, mapped))
+    if (_wgrad_queue is not None and 0 < dy.shape[0] < WGRAD_DEFER_MAX_ROWS
+            and all(q.is_leaf and q.requires_grad for q in pack.params)):   # gradients can only be written to ``.grad`` of leaves
+        _queue_weight_grads((dy, x, want_bias, row_map, out_rows, pack, mapped))
         return [None] * len(pack.params)
     dW, db = _hip.linear_wgrad(dy, x, want_bias, row_map, out_rows)
     return pack.split_grads(dW, db, mapped=mapped)
@@ -782,7 +805,7 @@ class _Linear(torch.autograd.Function):
         dx = (dy2 @ wb).reshape(x.shape)
         own = ctx.owner
         if (_wgrad_queue is not None and 0 < dy2.shape[0] < WGRAD_DEFER_MAX_ROWS and own.leaf()):
-            _wgrad_queue.append((dy2, x2, bdtype is not None, None, None, own, False))   # issued with the others at the end of the pass
+            _queue_weight_grads((dy2, x2, bdtype is not None, None, None, own, False))   # issued with the others at the end of the pass
             return dx, None, None
         dW, db = _hip.linear_wgrad(dy2, x2, bdtype is not None)
         return dx, dW.to(wdtype), None if db is None else db.to(bdtype)
@@ -820,6 +843,8 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
 FUSED_MLP = os.environ.get("VSDE_FUSED_MLP", "1") != "0"
 # VSDE_BLOCK_MLP=0: residual / LayerNorm passes stay separate kernels in the no-grad chain (A/B runs)
 BLOCK_MLP = os.environ.get("VSDE_BLOCK_MLP", "1") != "0"
+# one 256-row workgroup per CU and no column chunks: below ~128 rows per CU the two-launch form (column chunks fill the chip) is faster
+BLOCK_MLP_MIN_ROWS = int(os.environ.get("VSDE_BLOCK_MLP_MIN_ROWS", "32768"))
 
 
 class MlpImages:
@@ -870,7 +895,7 @@ def mlp_block_nograd_usable(x: Tensor, mods: Optional["Modulations"], width: int
     (``mlp_block_nograd``): no-grad calls on bf16 [B, N, C] streams with C in (128, 256) and packed modulations."""
     return (ENABLED and OWN_GEMM and FUSED_MLP and BLOCK_MLP and not torch.is_grad_enabled() and mods is not None and x.is_cuda
             and x.dtype == torch.bfloat16 and x.ndim == 3 and x.shape[-1] in (128, 256) and width % 64 == 0 and width >= 64
-            and x.numel() // x.shape[-1] >= OWN_GEMM_MIN_ROWS and mods.allm.dtype == torch.bfloat16)
+            and x.shape[1] >= 86 and x.numel() // x.shape[-1] >= BLOCK_MLP_MIN_ROWS and mods.allm.dtype == torch.bfloat16)
 
 
 @torch.no_grad()
@@ -900,7 +925,7 @@ class _SwiGLUMLP(torch.autograd.Function):
         w1, b1 = pin.operands()
         w2, b2 = pout.operands()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        if not train and FUSED_MLP and x2.shape[1] in (128, 256) and w2.shape[1] % 64 == 0:
+        if not train and FUSED_MLP and x2.shape[1] in (128, 256) and w2.shape[1] % 64 == 0 and x2.shape[0] >= BLOCK_MLP_MIN_ROWS:
             # no-grad call (posterior sampling): ONE kernel, neither u nor s is materialised (csrc/vsde_mlp.hip)
             img = getattr(pin, "_mlp_images", None)
             if img is None:
