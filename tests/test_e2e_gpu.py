@@ -386,7 +386,7 @@ def test_fp16_amp_route_trains_and_tracks_fp32():
     the fused encoder operators are bf16 / fp32 kernels, so under fp16 autocast the encoder runs as the torch autocast chain
     (library GEMMs, SDPA) and hands the GRU head an fp16 context, which the HIP head kernels take as fp32.  Three optimizer steps
     at the ``fused_dims`` size from one initial state on identical injected draws: finite ELBOs with a live loss scale, the fp16
-    trajectory within fp16 accuracy of the fp32 one (5e-3 relative, the bench's bf16 gate), and closer to it than bf16 must be."""
+    trajectory within fp16 accuracy of the fp32 one (5e-3 relative, the bench's bf16 gate)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from viforsdes_amd import AmpDtype, EncoderConfig, HeadConfig, TrainingConfig
@@ -427,6 +427,9 @@ def test_fp16_amp_route_trains_and_tracks_fp32():
 
     e32 = run(ref)
     tr16 = make(True, AmpDtype.FLOAT16)
+    # (the default initial loss scale of 65536 overflows fp16 for the first ~10 steps of ANY fp16 run -- those steps are skipped
+    #  and the scale halves; a small initial scale lets this 3-step comparison see applied optimizer steps from the start)
+    tr16.ctx.scaler._init_scale = 8.0
     e16 = run(tr16)
     ebf = run(make(True, AmpDtype.BFLOAT16))
     assert tr16.ctx.scaler.is_enabled() and float(tr16.ctx.scaler.get_scale()) >= 1.0

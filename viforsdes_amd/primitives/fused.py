@@ -18,9 +18,16 @@ from .. import _hip
 ENABLED = True  # set False to force the unfused torch chains (A/B tests)
 
 
+def fp16_autocast() -> bool:
+    """fp16 autocast (``TrainingConfig(amp_dtype=AmpDtype.FLOAT16)``, reference config.py:24-38): the fused encoder operators are
+    bf16 / fp32 kernels, so the whole encoder then runs as the torch autocast chain (library GEMMs, SDPA); the GRU head takes the
+    fp16 context as fp32."""
+    return torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.float16
+
+
 def usable(x: Tensor, channels: int, head_dim: int) -> bool:
     half = head_dim // 2
-    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and channels % 64 == 0 and channels <= 1024
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not fp16_autocast() and channels % 64 == 0 and channels <= 1024
             and head_dim % 2 == 0 and 1 <= half <= 64 and (half & (half - 1)) == 0)
 
 

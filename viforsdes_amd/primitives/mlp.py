@@ -42,7 +42,7 @@ class SwiGLU(nn.Module):
         return packs
 
     def forward(self, x: Tensor) -> Tensor:
-        if fused.ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        if fused.ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not fused.fp16_autocast():
             width = self.padded_width()
             if fused.packed_linear_usable(x, 2 * width, self.in_dim):
                 # bf16 operands of both projections (padded to `width`) live in a cache refreshed once per optimizer step
