@@ -332,6 +332,13 @@ int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const void *ga, cons
                             const void *sn, const void *hs, int64_t mp, int tokens, double eps, double eps_next, const void *w1_img,
                             const void *w2_img, const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H,
                             void *stream);
+/* Backward of the SwiGLU MLP in one pass (training step): du [M][2 H] = swiglu'(u) * (dy W_out) and dx [M][C] = du W_in, with the saved
+ * pre-activations u and du in the 16-row interleaved layout of primitives/fused.py::swiglu_packs(interleave=True) (64 columns per 32
+ * hidden units: [a16 | b16 | a16 | b16]).  img: H / 32 pair-tile images of vsde_mlp_bwd_image_bytes(C) bytes each (layout in
+ * csrc/vsde_mlp.hip, built by primitives/fused.py::MlpBwdImages).  Replaces vsde_linear_bf16(EPI_SWIGLU_BWD) + the dx GEMM over du. */
+int64_t vsde_mlp_bwd_image_bytes(int C);
+int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, int64_t ldu, const void *img, void *du, int64_t lddu, void *dx,
+                      int64_t lddx, int64_t M, int C, int H, void *stream);
 /* debugging aid (VSDE_MLP_DEBUG=16): device buffer that receives workgroup 0's per-phase cycle stamps */
 int vsde_mlp_debug_trace(void *buf);
 int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile);

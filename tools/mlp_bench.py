@@ -50,3 +50,13 @@ for name, fn, by in (
         ("fused train (writes s)", lambda: _hip.mlp_fwd(x, w1, w2, b1, b2o, H, want_s=True), 2.0 * M * (2 * C + H))):
     t = timeit(fn)
     print(f"{name:40s} {t:8.1f} us   {fl / t / 1e6:6.0f} TF/s" + (f"   {by / t / 1e3:6.0f} GB/s algorithmic" if by else ""))
+# backward: the rows kernel with the SwiGLU derivative + the library GEMM over du, against the fused kernel
+dy = torch.randn(M, C, device=dev).to(torch.bfloat16)
+u, _ = _hip.linear_swiglu_bf16(x, w1i, b1i, want_u=True)
+w2t, w1p = pout_i.transposed(), pin_i.weight
+bimg = fused.MlpBwdImages(pin_i, pout_i, H).operand()
+flb = 2.0 * M * (H * C + 2 * H * C)
+for name, fn in (("old bwd: rows+SwiGLU' | hipBLASLt dx", lambda: _hip.linear_swiglu_bwd_bf16(dy, w2t, u) @ w1p),
+                 ("fused bwd (du + dx)", lambda: _hip.mlp_bwd(dy, u, bimg, H))):
+    t = timeit(fn)
+    print(f"{name:40s} {t:8.1f} us   {flb / t / 1e6:6.0f} TF/s   {2.0 * M * (2 * C + 4 * H) / t / 1e3:6.0f} GB/s algorithmic")

@@ -19,7 +19,14 @@ x = torch.randn(M, C, device=dev).to(torch.bfloat16)
 pin, pout = fused.swiglu_packs(w_in, b_in, w_out, b_out, H, interleave=False)
 img = fused.MlpImages(pin, pout, H)
 w1, w2, b1 = img.operands()
+if mode == "bwd":
+    pin_i, pout_i = fused.swiglu_packs(w_in, b_in, w_out, b_out, H, interleave=True)
+    bimg = fused.MlpBwdImages(pin_i, pout_i, H).operand()
+    u, _ = _hip.linear_swiglu_bf16(x, *pin_i.operands(), want_u=True)
+    dy = torch.randn(M, C, device=dev).to(torch.bfloat16)
 for _ in range(5):
     if mode in ("fwd", "train"):
         _hip.mlp_fwd(x, w1, w2, b1, pout.bias, H, want_s=mode == "train")
+    elif mode == "bwd":
+        _hip.mlp_bwd(dy, u, bimg, H)
 torch.cuda.synchronize()

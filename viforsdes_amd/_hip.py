@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
-    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_debug_trace",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.vsde_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.vsde_linear_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
     lib.vsde_colsum_workspace_bytes.restype = ctypes.c_size_t
+    lib.vsde_mlp_bwd_image_bytes.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -900,6 +901,24 @@ def mlp_block_fwd(x, yin, ga, sc, sh, gm, sn, hs, eps: float, eps_next: float, w
               ctypes.c_int(N), ctypes.c_double(eps), ctypes.c_double(eps_next), _ptr(w1_img), _ptr(w2_img), _ptr(b1_img), _ptr(b2),
               _ptr(tok), _ptr(hnext), _i64(B * N), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
     return tok, hnext
+
+
+def mlp_bwd_image_bytes(C: int) -> int:
+    """Bytes per pair tile (32 hidden units) of the fused MLP backward's weight image; 0 = width not built."""
+    return int(load().vsde_mlp_bwd_image_bytes(ctypes.c_int(C)))
+
+
+def mlp_bwd(dy: torch.Tensor, u: torch.Tensor, img: torch.Tensor, H: int):
+    """Fused SwiGLU MLP backward (csrc/vsde_mlp.hip): dy [M,C], saved u [M,2H] (interleaved layout) -> (du [M,2H], dx [M,C])."""
+    lib = load(); dev = _require_hip(dy, u, img)
+    dy, lddy = _rows2d(dy); u, ldu = _rows2d(u)
+    M, C = dy.shape
+    du = torch.empty(M, 2 * H, device=dev, dtype=torch.bfloat16)
+    dx = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_mlp_bwd_bf16, _ptr(dy), _i64(lddy), _ptr(u), _i64(ldu), _ptr(img), _ptr(du), _i64(2 * H), _ptr(dx), _i64(C), _i64(M),
+              ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
+    return du, dx
 
 
 def linear_gate_bwd(dy: torch.Tensor, w_t: torch.Tensor, og: torch.Tensor, s: torch.Tensor, dgate: torch.Tensor, tokens: int):

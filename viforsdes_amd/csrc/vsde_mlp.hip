@@ -45,6 +45,11 @@ __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
+// Between the last MFMA of an accumulation chain and the first VALU read of its result: the wait states of the 16-pass
+// v_mfma_f32_32x32x16_bf16 (19), spelled out.  hipcc pads this hazard inside a basic block; with a branch in between (a run-time
+// trace flag in the first version of mlp_bwd_kernel) it did not, and the last accumulator rows were read one k-step early.
+__device__ __forceinline__ void mfma_result_guard() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+
 constexpr int NW = 8;     // waves per workgroup
 constexpr int SLD = 72;   // staging row pitch (bf16): 64 columns + 16 bytes
 constexpr int MODB = 4;   // block form: batch rows a 256-row stripe may touch (sequences of >= 86 tokens)
@@ -235,15 +240,15 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     // LDS: the tile slots | the waves' staging rows | b_out
     uint16_t *stage = (uint16_t *)(lsm + G::NSLOT * G::BUF) + wave * (32 * SLD);
     uint16_t *b2row = (uint16_t *)(lsm + G::NSLOT * G::BUF) + NW * (32 * SLD);   // [C] bf16
-    const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * 32;
-    if ((int64_t)blockIdx.x * NW * 32 >= p.M) return;
+    const int64_t wg0 = (int64_t)blockIdx.x * (NW * 32), row0 = wg0 + wave * 32;
+    if (wg0 >= p.M) return;
     // tiles 0 and 1 are on their way while the activations load (T >= 4: the host checks)
     // block form: this lane's 4 rows of the row-segment layout; their x / yin chunks are requested before anything else (the only
     // HBM latency of the prologue that nothing can hide: one workgroup per CU)
     int64_t mrow[4]; int brow[4];
     u32x4 xr[BLK ? C / 64 : 1][4], yr[BLK ? C / 64 : 1][4];
     if constexpr (BLK != 0) {
-        const int64_t b0 = ((int64_t)blockIdx.x * NW * 32) / p.tokens;
+        const int64_t b0 = wg0 / p.tokens;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t m = row0 + (lane >> 3) + 8 * i;
@@ -269,7 +274,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     // (ga, sc, sh, gm, sn, hs); per lane: the 4 rows of the row-segment layout and their batch-row slots
     const uint16_t *mods = (const uint16_t *)(lsm + G::NSLOT * G::BUF + NW * 32 * SLD * 2 + C * 2);
     if constexpr (BLK != 0) {
-        const int64_t wg0 = (int64_t)blockIdx.x * NW * 32, b0 = wg0 / p.tokens;
+        const int64_t b0 = wg0 / p.tokens;
         const uint16_t *const vecs[6] = {p.GA, p.SC, p.SH, p.GM, p.SN, p.HS};
         for (int idx = tid; idx < MODB * 6 * (C / 8); idx += 64 * NW) {
             const int ch = idx % (C / 8), v = (idx / (C / 8)) % 6, bb = idx / (6 * (C / 8));
@@ -492,7 +497,255 @@ static int launch_fwd(const FwdParams &p, hipStream_t s) {
     const size_t lds = fwd_lds_bytes<C>();
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp_fwd_kernel<C, SAVE, DBG, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t stripes = (p.M + NW * 32 - 1) / (NW * 32);
+    // (measured and dropped, profiles/r05_mlp_fwd.txt: half stripes -- waves 4..7 idle -- for the partly filled last round of one
+    //  workgroup per CU: the wave-uniform "active" branches cost the tile loop 5 scratch accesses and 15 % of its speed, the round
+    //  saved 3 %)
     hipLaunchKernelGGL((mlp_fwd_kernel<C, SAVE, DBG, BLK>), dim3((unsigned)stripes), dim3(64 * NW), lds, s, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ================================================================================================= backward
+// dx = (swiglu'(u) * (dy W_out)) W_in in ONE kernel (training step; reference primitives/mlp.py:50-54 differentiated): replaces the
+// rows kernel with the SwiGLU derivative in its epilogue + the library GEMM over du (csrc/vsde_linear.hip EPI_SWIGLU_BWD, Cijk_*):
+// du is written once (the weight gradient of W_in needs it) and never re-read, the 32 x C accumulators of dx stay in registers.
+// Per wave (32 rows) and PAIR tile P (32 hidden units = 64 columns of u / du, the 16-row interleaved layout [a16 | b16 | a16 | b16]
+// of primitives/fused.py::swiglu_packs(interleave=True)):
+//     G1'  ds = dy W2T-tile      16 k-steps over the resident dy fragments; lane (r, h) gets ds for the units tau = 8 g + 4 h + i
+//     E'   the u tile (prefetched one tile ahead as full 128-byte row segments) goes through the wave's staging rows into that
+//          lane layout; da = ds b sg (1 + a (1 - sg)), db = ds a sg (sg = sigmoid(a)), rounded to bf16, back into the staging rows
+//          (-> du leaves as full row segments) AND kept packed: by the k order of the W1 image they ARE the B fragments of G3
+//     G3   dx += du W1-tile      4 k-steps (a units 0..15, a 16..31, b 0..15, b 16..31) x C / 32 column blocks.
+// One wave per SIMD with the whole register file (dy 64 + dx 128 + tile staging 52 + u prefetch 16 ...): on this chip the matrix
+// pipe and the VALU of a SIMD do not overlap (profiles/r05_mfma_valu_overlap.txt), a second wave per SIMD would only hide
+// latencies -- and at <= 256 registers the resident operands alone take 192.  Weight tiles: global -> registers (requested a
+// tile ahead) -> LDS after the barrier (two slots); an LDS-DMA instruction costs its wave ~150 cycles, 12 per tile and wave.
+// Images (primitives/fused.py::MlpBwdImages), per pair tile P contiguous [W2T | W1]:
+//     W2T  [32 units][C + 8] bf16   W_out[:, 32 P + tau]                     (A fragments by ds_read_b128, immediate offsets)
+//     W1   [4 ks][2 h][C][8] bf16   ks = 2 ab + q, slot e = 4 g' + i  <->  W_in row of (ab, unit 32 P + 8 (2 q + g') + 4 h + i)
+namespace bwd {
+template <int C> struct Geo {
+    static constexpr int W2_PITCH = 2 * C + 16;
+    static constexpr int W2_BYTES = (32 * W2_PITCH + 1023) / 1024 * 1024;
+    static constexpr int W1_BYTES = 4 * 2 * C * 16;
+    static constexpr int BUF = (W2_BYTES + W1_BYTES + 4095) / 4096 * 4096;   // padded: every thread moves exactly NLD 16-byte chunks
+    static constexpr int NLD = BUF / 4096;                                     // (a load under an exec mask derailed hipcc's vmcnt
+                                                                               //  bookkeeping: a late arrival clobbered a reused register)
+    static constexpr int KS = C / 16, CB = C / 32;
+};
+}  // namespace bwd
+
+struct BwdParams {
+    const uint16_t *DY; int64_t lddy;    // [M][lddy] bf16
+    const uint16_t *U; int64_t ldu;      // saved pre-activations [M][ldu] (64 columns per pair tile)
+    const char *IMG;                     // weight images, bwd::Geo<C>::BUF bytes per pair tile
+    uint16_t *DU; int64_t lddu;          // [M][lddu]
+    uint16_t *DX; int64_t lddx;          // [M][lddx]
+    int64_t M; int TP;                   // TP = pair tiles (hidden / 32)
+    long long *trace;                    // debugging (vsde_mlp_debug_trace): per-wave phase cycle sums of workgroup 0, [4 waves][8]
+};
+
+template <int C, int VAR = 3, bool TRACE = false>
+__global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(BwdParams p) {
+    using G = bwd::Geo<C>;
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    uint16_t *stage = (uint16_t *)(lsm + 2 * G::BUF) + wave * (32 * SLD);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if ((int64_t)blockIdx.x * 128 >= p.M) return;
+    // tiles in an order rotated per workgroup: the workgroups of a round pull different lines of the images out of L2
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)p.TP);
+#define VSDE_TILE(t_) (((t_) + rot) % p.TP)
+    u32x4 wreg[G::NLD];   // the next tile's image on its way to LDS
+    auto wload = [&](int tile) {
+        const char *src = p.IMG + (int64_t)tile * G::BUF + tid * 16;
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) wreg[i] = *(const u32x4 *)(src + i * 4096);
+    };
+    auto wstore = [&](char *slot) {
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) *(u32x4 *)(slot + tid * 16 + i * 4096) = wreg[i];
+    };
+    // the slices of u of the next TWO tiles (rows (lane >> 3) + 8 i, 16-byte chunk lane & 7): HBM under load answers in 2-3 us, one
+    // tile lasts ~2.5 us
+    u32x4 ureg[2][4];
+    auto uload = [&](u32x4 (&dst)[4], int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = row0 + (lane >> 3) + 8 * i;
+            dst[i] = *(const u32x4 *)(p.U + (m < p.M ? m : p.M - 1) * p.ldu + tile * 64 + (lane & 7) * 8);
+        }
+    };
+    wload(VSDE_TILE(0));
+    uload(ureg[0], VSDE_TILE(0));
+    if (p.TP > 1) uload(ureg[1], VSDE_TILE(1));
+    bf16x8 dyfr[G::KS];
+    {
+        const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
+        const uint16_t *src = p.DY + m * p.lddy + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) dyfr[ks] = *(const bf16x8 *)(src + ks * 16);
+    }
+    f32x16 dx[G::CB];
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dx[cb][e] = 0.f;
+    wstore(lsm);
+    if (p.TP > 1) wload(VSDE_TILE(1));
+    // the resident fragments are complete BEFORE the loop: hipcc otherwise puts their vmcnt(15) .. vmcnt(0) ladder in front of the
+    // loop's MFMAs, and a vmcnt(0) inside the loop also drains the u / image loads just issued for the next tile (the first version
+    // spent 2,150 cycles per tile in the 16 MFMAs of G1')
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(dyfr[ks]));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (TRACE is a template flag, not a run-time one: a branch between the last MFMA of a chain and the first read of its result made
+    //  hipcc drop the MFMA -> VALU wait states -- the v_accvgpr_read of the last accumulator register then returned the value
+    //  before the last k-step; see also mfma_result_guard)
+#define VSDE_STAMP(k_) do { if constexpr (TRACE) { const long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - last_; last_ = now_; } } while (0)
+    long long last_ = TRACE ? __builtin_readcyclecounter() : 0;
+    for (int t0 = 0; t0 < p.TP; t0 += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int t = t0 + par;
+        if (t >= p.TP) break;
+        const char *slot = lsm + par * G::BUF;
+        const int tile = VSDE_TILE(t);
+        // the next tile's image: registers -> the other slot (its last readers finished before the barrier just passed), and the
+        // registers are re-issued at once for the tile after it: a whole tile time to arrive
+        if constexpr ((VAR & 1) != 0) {
+            if (t + 1 < p.TP) wstore(lsm + (1 - par) * G::BUF);
+            if (t + 2 < p.TP) wload(VSDE_TILE(t + 2));
+        }
+        VSDE_STAMP(6);
+        // G1': ds = dy W2T tile
+        f32x16 ds;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ds[e] = 0.f;
+        {
+            const char *src = slot + r * G::W2_PITCH + 16 * h;
+            constexpr int GK = 4, NG = G::KS / GK;
+            bf16x8 bq[2][GK];
+#pragma unroll
+            for (int k = 0; k < GK; ++k) bq[0][k] = *(const bf16x8 *)(src + 32 * k);
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+                if (gk + 1 < NG)
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) bq[(gk + 1) & 1][k] = *(const bf16x8 *)(src + 32 * ((gk + 1) * GK + k));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < GK; ++k) ds = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[gk & 1][k], dyfr[gk * GK + k], ds, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        mfma_result_guard();
+        VSDE_STAMP(7);
+        // u of this tile -> staging rows (full row segments); its register set is re-issued for the tile after the next one
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4 *)(stage + ((lane >> 3) + 8 * i) * SLD + (lane & 7) * 8) = ureg[par][i];
+        if (t + 2 < p.TP) uload(ureg[par], VSDE_TILE(t + 2));
+        VSDE_STAMP(0);
+        wave_lds_fence();
+        // E': du = swiglu'(u) ds, lane-local: quad g of ds <-> units tau = 8 g + 4 h + i <-> u columns 32 (g / 2) + 8 (g % 2) + 4 h + i (a), + 16 (b)
+        uint32_t daw[4][2], dbw[4][2];   // [g][pair of i]: packed bf16
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint16_t *pa = stage + r * SLD + 32 * (g >> 1) + 8 * (g & 1) + 4 * h, *pb = pa + 16;
+            const uint2 ua = *(const uint2 *)pa, ub = *(const uint2 *)pb;
+            const float a[4] = {bf_lo(ua.x), bf_hi(ua.x), bf_lo(ua.y), bf_hi(ua.y)};
+            const float b[4] = {bf_lo(ub.x), bf_hi(ub.x), bf_lo(ub.y), bf_hi(ub.y)};
+            float da[4], db[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gs = ds[4 * g + i], sg = fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * a[i]));
+                da[i] = gs * b[i] * sg * (1.0f + a[i] * (1.0f - sg));
+                db[i] = gs * a[i] * sg;
+            }
+            daw[g][0] = pack2(da[0], da[1]); daw[g][1] = pack2(da[2], da[3]);
+            dbw[g][0] = pack2(db[0], db[1]); dbw[g][1] = pack2(db[2], db[3]);
+            *(uint2 *)pa = make_uint2(daw[g][0], daw[g][1]);
+            *(uint2 *)pb = make_uint2(dbw[g][0], dbw[g][1]);
+        }
+        VSDE_STAMP(1);
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // du leaves as full 128-byte row segments
+            const int row = (lane >> 3) + 8 * i;
+            const u32x4 v = *(const u32x4 *)(stage + row * SLD + (lane & 7) * 8);
+            if (row0 + row < p.M) __builtin_nontemporal_store(v, (u32x4 *)(p.DU + (row0 + row) * p.lddu + tile * 64 + (lane & 7) * 8));
+        }
+        VSDE_STAMP(2);
+        // G3: dx += du W1 tile; k-step ks = 2 ab + q: this lane's B fragment = (ab ? db : da) of g = 2 q, 2 q + 1.  The 4 CB A fragments
+        // are fetched a group of 4 ahead of their MFMAs (left to hipcc every MFMA waited for its own ds_read: 2,100 cycles for 32)
+        {
+            const char *src = slot + G::W2_BYTES + h * (C * 16) + r * 16;
+            constexpr int GF = (VAR & 2) ? 4 : 1, NGR = 4 * G::CB / GF;   // fragment f = ks * CB + cb
+            bf16x8 fq[2][GF];
+#pragma unroll
+            for (int k = 0; k < GF; ++k) fq[0][k] = *(const bf16x8 *)(src + (k / G::CB) * (2 * C * 16) + (k % G::CB) * 512);
+#pragma unroll
+            for (int gr = 0; gr < NGR; ++gr) {
+                if (gr + 1 < NGR)
+#pragma unroll
+                    for (int k = 0; k < GF; ++k) {
+                        const int f = (gr + 1) * GF + k;
+                        fq[(gr + 1) & 1][k] = *(const bf16x8 *)(src + (f / G::CB) * (2 * C * 16) + (f % G::CB) * 512);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < GF; ++k) {
+                    const int f = gr * GF + k, ks = f / G::CB, cb = f % G::CB, ab = ks >> 1, q = ks & 1;
+                    const u32x4 bw = ab ? (u32x4){dbw[2 * q][0], dbw[2 * q][1], dbw[2 * q + 1][0], dbw[2 * q + 1][1]}
+                                        : (u32x4){daw[2 * q][0], daw[2 * q][1], daw[2 * q + 1][0], daw[2 * q + 1][1]};
+                    dx[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[gr & 1][k], __builtin_bit_cast(bf16x8, bw), dx[cb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        VSDE_STAMP(3);
+        if constexpr ((VAR & 1) == 0) {
+            if (t + 1 < p.TP) wstore(lsm + (1 - par) * G::BUF);
+            if (t + 2 < p.TP) wload(VSDE_TILE(t + 2));
+        }
+        VSDE_STAMP(4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        VSDE_STAMP(5);
+      }
+    }
+    if constexpr (TRACE) {
+        if (p.trace != nullptr && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p.trace[wave * 8 + k] = ph[k];
+        }
+    }
+#undef VSDE_STAMP
+#undef VSDE_TILE
+    // dx, 64 columns at a time through the wave's staging rows
+#pragma unroll
+    for (int q = 0; q < G::CB / 2; ++q) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x16 &a = dx[2 * q + half];
+            uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0], a[4 * g + 1]), pack2(a[4 * g + 2], a[4 * g + 3]));
+        }
+        wave_lds_fence();
+        flush64(stage, p.DX + 64 * q, p.lddx, row0, p.M, lane);
+        wave_lds_fence();
+    }
+}
+
+template <int C, int VAR = 3, bool TRACE = false>
+static int launch_bwd(const BwdParams &p, hipStream_t s) {
+    using G = bwd::Geo<C>;
+    const size_t lds = (size_t)2 * G::BUF + (size_t)4 * 32 * SLD * 2;
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp_bwd_kernel<C, VAR, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((mlp_bwd_kernel<C, VAR, TRACE>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -574,4 +827,34 @@ extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img,
     }
     if (C == 256) return s_out ? mlp::launch_fwd<256, 1>(p, st) : mlp::launch_fwd<256, 0>(p, st);
     return s_out ? mlp::launch_fwd<128, 1>(p, st) : mlp::launch_fwd<128, 0>(p, st);
+}
+
+// bytes of the backward's weight image per pair tile (32 hidden units): [W2T | W1], see mlp_bwd_kernel
+extern "C" int64_t vsde_mlp_bwd_image_bytes(int C) { return C == 128 ? mlp::bwd::Geo<128>::BUF : (C == 256 ? mlp::bwd::Geo<256>::BUF : 0); }
+
+// du [M][2 H] = swiglu'(u) * (dy W_out) and dx [M][C] = du W_in in one pass (u, du: 16-row interleaved layout, 64 columns per 32 units)
+extern "C" int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, int64_t ldu, const void *img, void *du, int64_t lddu, void *dx,
+                                 int64_t lddx, int64_t M, int C, int H, void *stream) {
+    VSDE_CHECK_ARG(dy && u && img && du && dx && M > 0, VSDE_E_BADARG, "bad mlp_bwd arguments");
+    VSDE_CHECK_ARG((C == 128 || C == 256) && H >= 64 && H % 64 == 0, VSDE_E_BADARG,
+                   "fused SwiGLU MLP is built for widths 128 / 256 and a hidden size that is a multiple of 64 (got %d, %d)", C, H);
+    VSDE_CHECK_ARG(lddy >= C && lddx >= C && ldu >= 2 * H && lddu >= 2 * H && lddy % 8 == 0 && lddx % 8 == 0 && ldu % 8 == 0 && lddu % 8 == 0 &&
+                   ((uintptr_t)dy % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)img % 16) == 0 && ((uintptr_t)du % 16) == 0 &&
+                   ((uintptr_t)dx % 16) == 0, VSDE_E_BADARG, "mlp_bwd operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    mlp::BwdParams p = {};
+    p.DY = (const uint16_t *)dy; p.lddy = lddy; p.U = (const uint16_t *)u; p.ldu = ldu; p.IMG = (const char *)img;
+    p.DU = (uint16_t *)du; p.lddu = lddu; p.DX = (uint16_t *)dx; p.lddx = lddx; p.M = M; p.TP = H / 32;
+    p.trace = g_mlp_trace;
+    static int var = -1;   // VSDE_MLP_BWD_VAR: bit 0 = tile staging right after the barrier, bit 1 = grouped fragment prefetch in the dx product (A/B runs)
+    if (var < 0) { const char *e = getenv("VSDE_MLP_BWD_VAR"); var = e ? atoi(e) : 3; }
+    if (C == 256 && g_mlp_trace != nullptr) return mlp::launch_bwd<256, 3, true>(p, (hipStream_t)stream);   // tools/mlp_bwd_trace.py
+    if (C == 256) {
+        switch (var & 3) {
+            case 0: return mlp::launch_bwd<256, 0>(p, (hipStream_t)stream);
+            case 1: return mlp::launch_bwd<256, 1>(p, (hipStream_t)stream);
+            case 2: return mlp::launch_bwd<256, 2>(p, (hipStream_t)stream);
+            default: return mlp::launch_bwd<256, 3>(p, (hipStream_t)stream);
+        }
+    }
+    return mlp::launch_bwd<128>(p, (hipStream_t)stream);
 }

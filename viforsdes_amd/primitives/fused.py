@@ -850,6 +850,8 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
 FUSED_MLP = os.environ.get("VSDE_FUSED_MLP", "1") != "0"
 # VSDE_BLOCK_MLP=0: residual / LayerNorm passes stay separate kernels in the no-grad chain (A/B runs)
 BLOCK_MLP = os.environ.get("VSDE_BLOCK_MLP", "1") != "0"
+# VSDE_FUSED_MLP_BWD=1: the training step's MLP backward as one kernel (du + dx) instead of rows kernel + library GEMM (opt-in, see above)
+FUSED_MLP_BWD = os.environ.get("VSDE_FUSED_MLP_BWD", "0") == "1"
 # one 256-row workgroup per CU and no column chunks: below ~128 rows per CU the two-launch form (column chunks fill the chip) is faster
 BLOCK_MLP_MIN_ROWS = int(os.environ.get("VSDE_BLOCK_MLP_MIN_ROWS", "32768"))
 
@@ -895,6 +897,50 @@ class MlpImages:
             pk.operands()
         self.refresh_if_stale()
         return self.w1, self.w2, self.b1
+
+
+class MlpBwdImages:
+    """Weight operand of the fused SwiGLU MLP backward (csrc/vsde_mlp.hip::mlp_bwd_kernel): per pair tile P (32 hidden units) one
+    contiguous image [W2T | W1] --
+    ``W2T`` [32 units, C + 8] (+ padding to whole KB): W_out[:, 32 P + tau], the A operand of ds = dy W_out;
+    ``W1`` [4 k-steps, 2 h, C, 8]: k-step 2 ab + q, slot 4 g' + i holds the W_in row of (ab, unit 32 P + 8 (2 q + g') + 4 h + i), so that the
+    du values a lane computes are, in register order, its B fragments of dx += du W_in.
+    Built from the interleaved bf16 packs (``swiglu_packs(..., interleave=True)``) and rebuilt whenever those are refreshed."""
+
+    def __init__(self, pin: PackedWeight, pout: PackedWeight, width: int) -> None:
+        assert pin.grad_rows is not None, "the fused backward works on the 16-row interleaved u / du layout"
+        C, TP, dev = pin.weight.shape[1], width // 32, pin.weight.device
+        self.nbytes = _hip.mlp_bwd_image_bytes(C)
+        self.w2_elems = 32 * (C + 8)
+        w2_bytes = (32 * (2 * C + 16) + 1023) // 1024 * 1024
+        self.w1_off = w2_bytes // 2
+        self.img = torch.zeros(TP, self.nbytes // 2, device=dev, dtype=torch.bfloat16)
+        ks, h, e = torch.meshgrid(torch.arange(4), torch.arange(2), torch.arange(8), indexing="ij")
+        ab, q, gp, i = ks >> 1, ks & 1, e >> 2, e & 3
+        unit = 8 * (2 * q + gp) + 4 * h + i                      # within the pair tile
+        rows = 32 * (unit // 16) + 16 * ab + unit % 16            # row within the tile's 64 interleaved rows
+        self.rows = (64 * torch.arange(TP)[:, None] + rows.reshape(1, -1)).reshape(-1).to(dev)
+        self.packs, self.width, self.C, self.TP = (pin, pout), width, C, TP
+        self._key = None
+        PackedWeight._derived.add(self)
+
+    @torch.no_grad()
+    def refresh_if_stale(self) -> None:
+        pin, pout = self.packs
+        key = (tuple(pin._versions or ()), tuple(pout._versions or ()))
+        if key == self._key:
+            return
+        C, TP = self.C, self.TP
+        self.img[:, :self.w2_elems].view(TP, 32, C + 8)[:, :, :C].copy_(pout.weight.t().reshape(TP, 32, C))
+        w1 = pin.weight.index_select(0, self.rows).view(TP, 4, 2, 8, C).permute(0, 1, 2, 4, 3)
+        self.img[:, self.w1_off:self.w1_off + 4 * 2 * C * 8].view(TP, 4, 2, C, 8).copy_(w1)
+        self._key = key
+
+    def operand(self) -> Tensor:
+        for pk in self.packs:
+            pk.operands()
+        self.refresh_if_stale()
+        return self.img
 
 
 def mlp_block_nograd_usable(x: Tensor, mods: Optional["Modulations"], width: int) -> bool:
@@ -955,11 +1001,20 @@ class _SwiGLUMLP(torch.autograd.Function):
         x2, u, s_, w1 = ctx.saved_tensors
         pin, pout = ctx.packs
         dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
-        du = _hip.linear_swiglu_bwd_bf16(dy2, pout.transposed(), u)
-        if own_gemm(du.shape[0], w1.shape[1], w1.shape[0]):
-            dx = _hip.linear_bf16(du, pin.transposed(), None)
+        if (FUSED_MLP_BWD and pin.grad_rows is not None and dy2.shape[1] in (128, 256) and pout.weight.shape[1] % 64 == 0
+                and dy2.shape[0] >= BLOCK_MLP_MIN_ROWS):
+            # one kernel for du AND dx (csrc/vsde_mlp.hip::mlp_bwd_kernel): du is never re-read.  Opt-in: at the LV shape it measures
+            # 470-480 us against 435 us for the two launches below (profiles/r05_mlp_bwd.txt says why)
+            img = getattr(pin, "_mlp_bwd_images", None)
+            if img is None:
+                img = pin._mlp_bwd_images = MlpBwdImages(pin, pout, pout.weight.shape[1])
+            du, dx = _hip.mlp_bwd(dy2, u, img.operand(), pout.weight.shape[1])
         else:
-            dx = du @ w1
+            du = _hip.linear_swiglu_bwd_bf16(dy2, pout.transposed(), u)
+            if own_gemm(du.shape[0], w1.shape[1], w1.shape[0]):
+                dx = _hip.linear_bf16(du, pin.transposed(), None)
+            else:
+                dx = du @ w1
         g1 = _pack_weight_grads(du, x2, pin, pin.grad_row_map, None if pin.grad_rows is None else pin.grad_rows.numel())
         g2 = _pack_weight_grads(dy2, s_, pout)
         return (dx.reshape(ctx.xshape), None, None, None, *g1, *g2)
