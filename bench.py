@@ -706,7 +706,22 @@ def measure(workload, batch, args, device, distributed, world):
     return out, (problem, enc)
 
 
+_JSON_OUT = None   # the process's real stdout, kept for the ONE JSON line (see quiet_stdout)
+
+
+def quiet_stdout():
+    """Everything native libraries print to file descriptor 1 -- RCCL's version banner at communicator creation, rocprofv3 child
+    chatter -- goes to stderr from here on; only the JSON line is written to the real stdout (the driver parses stdout)."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = sys.stderr
+
+
 def main():
+    quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)     # SURVEY 8(d): >= 50 timed iterations after >= 10 warm-up
@@ -775,7 +790,7 @@ def main():
         out["parity"] = None
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -144,6 +144,7 @@ __device__ __forceinline__ void gemm1(f32x16 &uacc, const bf16x8 (&xfr)[C / 16],
         if ((gk & 1) && gk / 2 < G::PER / 2 && tn >= 0) issue_piece<C>(p, tn, nbuf, wave, lane, gk / 2);
         __builtin_amdgcn_sched_barrier(0);
     }
+    mfma_result_guard();   // the caller reads uacc on the VALU, possibly across a branch (see mfma_result_guard)
 }
 
 // E: s = silu(a) * b from the bf16-rounded pre-activations, as the unfused chain computes it under autocast (mlp.py:21-24): quads
