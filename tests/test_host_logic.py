@@ -249,3 +249,23 @@ def test_pretraining_runs_and_returns_a_mean(oracle_backend):
     torch.manual_seed(1)
     mu = tr.pretrain_sde_parameters(PretrainConfig(n_iterations=5, batch_size=32))
     assert mu.shape == (3,) and torch.isfinite(mu).all()
+
+
+def test_only_optimizers_that_own_packed_parameters_mark_packs_stale():
+    """ADVICE round 4 (low): the process-wide ``Optimizer.step`` post-hook used to advance the parameter epoch for EVERY optimizer;
+    a step of an unrelated model then cost every live pack a refresh."""
+    import torch
+    from viforsdes_amd.primitives import fused
+    w = torch.nn.Parameter(torch.randn(8, 8))
+    other = torch.nn.Parameter(torch.randn(4))
+    pack = fused.PackedWeight(8, 8, [(w, 0, 8, 0)], None, "cpu")
+    pack.operands()
+    assert not pack.stale()
+    o_other = torch.optim.SGD([other], lr=0.1)
+    other.grad = torch.ones(4)
+    o_other.step()
+    assert not pack.stale()
+    o_own = torch.optim.SGD([w], lr=0.1)
+    w.grad = torch.ones(8, 8)
+    o_own.step()
+    assert pack.stale()

@@ -444,7 +444,24 @@ def note_parameters_changed() -> None:
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
 
-_register_step_post_hook(lambda opt, args, kwargs: note_parameters_changed())
+
+
+def _on_optimizer_step(opt, args, kwargs) -> None:
+    """Only optimizers that own a parameter of a live pack advance the epoch (an unrelated optimizer elsewhere in the process
+    used to mark every pack stale: one needless refresh per step of that other model)."""
+    ids = getattr(opt, "_vsde_param_ids", None)
+    n = sum(len(g["params"]) for g in opt.param_groups)
+    if ids is None or ids[0] != n:
+        ids = (n, {id(p) for g in opt.param_groups for p in g["params"]})
+        try:
+            opt._vsde_param_ids = ids
+        except Exception:
+            pass
+    if any(id(q) in ids[1] for pk in PackedWeight._live for q in pk.params):
+        note_parameters_changed()
+
+
+_register_step_post_hook(_on_optimizer_step)
 
 
 class PackedWeight:
