@@ -244,7 +244,7 @@ def test_ring_forward_is_bit_identical_to_the_resident_forward(B, N, gated, monk
     assert torch.isfinite(o1.float()).all() and torch.equal(o0, o1) and torch.equal(l0, l1)
 
 
-def test_backward_kernel_variants_agree_on_every_output():
+def test_backward_kernel_variants_agree_on_every_output(tmp_path):
     """The fused attention backward with the ragged last block shared by four waves (default) against the same kernels with the lone
     second round (VSDE_ATTN_SPLIT=0): the variants differ only in the order of fp32 partial sums, so every output -- the one
     cancelling scalar d lambda included, to 2e-5 of its value -- must agree (tools/attn_split_check.py; the switch is read once per
@@ -254,8 +254,11 @@ def test_backward_kernel_variants_agree_on_every_output():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "attn_split_check.py")
-    ref = subprocess.run([sys.executable, tool], cwd=root, env=dict(os.environ, VSDE_ATTN_SPLIT="0"), capture_output=True, text=True, timeout=600)
+    refpath = str(tmp_path / "attn_split_ref.npz")
+    ref = subprocess.run([sys.executable, tool], cwd=root, env=dict(os.environ, VSDE_ATTN_SPLIT="0", VSDE_SPLIT_REF=refpath),
+                         capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stdout[-2000:] + ref.stderr[-2000:]
-    chk = subprocess.run([sys.executable, tool], cwd=root, env={k: v for k, v in os.environ.items() if k != "VSDE_ATTN_SPLIT"},
+    chk = subprocess.run([sys.executable, tool], cwd=root,
+                         env=dict({k: v for k, v in os.environ.items() if k != "VSDE_ATTN_SPLIT"}, VSDE_SPLIT_REF=refpath),
                          capture_output=True, text=True, timeout=600)
     assert chk.returncode == 0 and "SPLIT CHECK PASS" in chk.stdout, chk.stdout[-3000:] + chk.stderr[-2000:]

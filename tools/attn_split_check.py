@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from viforsdes_amd import _hip
 
 ref_mode = os.environ.get("VSDE_ATTN_SPLIT", "1") == "0"
-path = "gpurun_out/attn_split_ref.npz"
+path = os.environ.get("VSDE_SPLIT_REF", "gpurun_out/attn_split_ref.npz")   # (tens of MB: the test suite points it at a temp dir)
 ref = None if ref_mode else dict(np.load(path))
 out, H, dev, bad = {}, 4, "cuda:0", 0
 for N in (385, 386, 400, 401, 402, 403, 416):
@@ -54,7 +54,7 @@ for N in (385, 386, 400, 401, 402, 403, 416):
                 bad += not ok
                 print(f"{key:18s} max|diff|/max|ref| {d:.2e}  elements that differ {n_diff} of {a.size}  {'ok' if ok else 'MISMATCH'}")
 if ref_mode:
-    os.makedirs("gpurun_out", exist_ok=True)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     np.savez(path, **out)
     print("reference written:", path, len(out), "arrays")
 else:
