@@ -61,7 +61,14 @@ def busy(path, marker="optim_update_kernel", first=35, last=65):
     rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if len(marks) <= last:
-        print("not enough marker launches:", len(marks)); return
+        # short runs (the synthetic workload is profiled with --steps 5 --warmup 2): the last timed steps of whatever there is --
+        # the final 4 markers belong to the per-kernel timing steps and the profiled eager step that follow the timed region
+        if len(marks) < 8:
+            print("not enough marker launches:", len(marks)); return
+        last = len(marks) - 5
+        first = max(last - 4, len(marks) // 2)
+        if last <= first:
+            print("not enough marker launches:", len(marks)); return
     a, b = marks[first], marks[last]
     t0, t1 = rows[a][1], rows[b][1]
     dur = sum(r[2] - r[1] for r in rows[a:b])
