@@ -332,6 +332,14 @@ int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const void *ga, cons
                             const void *sn, const void *hs, int64_t mp, int tokens, double eps, double eps_next, const void *w1_img,
                             const void *w2_img, const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H,
                             void *stream);
+/* Block form with the attention branch's out projection as the prologue's first product (reference primitives/attn.py:107-110 +
+ * sit.py:112-128):  yin = (attn * sigmoid(glog[:, k % 64])) W_o^T + b_o, then as vsde_mlp_block_fwd_bf16.  attn [M][C] bf16 (merged
+ * heads, token-major), glog [M][ldg] bf16 (64 gate logits per row), wo_img = W_o as C / 16 tiles in w2_img's format, bo [C] bf16 or
+ * NULL.  tok doubles as the scratch that holds x1 between the prologue and the epilogue: it must not alias x. */
+int vsde_mlp_attn_block_fwd_bf16(const void *x, const void *attn, const void *glog, int64_t ldg, const void *wo_img, const void *bo,
+                                 const void *ga, const void *sc, const void *sh, const void *gm, const void *sn, const void *hs,
+                                 int64_t mp, int tokens, double eps, double eps_next, const void *w1_img, const void *w2_img,
+                                 const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H, void *stream);
 /* Backward of the SwiGLU MLP in one pass (training step): du [M][2 H] = swiglu'(u) * (dy W_out) and dx [M][C] = du W_in, with the saved
  * pre-activations u and du in the 16-row interleaved layout of primitives/fused.py::swiglu_packs(interleave=True) (64 columns per 32
  * hidden units: [a16 | b16 | a16 | b16]).  img: H / 32 pair-tile images of vsde_mlp_bwd_image_bytes(C) bytes each (layout in

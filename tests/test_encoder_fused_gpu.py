@@ -113,6 +113,65 @@ def test_encoder_fused_vs_unfused_full_module_bf16_autocast():
     assert rel_err(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 3e-2
 
 
+def test_nograd_block_kernel_routes_agree_and_follow_the_optimizer():
+    """Posterior sampling at >= 32768 token rows runs each block's second half -- and the attention branch's gate + out projection --
+    as ONE kernel (csrc/vsde_mlp.hip block forms).  Whole encoder, bf16 autocast, no grad: the three routes (separate kernels |
+    block form | block form with the out projection) agree to bf16 round-off, and after a parameter update followed by the trainer's
+    pack refresh (which is all a captured step replays) every route sees the new weights through its derived tile images."""
+    from viforsdes_amd import EncoderConfig
+    from viforsdes_amd.models.encoder import ObservationContextEncoder
+    from viforsdes_amd.primitives import fused
+    torch.manual_seed(0)
+    enc = ObservationContextEncoder(2, 3, EncoderConfig(hidden_dim=256, num_heads=4, depth=2)).to(DEV)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.requires_grad and p.abs().sum() == 0:
+                p.add_(torch.randn_like(p) * 0.05)
+    obs_t, obs_v = torch.tensor([0.0, 1.0, 2.0, 4.0], device=DEV), torch.randn(4, 2, device=DEV)
+    theta = torch.rand(400, 3, device=DEV) + 0.2   # 400 x 101 tokens = 40400 rows
+
+    def run(block, outp):
+        old = fused.BLOCK_MLP, fused.BLOCK_OUT_PROJ
+        fused.BLOCK_MLP, fused.BLOCK_OUT_PROJ = block, outp
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return enc(obs_v, obs_t, theta, 5.0, 0.05).float()
+        finally:
+            fused.BLOCK_MLP, fused.BLOCK_OUT_PROJ = old
+
+    calls = {"block": 0, "attn_block": 0}
+    from viforsdes_amd import _hip
+    real = _hip.mlp_block_fwd, _hip.mlp_attn_block_fwd
+
+    def spy(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    _hip.mlp_block_fwd, _hip.mlp_attn_block_fwd = spy("block", real[0]), spy("attn_block", real[1])
+    try:
+        base = run(False, False)
+        assert calls == {"block": 0, "attn_block": 0}
+        blk = run(True, False)
+        assert calls == {"block": 2, "attn_block": 0}          # one launch per block (depth 2)
+        both = run(True, True)
+        assert calls == {"block": 2, "attn_block": 2}
+    finally:
+        _hip.mlp_block_fwd, _hip.mlp_attn_block_fwd = real
+    assert base.shape == (400, 101, 256) and torch.isfinite(both).all()
+    assert rel_err(blk.cpu().numpy(), base.cpu().numpy()) < 2e-2
+    assert rel_err(both.cpu().numpy(), blk.cpu().numpy()) < 2e-2
+    params = [p for p in enc.parameters() if p.requires_grad]
+    with torch.no_grad():
+        for p in params:
+            p.mul_(0.7)
+    fused.note_parameters_changed()
+    fused.PackedWeight.refresh_all(force=True, params={id(p) for p in params})
+    base2, both2 = run(False, False), run(True, True)
+    assert rel_err(both2.cpu().numpy(), base2.cpu().numpy()) < 2e-2
+    assert rel_err(base2.cpu().numpy(), base.cpu().numpy()) > 5e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(8192 + 37, 768, 256), (5000, 64, 256), (4100, 256, 768), (20000, 1536, 256), (4096, 8, 16),
                                    # tile counts that underfill one round of workgroups: finer splits in several rounds
                                    (20000 + 13, 2816, 512), (9000, 512, 1408)])

@@ -106,6 +106,42 @@ def test_block_form_matches_the_unfused_chain(B, N, C, H, hreal, last):
         assert _rel(hn, h_ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,N,C,H,hreal,last", [(40, 401, 256, 704, 682, False), (40, 401, 256, 704, 682, True), (33, 129, 128, 384, 341, False),
+                                               (128, 101, 256, 704, 682, False), (512, 401, 256, 704, 682, False)])
+def test_block_form_with_the_out_projection_in_front(B, N, C, H, hreal, last):
+    """vsde_mlp_attn_block_fwd_bf16 = vsde_linear_gated_bf16 (gate + out projection of the attention branch, attn.py:107-110) followed
+    by vsde_mlp_block_fwd_bf16: same operands, same rounding points, the same k order in the out projection -> the two routes differ by
+    the MFMA summation inside a k-step at most (one bf16 ulp of a few outputs)."""
+    from viforsdes_amd import _hip
+    from viforsdes_amd.primitives import fused
+    params, pin, pout, img = _packs(C, H, hreal)
+    w1, w2, b1 = img.operands()
+    g = torch.Generator(device="cpu").manual_seed(41)
+    wo = torch.nn.Parameter((torch.randn(C, C, generator=g) / C ** 0.5).cuda())
+    bo = torch.nn.Parameter((0.1 * torch.randn(C, generator=g)).cuda())
+    po = fused.plain_pack(wo, bo)
+    x, attn = _rand(B, N, C, seed=11), _rand(B, N, C, seed=12)
+    gbuf = _rand(B * N, 96, scale=2.0, seed=14)
+    glog = gbuf[:, 16:80]                               # a column range of a wider buffer: the row pitch is an argument
+    allm = _rand(B, 8 * C + 64, scale=0.5, seed=13)
+    ga, sc, sh, gm, sn, hs = [allm[:, i * C:(i + 1) * C] for i in range(6)]
+    eps = 1e-5
+    wo_b, bo_b = po.operands()
+    yin = _hip.linear_gated_bf16(attn.view(B * N, C), glog, wo_b, bo_b).view(B, N, C)
+    tok_ref, h_ref = _hip.mlp_block_fwd(x, yin, ga, sc, sh, gm, None if last else sn, None if last else hs, eps, eps, w1, w2, b1, pout.bias, H)
+    oimg = fused.OutProjImage(po)
+    tok, hn = _hip.mlp_attn_block_fwd(x, attn, glog, oimg.operand(), bo_b, ga, sc, sh, gm, None if last else sn, None if last else hs, eps, eps,
+                                      w1, w2, b1, pout.bias, H)
+    assert _rel(tok, tok_ref) < 4e-3
+    assert (hn is None) == last
+    if not last:
+        assert _rel(hn, h_ref) < 8e-3
+    # and against the plain float32 statement of the out projection
+    og = (attn.float() * torch.sigmoid(glog.float()).bfloat16().float().repeat(1, C // 64).view(B, N, C)).bfloat16().float()
+    yin32 = (og.view(B * N, C) @ wo_b.float().t() + bo_b.float()).view(B, N, C)
+    assert _rel(yin, yin32) < 1e-2
+
+
 @pytest.mark.parametrize("M,C,H,hreal", [(20000, 256, 704, 682), (4264, 128, 384, 341), (300, 128, 64, 64), (77, 256, 128, 100),
                                          (133000 + 5, 256, 704, 682), (205312, 256, 704, 682)])
 def test_fused_mlp_backward(M, C, H, hreal):

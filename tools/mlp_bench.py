@@ -60,3 +60,18 @@ for name, fn in (("old bwd: rows+SwiGLU' | hipBLASLt dx", lambda: _hip.linear_sw
                  ("fused bwd (du + dx)", lambda: _hip.mlp_bwd(dy, u, bimg, H))):
     t = timeit(fn)
     print(f"{name:40s} {t:8.1f} us   {flb / t / 1e6:6.0f} TF/s   {2.0 * M * (2 * C + 4 * H) / t / 1e3:6.0f} GB/s algorithmic")
+# block forms (no-grad sampling): [out projection |] residual + LN | MLP | residual + next LN
+if M % 401 == 0 and C in (128, 256):
+    B, N = M // 401, 401
+    xs, attn = torch.randn(B, N, C, device=dev).to(torch.bfloat16), torch.randn(B, N, C, device=dev).to(torch.bfloat16)
+    glog = torch.randn(M, 64, device=dev).to(torch.bfloat16)
+    allm = (0.5 * torch.randn(B, 6 * C, device=dev)).to(torch.bfloat16)
+    ga, sc, sh, gm, sn, hs = [allm[:, i * C:(i + 1) * C] for i in range(6)]
+    po = fused.plain_pack(P(C, C, sc=C ** -0.5), P(C))
+    wo, bo = po.operands()
+    oimg = fused.OutProjImage(po).operand()
+    for name, fn in (
+            ("gated out projection (rows kernel)", lambda: _hip.linear_gated_bf16(attn.view(M, C), glog, wo, bo)),
+            ("block form", lambda: _hip.mlp_block_fwd(xs, attn, ga, sc, sh, gm, sn, hs, 1e-5, 1e-5, w1, w2, b1, b2o, H)),
+            ("block form + out projection", lambda: _hip.mlp_attn_block_fwd(xs, attn, glog, oimg, bo, ga, sc, sh, gm, sn, hs, 1e-5, 1e-5, w1, w2, b1, b2o, H))):
+        print(f"{name:40s} {timeit(fn):8.1f} us")

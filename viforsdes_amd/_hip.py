@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
-    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_attn_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -900,6 +900,25 @@ def mlp_block_fwd(x, yin, ga, sc, sh, gm, sn, hs, eps: float, eps_next: float, w
         _call(lib.vsde_mlp_block_fwd_bf16, _ptr(x), _ptr(yin), _ptr(ga), _ptr(sc), _ptr(sh), _ptr(gm), _ptr(sn), _ptr(hs), _i64(mp),
               ctypes.c_int(N), ctypes.c_double(eps), ctypes.c_double(eps_next), _ptr(w1_img), _ptr(w2_img), _ptr(b1_img), _ptr(b2),
               _ptr(tok), _ptr(hnext), _i64(B * N), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
+    return tok, hnext
+
+
+def mlp_attn_block_fwd(x, attn, glog, wo_img, bo, ga, sc, sh, gm, sn, hs, eps: float, eps_next: float, w1_img, w2_img, b1_img, b2, H: int):
+    """``mlp_block_fwd`` with the attention out projection in front: attn [B,N,C] bf16 contiguous (merged heads), glog [B*N,64]
+    gate logits (row pitch free), wo_img the out projection's weight in the w2 image format.  See include/vsde_hip.h."""
+    lib = load(); dev = _require_hip(x, attn, glog, wo_img, ga, sc, sh, gm, w1_img, w2_img, b1_img)
+    B, N, C = x.shape
+    if not (x.is_contiguous() and attn.is_contiguous() and x.dtype == torch.bfloat16 and attn.dtype == torch.bfloat16 and attn.numel() == x.numel()):
+        raise ValueError("mlp_attn_block_fwd: x and attn must be contiguous bf16 tensors of one size")
+    if not (glog.ndim == 2 and glog.shape == (B * N, 64) and glog.dtype == torch.bfloat16 and glog.stride(1) == 1):
+        raise ValueError("mlp_attn_block_fwd: glog must be [B*N, 64] bf16 with unit column stride")
+    mp = _mod_pitch(C, ga, sc, sh, gm, sn, hs)
+    tok = torch.empty_like(x)
+    hnext = torch.empty_like(x) if sn is not None else None
+    with torch.cuda.device(dev):
+        _call(lib.vsde_mlp_attn_block_fwd_bf16, _ptr(x), _ptr(attn), _ptr(glog), _i64(glog.stride(0)), _ptr(wo_img), _ptr(bo), _ptr(ga), _ptr(sc),
+              _ptr(sh), _ptr(gm), _ptr(sn), _ptr(hs), _i64(mp), ctypes.c_int(N), ctypes.c_double(eps), ctypes.c_double(eps_next), _ptr(w1_img),
+              _ptr(w2_img), _ptr(b1_img), _ptr(b2), _ptr(tok), _ptr(hnext), _i64(B * N), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
     return tok, hnext
 
 

@@ -63,6 +63,9 @@ template <int C> struct Geo {
     static constexpr int PER = (W1_PIECES + W2_PIECES + 1 + NW - 1) / NW;         // DMA instructions per wave and tile
     static constexpr int NSLOT = 4;
     static constexpr int KS = C / 16, CB = C / 32;
+    // BLK == 2: W_o arrives in chunks of 4 k-steps (4 x [2][C][16 bytes]); three chunk regions fit in the tile slots
+    static constexpr int WO_CHUNK_BYTES = 4 * 32 * C, WO_CHUNKS = KS / 4, WO_PER = WO_CHUNK_BYTES / 1024 / NW;
+    static_assert(3 * WO_CHUNK_BYTES <= NSLOT * BUF && WO_CHUNK_BYTES % (1024 * NW) == 0 && WO_CHUNKS <= 4, "W_o chunk regions");
 };
 
 struct FwdParams {
@@ -82,6 +85,11 @@ struct FwdParams {
     const uint16_t *R0, *R1, *GA, *SC, *SH, *GM, *SN, *HS;
     uint16_t *TOK, *HOUT;
     int64_t mp; int tokens; float eps, eps_next;
+    // BLK == 2: the attention branch's out projection is the prologue's first product (reference primitives/attn.py:107-110):
+    //     yin = (o * sigmoid(glog[:, k % 64])) W_o^T + b_o   from the attention output o [M][C] and the gate logits [M][ldg] (64 columns);
+    // WOI = W_o as C / 16 tiles in the W2 image's format ([2 h][C][8]: W_o[n][16 t + 8 h + 0..7]).  R1 is unused; x1 is parked in TOK
+    // between the prologue and the epilogue (same lanes, same addresses).
+    const uint16_t *OA, *GL, *WOI, *BO; int64_t ldg;
     int rotate;                         // 1: per-workgroup rotated tile order (default)
     int antiphase;                      // 2: lockstep, one barrier per tile (default); 1: waves 4..7 run one phase behind waves 0..3 (two barriers
                                         // per tile); 0: lockstep with two barriers (VSDE_MLP_ANTIPHASE, A/B runs)
@@ -108,6 +116,41 @@ template <int C>
 __device__ __forceinline__ void issue_tile(const FwdParams &p, int t, char *buf, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < Geo<C>::PER; ++i) issue_piece<C>(p, t, buf, wave, lane, i);
+}
+
+// BLK == 2: chunk ck of the W_o image (4 k-steps) into `buf`, WO_PER DMA instructions per wave
+template <int C>
+__device__ __forceinline__ void issue_wo_chunk(const FwdParams &p, int ck, char *buf, int wave, int lane) {
+    using G = Geo<C>;
+#pragma unroll
+    for (int i = 0; i < G::WO_PER; ++i) {
+        const int piece = wave + NW * i;
+        __builtin_amdgcn_global_load_lds((const void *)((const char *)p.WOI + (int64_t)ck * G::WO_CHUNK_BYTES + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(buf + piece * 1024), 16, 0, 0);
+    }
+}
+// BLK == 2: yin accumulators += the 4 k-steps of one W_o chunk over the gated o fragments og[4 ck ..]; A fragments in two register
+// sets of C / 64 (half a k-step), fetched one group ahead
+template <int C>
+__device__ __forceinline__ void gemm0_chunk(f32x16 (&yacc)[C / 32], const bf16x8 (&og)[C / 16], int ck, const char *buf, int lane) {
+    using G = Geo<C>;
+    constexpr int HC = G::CB / 2, NG = 8;   // groups: (k-step, half of the column blocks)
+    const char *src = buf + (lane >> 5) * (16 * C) + (lane & 31) * 16;
+    bf16x8 wa[2][HC];
+#pragma unroll
+    for (int cb = 0; cb < HC; ++cb) wa[0][cb] = *(const bf16x8 *)(src + cb * 512);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG)
+#pragma unroll
+            for (int cb = 0; cb < HC; ++cb)
+                wa[(g + 1) & 1][cb] = *(const bf16x8 *)(src + ((g + 1) >> 1) * (32 * C) + (((g + 1) & 1) * HC + cb) * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < HC; ++cb)
+            yacc[(g & 1) * HC + cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[g & 1][cb], og[4 * ck + (g >> 1)], yacc[(g & 1) * HC + cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // G1: u accumulators of one tile: bias, then KS k-steps over the resident x fragments; weight fragments are fetched a group of GK
@@ -247,7 +290,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     // block form: this lane's 4 rows of the row-segment layout; their x / yin chunks are requested before anything else (the only
     // HBM latency of the prologue that nothing can hide: one workgroup per CU)
     int64_t mrow[4]; int brow[4];
-    u32x4 xr[BLK ? C / 64 : 1][4], yr[BLK ? C / 64 : 1][4];
+    u32x4 xr[BLK == 1 ? C / 64 : 1][4], yr[BLK == 1 ? C / 64 : 1][4];
     if constexpr (BLK != 0) {
         const int64_t b0 = wg0 / p.tokens;
 #pragma unroll
@@ -256,6 +299,8 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
             mrow[i] = m < p.M ? m : p.M - 1;
             brow[i] = (int)(mrow[i] / p.tokens - b0);
         }
+    }
+    if constexpr (BLK == 1) {
 #pragma unroll
         for (int q = 0; q < C / 64; ++q)
 #pragma unroll
@@ -267,10 +312,26 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
     // Tiles are visited in an order rotated per workgroup (in whole groups of 4 tiles = 64 columns of s): the 256 workgroups of a
     // round pull different lines of the images out of L2 at any moment instead of all queueing for the same ones.
     const int rot = p.rotate ? 4 * (int)((blockIdx.x * 5u) % (unsigned)(p.T / 4)) : 0;
-    issue_tile<C>(p, rot % p.T, lsm, wave, lane);
-    issue_tile<C>(p, (1 + rot) % p.T, lsm + G::BUF, wave, lane);
-    if (tid < C / 8) *(u32x4 *)(b2row + 8 * tid) = p.b2 ? *(const u32x4 *)(p.b2 + 8 * tid) : (u32x4){0u, 0u, 0u, 0u};
     bf16x8 xfr[G::KS];
+    u32x4 gl[4];
+    if constexpr (BLK == 2) {
+        // the out projection's operands first: this lane's fragments of o and of the gate logits (row r, columns 16 ks + 8 h .. + 7),
+        // and W_o's first chunks (4 k-steps each) into the tile slots, which the MLP does not need yet
+        const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;
+        const uint16_t *osrc = p.OA + m * C + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) xfr[ks] = *(const bf16x8 *)(osrc + ks * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gl[j] = *(const u32x4 *)(p.GL + m * p.ldg + 16 * j + 8 * h);
+#pragma unroll
+        for (int ck = 0; ck < (G::WO_CHUNKS < 3 ? G::WO_CHUNKS : 3); ++ck) issue_wo_chunk<C>(p, ck, lsm + ck * G::WO_CHUNK_BYTES, wave, lane);
+    } else {
+        issue_tile<C>(p, rot % p.T, lsm, wave, lane);
+        issue_tile<C>(p, (1 + rot) % p.T, lsm + G::BUF, wave, lane);
+    }
+    if (tid < C / 8) *(u32x4 *)(b2row + 8 * tid) = p.b2 ? *(const u32x4 *)(p.b2 + 8 * tid) : (u32x4){0u, 0u, 0u, 0u};
+    uint16_t *borow = (uint16_t *)(lsm + G::NSLOT * G::BUF + NW * 32 * SLD * 2 + C * 2 + MODB * 6 * C * 2);   // [C] bf16 (BLK == 2)
+    if constexpr (BLK == 2) { if (tid < C / 8) *(u32x4 *)(borow + 8 * tid) = p.BO ? *(const u32x4 *)(p.BO + 8 * tid) : (u32x4){0u, 0u, 0u, 0u}; }
     // block form: the modulation vectors of the (at most MODB) batch rows this workgroup's 256 rows belong to, [MODB][6][C] bf16 in LDS
     // (ga, sc, sh, gm, sn, hs); per lane: the 4 rows of the row-segment layout and their batch-row slots
     const uint16_t *mods = (const uint16_t *)(lsm + G::NSLOT * G::BUF + NW * 32 * SLD * 2 + C * 2);
@@ -288,6 +349,11 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         }
         __syncthreads();   // (before any DMA wait is counted: the tile DMAs above stay in flight -- __syncthreads drains vmcnt, which only costs the prologue some overlap)
     }
+    f32x16 yacc[G::CB];
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
     if constexpr (BLK == 0) {
         const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
         const uint16_t *src = p.X + m * p.ldx + 8 * h;
@@ -302,6 +368,83 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         const int c = lane & 7;
         u32x4 x1[NQ][4];
         float s1[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BLK == 2) {
+            // out projection: og = o * rnd(sigmoid(gate logit)) rounded to bf16 (the operand csrc/vsde_linear.hip's gated load builds),
+            // then C / 16 k-steps into the (still unused) y accumulators.  Chunks 0..2 of W_o landed before the __syncthreads above.
+            u32x4 sg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sg[j][e] = pack2(sigm(bf_lo(gl[j][e])), sigm(bf_hi(gl[j][e])));
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const u32x4 a = __builtin_bit_cast(u32x4, xfr[ks]), g = sg[ks & 3];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2(bf_lo(a[e]) * bf_lo(g[e]), bf_hi(a[e]) * bf_hi(g[e]));
+                xfr[ks] = __builtin_bit_cast(bf16x8, o);
+            }
+            gemm0_chunk<C>(yacc, xfr, 0, lsm, lane);
+            if constexpr (G::WO_CHUNKS == 4) {   // region 0 is free once every wave is through chunk 0: the last chunk goes there
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_wo_chunk<C>(p, 3, lsm, wave, lane);
+            }
+#pragma unroll
+            for (int ck = 1; ck < (G::WO_CHUNKS < 3 ? G::WO_CHUNKS : 3); ++ck) gemm0_chunk<C>(yacc, xfr, ck, lsm + ck * G::WO_CHUNK_BYTES, lane);
+            if constexpr (G::WO_CHUNKS == 4) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                gemm0_chunk<C>(yacc, xfr, 3, lsm, lane);
+            }
+            mfma_result_guard();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with W_o: the slots are the MLP's
+            issue_tile<C>(p, rot % p.T, lsm, wave, lane);
+            issue_tile<C>(p, (1 + rot) % p.T, lsm + G::BUF, wave, lane);
+            // yin = acc + b_o (bf16) through the staging rows into the row-segment layout; x1 = x + ga * yin is parked in TOK
+            u32x4 xn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 8 * c);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const f32x16 &a = yacc[2 * q + half];
+                    const uint16_t *bias32 = borow + 64 * q + 32 * half;
+                    uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+                        *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                                     pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                    }
+                }
+                u32x4 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[i] = xn[i];
+                if (q + 1 < NQ) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 64 * (q + 1) + 8 * c);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 64 * q + 8 * c;
+                    const u32x4 yv = *(const u32x4 *)(stage + ((lane >> 3) + 8 * i) * SLD + c * 8);
+                    const u32x4 gv = *(const u32x4 *)(mods + (brow[i] * 6 + 0) * C + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t t = pack2(bf_lo(gv[e]) * bf_lo(yv[e]), bf_hi(gv[e]) * bf_hi(yv[e]));
+                        x1[q][i][e] = pack2(bf_lo(xv[i][e]) + bf_lo(t), bf_hi(xv[i][e]) + bf_hi(t));
+                        s1[i] += bf_lo(x1[q][i][e]) + bf_hi(x1[q][i][e]);
+                    }
+                    if (row0 + (lane >> 3) + 8 * i < p.M) *(u32x4 *)(p.TOK + mrow[i] * C + col) = x1[q][i];
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int cb = 0; cb < G::CB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
+        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -316,6 +459,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
                     s1[i] += bf_lo(x1[q][i][e]) + bf_hi(x1[q][i][e]);
                 }
             }
+        }
         float mu[4], rs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -349,11 +493,6 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
             wave_lds_fence();
         }
     }
-    f32x16 yacc[G::CB];
-#pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
     // tile 0 has landed once at most tile 1's instructions are in flight (the x loads above are older still)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::PER) : "memory");
     const int off = p.antiphase == 1 ? wave >> 2 : 0;   // phase offset of this wave
@@ -410,8 +549,12 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         u32x4 tk[NQ][4];
         float s1[4] = {0.f, 0.f, 0.f, 0.f};
         u32x4 xn[4], yn[4];
+        const uint16_t *xsrc = BLK == 2 ? p.TOK : p.R0;   // BLK == 2: x1 itself, parked by the prologue
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 8 * c); yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 8 * c); }
+        for (int i = 0; i < 4; ++i) {
+            xn[i] = *(const u32x4 *)(xsrc + mrow[i] * C + 8 * c);
+            if constexpr (BLK == 1) yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 8 * c);
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -428,12 +571,12 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
             }
             u32x4 xv[4], yv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; yv[i] = yn[i]; }
+            for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; if constexpr (BLK == 1) yv[i] = yn[i]; }
             if (q + 1 < NQ) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    xn[i] = *(const u32x4 *)(p.R0 + mrow[i] * C + 64 * (q + 1) + 8 * c);
-                    yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 64 * (q + 1) + 8 * c);
+                    xn[i] = *(const u32x4 *)(xsrc + mrow[i] * C + 64 * (q + 1) + 8 * c);
+                    if constexpr (BLK == 1) yn[i] = *(const u32x4 *)(p.R1 + mrow[i] * C + 64 * (q + 1) + 8 * c);
                 }
             }
             wave_lds_fence();
@@ -445,8 +588,11 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
                 u32x4 t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t gy = pack2(bf_lo(gv[e]) * bf_lo(yv[i][e]), bf_hi(gv[e]) * bf_hi(yv[i][e]));
-                    const uint32_t x1 = pack2(bf_lo(xv[i][e]) + bf_lo(gy), bf_hi(xv[i][e]) + bf_hi(gy));
+                    uint32_t x1 = xv[i][e];
+                    if constexpr (BLK == 1) {
+                        const uint32_t gy = pack2(bf_lo(gv[e]) * bf_lo(yv[i][e]), bf_hi(gv[e]) * bf_hi(yv[i][e]));
+                        x1 = pack2(bf_lo(xv[i][e]) + bf_lo(gy), bf_hi(xv[i][e]) + bf_hi(gy));
+                    }
                     const uint32_t gm = pack2(bf_lo(mv[e]) * bf_lo(ml[e]), bf_hi(mv[e]) * bf_hi(ml[e]));
                     t[e] = pack2(bf_lo(x1) + bf_lo(gm), bf_hi(x1) + bf_hi(gm));
                     s1[i] += bf_lo(t[e]) + bf_hi(t[e]);
@@ -490,7 +636,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
 
 template <int C> static size_t fwd_lds_bytes() {
     using G = Geo<C>;
-    return (size_t)G::NSLOT * G::BUF + (size_t)NW * 32 * SLD * 2 + (size_t)C * 2 + (size_t)MODB * 6 * C * 2;
+    return (size_t)G::NSLOT * G::BUF + (size_t)NW * 32 * SLD * 2 + (size_t)C * 2 + (size_t)MODB * 6 * C * 2 + (size_t)C * 2;
 }
 
 template <int C, int SAVE, int DBG = 0, int BLK = 0>
@@ -797,6 +943,30 @@ extern "C" int vsde_mlp_block_fwd_bf16(const void *x, const void *yin, const voi
     p.W1I = (const uint16_t *)w1_img; p.W2I = (const uint16_t *)w2_img; p.B1I = b1_img; p.b2 = (const uint16_t *)b2; p.M = M; p.T = H / 16;
     mlp_env(p);
     return C == 256 ? mlp::launch_fwd<256, 0, 0, 1>(p, (hipStream_t)stream) : mlp::launch_fwd<128, 0, 0, 1>(p, (hipStream_t)stream);
+}
+
+extern "C" int vsde_mlp_attn_block_fwd_bf16(const void *x, const void *attn, const void *glog, int64_t ldg, const void *wo_img, const void *bo,
+                                            const void *ga, const void *sc, const void *sh, const void *gm, const void *sn, const void *hs,
+                                            int64_t mp, int tokens, double eps, double eps_next, const void *w1_img, const void *w2_img,
+                                            const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H, void *stream) {
+    VSDE_CHECK_ARG(x && attn && glog && wo_img && ga && sc && sh && gm && w1_img && w2_img && b1_img && tok && M > 0 && tokens > 0, VSDE_E_BADARG,
+                   "bad mlp_attn_block_fwd arguments");
+    VSDE_CHECK_ARG((C == 128 || C == 256) && H >= 64 && H % 64 == 0, VSDE_E_BADARG,
+                   "fused SwiGLU MLP is built for widths 128 / 256 and a hidden size that is a multiple of 64 (got %d, %d)", C, H);
+    VSDE_CHECK_ARG((!sn) == (!hs) && (!sn) == (!hnext), VSDE_E_BADARG, "next-norm scale, shift and output go together");
+    const void *ptrs[] = {x, attn, glog, wo_img, bo, ga, sc, sh, gm, sn, hs, w1_img, w2_img, b1_img, b2, tok, hnext};
+    for (const void *q : ptrs) VSDE_CHECK_ARG(((uintptr_t)q % 16) == 0, VSDE_E_BADARG, "mlp_attn_block_fwd operands must be 16-byte aligned");
+    VSDE_CHECK_ARG(mp >= C && mp % 8 == 0 && ldg >= 64 && ldg % 8 == 0, VSDE_E_BADARG, "bad modulation / gate row pitch");
+    VSDE_CHECK_ARG(tok != x, VSDE_E_BADARG, "mlp_attn_block_fwd parks x1 in tok: it must not alias x");
+    VSDE_CHECK_ARG(tokens >= 86, VSDE_E_BADARG, "mlp_attn_block_fwd keeps the modulation vectors of %d batch rows per 256-row stripe: sequences of >= 86 tokens", mlp::MODB);
+    mlp::FwdParams p = {};
+    p.R0 = (const uint16_t *)x; p.OA = (const uint16_t *)attn; p.GL = (const uint16_t *)glog; p.ldg = ldg; p.WOI = (const uint16_t *)wo_img;
+    p.BO = (const uint16_t *)bo; p.GA = (const uint16_t *)ga; p.SC = (const uint16_t *)sc; p.SH = (const uint16_t *)sh;
+    p.GM = (const uint16_t *)gm; p.SN = (const uint16_t *)sn; p.HS = (const uint16_t *)hs; p.TOK = (uint16_t *)tok; p.HOUT = (uint16_t *)hnext;
+    p.mp = mp; p.tokens = tokens; p.eps = (float)eps; p.eps_next = (float)eps_next;
+    p.W1I = (const uint16_t *)w1_img; p.W2I = (const uint16_t *)w2_img; p.B1I = b1_img; p.b2 = (const uint16_t *)b2; p.M = M; p.T = H / 16;
+    mlp_env(p);
+    return C == 256 ? mlp::launch_fwd<256, 0, 0, 2>(p, (hipStream_t)stream) : mlp::launch_fwd<128, 0, 0, 2>(p, (hipStream_t)stream);
 }
 
 extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img, const void *w2_img, const float *b1_img, const void *b2,

@@ -58,7 +58,7 @@ class Attention(nn.Module):
                 and fused.usable(hidden_states, self.embed_dim, self.head_dim))
 
     def forward_fused(self, hidden_states: Tensor, *, rotary: RotarySpec, v0: Optional[Tensor],
-                      v0link: Optional["fused.GradLink"] = None) -> tuple[Tensor, Tensor]:
+                      v0link: Optional["fused.GradLink"] = None, defer_out: bool = False) -> tuple[Tensor, Tensor]:
         """Same map as ``forward(..., return_value=True)`` with the elementwise chains as fused HIP ops:
         qkv GEMM -> [RMS + RoPE + value mix + head layout] -> SDPA -> [sigmoid gate + merge heads] -> out GEMM.
 
@@ -100,6 +100,10 @@ class Attention(nn.Module):
                 if glog.shape[-1] == 64 and self.head_dim == 64 and self.out_proj.weight.shape[0] % 64 == 0:
                     # gate_merge folded into the out projection's operand load (one kernel instead of two)
                     po = fused.plain_pack(self.out_proj.weight, self.out_proj.bias)
+                    if defer_out and fused.BLOCK_OUT_PROJ and self.out_proj.weight.shape[0] == self.embed_dim:
+                        # the caller's block kernel applies gate, projection and bias in its prologue (csrc/vsde_mlp.hip, BLK == 2)
+                        return (fused.DeferredOutProjection(out_tm.contiguous().view(B_, N_, self.embed_dim), glog.reshape(B_ * N_, 64), po),
+                                v.transpose(1, 2))
                     wo, bo = po.operands()
                     y_out = fused._hip.linear_gated_bf16(out_tm.contiguous().view(B_ * N_, self.embed_dim), glog.reshape(B_ * N_, 64), wo, bo)
                     return y_out.view(B_, N_, -1), v.transpose(1, 2)

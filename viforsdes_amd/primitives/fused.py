@@ -867,6 +867,8 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
 FUSED_MLP = os.environ.get("VSDE_FUSED_MLP", "1") != "0"
 # VSDE_BLOCK_MLP=0: residual / LayerNorm passes stay separate kernels in the no-grad chain (A/B runs)
 BLOCK_MLP = os.environ.get("VSDE_BLOCK_MLP", "1") != "0"
+# block form: also the attention branch's gate + out projection in the kernel's prologue (VSDE_BLOCK_OUT_PROJ=0: separate launch)
+BLOCK_OUT_PROJ = os.environ.get("VSDE_BLOCK_OUT_PROJ", "1") != "0"
 # VSDE_FUSED_MLP_BWD=1: the training step's MLP backward as one kernel (du + dx) instead of rows kernel + library GEMM (opt-in, see above)
 FUSED_MLP_BWD = os.environ.get("VSDE_FUSED_MLP_BWD", "0") == "1"
 # one 256-row workgroup per CU and no column chunks: below ~128 rows per CU the two-launch form (column chunks fill the chip) is faster
@@ -914,6 +916,41 @@ class MlpImages:
             pk.operands()
         self.refresh_if_stale()
         return self.w1, self.w2, self.b1
+
+
+class OutProjImage:
+    """The attention out projection's weight [C, C] as C / 16 tiles in the W2 image format ([2 h][C][8]: W_o[n, 16 t + 8 h + 0..7]),
+    the operand of the block kernel's out-projection prologue (csrc/vsde_mlp.hip, BLK == 2); rebuilt whenever the pack is refreshed."""
+
+    def __init__(self, pack: PackedWeight) -> None:
+        C = pack.weight.shape[0]
+        self.img = torch.zeros(C // 16, 2, C, 8, device=pack.weight.device, dtype=torch.bfloat16)
+        self.packs, self.C, self._key = (pack,), C, None   # `.packs`: the protocol of PackedWeight._derived
+        PackedWeight._derived.add(self)
+
+    @torch.no_grad()
+    def refresh_if_stale(self) -> None:
+        pack = self.packs[0]
+        key = tuple(pack._versions or ())
+        if key == self._key:
+            return
+        C = self.C
+        self.img.copy_(pack.weight.view(C, C // 16, 2, 8).permute(1, 2, 0, 3))
+        self._key = key
+
+    def operand(self) -> Tensor:
+        self.packs[0].operands()
+        self.refresh_if_stale()
+        return self.img
+
+
+class DeferredOutProjection:
+    """What ``SelfAttention.forward_fused(defer_out=True)`` hands back instead of the projected branch output in no-grad calls:
+    the merged attention output [B, N, C], the gate logits [B*N, 64] and the out projection's pack -- the block kernel applies
+    gate, projection and bias in its prologue (``mlp_block_nograd``)."""
+
+    def __init__(self, attn: Tensor, glog: Tensor, pack: PackedWeight) -> None:
+        self.attn, self.glog, self.pack = attn, glog, pack
 
 
 class MlpBwdImages:
@@ -969,10 +1006,11 @@ def mlp_block_nograd_usable(x: Tensor, mods: Optional["Modulations"], width: int
 
 
 @torch.no_grad()
-def mlp_block_nograd(x: Tensor, attn_out: Tensor, mods: "Modulations", block: int, nxt: Optional[int], eps: float, eps_next: float,
+def mlp_block_nograd(x: Tensor, attn_out, mods: "Modulations", block: int, nxt: Optional[int], eps: float, eps_next: float,
                      pin: PackedWeight, pout: PackedWeight):
     """(tokens_new, h_next) of one SiT block's second half (reference primitives/sit.py:112-128) from the stream ``x`` and the
-    attention branch's output: csrc/vsde_mlp.hip in its block form.  ``nxt``: index of the block whose first norm follows (None:
+    attention branch's output (a tensor, or a ``DeferredOutProjection``: the kernel then runs the out projection too):
+    csrc/vsde_mlp.hip in its block form.  ``nxt``: index of the block whose first norm follows (None:
     last block, ``h_next`` is None).  Chunk order of a block's modulations: (sa, ha, ga, sm, hm, gm)."""
     img = getattr(pin, "_mlp_images", None)
     if img is None:
@@ -980,6 +1018,14 @@ def mlp_block_nograd(x: Tensor, attn_out: Tensor, mods: "Modulations", block: in
     w1i, w2i, b1i = img.operands()
     sn = None if nxt is None else mods.vec(nxt, 0)
     hs = None if nxt is None else mods.vec(nxt, 1)
+    if isinstance(attn_out, DeferredOutProjection):
+        po = attn_out.pack
+        oimg = getattr(po, "_out_image", None)
+        if oimg is None:
+            oimg = po._out_image = OutProjImage(po)
+        return _hip.mlp_attn_block_fwd(x.contiguous(), attn_out.attn, attn_out.glog, oimg.operand(), po.bias, mods.vec(block, 2),
+                                       mods.vec(block, 3), mods.vec(block, 4), mods.vec(block, 5), sn, hs, eps, eps_next, w1i, w2i, b1i,
+                                       pout.bias, pout.weight.shape[1])
     return _hip.mlp_block_fwd(x.contiguous(), attn_out.to(x.dtype).contiguous(), mods.vec(block, 2), mods.vec(block, 3), mods.vec(block, 4),
                               mods.vec(block, 5), sn, hs, eps, eps_next, w1i, w2i, b1i, pout.bias, pout.weight.shape[1])
 

@@ -138,13 +138,14 @@ class SiT(nn.Module):
         v0: Optional[Tensor] = None
         v0link = fused.GradLink() if self.config.attn_residual_v else None  # one buffer for the value-residual gradient
         for k, blk in enumerate(blocks):
-            attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0, v0link=v0link)
+            block_form = (isinstance(blk.mlp, SwiGLU) and blk.mlp.input_proj.bias is not None
+                          and fused.mlp_block_nograd_usable(tokens, mods, blk.mlp.padded_width())
+                          and fused.swiglu_mlp_usable(tokens, blk.mlp.padded_width()))
+            attn_out, values = blk.self_attn.forward_fused(h1, rotary=rotary, v0=v0, v0link=v0link, defer_out=block_form)
             if v0 is None and self.config.attn_residual_v:
                 v0 = values
             lk = link0 if k == 0 else None
-            if (isinstance(blk.mlp, SwiGLU) and blk.mlp.input_proj.bias is not None
-                    and fused.mlp_block_nograd_usable(tokens, mods, blk.mlp.padded_width())
-                    and fused.swiglu_mlp_usable(tokens, blk.mlp.padded_width())):
+            if block_form:
                 # no-grad call: [res1 + LN2 | MLP | res2 + next LN1] is ONE kernel (csrc/vsde_mlp.hip, block form)
                 pin, pout = blk.mlp.packs(tokens, True)
                 tokens, h1 = fused.mlp_block_nograd(tokens, attn_out, mods, k, k + 1 if k + 1 < nb else None, blk.mlp_norm.eps,
