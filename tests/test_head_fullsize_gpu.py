@@ -62,7 +62,7 @@ def _inputs(B, T, S, C, P, H, L, seed, bf16_ctx):
 
 # workloads the multi-path MFMA forward kernel (csrc/vsde_head_mp.hip: hidden_dim 64, L <= 2, state_dim <= 2) can take run twice,
 # once per forward kernel (forced: the sub-batch launch below must take the same kernel as the full launch)
-CASES = [(n, mp) for n, v in WORKLOADS.items() for mp in ((0, 4, 16) if (v[3] <= 2 and v[7] <= 2 and v[6] == 64) else (0,))]
+CASES = [(n, mp) for n, v in WORKLOADS.items() for mp in ((0, 2, 4, 16) if (v[3] <= 2 and v[7] <= 2 and v[6] == 64) else (0,))]
 
 
 @pytest.fixture()

@@ -70,11 +70,11 @@ def test_default_dispatch_above_the_batch_thresholds_vs_golden(name):
     test_forward_backward_vs_golden(name)
 
 
-@pytest.mark.parametrize("np_group", [4, 8, 16])
+@pytest.mark.parametrize("np_group", [2, 4, 8, 16])
 @pytest.mark.parametrize("name", ["ou_dims", "lv_dims"])
 def test_multi_path_mfma_forward_vs_golden(name, np_group):
     """The reference-generated cases with hidden_dim 64 / two layers / state_dim 1, 2 through the multi-path MFMA forward kernel
-    (csrc/vsde_head_mp.hip, forced, 4 / 8 / 16 paths per workgroup; batches of 3 / 2 paths = one partly filled group): same
+    (csrc/vsde_head_mp.hip, forced, 2 / 4 / 8 / 16 paths per workgroup; batches of 3 / 2 paths = one partly filled group): same
     tolerances as the v2 kernel, the backward consumes the activations this forward saved."""
     from viforsdes_amd import _hip
     _hip.debug_head_mp(np_group)
@@ -141,7 +141,7 @@ def test_argument_errors_raise():
 
 @pytest.fixture()
 def forward_kernel(request):
-    """Forces the forward time-stepping kernel: 0 = four waves per path (v2), 4 / 8 / 16 = the multi-path MFMA kernel with that
+    """Forces the forward time-stepping kernel: 0 = four waves per path (v2), 2 / 4 / 8 / 16 = the multi-path MFMA kernel with that
     many paths per workgroup (the default picks by batch size, so a sub-batch could take another kernel than the full batch)."""
     from viforsdes_amd import _hip
     _hip.debug_head_mp(request.param)
@@ -149,7 +149,7 @@ def forward_kernel(request):
     _hip.debug_head_mp(-1)
 
 
-@pytest.mark.parametrize("forward_kernel", [0, 4, 8, 16], indirect=True, ids=["v2", "mfma4", "mfma8", "mfma16"])
+@pytest.mark.parametrize("forward_kernel", [0, 2, 4, 8, 16], indirect=True, ids=["v2", "mfma2", "mfma4", "mfma8", "mfma16"])
 def test_full_size_properties_lv(forward_kernel):
     """LV size (B=512, T=400, S=2, C=256, H=64, L=2): size-independent properties.
 
@@ -301,7 +301,7 @@ def test_ragged_step_counts_with_staggered_chunks(S, L, T):
 
 
 @pytest.mark.parametrize("T", [1, 2, 3])
-@pytest.mark.parametrize("forward_kernel", [4, 8, 16], indirect=True, ids=["mfma4", "mfma8", "mfma16"])
+@pytest.mark.parametrize("forward_kernel", [2, 4, 8, 16], indirect=True, ids=["mfma2", "mfma4", "mfma8", "mfma16"])
 def test_multi_path_kernels_on_very_short_grids(forward_kernel, T):
     """One, two and three Euler steps (the kernels prefetch one / two steps ahead, store outputs one step late and walk the reverse sweep
     two steps per loop trip): forward and all 13 gradients against the float64 oracle, 5 paths = one partly filled group, one emission
@@ -331,7 +331,7 @@ def test_multi_path_kernels_on_very_short_grids(forward_kernel, T):
             assert rel_err(a.cpu().numpy(), b_) < BWD_TOL, n
 
 
-@pytest.mark.parametrize("forward_kernel", [4, 8, 16], indirect=True, ids=["mfma4", "mfma8", "mfma16"])
+@pytest.mark.parametrize("forward_kernel", [2, 4, 8, 16], indirect=True, ids=["mfma2", "mfma4", "mfma8", "mfma16"])
 def test_a_non_finite_path_does_not_contaminate_its_group(forward_kernel):
     """The multi-path forward puts 4 / 8 / 16 paths into the columns of one MFMA operand.  A path whose noise turns NaN / inf at some step
     must turn NaN / inf itself from there on (the emission floor propagates NaN like ``torch.maximum``, reference primitives/bounds.py:10-31)

@@ -45,7 +45,7 @@ def check():
         outs, grads = {}, {}
         gg = torch.Generator(device="cpu").manual_seed(5)
         gp, gm, gl = (torch.randn(B, T + 1, S, generator=gg), torch.randn(B, T, S, generator=gg), torch.randn(B, T, S, S, generator=gg))
-        for mode in (0, 4, 8, 16):
+        for mode in (0, 2, 4, 8, 16):
             _hip.debug_head_mp(mode)
             fo = _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, True)
             outs[mode] = [None if t is None else t.cpu().numpy() for t in fo]
@@ -65,8 +65,8 @@ def check():
         line = f"B={B} T={T} S={S} L={L} C={C}:"
         for k, nm in enumerate(names):
             e_v2 = rel(outs[0][k], ref[k])
-            e_mp = {m: rel(outs[m][k], ref[k]) for m in (4, 8, 16)}
-            line += f" {nm} v2 {e_v2:.1e} mp4 {e_mp[4]:.1e} mp8 {e_mp[8]:.1e} mp16 {e_mp[16]:.1e};"
+            e_mp = {m: rel(outs[m][k], ref[k]) for m in (2, 4, 8, 16)}
+            line += f" {nm} v2 {e_v2:.1e} mp2 {e_mp[2]:.1e} mp4 {e_mp[4]:.1e} mp8 {e_mp[8]:.1e} mp16 {e_mp[16]:.1e};"
             if not (max(e_mp.values()) < 2e-5):
                 ok = False
         outs[1] = outs[4] if max(rel(outs[4][4], ref[4]), 0) >= rel(outs[16][4], ref[4]) else outs[16]   # the worse one for the breakdown below
@@ -119,7 +119,7 @@ def timing():
         wd = [d(w) for w in ws]
         x0, ctx, theta, eps = d(x0), d(ctx), d(theta), d(eps)
         row = f"B={B:6d}"
-        for mode in (0, 4, 8, 16):
+        for mode in (0, 2, 4, 8, 16):
             _hip.debug_head_mp(mode)
             for save in (True, False):
                 _hip.profile_enable(True)

@@ -81,7 +81,7 @@ def load() -> ctypes.CDLL:
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m viforsdes_amd.build` "
             "(there is no CPU fallback for the fused head / ELBO kernels)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(os.environ.get("VSDE_HIP_LIB") or LIB_PATH)   # VSDE_HIP_LIB: an A/B build of the same sources (tools only)
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise HipLibraryError(f"{LIB_PATH} does not export {name}")

@@ -1567,7 +1567,10 @@ static bool mp_auto(const vsde_head_dims *d, int save) {
     // 461 / 441, 256 paths 535 / 440 vs 462 / 441, 512 paths 676 / 549 vs 492 / 445, 4096 paths 4709 / 3967 vs 1104 / 591.  The
     // no-grad launch of the v2 kernel (one path per CU up to 256 paths) keeps its edge there; the training launch does not since the
     // layer-1 role's records leave through LDS.
-    return save ? d->B >= 96 : d->B > 256;
+    // Round 5 (spread forms, groups of 2 paths up to 512; tools/head_mp_check.py time): 128 paths 507 / 423 (v2) vs 306 / 301, 256 paths
+    // 530 / 434 vs 319 / 306, 512 paths 688 / 539 vs 380 / 329: the multi-path kernel from 32 paths on, both launches.
+    (void)save;
+    return d->B >= 32;
 }
 static bool use_mp(const vsde_head_dims *d, int save) {
     if (!mp_applicable(d->H, d->L, d->S) || mp_weights_overflowed()) return false;

@@ -134,8 +134,17 @@ template <int N> __device__ __forceinline__ float mp_row_shl(float v) {   // lan
 //   NP < 16 : ONE B operand holds both planes side by side -- columns [0, NP) the hi parts of the NP paths, [NP, 2 NP) their lo'
 //             parts -- so W_hi x B gives hi*hi (column c) AND hi*lo' (column c + NP) in one MFMA and W_lo' x B adds lo'*hi: two
 //             MFMAs per tile and k-step instead of three; lane c pulls the hi*lo' sum from lane c + NP of its row (one DPP op).
-template <int NP>
-__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], f32x4 (&R)[3]) {
+//   UPL < 4 ("spread", NP = 4 UPL): both planes again (three MFMAs), but the 16 columns of an operand hold the NP paths 16 / NP times
+//             over -- every replica lane gets the four rows of its lane group and keeps only ITS UPL of them (replica index rr): the
+//             gate block of a step then costs a lane UPL units' worth of transcendentals instead of four (the step is a latency
+//             chain: the idle columns of a 4- or 8-path group were free).
+//   UPL < 4, NP = 2 UPL: the same with the planes side by side again (two MFMAs): columns = [hi of the NP paths | their lo' parts] x
+//             4 / UPL replicas; the lanes of the hi columns own the paths.  Per SIMD and step the two-layer kernel then issues 44
+//             MFMAs instead of 66 -- and the SIMD's issue slots are what a step costs: its two waves' MFMAs and VALU operations
+//             do not overlap (profiles/r05_mfma_valu_overlap.txt), "slack" products of one role delay the other role's chain.
+template <int NP, int UPL>
+__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], float (&R)[3][UPL], int rr) {
+    constexpr bool P2 = NP == 4 * UPL;
     f32x4 A1[3], A2[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) { A1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; A2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -143,7 +152,7 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) A1[g] = mp_mfma(wf[g][ks][0], hb[0][ks], A1[g]);
-        if (NP == 16) {
+        if (P2) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][0], hb[1][ks], A2[g]);
         }
@@ -151,10 +160,35 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
         for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][1], hb[0][ks], A2[g]);
     }
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
+        // this lane's UPL rows of the four (replica rr), then the planes are folded
+        float s1[UPL], s2[UPL];
+        if constexpr (UPL == 4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            R[g][r] = NP == 16 ? fmaf(A2[g][r], kMpLoInv, A1[g][r]) : fmaf(mp_row_shl<NP & 15>(A1[g][r]) + A2[g][r], kMpLoInv, A1[g][r]);
+            for (int r = 0; r < 4; ++r) { s1[r] = A1[g][r]; s2[r] = A2[g][r]; }
+        } else if constexpr (UPL == 2) {
+            s1[0] = rr ? A1[g][2] : A1[g][0]; s1[1] = rr ? A1[g][3] : A1[g][1];
+            s2[0] = rr ? A2[g][2] : A2[g][0]; s2[1] = rr ? A2[g][3] : A2[g][1];
+        } else {
+            const float l1 = (rr & 1) ? A1[g][1] : A1[g][0], h1 = (rr & 1) ? A1[g][3] : A1[g][2];
+            const float l2 = (rr & 1) ? A2[g][1] : A2[g][0], h2 = (rr & 1) ? A2[g][3] : A2[g][2];
+            s1[0] = (rr & 2) ? h1 : l1; s2[0] = (rr & 2) ? h2 : l2;
+        }
+#pragma unroll
+        for (int r = 0; r < UPL; ++r)
+            R[g][r] = P2 ? fmaf(s2[r], kMpLoInv, s1[r]) : fmaf(mp_row_shl<NP & 15>(s1[r]) + s2[r], kMpLoInv, s1[r]);
+    }
+}
+// UPL consecutive floats
+template <int UPL> __device__ __forceinline__ void mp_ldu(float (&d)[UPL], const float *src) {
+    if constexpr (UPL == 4) { const f32x4 v = *(const f32x4 *)src; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+    else if constexpr (UPL == 2) { const float2 v = *(const float2 *)src; d[0] = v.x; d[1] = v.y; }
+    else d[0] = *src;
+}
+template <int UPL> __device__ __forceinline__ void mp_stu(float *dst, const float (&v)[UPL], float sc = 1.0f) {
+    if constexpr (UPL == 4) *(f32x4 *)dst = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+    else if constexpr (UPL == 2) *(float2 *)dst = make_float2(v[0] * sc, v[1] * sc);
+    else *dst = v[0] * sc;
 }
 
 // Roles.  One layer: four waves (wave w = units 16 w ..).  Two layers: EIGHT waves, two per SIMD -- waves 0-3 are layer 0 (W_hh_l0
@@ -164,10 +198,14 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
 // does not need at once (W_hh h_t, consumed by step t + 1) run on one role's matrix pipe while the other role's VALU does gates.
 //   step t:  [L0: gates -> h0_t]  barrier A  [L1: W_ih1 h0_t, gates -> h1_t | L0: W_hh0 h0_t]  barrier B
 //            [L0: emission rows x h1_t, z_{t+1}, outputs, then gates of step t + 1 | L1: W_hh1 h1_t]
-template <int L, bool SAVE, int S, int NP>
+template <int L, bool SAVE, int S, int NP, int UPL = 4>
 __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p) {
-    constexpr int NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4, PL = NP == 16 ? 2 : 1;
-    static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2 && (NP == 16 || NP == 8 || NP == 4), "multi-path kernel: L <= 2, state_dim <= 2");
+    constexpr bool SPREAD = UPL != 4, P2 = NP == 4 * UPL;   // SPREAD: replicated path columns, UPL units per lane; P2: one operand per plane (see mp_matmul)
+    constexpr int NTRIL = S * (S + 1) / 2, NO = S + NTRIL, NTO = (NO + 3) / 4, PL = P2 ? 2 : 1;
+    constexpr int CW = P2 ? NP : 2 * NP;                    // columns of one replica
+    static_assert(L >= 1 && L <= 2 && S >= 1 && S <= 2 && (NP == 16 || NP == 8 || NP == 4 || NP == 2), "multi-path kernel: L <= 2, state_dim <= 2");
+    static_assert(UPL == 4 || NP == 4 * UPL || NP == 2 * UPL, "spread form: 4 / UPL replicas of every path's column(s)");
+    static_assert(NP >= 4 || SPREAD, "groups of 2 paths exist in the spread form only");
     // hidden state in B-fragment order: [step parity][layer][plane][k-step][lane group][column] x 8 f16 (NP < 16: one plane, the hi parts
     // in columns [0, NP), the lo' parts in [NP, 2 NP), the rest zero)
     __shared__ __attribute__((aligned(16))) f16x8 hbuf[2][L][PL][2][4][16];
@@ -178,14 +216,18 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     constexpr bool STASH = SAVE && L > 1;
     constexpr int SPITCH = 324;                           // floats per path: 320 + 4, so that the 8-lane groups of a ds_write_b128 (paths
                                                           // 0..7 of one row group) fall on different banks (320 = 0 mod 32: 4-way conflicts)
+    // (measured and dropped, round 5: the layer-0 role leaving its record there too, both copied out as 16-byte lanes -- 420 vs 407-417 us
+    //  at 512 paths on one box: its five 4-byte stores per lane are not what the step waits for)
     constexpr int SREC = STASH ? NP * SPITCH : 4;         // floats per record (all paths of the group)
     __shared__ __attribute__((aligned(16))) float srec[2][SREC];
     const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
-    const int b_raw = blockIdx.x * NP + (pp & (NP - 1));
-    const bool owner = pp < NP;                    // NP < 16: lanes of the other columns run along and store nothing
+    const int pc = pp & (NP - 1), rr = SPREAD ? pp / CW : 0;   // path column; replica index (SPREAD: this lane's units are rows rr UPL .. of its group's four)
+    const int b_raw = blockIdx.x * NP + pc;
+    const bool owner = SPREAD ? (P2 || (pp & (CW - 1)) < NP) : pp < NP;   // side-by-side planes: the lanes of the lo' columns (and, not spread, of the unused ones) run along and store nothing
     const bool live = owner && b_raw < p.B;
+    const bool first = live && rr == 0;            // the lane that stores what exists once per path
     const int b = b_raw < p.B ? b_raw : p.B - 1;   // lanes beyond the batch recompute the last path and store nothing
-    const int j0 = 16 * w + 4 * q, T = p.T, I = S + p.C + p.P;
+    const int j0 = 16 * w + 4 * q + rr * UPL, T = p.T, I = S + p.C + p.P;
     mp_flush_f16_denormals();
     if (NP < 16) {
         for (int e = tid; e < 2 * L * PL * 2 * 4 * 16; e += 256 * L) (&hbuf[0][0][0][0][0][0])[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -194,11 +236,24 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 
     // the 4 owned units' new state -> f16 hi / lo' in B-fragment order (unit j = 16 w + 4 q + r -> k-step j >> 5, lane group (j >> 3) & 3,
     // element j & 7)
-    auto publish = [&](const float (&h)[4], int t, int l) {
+    auto publish = [&](const float (&h)[UPL], int t, int l) {
+        const int par = t & 1;
+        if constexpr (SPREAD) {   // UPL f16 per plane, element 4 (q & 1) + rr UPL of the path's column (the readers replicate)
+            if (!owner) return;
+            _Float16 *dh = (_Float16 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pc] + 4 * (q & 1) + rr * UPL;
+            _Float16 *dl = (_Float16 *)&hbuf[par][l][PL - 1][w >> 1][2 * (w & 1) + (q >> 1)][P2 ? pc : pc + NP] + 4 * (q & 1) + rr * UPL;
+            _Float16 a[UPL], c[UPL];
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) mp_split_fast(h[r], a[r], c[r]);
+            if constexpr (UPL == 2) {
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                *(f16x2 *)dh = f16x2{a[0], a[1]}; *(f16x2 *)dl = f16x2{c[0], c[1]};
+            } else { *dh = a[0]; *dl = c[0]; }
+            return;
+        }
         f16x4 hi, lo;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { _Float16 a, c; mp_split_fast(h[r], a, c); hi[r] = a; lo[r] = c; }
-        const int par = t & 1;
+        for (int r = 0; r < UPL; ++r) { _Float16 a, c; mp_split_fast(h[r], a, c); hi[r & 3] = a; lo[r & 3] = c; }
         if (NP == 16) {
             *((f16x4 *)&hbuf[par][l][0][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = hi;
             *((f16x4 *)&hbuf[par][l][PL - 1][w >> 1][2 * (w & 1) + (q >> 1)][pp] + (q & 1)) = lo;
@@ -209,22 +264,18 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     };
     // saved activations acts[b][t][l][{h, r, z, n, n_hh}][64] (kernels/weights.py:11-23): 16-byte lanes, issued BEHIND the barrier that
     // publishes the state -- in the slack where this role waits for the other one, not on the step's critical path
-    auto save_acts = [&](const float (&h)[4], const float (&rg)[4], const float (&ug)[4], const float (&ng)[4], const float (&cn)[4],
+    auto save_acts = [&](const float (&h)[UPL], const float (&rg)[UPL], const float (&ug)[UPL], const float (&ng)[UPL], const float (&cn)[UPL],
                          int t, int l) {
         if (SAVE && live && !(p.abl & (1 << l))) {
             float *ab = p.acts + (((int64_t)b * T + t) * L + l) * 320 + j0;
-            *(f32x4 *)(ab) = f32x4{h[0], h[1], h[2], h[3]};
-            *(f32x4 *)(ab + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
-            *(f32x4 *)(ab + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
-            *(f32x4 *)(ab + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
-            *(f32x4 *)(ab + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
+            mp_stu<UPL>(ab, h); mp_stu<UPL>(ab + 64, rg); mp_stu<UPL>(ab + 128, ug); mp_stu<UPL>(ab + 192, ng); mp_stu<UPL>(ab + 256, cn, kMpInvSn);
         }
     };
     // gate block of one layer for the 4 owned units (exp2 domain: r = 1 / (1 + 2^x_r), n = 1 - 2 / (1 + 2^(a_n + r c_n)))
-    auto gates = [&](const float (&ar)[4], const float (&au)[4], const float (&an)[4], const f32x4 (&c)[3],
-                     const float (&bn)[4], float (&h)[4], float (&rg)[4], float (&ug)[4], float (&ng)[4], float (&cn)[4], int t, int l) {
+    auto gates = [&](const float (&ar)[UPL], const float (&au)[UPL], const float (&an)[UPL], const float (&c)[3][UPL],
+                     const float (&bn)[UPL], float (&h)[UPL], float (&rg)[UPL], float (&ug)[UPL], float (&ng)[UPL], float (&cn)[UPL], int t, int l) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < UPL; ++r) {
             cn[r] = bn[r] + c[2][r];
             rg[r] = fast_rcp(1.0f + fast_exp2(ar[r] + c[0][r]));
             ug[r] = fast_rcp(1.0f + fast_exp2(au[r] + c[1][r]));
@@ -239,7 +290,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][pp];
+            for (int ks = 0; ks < 2; ++ks) hb[pl][ks] = hbuf[par][l][pl][ks][q][SPREAD ? (pp & (CW - 1)) : pp];
     };
     auto load_matrix = [&](int m, f16x8 (&wf)[3][2][2]) {
 #pragma unroll
@@ -257,41 +308,41 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
             f16x8 wi[3][2][2], wh[3][2][2];
             load_matrix(1, wi);
             load_matrix(2, wh);
-            float k1[3][4], bn1[4], h1[4] = {0.f, 0.f, 0.f, 0.f};
+            float k1[3][UPL], bn1[UPL], h1[UPL];
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) h1[r] = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < UPL; ++r) {
                     const int row = g * 64 + j0 + r;
                     const float sc = g < 2 ? kMpSr : kMpSn;
                     k1[g][r] = sc * p.b_ih1[row] + (g < 2 ? sc * p.b_hh1[row] : 0.f);
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bn1[r] = kMpSn * p.b_hh1[128 + j0 + r];
-            f32x4 c1[3];                               // W_hh^1 h^1_{t-1}: h_{-1} = 0
+            for (int r = 0; r < UPL; ++r) bn1[r] = kMpSn * p.b_hh1[128 + j0 + r];
+            float c1[3][UPL];                          // W_hh^1 h^1_{t-1}: h_{-1} = 0
 #pragma unroll
-            for (int g = 0; g < 3; ++g) c1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < UPL; ++r) c1[g][r] = 0.f;
             for (int t = 0; t < T; ++t) {
                 barrier();                             // A: h^0_t published
                 f16x8 hb[2][2];
                 read_state(t, 0, hb);
-                f32x4 a1[3];
-                mp_matmul<NP>(wi, hb, a1);             // W_ih^1 h^0_t
-                float ar[4], au[4], an[4], rg[4], ug[4], ng[4], cn[4];
+                float a1[3][UPL];
+                mp_matmul<NP, UPL>(wi, hb, a1, rr);    // W_ih^1 h^0_t
+                float ar[UPL], au[UPL], an[UPL], rg[UPL], ug[UPL], ng[UPL], cn[UPL];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
+                for (int r = 0; r < UPL; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
                 gates(ar, au, an, c1, bn1, h1, rg, ug, ng, cn, t, L - 1);
                 barrier();                             // B: h^1_t published
                 if (STASH && owner && !(p.abl & 2)) {      // the record of step t for the layer-0 waves (copied out behind barrier A of step t + 1)
-                    float *rec = &srec[t & 1][0] + pp * SPITCH + j0;
-                    *(f32x4 *)(rec) = f32x4{h1[0], h1[1], h1[2], h1[3]};
-                    *(f32x4 *)(rec + 64) = f32x4{rg[0], rg[1], rg[2], rg[3]};
-                    *(f32x4 *)(rec + 128) = f32x4{ug[0], ug[1], ug[2], ug[3]};
-                    *(f32x4 *)(rec + 192) = f32x4{ng[0], ng[1], ng[2], ng[3]};
-                    *(f32x4 *)(rec + 256) = f32x4{cn[0] * kMpInvSn, cn[1] * kMpInvSn, cn[2] * kMpInvSn, cn[3] * kMpInvSn};
+                    float *rec = &srec[t & 1][0] + pc * SPITCH + j0;
+                    mp_stu<UPL>(rec, h1); mp_stu<UPL>(rec + 64, rg); mp_stu<UPL>(rec + 128, ug); mp_stu<UPL>(rec + 192, ng); mp_stu<UPL>(rec + 256, cn, kMpInvSn);
                 }
                 read_state(t, L - 1, hb);
-                mp_matmul<NP>(wh, hb, c1);             // W_hh^1 h^1_t: consumed by step t + 1
+                mp_matmul<NP, UPL>(wh, hb, c1, rr);    // W_hh^1 h^1_t: consumed by step t + 1
             }
             if (STASH) barrier();                      // the last record is complete: the layer-0 waves copy it out
         }
@@ -310,11 +361,11 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 of[tl][ks][pl] = p.frags[(int64_t)(2 * L - 1) * kMpMatFrags + (((tl * 2 + ks) * 2) + pl) * 64 + lane];
 
     // per-lane constants of the 4 owned units (exp2 domain): biases, hoisted theta projection, state columns of W_ih_l0
-    float k0[3][4], bn0[4], wx[S][3][4], ob[NO];
+    float k0[3][UPL], bn0[UPL], wx[S][3][UPL], ob[NO];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < UPL; ++r) {
             const int row = g * 64 + j0 + r;
             const float sc = g < 2 ? kMpSr : kMpSn;
             float th = 0.f;   // theta term (forward.py:157-175)
@@ -324,17 +375,17 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
             for (int i = 0; i < S; ++i) wx[i][g][r] = sc * p.W_ih0[(int64_t)row * I + i];
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bn0[r] = kMpSn * p.b_hh0[128 + j0 + r];
+    for (int r = 0; r < UPL; ++r) bn0[r] = kMpSn * p.b_hh0[128 + j0 + r];
 #pragma unroll
     for (int r = 0; r < NO; ++r) ob[r] = p.out_b[r];
 
-    float z[S], h0[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c0[3];                                       // W_hh^0 h^0_{t-1}: h_{-1} = 0
+    float z[S], h0[UPL];
+    float c0[3][UPL];                                  // W_hh^0 h^0_{t-1}: h_{-1} = 0
 #pragma unroll
-    for (int g = 0; g < 3; ++g) c0[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < UPL; ++r) { h0[r] = 0.f; c0[0][r] = 0.f; c0[1][r] = 0.f; c0[2][r] = 0.f; }
 #pragma unroll
     for (int i = 0; i < S; ++i) z[i] = p.x0[(int64_t)b * S + i];
-    if (w == 0 && q == 0 && live) {
+    if (w == 0 && q == 0 && first) {
 #pragma unroll
         for (int i = 0; i < S; ++i) p.paths[(int64_t)b * (T + 1) * S + i] = z[i];
     }
@@ -342,12 +393,12 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // the projected context record and eps, one step ahead in registers (the wait for them at the top of a step is a vmcnt(0))
     const float *Gb = p.G + (int64_t)b * T * 192 + j0;
     const float *eb = p.eps + (int64_t)b * T * S;
-    f32x4 gq[3];
+    float gq[3][UPL];
     float ev[S];
     auto fetch = [&](int t) {
         const int tc = t < T ? t : T - 1;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gq[g] = *(const f32x4 *)(Gb + (int64_t)tc * 192 + g * 64);
+        for (int g = 0; g < 3; ++g) mp_ldu<UPL>(gq[g], Gb + (int64_t)tc * 192 + g * 64);
 #pragma unroll
         for (int i = 0; i < S; ++i) ev[i] = eb[(int64_t)tc * S + i];
     };
@@ -358,7 +409,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     // cannot count), and a store issued just before it would put a full store round trip on every step.
     float pz[S], pmu[S], pL[S][S], praw[NTRIL];
     auto store_outputs = [&](int t) {     // paths[b, t + 1], means[b, t], chol[b, t], chol_raw[b, t]: one wave each
-        if (q == 0 && live && !(p.abl & 4)) {
+        if (q == 0 && first && !(p.abl & 4)) {
             const int64_t bt = (int64_t)b * T + t;
             if (w == 0) {
 #pragma unroll
@@ -393,15 +444,17 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         }
     };
     for (int t = 0; t < T; ++t) {
-        f32x4 g0 = gq[0], g1 = gq[1], g2 = gq[2];
+        float g0[UPL], g1[UPL], g2[UPL];
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) { g0[r] = gq[0][r]; g1[r] = gq[1][r]; g2[r] = gq[2][r]; }
         float e[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) e[i] = ev[i];
         fetch(t + 1);
         // ---- layer 0: a = G_t (context projection + b_ih) + theta term + z_t W_x   (forward.py:195-219)
-        float ar[4], au[4], an[4], rg[4], ug[4], ng[4], cn[4];
+        float ar[UPL], au[UPL], an[UPL], rg[UPL], ug[UPL], ng[UPL], cn[UPL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < UPL; ++r) {
             ar[r] = fmaf(g0[r], kMpSr, k0[0][r]); au[r] = fmaf(g1[r], kMpSr, k0[1][r]); an[r] = fmaf(g2[r], kMpSn, k0[2][r]);
 #pragma unroll
             for (int i = 0; i < S; ++i) {
@@ -413,7 +466,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         f16x8 hb[2][2];
         read_state(t, 0, hb);
         if (L > 1) {
-            mp_matmul<NP>(wf, hb, c0);                 // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
+            mp_matmul<NP, UPL>(wf, hb, c0, rr);        // W_hh^0 h^0_t: consumed by step t + 1, runs beside layer 1's gates
             save_acts(h0, rg, ug, ng, cn, t, 0);
             if (t > 0) { store_outputs(t - 1); copy_l1_record(t - 1); }
             __builtin_amdgcn_sched_barrier(0);         // (register-only MFMAs are not ordered by the barrier's "memory" clobber)
@@ -429,11 +482,11 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 #pragma unroll
             for (int tl = 0; tl < NTO; ++tl) {
                 O1[tl] = mp_mfma(of[tl][ks][0], hb[0][ks], O1[tl]);
-                if (NP == 16) O2[tl] = mp_mfma(of[tl][ks][0], hb[PL - 1][ks], O2[tl]);
+                if (P2) O2[tl] = mp_mfma(of[tl][ks][0], hb[PL - 1][ks], O2[tl]);
                 O2[tl] = mp_mfma(of[tl][ks][1], hb[0][ks], O2[tl]);
             }
         if (L == 1) {
-            mp_matmul<NP>(wf, hb, c0);
+            mp_matmul<NP, UPL>(wf, hb, c0, rr);
             save_acts(h0, rg, ug, ng, cn, t, 0);
             if (t > 0) store_outputs(t - 1);
         }
@@ -441,7 +494,7 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
 #pragma unroll
         for (int r = 0; r < NO; ++r) {
             const float a1 = O1[r >> 2][r & 3], a2 = O2[r >> 2][r & 3];
-            o[r] = ob[r] + (NP == 16 ? fmaf(a2, kMpLoInv, a1) : fmaf(mp_row_shl<NP & 15>(a1) + a2, kMpLoInv, a1));
+            o[r] = ob[r] + (P2 ? fmaf(a2, kMpLoInv, a1) : fmaf(mp_row_shl<NP & 15>(a1) + a2, kMpLoInv, a1));
         }
         float mu[S], Lc[S][S];
 #pragma unroll
@@ -929,16 +982,26 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     // paths per workgroup: 16 fills the matrix pipe (large batches); a small batch takes 4 or 8 so that its groups spread over more CUs --
     // the time of a launch is T x one step's latency whatever the group size, and ONE CU's vector-memory pipe would have to carry the
     // saved activations of all its paths (41 KB per step for 16 paths: +30 % at 512 paths, profiles/r04_head_mp.txt)
+    static int spread = -1;   // VSDE_MP_SPREAD: see below
+    if (spread < 0) { const char *e = getenv("VSDE_MP_SPREAD"); spread = e ? atoi(e) : 1; }
     int np = a.np;
-    if (np != 4 && np != 8 && np != 16) np = a.B <= 1024 ? 4 : (a.B <= 2048 ? 8 : 16);
+    if (np != 2 && np != 4 && np != 8 && np != 16) np = (a.B <= 512 && spread) ? 2 : (a.B <= 1024 ? 4 : (a.B <= 2048 ? 8 : 16));
     const dim3 grid((a.B + np - 1) / np), block(256 * a.L);
     if (mark) mark(0, 0, s);
-#define VSDE_MP_LAUNCH_(LL, SV, SS, NN) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS, NN>), grid, block, 0, s, p)
+    // groups of 4 paths: the spread form (every path 4 times across the operand columns, ONE unit per lane; see mp_matmul): 519 -> 442 us
+    // (training) and 479 -> 394 us (sampling) at 512 paths.  Groups of 8 (two units per lane) measure 3 % slower than the side-by-side
+    // planes (842 vs 817 us at 2048 paths: a third more MFMAs for half the gate work) and stay as they were.
+    // VSDE_MP_SPREAD=0: the side-by-side planes of round 4 everywhere, =2: the spread form for groups of 8 as well (A/B runs)
+#define VSDE_MP_LAUNCH_(LL, SV, SS, NN, UU) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS, NN, UU>), grid, block, 0, s, p)
 #define VSDE_MP_LAUNCH(LL, SV, SS)                                  \
     do {                                                            \
-        if (np == 4) VSDE_MP_LAUNCH_(LL, SV, SS, 4);                \
-        else if (np == 8) VSDE_MP_LAUNCH_(LL, SV, SS, 8);           \
-        else VSDE_MP_LAUNCH_(LL, SV, SS, 16);                       \
+        if (np == 2) VSDE_MP_LAUNCH_(LL, SV, SS, 2, 1);             \
+        else if (np == 4 && spread == 3) VSDE_MP_LAUNCH_(LL, SV, SS, 4, 2); \
+        else if (np == 4 && spread) VSDE_MP_LAUNCH_(LL, SV, SS, 4, 1);   \
+        else if (np == 4) VSDE_MP_LAUNCH_(LL, SV, SS, 4, 4);        \
+        else if (np == 8 && spread >= 2) VSDE_MP_LAUNCH_(LL, SV, SS, 8, 2); \
+        else if (np == 8) VSDE_MP_LAUNCH_(LL, SV, SS, 8, 4);        \
+        else VSDE_MP_LAUNCH_(LL, SV, SS, 16, 4);                    \
     } while (0)
     if (a.L == 1) {
         if (a.save) { if (a.S == 1) VSDE_MP_LAUNCH(1, true, 1); else VSDE_MP_LAUNCH(1, true, 2); }
