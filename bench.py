@@ -74,7 +74,7 @@ PMC_FILE = "profiles/r04_pmc_head_lv.txt"
 
 
 FWD_KERNELS = ("head_fwd_mp_kernel<2, true", "head_fwd_v2_kernel<2, true")
-BWD_KERNELS = ("head_bwd_v2_kernel<2", "head_bwd_mp_kernel<")
+BWD_KERNELS = ("head_bwd_mps_kernel<2", "head_bwd_v2_kernel<2", "head_bwd_mp_kernel<")
 
 
 def _fetch_factor(kernel_name):

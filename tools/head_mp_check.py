@@ -49,7 +49,7 @@ def check():
             _hip.debug_head_mp(mode)
             fo = _hip.head_forward(d(x0), d(ctx)[:, :-1], d(theta), d(eps), wd, 0.1, True)
             outs[mode] = [None if t is None else t.cpu().numpy() for t in fo]
-            if L == 2 and mode in (0, 4, 8):
+            if L == 2 and mode in (0, 2, 4, 8):
                 for gscale in (1.0, 65536.0 * 3.0, 1e-9):   # the sweep is normalised by max |g|: any upstream scale must work
                     gr = _hip.head_backward(d(gp) * gscale, d(gm) * gscale, d(gl) * gscale, d(ctx)[:, :-1], d(theta), d(eps), fo[0], fo[3], fo[4], wd, 0.1)
                     grads[(mode, gscale)] = [t.float().cpu().numpy() / gscale for t in gr]
@@ -130,7 +130,7 @@ def timing():
                         ms.append(_hip.profile_elapsed_ms(0))
                 _hip.profile_enable(False)
                 row += f" | {'mp%d' % mode if mode else 'v2'} {'train' if save else 'eval'} {1e3 * sum(ms) / len(ms):6.0f}"
-                if save and mode in (0, 4, 8):
+                if save and mode in (0, 2, 4, 8):
                     fo = _hip.head_forward(x0, ctx[:, :-1], theta, eps, wd, 0.1, True)
                     gp_, gm_, gl_ = torch.randn(B, T + 1, S, device=dev), torch.randn(B, T, S, device=dev), torch.randn(B, T, S, S, device=dev)
                     _hip.profile_enable(True)

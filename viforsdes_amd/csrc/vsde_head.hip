@@ -1588,7 +1588,9 @@ static bool use_mp_bwd(const vsde_head_dims *d) {
     const int mode = g_mp_mode >= 0 ? g_mp_mode : mp_env();
     if (mode == 0) return false;
     if (mode > 0) return true;
-    return d->B > 640;
+    // Round 5 (spread sweep head_bwd_mps_kernel, tools/head_mp_check.py time): 128 paths 721 (v2) vs 490 us, 512 paths 812 vs 501, 1024 paths
+    // 1567 vs 817: the matrix-core sweep from 32 paths on
+    return d->B >= 32;
 }
 
 static int pick_wpb(int B, size_t lds_fixed, size_t lds_per_wave) {

@@ -691,12 +691,14 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     // saved activations of (t, layer): r, u, n, n_hh, and h of step t - 1 (zero before the first step)
     const float *ab = p.acts + (int64_t)b * T * L * 320 + j0;
     auto load_acts = [&](int t, int l, f32x4 (&a)[5]) {
-        if ((ABL & 2) && t < T - 2) return;
+        if ((ABL & (2 | 32)) && t < T - 2) return;
         const int tc = t < 0 ? 0 : t;
         const float *o = ab + ((int64_t)tc * L + l) * 320;
 #pragma unroll
         for (int k = 1; k < 5; ++k) a[k] = *(const f32x4 *)(o + 64 * k);
-        a[0] = tc > 0 ? *(const f32x4 *)(o - L * 320) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // h of step t - 1; step 0 has none: the CONSUMER puts the zero there (a select here reads the register the load has just been
+        // issued for -- an s_waitcnt vmcnt on a two-steps-ahead load, one HBM round trip per step: 370 of the sweep's 1019 us in round 4)
+        a[0] = *(const f32x4 *)(o - (tc > 0 ? L * 320 : 0));
     };
 
     if (role == 1) {
@@ -719,7 +721,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
         float gp[2][S], gm[2][S], gl[2][S][S], ee[2][S], raw[2][NTRIL];
         auto load_up = [&](int t, auto slot_c) {
             constexpr int sl = decltype(slot_c)::value;
-            if ((ABL & 2) && t < T - 2) return;
+            if ((ABL & (2 | 16)) && t < T - 2) return;
             const int tc = t < 0 ? 0 : t;
             const int64_t bt = (int64_t)b * T + tc;
 #pragma unroll
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < S; ++i) dx[i] += dxd[i];
             }
-            f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = act[sl][0];
+            f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = t > 0 ? act[sl][0] : f32x4{0.f, 0.f, 0.f, 0.f};
             float cgp[S], cgm[S], cgl[S][S], ce[S], craw[NTRIL];
 #pragma unroll
             for (int i = 0; i < S; ++i) {
@@ -838,7 +840,7 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
     auto step = [&](int t, auto slot_c) {
         constexpr int sl = decltype(slot_c)::value;
         const int par = t & 1;
-        f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = act[sl][0];
+        f32x4 a_r = act[sl][1], a_u = act[sl][2], a_n = act[sl][3], a_cn = act[sl][4], a_hp = t > 0 ? act[sl][0] : f32x4{0.f, 0.f, 0.f, 0.f};
         load_acts(t - 2, 0, act[sl]);
         barrier();                                     // 2
         f32x4 dcur;
@@ -887,6 +889,345 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: the reverse-time sweep for SMALL groups -- 2 or 4 paths per workgroup (512 / 1024 paths on 256 CUs) -- in the spread form
+// of the forward kernel (every path's [hi | lo'] columns 4 / 2 times across the operand, so a lane owns UPL = NP / 2 hidden units
+// instead of four: a quarter / half of the gate-gradient and f16-split arithmetic per lane), and with the per-step records out of the
+// wave's way:
+//   * round 4's kernel loaded the saved activations (five 16-byte loads per lane, layer and step) and thirteen upstream scalars into
+//     registers two steps ahead; hipcc's counter for them degenerates to s_waitcnt vmcnt(0) at the loop boundary and the loads cost
+//     the sweep 330 + 130 of its 1,080 us (VSDE_MP_BWD_ABL = 32 / 16).  Here they arrive by LDS-DMA (global_load_lds: no registers, no
+//     compiler-inserted waits): record r of a layer = NP x 1,280 contiguous bytes, one 1 KB piece per wave, THREE steps ahead into a ring
+//     of four slots; the upstream scalars of the group (3 S + S^2 + S (S + 1) / 2 per path from five tensors) are ONE 4-byte DMA by wave 3
+//     of the layer-0 role.  A wave waits for its own piece with a counted vmcnt in front of the step's last barrier (every
+//     vector-memory instruction below is issued unconditionally -- stores of lanes without an owner go to a sink -- so the count is exact).
+//   * h_{t-1} is the h part of record t - 1, which is in the ring anyway.
+template <int S, int NP>
+__global__ void __launch_bounds__(512, 1) head_bwd_mps_kernel(MpBwdParams p) {
+    constexpr int L = 2, NTRIL = S * (S + 1) / 2, NO = S + NTRIL, UPL = NP / 2, CW = 2 * NP;
+    constexpr int NUP = 3 * S + S * S + NTRIL;                       // upstream items per path and step
+    constexpr int APIECES = (NP * 1280 + 1023) / 1024, APW = (APIECES + 3) / 4, ASLOT = APW * 4 * 1024;   // bytes per (ring slot, layer)
+    static_assert(S >= 1 && S <= 2 && (NP == 2 || NP == 4) && NUP <= 16 && NP * 16 <= 64, "spread sweep: 2 or 4 paths per group");
+    extern __shared__ __attribute__((aligned(16))) char mps_lds[];
+    typedef f16x8 (*dbuf_t)[L][4][2][4][16];
+    dbuf_t dbuf = (dbuf_t)mps_lds;                                   // [2][L][4][2][4][16] x 16 bytes = 32 KB: gate gradients in B-fragment order
+    f16x8 (*obuf)[4][16] = (f16x8 (*)[4][16])(mps_lds + 32768);      // [4][4][16]: dO as a one-k-step B operand, per layer-1 wave
+    char *abuf = mps_lds + 32768 + 4096;                             // [4 slots][L][ASLOT]: saved-activation records
+    float *ubuf = (float *)(abuf + 4 * L * ASLOT);                   // [4 slots][64]: upstream records [path][16]
+    const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
+    const int pc = pp & (NP - 1), rr = pp / CW, colr = pp & (CW - 1);
+    const int b0 = blockIdx.x * NP, b_raw = b0 + pc;
+    const bool owner = colr < NP, live = owner && b_raw < p.B, first = live && rr == 0;
+    const int b = b_raw < p.B ? b_raw : p.B - 1;
+    const int j0 = 16 * w + 4 * q + rr * UPL, T = p.T, I = S + p.C + p.P;
+    mp_flush_f16_denormals();
+    for (int e = tid; e < (32768 + 4096) / 16; e += 512) ((f16x8 *)mps_lds)[e] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned am = *p.absmax;
+    int E = (int)(am >> 23);
+    E = E < 1 ? 126 : (E > 250 ? 250 : E);
+    const float Sg = __uint_as_float((unsigned)(E + 1) << 23), inv = __uint_as_float((unsigned)(253 - E) << 23);
+    float *sink = (float *)((char *)p.frags + (size_t)kMpBwdTotal * sizeof(f16x8) + 256) + 2 * tid;   // 4 KB behind the absmax word (8-byte slots)
+
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wait_vm = [&](int n) {   // wave-uniform n
+        switch (n) {
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    // this wave's piece(s) of the layer's record r (clamped at 0: the last steps re-fetch record 0 into slots nobody reads)
+    int a_path[APW], a_off[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int c = (w + 4 * i) * 64 + lane, path = c / 80;
+        const bool ok = w + 4 * i < APIECES && path < NP && b0 + path < p.B;
+        a_path[i] = ok ? path : 0; a_off[i] = ok ? c - path * 80 : lane;
+    }
+    auto dma_acts = [&](int r, int l_) {
+        const int rc = r < 0 ? 0 : r;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const float *src = p.acts + ((((int64_t)b0 + a_path[i]) * T + rc) * L + l_) * 320 + a_off[i] * 4;
+            __builtin_amdgcn_global_load_lds((const void *)src, (__attribute__((address_space(3))) void *)(abuf + ((r & 3) * L + l_) * ASLOT + (w + 4 * i) * 1024),
+                                             16, 0, 0);
+        }
+    };
+    // upstream record of step r: lane = [path][16 items]: g_paths[r + 1], g_means[r], eps[r] (S each), g_chol[r] (S S), chol_raw[r]
+    const float *u_base; int u_stride;
+    {
+        const int path = lane >> 4, item = lane & 15;
+        const bool ok = path < NP && item < NUP && b0 + path < p.B;
+        const int64_t bb = ok ? b0 + path : b0;
+        const int it = ok ? item : 0;
+        if (it < S) { u_base = p.g_paths + (bb * (T + 1) + 1) * S + it; u_stride = S; }
+        else if (it < 2 * S) { u_base = p.g_means + bb * T * S + (it - S); u_stride = S; }
+        else if (it < 3 * S) { u_base = p.eps + bb * T * S + (it - 2 * S); u_stride = S; }
+        else if (it < 3 * S + S * S) { u_base = p.g_chol + bb * T * S * S + (it - 3 * S); u_stride = S * S; }
+        else { u_base = p.chol_raw + bb * T * NTRIL + (it - 3 * S - S * S); u_stride = NTRIL; }
+    }
+    auto dma_up = [&](int r) {
+        const int rc = r < 0 ? 0 : r;
+        __builtin_amdgcn_global_load_lds((const void *)(u_base + (int64_t)rc * u_stride), (__attribute__((address_space(3))) void *)(ubuf + (r & 3) * 64), 4, 0, 0);
+    };
+    auto load_t = [&](int m, f16x8 (&af)[6][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[ks][pl] = p.frags[(int64_t)m * kMpMatFrags + (((w * 6 + ks) * 2) + pl) * 64 + lane];
+    };
+    // this lane's UPL rows (replica rr) of a product's four, planes folded
+    auto fold = [&](const f32x4 &A1, const f32x4 &A2, float (&R)[UPL]) {
+        float s1[UPL], s2[UPL];
+        if constexpr (UPL == 2) {
+            s1[0] = rr ? A1[2] : A1[0]; s1[1] = rr ? A1[3] : A1[1]; s2[0] = rr ? A2[2] : A2[0]; s2[1] = rr ? A2[3] : A2[1];
+        } else {
+            const float l1 = (rr & 1) ? A1[1] : A1[0], h1 = (rr & 1) ? A1[3] : A1[2], l2 = (rr & 1) ? A2[1] : A2[0], h2 = (rr & 1) ? A2[3] : A2[2];
+            s1[0] = (rr & 2) ? h1 : l1; s2[0] = (rr & 2) ? h2 : l2;
+        }
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) R[r] = fmaf(mp_row_shl<NP>(s1[r]) + s2[r], kMpLoInv, s1[r]);
+    };
+    auto matmul_sel = [&](const f16x8 (&af)[6][2], const f16x8 (&bf)[6], float (&R)[UPL]) {
+        f32x4 A1 = {0.f, 0.f, 0.f, 0.f}, A2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) { A1 = mp_mfma(af[ks][0], bf[ks], A1); A2 = mp_mfma(af[ks][1], bf[ks], A2); }
+        fold(A1, A2, R);
+    };
+    auto gate_grads = [&](const float (&d)[UPL], const float (&r)[UPL], const float (&u)[UPL], const float (&n)[UPL], const float (&cn)[UPL],
+                          const float (&hp)[UPL], float (&dr)[UPL], float (&du)[UPL], float (&dn)[UPL], float (&dcn)[UPL], float (&carry)[UPL]) {
+#pragma unroll
+        for (int e = 0; e < UPL; ++e) {
+            const float dnn = (1.0f - u[e]) * d[e], duu = (hp[e] - n[e]) * d[e];
+            dn[e] = dnn * (1.0f - n[e] * n[e]);
+            du[e] = duu * (u[e] * (1.0f - u[e]));
+            dcn[e] = dn[e] * r[e];
+            dr[e] = (dn[e] * cn[e]) * (r[e] * (1.0f - r[e]));
+            carry[e] = u[e] * d[e];
+        }
+    };
+    auto publish = [&](const float (&v)[UPL], int par, int l, int blk) {
+        _Float16 a[UPL], c[UPL];
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) mp_split_fast(v[r], a[r], c[r]);
+        if (owner) {
+            _Float16 *dh = (_Float16 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pc] + 4 * (q & 1) + rr * UPL;
+            _Float16 *dl = (_Float16 *)&dbuf[par][l][blk][w >> 1][2 * (w & 1) + (q >> 1)][pc + NP] + 4 * (q & 1) + rr * UPL;
+            if constexpr (UPL == 2) {
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                *(f16x2 *)dh = f16x2{a[0], a[1]}; *(f16x2 *)dl = f16x2{c[0], c[1]};
+            } else { *dh = a[0]; *dl = c[0]; }
+        }
+    };
+    auto read_d = [&](int par, int l, bool hh, f16x8 (&bf)[6]) {    // (dr, du, dn) or, hh, (dr, du, dc_n)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) bf[ks] = dbuf[par][l][(ks >> 1) == 2 ? (hh ? 3 : 2) : (ks >> 1)][ks & 1][q][colr];
+    };
+    auto store_d4 = [&](const float (&dr)[UPL], const float (&du)[UPL], const float (&dn)[UPL], const float (&dcn)[UPL], int t, int l) {
+        // D4[b][t][l][{dr, du, dn, dc_n}][64]; four instructions, always issued (lanes without an owner write the sink)
+        float *o = live ? p.D4 + (((int64_t)b * T + t) * L + l) * 256 + j0 : sink;
+        const int st = live ? 64 : 0;
+        mp_stu<UPL>(o, dr, Sg); mp_stu<UPL>(o + st, du, Sg); mp_stu<UPL>(o + 2 * st, dn, Sg); mp_stu<UPL>(o + 3 * st, dcn, Sg);
+    };
+    // saved activations of (t, layer) out of the ring: r, u, n, n_hh, and h of step t - 1 (zero before the first step)
+    auto read_acts = [&](int t, int l, float (&a)[5][UPL]) {
+        const float *rec = (const float *)(abuf + ((t & 3) * L + l) * ASLOT) + pc * 320 + j0;
+        const float *prv = (const float *)(abuf + (((t - 1) & 3) * L + l) * ASLOT) + pc * 320 + j0;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) mp_ldu<UPL>(a[k], rec + 64 * k);
+        mp_ldu<UPL>(a[0], prv);
+        if (t <= 0) {
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) a[0][r] = 0.f;
+        }
+    };
+
+    // records T - 1, T - 2, T - 3 before the first step
+    for (int r = T - 1; r >= T - 3; --r) { dma_acts(r, role == 1 ? 1 : 0); if (role == 0 && w == 3) dma_up(r); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (role == 1) {
+        // =================================================================== layer-1 waves
+        f16x8 whh[6][2], wxs[6][2], wo[2];
+        load_t(2, whh);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wxs[ks][pl] = p.frags[kMpBwdWx + ((ks * 2) + pl) * 64 + lane];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo[pl] = p.frags[kMpBwdOut + ((w * 2) + pl) * 64 + lane];
+        float dx[S], dh1[UPL];
+#pragma unroll
+        for (int i = 0; i < S; ++i) dx[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) dh1[r] = 0.f;
+        // this wave's DO item: lane group q of waves 0 / 1 stores emission row 4 (w & 1) + q of its path (replica 0), everyone else the sink
+        const int doi = 4 * (w & 1) + q;
+        const bool do_ok = first && w < 2 && doi < NO;
+        for (int t = T - 1; t >= 0; --t) {
+            const int par = t & 1;
+            dma_acts(t - 3, 1);
+            if (t < T - 1) {   // d z_{t+1} through layer 0's input of step t + 1: W_x^T pi0  (backward.py:494-509)
+                f16x8 bf[6];
+                read_d(par ^ 1, 0, false, bf);
+                f32x4 dxd;
+                mp_matmul_t<NP>(wxs, bf, dxd);
+#pragma unroll
+                for (int i = 0; i < S; ++i) dx[i] += dxd[i];
+            }
+            float act[5][UPL];
+            read_acts(t, 1, act);
+            const float *ur = ubuf + (t & 3) * 64 + pc * 16;
+            float cgp[S], cgm[S], cgl[S][S], ce[S], craw[NTRIL];
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                cgp[i] = ur[i]; cgm[i] = ur[S + i]; ce[i] = ur[2 * S + i];
+#pragma unroll
+                for (int c = 0; c < S; ++c) cgl[i][c] = ur[3 * S + i * S + c];
+            }
+#pragma unroll
+            for (int r = 0; r < NTRIL; ++r) craw[r] = ur[3 * S + S * S + r];
+            // ---- dO_t  (backward.py:278-334)
+            float dO[NO];
+#pragma unroll
+            for (int i = 0; i < S; ++i) { dx[i] = fmaf(cgp[i], inv, dx[i]); dO[i] = fmaf(dx[i], p.dt, cgm[i] * inv); }
+            {
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int c = 0; c <= i; ++c, ++k) {
+                        float dL = fmaf(dx[i] * ce[c], p.sqdt, cgl[i][c] * inv);
+                        if (i == c && !(craw[k] >= p.diag_min || dL < 0.f)) dL = 0.f;    // bounds.py:20
+                        dO[S + k] = dL;
+                    }
+            }
+            {
+                float v = dO[0];
+#pragma unroll
+                for (int r = 1; r < NO; ++r) v = doi == r ? dO[r] : v;
+                float *dst = do_ok ? p.DO + ((int64_t)b * T + t) * NO + doi : sink;
+                *dst = v * Sg;
+            }
+            if (q == 0 && owner && rr == 0) {   // dO as a B operand (k = emission row, in lane group 0), through this wave's private tile
+                f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+#pragma unroll
+                for (int r = 0; r < NO; ++r) { _Float16 a, c; mp_split_fast(dO[r], a, c); hi[r] = a; lo[r] = c; }
+                obuf[w][0][pc] = hi; obuf[w][0][pc + NP] = lo;
+            }
+            wave_lds_fence();
+            const f16x8 ob = obuf[w][q][colr];
+            float dcur[UPL];
+            {
+                f32x4 A1 = {0.f, 0.f, 0.f, 0.f}, A2 = A1;
+                A1 = mp_mfma(wo[0], ob, A1); A2 = mp_mfma(wo[1], ob, A2);
+                fold(A1, A2, dcur);                    // out_proj^T dO  (:296-349)
+            }
+            float d[UPL], dr[UPL], du[UPL], dn[UPL], dcn[UPL], carry[UPL];
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) d[r] = dcur[r] + dh1[r];
+            gate_grads(d, act[1], act[2], act[3], act[4], act[0], dr, du, dn, dcn, carry);
+            publish(dr, par, 1, 0); publish(du, par, 1, 1); publish(dn, par, 1, 2); publish(dcn, par, 1, 3);
+            barrier();                                 // 2: layer 1's gate gradients published
+            {
+                f16x8 bf[6];
+                read_d(par, 1, true, bf);
+                float rec[UPL];
+                matmul_sel(whh, bf, rec);              // W_hh_l1^T ph1  (:96-105)
+#pragma unroll
+                for (int r = 0; r < UPL; ++r) dh1[r] = carry[r] + rec[r];
+            }
+            store_d4(dr, du, dn, dcn, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // record t - 2 (issued at step t + 1) has landed once at most the instructions issued after it are in flight:
+            // DO + D4 of step t + 1, this step's DMA(s), DO and D4
+            wait_vm(10 + APW);
+            barrier();                                 // 3: layer 0's gate gradients published; records t - 2 visible
+        }
+        {   // the step-0 term of d z_0, then grad x0  (:620-624)
+            f16x8 bf[6];
+            read_d(0, 0, false, bf);
+            f32x4 dxd;
+            mp_matmul_t<NP>(wxs, bf, dxd);
+            if (w == 0 && q == 0 && first) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) p.g_x0[(int64_t)b * S + i] = (dx[i] + dxd[i] + p.g_paths[(int64_t)b * (T + 1) * S + i] * inv) * Sg;
+            }
+        }
+        barrier();                                     // X: the gate-gradient tiles are free (layer 0 puts its theta sums there)
+        barrier();                                     // Y: pairs with the layer-0 waves' barrier in front of the grad-theta sums
+        return;
+    }
+
+    // ======================================================================= layer-0 waves
+    f16x8 wih1[6][2], whh0[6][2];
+    load_t(1, wih1);
+    load_t(0, whh0);
+    float dh0[UPL], ths[3][UPL];
+#pragma unroll
+    for (int r = 0; r < UPL; ++r) { dh0[r] = 0.f; ths[0][r] = 0.f; ths[1][r] = 0.f; ths[2][r] = 0.f; }
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        dma_acts(t - 3, 0);
+        if (w == 3) dma_up(t - 3);
+        float act[5][UPL];
+        read_acts(t, 0, act);
+        barrier();                                     // 2
+        float dcur[UPL];
+        {
+            f16x8 bf[6];
+            read_d(par, 1, false, bf);
+            matmul_sel(wih1, bf, dcur);                // W_ih_l1^T pi1: gradient of layer 0's output  (:83-94)
+        }
+        float d[UPL], dr[UPL], du[UPL], dn[UPL], dcn[UPL], carry[UPL];
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) d[r] = dcur[r] + dh0[r];
+        gate_grads(d, act[1], act[2], act[3], act[4], act[0], dr, du, dn, dcn, carry);
+        publish(dr, par, 0, 0); publish(du, par, 0, 1); publish(dn, par, 0, 2); publish(dcn, par, 0, 3);
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) { ths[0][r] += dr[r]; ths[1][r] += du[r]; ths[2][r] += dn[r]; }   // sum_t pi0: grad theta = W_theta^T of it (:511-548)
+        // records t - 2 (issued at step t + 1): behind them this wave issued [the upstream DMA,] D4 of step t + 1 and this step's DMA(s)
+        wait_vm(w == 3 ? 5 + APW : 4 + APW);
+        barrier();                                     // 3
+        {
+            f16x8 bf[6];
+            read_d(par, 0, true, bf);
+            float rec[UPL];
+            matmul_sel(whh0, bf, rec);                 // W_hh_l0^T ph0  (:566-573)
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) dh0[r] = carry[r] + rec[r];
+        }
+        store_d4(dr, du, dn, dcn, t, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // grad theta[b][e] = sum_rows W_ih_l0[row][S + C + e] * sum_t pi0[row]: the sums go through LDS (the gate-gradient tiles are free now)
+    float *tsum = (float *)mps_lds;                    // [NP][192]
+    barrier();                                         // X: the layer-1 waves have read dbuf[0][0] (step 0) for grad x0
+    if (owner) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) tsum[pc * 192 + g * 64 + j0 + r] = ths[g][r];
+    }
+    barrier();                                         // Y
+    for (int o = tid; o < NP * p.P; o += 256) {
+        const int path = o / p.P, e = o - path * p.P, bb = blockIdx.x * NP + path;
+        if (bb < p.B) {
+            float acc = 0.f;
+            for (int row = 0; row < 192; ++row) acc = fmaf(p.W_ih0[(int64_t)row * I + S + p.C + e], tsum[path * 192 + row], acc);
+            p.g_theta[(int64_t)bb * p.P + e] = acc * Sg;
+        }
+    }
+}
+template <int S, int NP> static constexpr size_t mps_lds_bytes() {
+    constexpr int APIECES = (NP * 1280 + 1023) / 1024, APW = (APIECES + 3) / 4, ASLOT = APW * 4 * 1024;
+    return 32768 + 4096 + (size_t)4 * 2 * ASLOT + 4 * 64 * 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 size_t mp_frag_bytes(int L, int S) {
     const int no = S + S * (S + 1) / 2, nto = (no + 3) / 4;
     return ((size_t)(2 * L - 1) * kMpMatFrags + (size_t)nto * 2 * 2 * 64) * sizeof(f16x8);
@@ -894,7 +1235,7 @@ size_t mp_frag_bytes(int L, int S) {
 
 bool mp_applicable(int H, int L, int S) { return H == 64 && L >= 1 && L <= 2 && S >= 1 && S <= 2; }
 bool mp_bwd_applicable(int H, int L, int S) { return H == 64 && L == 2 && S >= 1 && S <= 2; }
-size_t mp_bwd_frag_bytes(void) { return (size_t)kMpBwdTotal * sizeof(f16x8) + 256; }   // fragments + the absmax word
+size_t mp_bwd_frag_bytes(void) { return (size_t)kMpBwdTotal * sizeof(f16x8) + 256 + 4096 + 64; }   // fragments + the absmax word + the spread sweep's store sink (512 x 8 bytes)
 
 int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t)) {
     const int no = a.S + a.S * (a.S + 1) / 2;
@@ -915,9 +1256,28 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     p.W_ih0 = a.W_ih0; p.frags = frags; p.absmax = absmax;
     p.dt = a.dt; p.sqdt = a.sqdt; p.diag_min = a.diag_min;
     p.D4 = a.D4; p.DO = a.DO; p.g_x0 = a.g_x0; p.g_theta = a.g_theta;
-    int np = a.np == 4 || a.np == 8 ? a.np : (a.np == 16 ? 8 : (a.B <= 1024 ? 4 : 8));
+    // groups of 2 (up to 512 paths) / 4 (up to 1024): the spread sweep (head_bwd_mps_kernel); VSDE_MP_BWD_SPREAD=0: round 4's kernel (A/B runs)
+    static int spread = -1;
+    if (spread < 0) { const char *e = getenv("VSDE_MP_BWD_SPREAD"); spread = e ? atoi(e) : 1; }
+    int np = a.np == 2 || a.np == 4 || a.np == 8 ? a.np : (a.np == 16 ? 8 : (a.B <= 512 ? 2 : (a.B <= 1024 ? 4 : 8)));
+    if (!spread && np == 2) np = 4;
     const dim3 grid((a.B + np - 1) / np), block(512);
     if (mark) mark(1, 0, s);
+    if (spread && (np == 2 || np == 4)) {
+#define VSDE_MPS_LAUNCH(SS, NN)                                                                                                       \
+        do {                                                                                                                           \
+            auto kern = head_bwd_mps_kernel<SS, NN>;                                                                                   \
+            const size_t lds = mps_lds_bytes<SS, NN>();                                                                                \
+            VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                                          \
+        } while (0)
+        if (a.S == 1) { if (np == 2) VSDE_MPS_LAUNCH(1, 2); else VSDE_MPS_LAUNCH(1, 4); }
+        else { if (np == 2) VSDE_MPS_LAUNCH(2, 2); else VSDE_MPS_LAUNCH(2, 4); }
+#undef VSDE_MPS_LAUNCH
+        if (mark) mark(1, 1, s);
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     static int abl = -1;
     if (abl < 0) abl = ablation_env("VSDE_MP_BWD_ABL");
     if (abl && a.S == 2 && np == 4) {
@@ -928,6 +1288,8 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
             case 4: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 4>), grid, block, 0, s, p); break;
             case 8: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 8>), grid, block, 0, s, p); break;
             case 7: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 7>), grid, block, 0, s, p); break;
+            case 16: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 16>), grid, block, 0, s, p); break;   // 16: upstream-gradient loads only
+            case 32: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 32>), grid, block, 0, s, p); break;   // 32: saved-activation loads only
             default: hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4, 15>), grid, block, 0, s, p); break;
         }
     } else
