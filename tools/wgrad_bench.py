@@ -23,7 +23,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, N, K in (("qkv+gate", 832, 256), ("out_proj", 256, 256), ("mlp.in", 1536, 256), ("mlp.out", 256, 768)):
+for name, N, K in (("qkv+gate", 832, 256), ("out_proj", 256, 256), ("mlp.in", 1408, 256), ("mlp.out", 256, 704)):
     dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     t = timeit(lambda: _hip.linear_wgrad(dy, x, True))

@@ -33,8 +33,10 @@ typedef short w2bf4 __attribute__((ext_vector_type(4)));
 constexpr int W2_TK = 256, W2_BM = 32;
 constexpr int W2_LDB = W2_TK + 32;   // LDS row pitch of the x tile (bf16)
 
-template <int TN> struct W2 {
-    static constexpr int THREADS = 2 * TN;              // waves: (TN / 64) along n x 2 along k
+template <int TN, int TH = 2 * TN> struct W2 {
+    static constexpr int THREADS = TH;                  // waves: (TH / 128) along n x 2 along k; a wave owns (TN / (TH / 128)) x 128 of the tile:
+                                                        // 64 x 128 (TH = 2 TN) or, TN = 256 on FOUR waves, 128 x 128 (see wgrad_tr_body)
+    static constexpr int AB = TN / (TH / 128) / 32;     // 32-row blocks of the wave's tile along n (2 | 4)
     static constexpr int LDA = TN + 32;                  // LDS row pitch of the dy tile
     static constexpr int BUF = W2_BM * (LDA + W2_LDB);   // bf16 elements per buffer
     static constexpr int PART = TN * W2_TK + TN;         // fp32 partial tile + bias row
@@ -79,9 +81,12 @@ struct Wgrad2Group {
     int n;
 };
 
-template <int TN>
+// TH = 256 with TN = 256 (round 5, opt-in, slower -- see wgrad2_four_waves): four waves, one per SIMD, each with a 128 x 128 block = 4 x 4
+// MFMA tiles in 256 accumulator registers; a step's fragments are (AB + 4) KB per wave and 16-row half for 4 AB MFMAs: 0.75 KB per MFMA at
+// AB = 2, 0.5 KB at AB = 4.
+template <int TN, int TH = 2 * TN>
 __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int bid) {
-    using C = W2<TN>;
+    using C = W2<TN, TH>;
     extern __shared__ __attribute__((aligned(16))) uint16_t w2s[];
     __shared__ float bred[C::YR][TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,14 +132,15 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
                 }                                                                                                        \
         }                                                                                                                \
     } while (0)
-    f32x16 acc[2][4];
+    constexpr int AB = C::AB;
+    f32x16 acc[AB][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+    const int wn = (wave >> 1) * (32 * AB), wk = (wave & 1) * 128;
     const int nsteps = (int)((p.chunks - split + p.nsplit - 1) / p.nsplit);
 // step s_: MFMAs out of LDS buffer PAR_, then step s + 1 (register set 1 - PAR_) goes to the other buffer and that set is
 // re-requested for step s + 3
@@ -142,10 +148,10 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
     do {                                                                                                                 \
         const uint16_t *buf = w2s + (PAR_) * C::BUF, *ay = buf, *bx = buf + W2_BM * C::LDA;                              \
         _Pragma("unroll") for (int mc = 0; mc < 2; ++mc) {                                                               \
-            bf16x8 af[2], bf[4];                                                                                         \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a) af[a] = w2_frag(ay, C::LDA, wn + 32 * a, mc, lane);            \
+            bf16x8 af[AB], bf[4];                                                                                        \
+            _Pragma("unroll") for (int a = 0; a < AB; ++a) af[a] = w2_frag(ay, C::LDA, wn + 32 * a, mc, lane);           \
             _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = w2_frag(bx, W2_LDB, wk + 32 * b, mc, lane);            \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                \
+            _Pragma("unroll") for (int a = 0; a < AB; ++a)                                                               \
                 _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                            \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);               \
         }                                                                                                                \
@@ -176,7 +182,7 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
     float *out = p.partial + ((int64_t)tile * p.nsplit + split) * C::PART;
     const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AB; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -197,14 +203,14 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
     }
 }
 
-template <int TN>
-__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) { wgrad_tr_body<TN>(p, (int)blockIdx.x); }
+template <int TN, int TH = 2 * TN>
+__global__ void __launch_bounds__(TH, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) { wgrad_tr_body<TN, TH>(p, (int)blockIdx.x); }
 
-template <int TN>
-__global__ void __launch_bounds__(2 * TN, TN == 128 ? 2 : 1) wgrad_tr_group_kernel(Wgrad2Group G) {
+template <int TN, int TH = 2 * TN>
+__global__ void __launch_bounds__(TH, TN == 128 ? 2 : 1) wgrad_tr_group_kernel(Wgrad2Group G) {
     int g = 0;
     while (g + 1 < G.n && (int)blockIdx.x >= G.first[g + 1]) ++g;   // workgroup-uniform
-    wgrad_tr_body<TN>(G.g[g], (int)blockIdx.x - G.first[g]);
+    wgrad_tr_body<TN, TH>(G.g[g], (int)blockIdx.x - G.first[g]);
 }
 
 
@@ -334,11 +340,20 @@ static size_t wgrad2_workspace(const Wgrad2Params &p) {
     return (size_t)p.tiles * p.nsplit * (p.tn == 256 ? W2<256>::PART : W2<128>::PART) * sizeof(float);
 }
 
-template <int TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s) {
-    using C = W2<TN>;
+// TN = 256: eight waves with 64 x 128 blocks (default), or four with 128 x 128 (VSDE_WGRAD_WAVES=4; A/B runs).  Measured, round 5, LV
+// shapes, one box: four waves 194 | 275 | 143 us against 166 | 234 | 133 us for dW[832,256] | [1408,256] | [256,704] -- a third fewer LDS
+// bytes per MFMA does not pay for one wave per SIMD having nobody to hide its LDS latency behind.
+static bool wgrad2_four_waves() {
+    static int w = -1;
+    if (w < 0) { const char *e = getenv("VSDE_WGRAD_WAVES"); w = (e && atoi(e) == 4) ? 4 : 8; }
+    return w == 4;
+}
+template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s) {
+    using C = W2<TN, TH>;
     const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_tr_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wgrad_tr_kernel<TN>, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(C::THREADS), lds, s, p);
+    auto kern = wgrad_tr_kernel<TN, TH>;
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(C::THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(wgrad_tr_reduce_kernel<TN>, dim3(TN * W2_TK / 4 / 64 + 1, p.tiles), dim3(256), 0, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -347,12 +362,13 @@ template <int TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s)
 
 }  // namespace vsde
 
-template <int TN> static int wgrad2_launch_group(const vsde::Wgrad2Group &G, int wgs, hipStream_t s) {
+template <int TN, int TH = 2 * TN> static int wgrad2_launch_group(const vsde::Wgrad2Group &G, int wgs, hipStream_t s) {
     using namespace vsde;
-    using C = W2<TN>;
+    using C = W2<TN, TH>;
     const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_tr_group_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wgrad_tr_group_kernel<TN>, dim3((unsigned)wgs), dim3(C::THREADS), lds, s, G);
+    auto kern = wgrad_tr_group_kernel<TN, TH>;
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(C::THREADS), lds, s, G);
     VSDE_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(wgrad_tr_reduce_group_kernel<TN>, dim3(TN * W2_TK / 4 / 64 + 1, (unsigned)G.tile0[G.n]), dim3(256), 0, s, G);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -431,7 +447,9 @@ extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, int group
                 w += bytes;
             }
             if (flush && G.n > 0) {
-                const int rc = tn == 256 ? wgrad2_launch_group<256>(G, G.first[G.n], (hipStream_t)stream) : wgrad2_launch_group<128>(G, G.first[G.n], (hipStream_t)stream);
+                const int rc = tn == 256 ? (wgrad2_four_waves() ? wgrad2_launch_group<256, 256>(G, G.first[G.n], (hipStream_t)stream)
+                                                                : wgrad2_launch_group<256>(G, G.first[G.n], (hipStream_t)stream))
+                                         : wgrad2_launch_group<128>(G, G.first[G.n], (hipStream_t)stream);
                 if (rc != 0) return rc;
                 G.n = 0; G.first[0] = 0; G.tile0[0] = 0;
             }
@@ -466,5 +484,6 @@ extern "C" int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_
     const size_t need = wgrad2_workspace(p);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "linear_wgrad workspace too small: %zu < %zu", workspace_bytes, need);
     p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db; p.row_map = row_map;
-    return p.tn == 256 ? wgrad2_launch<256>(p, (hipStream_t)stream) : wgrad2_launch<128>(p, (hipStream_t)stream);
+    if (p.tn == 256) return wgrad2_four_waves() ? wgrad2_launch<256, 256>(p, (hipStream_t)stream) : wgrad2_launch<256>(p, (hipStream_t)stream);
+    return wgrad2_launch<128>(p, (hipStream_t)stream);
 }
