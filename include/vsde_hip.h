@@ -349,6 +349,8 @@ int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, int64_t ldu, 
                       int64_t lddx, int64_t M, int C, int H, void *stream);
 /* debugging aid (VSDE_MLP_DEBUG=16): device buffer that receives workgroup 0's per-phase cycle stamps */
 int vsde_mlp_debug_trace(void *buf);
+/* The same for the weight-gradient kernel (eight-wave TN = 256 form): [8 waves][4 phase cycle sums + step count] (tools/wgrad_trace.py). */
+int vsde_wgrad_debug_trace(void *buf);
 int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile);
 int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img, const void *w2_img, const float *b1_img, const void *b2, void *y,
                       int64_t ldy, void *s_out, int64_t lds, int64_t M, int C, int H, void *stream);

@@ -54,6 +54,7 @@ struct Wgrad2Params {
     int64_t chunks;           // 32-row blocks of the reduction index
     float *partial, *dW, *db;
     const int32_t *row_map;   // output row of product row n (dW[row_map[n]], db[row_map[n]]; < 0: dropped), or nullptr = identity
+    long long *trace;         // debugging (vsde_wgrad_debug_trace): per-wave phase cycle sums of workgroup 0, [waves][4] + step count
 };
 
 __device__ __forceinline__ uint2 w2_read_tr(const uint16_t *ptr) {
@@ -84,7 +85,7 @@ struct Wgrad2Group {
 // TH = 256 with TN = 256 (round 5, opt-in, slower -- see wgrad2_four_waves): four waves, one per SIMD, each with a 128 x 128 block = 4 x 4
 // MFMA tiles in 256 accumulator registers; a step's fragments are (AB + 4) KB per wave and 16-row half for 4 AB MFMAs: 0.75 KB per MFMA at
 // AB = 2, 0.5 KB at AB = 4.
-template <int TN, int TH = 2 * TN>
+template <int TN, int TH = 2 * TN, bool TRACE = false>
 __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int bid) {
     using C = W2<TN, TH>;
     extern __shared__ __attribute__((aligned(16))) uint16_t w2s[];
@@ -104,8 +105,12 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
     const int xb_c = tid & 31, xb_r = tid >> 5;         // + XR rows per i
     const bool ya_ok = n_blk + ya_c * 8 < p.N, xb_ok = k_blk + xb_c * 8 < p.K;   // N, K multiples of 8
     const uint16_t *ysrc = p.dy + (ya_ok ? n_blk + ya_c * 8 : 0), *xsrc = p.x + (xb_ok ? k_blk + xb_c * 8 : 0);
-    // two register sets: step t travels in set t & 1, requested two steps before its LDS store
-    w2u4 ry[2][C::NY], rx[2][C::NX];
+    // NSET register sets: step t travels in set t % NSET, requested NSET steps before its LDS store.  Four sets for the eight-wave
+    // TN = 256 form (round 5): the phase stamps (tools/wgrad_trace.py) showed ~1,000 of a step's 2,530 cycles in the LDS store waiting
+    // for loads requested two steps = 5,000 cycles earlier -- at 32 KB per workgroup and step the requests of two steps are all a CU
+    // has in flight, and HBM under this load answers in ~2.4 us.  (The four-wave forms have no registers left for it.)
+    constexpr int NSET = (TN == 256 && TH == 512) ? 4 : 2;
+    w2u4 ry[NSET][C::NY], rx[NSET][C::NX];
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define W2_FETCH(set_, m0_)                                                                                              \
     do {                                                                                                                 \
@@ -142,9 +147,12 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int wn = (wave >> 1) * (32 * AB), wk = (wave & 1) * 128;
     const int nsteps = (int)((p.chunks - split + p.nsplit - 1) / p.nsplit);
-// step s_: MFMAs out of LDS buffer PAR_, then step s + 1 (register set 1 - PAR_) goes to the other buffer and that set is
-// re-requested for step s + 3
-#define W2_BODY(s_, PAR_)                                                                                                \
+// step s_: MFMAs out of LDS buffer PAR_, then step s + 1 (register set SET_ = (s + 1) % NSET) goes to the other buffer and that set is
+// re-requested for step s + 1 + NSET
+    long long ph[4] = {0, 0, 0, 0}, last_ = 0;
+    if constexpr (TRACE) last_ = __builtin_readcyclecounter();
+#define W2_STAMP(k_) do { if constexpr (TRACE) { const long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - last_; last_ = now_; } } while (0)
+#define W2_BODY(s_, PAR_, SET_)                                                                                              \
     do {                                                                                                                 \
         const uint16_t *buf = w2s + (PAR_) * C::BUF, *ay = buf, *bx = buf + W2_BM * C::LDA;                              \
         _Pragma("unroll") for (int mc = 0; mc < 2; ++mc) {                                                               \
@@ -155,25 +163,49 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
                 _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                            \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);               \
         }                                                                                                                \
-        if ((s_) + 1 < nsteps) W2_COMMIT(1 - (PAR_), w2s + (1 - (PAR_)) * C::BUF, W2_ROW0((s_) + 1));                    \
+        W2_STAMP(0);                                                                                                     \
+        if ((s_) + 1 < nsteps) W2_COMMIT(SET_, w2s + (1 - (PAR_)) * C::BUF, W2_ROW0((s_) + 1));                          \
+        W2_STAMP(1);                                                                                                     \
         w2_barrier();                                                                                                    \
-        W2_FETCH(1 - (PAR_), W2_ROW0((s_) + 3));                                                                         \
+        W2_STAMP(2);                                                                                                     \
+        W2_FETCH(SET_, W2_ROW0((s_) + 1 + NSET));                                                                        \
+        W2_STAMP(3);                                                                                                     \
     } while (0)
     if (nsteps > 0) {
         W2_FETCH(0, W2_ROW0(0));
         W2_COMMIT(0, w2s, W2_ROW0(0));
         w2_barrier();
-        W2_FETCH(1, W2_ROW0(1));
-        W2_FETCH(0, W2_ROW0(2));
+        if constexpr (NSET == 4) { W2_FETCH(1, W2_ROW0(1)); W2_FETCH(2, W2_ROW0(2)); W2_FETCH(3, W2_ROW0(3)); W2_FETCH(0, W2_ROW0(4)); }
+        else { W2_FETCH(1, W2_ROW0(1)); W2_FETCH(0, W2_ROW0(2)); }
     }
-    // no condition on the odd step inside the loop: a merge of "taken / not taken" makes hipcc's vmcnt bookkeeping fall back to a
-    // full drain at the even step
+    // no condition on the later steps inside the loop: a merge of "taken / not taken" makes hipcc's vmcnt bookkeeping fall back to a
+    // full drain at the first step
     int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        W2_BODY(s, 0);
-        W2_BODY(s + 1, 1);
+    if constexpr (NSET == 4) {
+        for (; s + 3 < nsteps; s += 4) {
+            W2_BODY(s, 0, 1);
+            W2_BODY(s + 1, 1, 2);
+            W2_BODY(s + 2, 0, 3);
+            W2_BODY(s + 3, 1, 0);
+        }
+        if (s < nsteps) W2_BODY(s, 0, 1);
+        if (s + 1 < nsteps) W2_BODY(s + 1, 1, 2);
+        if (s + 2 < nsteps) W2_BODY(s + 2, 0, 3);
+    } else {
+        for (; s + 1 < nsteps; s += 2) {
+            W2_BODY(s, 0, 1);
+            W2_BODY(s + 1, 1, 0);
+        }
+        if (s < nsteps) W2_BODY(s, 0, 1);
     }
-    if (s < nsteps) W2_BODY(s, 0);
+    if constexpr (TRACE) {
+        if (bid == 0 && lane == 0 && p.trace) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.trace[wave * 5 + k] = ph[k];
+            p.trace[wave * 5 + 4] = nsteps;
+        }
+    }
+#undef W2_STAMP
 #undef W2_BODY
 #undef W2_COMMIT
 #undef W2_FETCH
@@ -203,8 +235,125 @@ __device__ __forceinline__ void wgrad_tr_body(const Wgrad2Params &p, const int b
     }
 }
 
-template <int TN, int TH = 2 * TN>
-__global__ void __launch_bounds__(TH, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) { wgrad_tr_body<TN, TH>(p, (int)blockIdx.x); }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same product with the operand rows brought in by LDS-DMA (global_load_lds_dwordx4) instead of registers + ds_write.
+// The phase stamps of wgrad_tr_body (tools/wgrad_trace.py, dW[1408,256]) read, per 32-row step of 2,530 cycles: fragment reads + MFMAs
+// 540 / 940 (first / second wave of a SIMD), staging registers -> LDS ~1,000 -- whether the loads were requested two or four steps ahead:
+// it is the 4 x ds_write_b128 + zero-masking + bias adds of sixteen waves in lockstep, not load latency --, barrier 170, issue of the next
+// loads 200-470.  Only the first item is work.  Here a step's 36 KB ([32 rows][256 + 32] of dy, then of x: the layout the transposing
+// fragment reads want) arrive as 36 pieces of 1 KB, five DMA instructions per wave (the last four of the forty are dummies, so that
+// every wave's vmcnt counts the same), three steps ahead into a ring of four LDS buffers; no staging registers, no ds_write, no masking:
+//   * a lane's 16 bytes land at piece * 1024 + 16 * lane, so the lane computes which (row, 16-byte chunk) that is -- chunks 32..35 of a
+//     row are the padding: the lane loads chunk 0 again, nobody reads it;
+//   * columns past N / K load column 0 of their row instead of zeros: they only reach output rows / columns that are never read back;
+//   * rows past M cannot be zeroed this way: the kernel takes M % 32 == 0 only (the encoder's B x tokens at the benchmark shapes);
+//   * the bias column sums come from the dy fragments the MFMAs use anyway (v_dot2c_f32_bf16 against a pair of ones).
+template <int TN>
+__device__ __forceinline__ void wgrad_dma_body(const Wgrad2Params &p, const int bid) {
+    static_assert(TN == 256, "DMA staging: the eight-wave 256 x 256 form");
+    using C = W2<TN, 512>;
+    constexpr int NBUF = 4, TILE_BYTES = W2_BM * C::LDA * 2, PIECES = 2 * TILE_BYTES / 1024, PW = (PIECES + 7) / 8;
+    static_assert(C::LDA == W2_LDB && 2 * TILE_BYTES == C::BUF * 2 && 2 * TILE_BYTES % 1024 == 0, "one buffer = whole 1 KB pieces");
+    extern __shared__ __attribute__((aligned(16))) uint16_t w2s[];   // NBUF buffers + 1 KB for the dummy pieces
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = bid & 7, local = bid >> 3;
+    const int tile = local % p.tiles, split = (local / p.tiles) * 8 + xcd;
+    if (split >= p.nsplit) return;
+    const int n_blk = (tile / p.tiles_k) * TN, k_blk = (tile % p.tiles_k) * W2_TK;
+    const bool want_bias = p.db != nullptr && k_blk == 0;
+    const int nsteps = (int)((p.chunks - split + p.nsplit - 1) / p.nsplit);
+    // this lane's source of piece wave + 8 i at step 0, and the per-step advance of that operand (elements)
+    const uint16_t *src[PW];
+    int64_t adv[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int q = wave + 8 * i, o = (q < PIECES ? q : 0) * 1024 + 16 * lane;
+        const int op = o >= TILE_BYTES, o2 = o - op * TILE_BYTES, row = o2 / (C::LDA * 2), cb = (o2 - row * (C::LDA * 2)) / 16;
+        const int ld = op ? p.K : p.N, col0 = op ? k_blk : n_blk, lim = op ? p.K : p.N;
+        const int col = (cb < TN / 8 && col0 + cb * 8 < lim) ? col0 + cb * 8 : col0;   // padding chunk / past the operand's width: any valid column
+        src[i] = (op ? p.x : p.dy) + ((int64_t)split * W2_BM + row) * ld + col;
+        adv[i] = (int64_t)p.nsplit * W2_BM * ld;
+    }
+    char *ring = (char *)w2s;
+    auto dma = [&](int t) {   // step t (clamped: the last steps re-request the last block into buffers nobody reads)
+        const int tc = t < nsteps ? t : nsteps - 1;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int q = wave + 8 * i;
+            char *dst = q < PIECES ? ring + (t & (NBUF - 1)) * (2 * TILE_BYTES) + q * 1024 : ring + NBUF * 2 * TILE_BYTES;
+            __builtin_amdgcn_global_load_lds((const void *)(src[i] + tc * adv[i]), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+    const bool bias_wave = want_bias && (wave & 1) == 0;
+    if (nsteps > 0) {
+        dma(0); dma(1); dma(2);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PW) : "memory");   // step 0 has landed (everybody's pieces)
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const uint16_t *buf = (const uint16_t *)(ring + (s & (NBUF - 1)) * (2 * TILE_BYTES)), *ay = buf, *bx = buf + W2_BM * C::LDA;
+#pragma unroll
+        for (int mc = 0; mc < 2; ++mc) {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = w2_frag(ay, C::LDA, wn + 32 * a, mc, lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = w2_frag(bx, W2_LDB, wk + 32 * b, mc, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            if (bias_wave) {   // wave-uniform
+                const uint32_t ones = 0x3f803f80u;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const w2u4 w = __builtin_bit_cast(w2u4, af[a]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(bsum[a]) : "v"(w[j]), "v"(ones));
+                }
+            }
+        }
+        dma(s + 3);   // into the buffer of step s - 1: everyone left it at the previous barrier.  (Issued BEHIND this step's fragment reads:
+                      // in front of them hipcc orders the reads after the DMA -- s_waitcnt vmcnt(0) -- since it cannot tell the buffers apart.)
+        // step s + 1 (requested at the end of step s - 2) has landed once at most the pieces of steps s + 2 and s + 3 are in flight;
+        // everyone is done reading this step's buffer (lgkmcnt) before the next trip's DMA overwrites the one of step s - 1 ... s
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PW) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (clamped) requests must not outlive the workgroup's LDS
+    float *out = p.partial + ((int64_t)tile * p.nsplit + split) * C::PART;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wn + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * fh, col = wk + 32 * b + fr;
+                if (n_blk + wn + 32 * a < p.N) out[row * W2_TK + col] = acc[a][b][e];
+            }
+    if (bias_wave) {   // lanes l and l + 32 hold the two halves of every 16-row k-step: one sum per column
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const uint32_t u = __float_as_uint(bsum[a]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            const float t = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            if (fh == 0) out[TN * W2_TK + wn + 32 * a + fr] = t;
+        }
+    }
+}
+template <int TN>
+__global__ void __launch_bounds__(512, 1) wgrad_dma_kernel(Wgrad2Params p) { wgrad_dma_body<TN>(p, (int)blockIdx.x); }
+
+template <int TN, int TH = 2 * TN, bool TRACE = false>
+__global__ void __launch_bounds__(TH, TN == 128 ? 2 : 1) wgrad_tr_kernel(Wgrad2Params p) { wgrad_tr_body<TN, TH, TRACE>(p, (int)blockIdx.x); }
 
 template <int TN, int TH = 2 * TN>
 __global__ void __launch_bounds__(TH, TN == 128 ? 2 : 1) wgrad_tr_group_kernel(Wgrad2Group G) {
@@ -348,10 +497,30 @@ static bool wgrad2_four_waves() {
     if (w < 0) { const char *e = getenv("VSDE_WGRAD_WAVES"); w = (e && atoi(e) == 4) ? 4 : 8; }
     return w == 4;
 }
-template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &p, hipStream_t s) {
+static long long *g_wgrad_trace = nullptr;
+template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &p_, hipStream_t s) {
     using C = W2<TN, TH>;
     const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
-    auto kern = wgrad_tr_kernel<TN, TH>;
+    Wgrad2Params p = p_;
+    p.trace = g_wgrad_trace;
+    auto kern = (g_wgrad_trace && TN == 256 && TH == 512) ? wgrad_tr_kernel<TN, TH, (TN == 256 && TH == 512)> : wgrad_tr_kernel<TN, TH>;
+    // VSDE_WGRAD_DMA=1: the LDS-DMA form (wgrad_dma_kernel; A/B runs).  Opt-in: measured 184 | 251 | 143 us against 169 | 232 | 131 us for
+    // dW[832,256] | [1408,256] | [256,704] -- the ~1,000 cycles per step the register form spends storing to LDS are not what bounds
+    // it: with them gone the step waits as long for its data (36 KB per CU and step arrive at ~13 B/clk either way, three or four steps
+    // ahead make no difference: profiles/r05_wgrad.txt)
+    static int use_dma = -1;
+    if (use_dma < 0) { const char *e = getenv("VSDE_WGRAD_DMA"); use_dma = (e && e[0] == '1') ? 1 : 0; }
+    if constexpr (TN == 256 && TH == 512) {
+        if (use_dma && !g_wgrad_trace && p.M % W2_BM == 0) {   // whole 32-row blocks only (rows past M cannot be zeroed on the way in)
+            const size_t dlds = (size_t)4 * C::BUF * sizeof(uint16_t) + 1024;
+            VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)wgrad_dma_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+            hipLaunchKernelGGL(wgrad_dma_kernel<256>, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(512), dlds, s, p);
+            VSDE_CHECK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(wgrad_tr_reduce_kernel<TN>, dim3(TN * W2_TK / 4 / 64 + 1, p.tiles), dim3(256), 0, s, p);
+            VSDE_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(C::THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -361,6 +530,9 @@ template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &
 }
 
 }  // namespace vsde
+
+// debugging: the next single-problem launches of the eight-wave TN = 256 kernel stamp their phases (tools/wgrad_trace.py); nullptr: off
+extern "C" int vsde_wgrad_debug_trace(void *buf) { vsde::g_wgrad_trace = (long long *)buf; return 0; }
 
 template <int TN, int TH = 2 * TN> static int wgrad2_launch_group(const vsde::Wgrad2Group &G, int wgs, hipStream_t s) {
     using namespace vsde;
