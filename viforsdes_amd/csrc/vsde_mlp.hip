@@ -646,7 +646,9 @@ static int launch_fwd(const FwdParams &p, hipStream_t s) {
     const int64_t stripes = (p.M + NW * 32 - 1) / (NW * 32);
     // (measured and dropped, profiles/r05_mlp_fwd.txt: half stripes -- waves 4..7 idle -- for the partly filled last round of one
     //  workgroup per CU: the wave-uniform "active" branches cost the tile loop 5 scratch accesses and 15 % of its speed, the round
-    //  saved 3 %)
+    //  saved 3 %.  Second attempt: the last round's 34 stripes as a SECOND launch of four-wave workgroups (the wave count as a template
+    //  parameter, 512 registers): 304.1 vs 304.2 us plain, 404 vs 409 us block form -- a four-wave workgroup takes ~0.9 of the
+    //  eight-wave time, not the 0.6 its issue slots suggest, and the launch boundary eats the rest.  Dropped as well.)
     hipLaunchKernelGGL((mlp_fwd_kernel<C, SAVE, DBG, BLK>), dim3((unsigned)stripes), dim3(64 * NW), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
