@@ -351,6 +351,8 @@ int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, int64_t ldu, 
 int vsde_mlp_debug_trace(void *buf);
 /* The same for the weight-gradient kernel (eight-wave TN = 256 form): [8 waves][4 phase cycle sums + step count] (tools/wgrad_trace.py). */
 int vsde_wgrad_debug_trace(void *buf);
+/* ... and for the persistent LDS-resident attention forward: [12 waves][4 phase cycle sums + pair count] (tools/attn_trace.py). */
+int vsde_attn_debug_trace(void *buf);
 int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile);
 int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img, const void *w2_img, const float *b1_img, const void *b2, void *y,
                       int64_t ldy, void *s_out, int64_t lds, int64_t M, int C, int H, void *stream);

@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
-    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_attn_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_wgrad_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_attn_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_wgrad_debug_trace", "vsde_attn_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 

@@ -45,6 +45,7 @@ struct AttnParams {
     int64_t pairs;              // B * H (the persistent kernel's loop bound)
     int dbg;                    // ring kernel, timing-only ablations (VSDE_ATTN_RING_DBG): 1 = the producer loads only the first pair, 2 = no tile-step
                                 // barriers, 4 = the consumers skip their tile steps, 8 = no epilogue stores
+    long long *trace;           // ABL = 16 (vsde_attn_debug_trace): per-wave phase cycle sums of workgroup 0, [12 waves][4] + pairs
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -160,6 +161,12 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
         const int64_t hb = head_ / p.H, base_ = (hb * N * p.H + (head_ - hb * p.H)) * AT_D;
         qtouch = *(const uint32_t *)(p.q + base_ + (pq < N ? pq : N - 1) * ts + (ln >> 5) * 32);
     };
+    // (Round 5, tools/attn_trace.py: per pair of ~36 k cycles the tile loops take 16 k, the staging 11 k, the blocks' prologues -- the
+    //  row-strided q fragment loads in front of the first MFMA -- 4-7 k, the epilogues 1-3 k.  Requesting the wave's q fragments behind
+    //  the staging commit, in front of the barrier every wave waits at anyway, cost 26 spilled registers and 20 % of the kernel: the 16
+    //  registers do not fit anywhere around the tile loop.  Second form: the q rows by LDS-DMA into 4 KB per wave behind K and V^T (a
+    //  swizzled [32][8 x 16 B] image, conflict-free fragment reads), requested when the wave is done with the previous pair: 19 spilled
+    //  registers for its addressing, 203 vs 175 us.  The kernel sits at its 168-register cap; both dropped.)
 #define VSDE_FWD_STAGE(head_, first_)                                                                          \
     do {                                                                                                       \
         uint4 kreg[KIT], vreg[VIT][8];                                                                         \
@@ -173,7 +180,11 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     } while (0)
     const int64_t nheads = p.pairs;              // total (batch, head) pairs
     int64_t head = blockIdx.x;
+    long long ph[4] = {0, 0, 0, 0}, last_ = 0, npairs_ = 0;
+    if constexpr ((ABL & 16) != 0) last_ = __builtin_readcyclecounter();
+#define VSDE_AT_STAMP(k_) do { if constexpr ((ABL & 16) != 0) { const long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - last_; last_ = now_; } } while (0)
     VSDE_FWD_STAGE(head, true);
+    VSDE_AT_STAMP(0);
   while (true) {
     const int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
     const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
             aw = make_uint4(vf[6].x, vf[6].y, vf[7].x, vf[7].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o1, 0, 0, 0);
         };
         f32x16 sa = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = sa;
+        VSDE_AT_STAMP(1);
         {
             const uint16_t *krow = Ks + fr * AT_KLD + h2 * 8;
 #pragma unroll
@@ -299,6 +311,7 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
         }
         lsum += lsum2;
         lsum = sum_xor32(lsum);
+        VSDE_AT_STAMP(2);
         if (qok) {
             const float inv = 1.0f / lsum;
             uint16_t *orow = p.o + base + query * ts;
@@ -322,14 +335,25 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
             }
             if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = mx * p.scale + __logf(lsum);
         }
+        VSDE_AT_STAMP(3);
     }
+    ++npairs_;
     if constexpr (!PERSIST) break;
     if (!has_next) break;
     // this wave is done with the current pair: its share of the next pair's K / V is requested NOW (a wave with a second block
     // has pt < 0: no loads) and lands while the wave that owns the 13th block is still computing
     VSDE_FWD_STAGE(next, false);
+    VSDE_AT_STAMP(0);
     head = next;
   }
+    if constexpr ((ABL & 16) != 0) {
+        if (blockIdx.x == 0 && lane == 0 && p.trace) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p.trace[wave * 5 + k] = ph[k];
+            p.trace[wave * 5 + 4] = npairs_;
+        }
+    }
+#undef VSDE_AT_STAMP
 #undef VSDE_FWD_STAGE
 }
 
@@ -1531,18 +1555,27 @@ static int attn_cus() {
 
 // forward launch: persistent workgroups (one per CU, next pair's operands requested behind the 13th query block) when a pair
 // has at most 13 query blocks and there are at least two pairs per CU; one workgroup per pair otherwise
-static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipStream_t stream) {
+static long long *g_attn_trace = nullptr;
+static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hipStream_t stream) {
     const int cus = attn_cus();
+    const size_t lds = lds_kv, lds_p = lds_kv;
     AttnParams q = p;
     q.pairs = pairs;
+    q.trace = g_attn_trace;
+    if (g_attn_trace && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // phase stamps (tools/attn_trace.py)
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        hipLaunchKernelGGL((attn_fwd_kernel<true, 16>), dim3((unsigned)cus), dim3(768), lds_p, stream, q);
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     { static int dbg = -1; if (dbg < 0) dbg = ablation_env("VSDE_ATTN_RING_DBG"); q.dbg = dbg; }
     static int abl = -1;
     if (abl < 0) abl = ablation_env("VSDE_ATTN_FWD_ABL");
     if (abl && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // timing-only variants (wrong results)
 #define VSDE_ABL_LAUNCH(A_)                                                                                                      \
     do {                                                                                                                         \
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((attn_fwd_kernel<true, A_>), dim3((unsigned)cus), dim3(768), lds, stream, q);                          \
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p)); \
+        hipLaunchKernelGGL((attn_fwd_kernel<true, A_>), dim3((unsigned)cus), dim3(768), lds_p, stream, q);                        \
     } while (0)
         if (abl == 1) VSDE_ABL_LAUNCH(1); else if (abl == 2) VSDE_ABL_LAUNCH(2); else if (abl == 3) VSDE_ABL_LAUNCH(3); else VSDE_ABL_LAUNCH(7);
 #undef VSDE_ABL_LAUNCH
@@ -1555,8 +1588,8 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring));
         hipLaunchKernelGGL(attn_fwd_ring_kernel, dim3((unsigned)cus), dim3(64 * RG_NW), ring, stream, q);
     } else if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds, stream, q);
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds_p, stream, q);
     } else {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)pairs), dim3(768), lds, stream, q);
@@ -1566,6 +1599,8 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds, hipSt
 }
 
 extern "C" int vsde_attention_max_tokens(void) { return AT_MAXN; }
+// debugging: the next persistent forward launches stamp their phases into buf ([12 waves][4 sums + pair count]); nullptr: off
+extern "C" int vsde_attn_debug_trace(void *buf) { g_attn_trace = (long long *)buf; return 0; }
 
 extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int N, int H,
                                        int head_dim, double scale, void *stream) {
