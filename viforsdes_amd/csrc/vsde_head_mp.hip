@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
     constexpr int SPITCH = 324;                           // floats per path: 320 + 4, so that the 8-lane groups of a ds_write_b128 (paths
                                                           // 0..7 of one row group) fall on different banks (320 = 0 mod 32: 4-way conflicts)
     // (measured and dropped, round 5: the layer-0 role leaving its record there too, both copied out as 16-byte lanes -- 420 vs 407-417 us
-    //  at 512 paths on one box: its five 4-byte stores per lane are not what the step waits for)
+    //  at 512 paths on one box: its five 4-byte stores per lane are not what the step waits for.  Nor is their number: with the idle
+    //  lo'-column lanes taking two of the five stores (three instructions instead of five, values handed over by DPP) the training launch
+    //  went 425 -> 437 us, the reverse sweep with two D4 stores instead of four 527 -> 534 us: tools/ab_lib.sh + tools/head_ab.py)
     constexpr int SREC = STASH ? NP * SPITCH : 4;         // floats per record (all paths of the group)
     __shared__ __attribute__((aligned(16))) float srec[2][SREC];
     const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, lane = tid & 63, q = lane >> 4, pp = lane & 15;
