@@ -194,25 +194,9 @@ __device__ __forceinline__ void gemm1(f32x16 &uacc, const bf16x8 (&xfr)[C / 16],
 // g = 0, 1 of the accumulator are a_j (j = 8 h + 4 g + i), g = 2, 3 the matching b_j.  Written stage by stage over all 8 values:
 // a wave issues in order and a dependent VALU result is ~2 issue slots away, so the per-value chains (convert, exp, add, rcp, mul,
 // round, mul, round) must be interleaved 8 wide -- pair by pair the phase ran at one instruction per ~9 cycles.
-// ROUND = false (the no-grad kernels, which write neither u nor s): s = silu(a) * b straight from the fp32 accumulators, ONE rounding at
-// the end -- the three intermediate roundings of the unfused chain (u to bf16, silu(a) to bf16) are 36 of the phase's 72 plain VALU
-// instructions per tile and wave, and here nothing downstream depends on reproducing them (s differs by at most a bf16 ulp, towards
-// the fp32 value).  The training variant keeps them: its s is what the unfused backward would have seen.
-template <bool ROUND = true>
+// (Measured and dropped for the no-grad kernels: one rounding at the end instead of the chain's three -- 36 of the 72 plain VALU
+// instructions -- 304-311 vs 305 us, block form 421-427 vs 416-419 us: the instruction count of this phase is not what the tile waits for.)
 __device__ __forceinline__ bf16x8 swiglu8(const f32x16 &u) {
-    if constexpr (!ROUND) {
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = fast_exp2(-1.4426950408889634f * u[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = fast_rcp(1.0f + e[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (e[j] * u[j]) * u[8 + j];
-        u32x4 out;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[q] = pack2(e[2 * q], e[2 * q + 1]);
-        return __builtin_bit_cast(bf16x8, out);
-    }
     uint32_t aw[4], bw[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { aw[q] = pack2(u[2 * q], u[2 * q + 1]); bw[q] = pack2(u[8 + 2 * q], u[8 + 2 * q + 1]); }
@@ -524,7 +508,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_kernel(FwdParams p) {
         if (p.antiphase != 2) { end_phase<C, DBG>(p, n, true, t + 2 >= p.T, wave, lane); ++n; }
         bf16x8 sfr, w2a[G::CB / 2];
         if (!(DBG & 4)) gemm2_prefetch<C>(w2a, slot, lane);
-        if (!(DBG & 2)) sfr = swiglu8<SAVE != 0>(u);
+        if (!(DBG & 2)) sfr = swiglu8(u);
         if constexpr (SAVE == 1) {
             *(bf16x8 *)(stage + r * SLD + (t & 3) * 16 + 8 * h) = sfr;
             if ((t & 3) == 3) {
