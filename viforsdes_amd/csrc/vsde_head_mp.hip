@@ -392,7 +392,11 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
         for (int i = 0; i < S; ++i) p.paths[(int64_t)b * (T + 1) * S + i] = z[i];
     }
 
-    // the projected context record and eps, one step ahead in registers (the wait for them at the top of a step is a vmcnt(0))
+    // the projected context record and eps, one step ahead in registers (the wait for them at the top of a step is a vmcnt(0)).
+    // (Round 5, measured and dropped: both records by LDS-DMA from the layer-1 waves -- whose vector-memory queue is otherwise empty, so a
+    // counted vmcnt(1) is exact -- into a ring of four slots, the layer-0 waves reading them out of LDS behind barrier B: five loads per
+    // lane and step less on the layer-0 role, 425-437 / 356-366 us against 432-436 / 364 us (training / sampling launch): the sampling
+    // launch's 1,640 cycles per step ARE its 44 MFMAs x 16 + ~190 VALU x 2.6 + 12 transcendentals x 12 per SIMD; loads issue elsewhere.)
     const float *Gb = p.G + (int64_t)b * T * 192 + j0;
     const float *eb = p.eps + (int64_t)b * T * S;
     float gq[3][UPL];
