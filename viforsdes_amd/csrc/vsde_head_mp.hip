@@ -905,7 +905,8 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mp_kernel(MpBwdParams p) {
 //     compiler-inserted waits): record r of a layer = NP x 1,280 contiguous bytes, one 1 KB piece per wave, THREE steps ahead into a ring
 //     of four slots; the upstream scalars of the group (3 S + S^2 + S (S + 1) / 2 per path from five tensors) are ONE 4-byte DMA by wave 3
 //     of the layer-0 role.  A wave waits for its own piece with a counted vmcnt in front of the step's last barrier (every
-//     vector-memory instruction below is issued unconditionally -- stores of lanes without an owner go to a sink -- so the count is exact).
+//     vector-memory instruction below is issued by every wave in every step -- a store is masked per lane, never skipped: each wave holds
+//     owner lanes of its group's first path; the one-lane DO store goes to a sink where it has no target -- so the count is exact).
 //   * h_{t-1} is the h part of record t - 1, which is in the ring anyway.
 template <int S, int NP>
 __global__ void __launch_bounds__(512, 1) head_bwd_mps_kernel(MpBwdParams p) {
@@ -1032,10 +1033,12 @@ __global__ void __launch_bounds__(512, 1) head_bwd_mps_kernel(MpBwdParams p) {
         for (int ks = 0; ks < 6; ++ks) bf[ks] = dbuf[par][l][(ks >> 1) == 2 ? (hh ? 3 : 2) : (ks >> 1)][ks & 1][q][colr];
     };
     auto store_d4 = [&](const float (&dr)[UPL], const float (&du)[UPL], const float (&dn)[UPL], const float (&dcn)[UPL], int t, int l) {
-        // D4[b][t][l][{dr, du, dn, dc_n}][64]; four instructions, always issued (lanes without an owner write the sink)
-        float *o = live ? p.D4 + (((int64_t)b * T + t) * L + l) * 256 + j0 : sink;
-        const int st = live ? 64 : 0;
-        mp_stu<UPL>(o, dr, Sg); mp_stu<UPL>(o + st, du, Sg); mp_stu<UPL>(o + 2 * st, dn, Sg); mp_stu<UPL>(o + 3 * st, dcn, Sg);
+        // D4[b][t][l][{dr, du, dn, dc_n}][64]; four instructions, always ISSUED: every wave of every workgroup holds the owner lanes of
+        // its group's first path, which exists (grid = ceil(B / NP)) -- the other lanes are masked, not redirected
+        if (live) {
+            float *o = p.D4 + (((int64_t)b * T + t) * L + l) * 256 + j0;
+            mp_stu<UPL>(o, dr, Sg); mp_stu<UPL>(o + 64, du, Sg); mp_stu<UPL>(o + 128, dn, Sg); mp_stu<UPL>(o + 192, dcn, Sg);
+        }
     };
     // saved activations of (t, layer) out of the ring: r, u, n, n_hh, and h of step t - 1 (zero before the first step)
     auto read_acts = [&](int t, int l, float (&a)[5][UPL]) {
