@@ -142,12 +142,10 @@ template <int N> __device__ __forceinline__ float mp_row_shl(float v) {   // lan
 //             4 / UPL replicas; the lanes of the hi columns own the paths.  Per SIMD and step the two-layer kernel then issues 44
 //             MFMAs instead of 66 -- and the SIMD's issue slots are what a step costs: its two waves' MFMAs and VALU operations
 //             do not overlap (profiles/r05_mfma_valu_overlap.txt), "slack" products of one role delay the other role's chain.
+// the MFMAs of one product, accumulated into A1 / A2 (which may carry another product's sums: see mp_fold)
 template <int NP, int UPL>
-__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], float (&R)[3][UPL], int rr) {
+__device__ __forceinline__ void mp_matmul_acc(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], f32x4 (&A1)[3], f32x4 (&A2)[3]) {
     constexpr bool P2 = NP == 4 * UPL;
-    f32x4 A1[3], A2[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) { A1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; A2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -159,25 +157,37 @@ __device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x
 #pragma unroll
         for (int g = 0; g < 3; ++g) A2[g] = mp_mfma(wf[g][ks][1], hb[0][ks], A2[g]);
     }
+}
+// this lane's UPL rows of a tile's four (replica rr), planes folded.  Selecting costs 6 v_cndmask + 3 more instructions per value: sums
+// that a step needs only TOGETHER (W_ih h^0_t + W_hh h^1_{t-1} of the r and u gates) are therefore accumulated in ONE pair of
+// accumulators across the two products and folded once.
+template <int NP, int UPL>
+__device__ __forceinline__ void mp_fold(const f32x4 &A1, const f32x4 &A2, int rr, float (&R)[UPL]) {
+    constexpr bool P2 = NP == 4 * UPL;
+    float s1[UPL], s2[UPL];
+    if constexpr (UPL == 4) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        // this lane's UPL rows of the four (replica rr), then the planes are folded
-        float s1[UPL], s2[UPL];
-        if constexpr (UPL == 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[r] = A1[g][r]; s2[r] = A2[g][r]; }
-        } else if constexpr (UPL == 2) {
-            s1[0] = rr ? A1[g][2] : A1[g][0]; s1[1] = rr ? A1[g][3] : A1[g][1];
-            s2[0] = rr ? A2[g][2] : A2[g][0]; s2[1] = rr ? A2[g][3] : A2[g][1];
-        } else {
-            const float l1 = (rr & 1) ? A1[g][1] : A1[g][0], h1 = (rr & 1) ? A1[g][3] : A1[g][2];
-            const float l2 = (rr & 1) ? A2[g][1] : A2[g][0], h2 = (rr & 1) ? A2[g][3] : A2[g][2];
-            s1[0] = (rr & 2) ? h1 : l1; s2[0] = (rr & 2) ? h2 : l2;
-        }
-#pragma unroll
-        for (int r = 0; r < UPL; ++r)
-            R[g][r] = P2 ? fmaf(s2[r], kMpLoInv, s1[r]) : fmaf(mp_row_shl<NP & 15>(s1[r]) + s2[r], kMpLoInv, s1[r]);
+        for (int r = 0; r < 4; ++r) { s1[r] = A1[r]; s2[r] = A2[r]; }
+    } else if constexpr (UPL == 2) {
+        s1[0] = rr ? A1[2] : A1[0]; s1[1] = rr ? A1[3] : A1[1];
+        s2[0] = rr ? A2[2] : A2[0]; s2[1] = rr ? A2[3] : A2[1];
+    } else {
+        const float l1 = (rr & 1) ? A1[1] : A1[0], h1 = (rr & 1) ? A1[3] : A1[2];
+        const float l2 = (rr & 1) ? A2[1] : A2[0], h2 = (rr & 1) ? A2[3] : A2[2];
+        s1[0] = (rr & 2) ? h1 : l1; s2[0] = (rr & 2) ? h2 : l2;
     }
+#pragma unroll
+    for (int r = 0; r < UPL; ++r)
+        R[r] = P2 ? fmaf(s2[r], kMpLoInv, s1[r]) : fmaf(mp_row_shl<NP & 15>(s1[r]) + s2[r], kMpLoInv, s1[r]);
+}
+template <int NP, int UPL>
+__device__ __forceinline__ void mp_matmul(const f16x8 (&wf)[3][2][2], const f16x8 (&hb)[2][2], float (&R)[3][UPL], int rr) {
+    f32x4 A1[3], A2[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { A1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; A2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    mp_matmul_acc<NP, UPL>(wf, hb, A1, A2);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) mp_fold<NP, UPL>(A1[g], A2[g], rr, R[g]);
 }
 // UPL consecutive floats
 template <int UPL> __device__ __forceinline__ void mp_ldu(float (&d)[UPL], const float *src) {
@@ -323,17 +333,25 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                 }
 #pragma unroll
             for (int r = 0; r < UPL; ++r) bn1[r] = kMpSn * p.b_hh1[128 + j0 + r];
-            float c1[3][UPL];                          // W_hh^1 h^1_{t-1}: h_{-1} = 0
+            // W_hh^1 h^1_{t-1} (h_{-1} = 0): the r / u tiles' sums stay in their accumulators (C1 / C2) and W_ih^1 h^0_t is accumulated on
+            // top of them; only the n tile's c_n is needed by itself (c1[2])
+            float c1[3][UPL];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int r = 0; r < UPL; ++r) c1[g][r] = 0.f;
+            f32x4 C1[3], C2[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { C1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; C2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             for (int t = 0; t < T; ++t) {
                 barrier();                             // A: h^0_t published
                 f16x8 hb[2][2];
                 read_state(t, 0, hb);
                 float a1[3][UPL];
-                mp_matmul<NP, UPL>(wi, hb, a1, rr);    // W_ih^1 h^0_t
+                C1[2] = f32x4{0.f, 0.f, 0.f, 0.f}; C2[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mp_matmul_acc<NP, UPL>(wi, hb, C1, C2);   // W_ih^1 h^0_t (+ the carried r / u sums)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) mp_fold<NP, UPL>(C1[g], C2[g], rr, a1[g]);
                 float ar[UPL], au[UPL], an[UPL], rg[UPL], ug[UPL], ng[UPL], cn[UPL];
 #pragma unroll
                 for (int r = 0; r < UPL; ++r) { ar[r] = k1[0][r] + a1[0][r]; au[r] = k1[1][r] + a1[1][r]; an[r] = k1[2][r] + a1[2][r]; }
@@ -344,7 +362,10 @@ __global__ void __launch_bounds__(256 * L, 3 - L) head_fwd_mp_kernel(MpParams p)
                     mp_stu<UPL>(rec, h1); mp_stu<UPL>(rec + 64, rg); mp_stu<UPL>(rec + 128, ug); mp_stu<UPL>(rec + 192, ng); mp_stu<UPL>(rec + 256, cn, kMpInvSn);
                 }
                 read_state(t, L - 1, hb);
-                mp_matmul<NP, UPL>(wh, hb, c1, rr);    // W_hh^1 h^1_t: consumed by step t + 1
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { C1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; C2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                mp_matmul_acc<NP, UPL>(wh, hb, C1, C2);   // W_hh^1 h^1_t: consumed by step t + 1
+                mp_fold<NP, UPL>(C1[2], C2[2], rr, c1[2]);
             }
             if (STASH) barrier();                      // the last record is complete: the layer-0 waves copy it out
         }
