@@ -340,6 +340,12 @@ int vsde_mlp_attn_block_fwd_bf16(const void *x, const void *attn, const void *gl
                                  const void *ga, const void *sc, const void *sh, const void *gm, const void *sn, const void *hs,
                                  int64_t mp, int tokens, double eps, double eps_next, const void *w1_img, const void *w2_img,
                                  const float *b1_img, const void *b2, void *tok, void *hnext, int64_t M, int C, int H, void *stream);
+/* y [M][256] = x [M][K] W^T (+ bias) for a DEEP reduction (K % 64 == 0, K >= 256) at the encoder's width 256 (csrc/vsde_mlp.hip,
+ * round 5): the SwiGLU output projection (primitives/mlp.py:54) and the input-gradient GEMMs of mlp.py:50 / attn.py:80-82 -- the
+ * three products the library ran until then.  w_img = W as K / 16 k-step images [2][256][8] bf16 (W[n][16 t + 8 h + 0..7]: the
+ * layout of w2_img above; built by primitives/fused.py::DeepImage), bias [256] bf16 or NULL. */
+int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *w_img, const void *bias, void *y, int64_t ldy, int64_t M, int K,
+                             void *stream);
 /* Backward of the SwiGLU MLP in one pass (training step): du [M][2 H] = swiglu'(u) * (dy W_out) and dx [M][C] = du W_in, with the saved
  * pre-activations u and du in the 16-row interleaved layout of primitives/fused.py::swiglu_packs(interleave=True) (64 columns per 32
  * hidden units: [a16 | b16 | a16 | b16]).  img: H / 32 pair-tile images of vsde_mlp_bwd_image_bytes(C) bytes each (layout in

@@ -192,3 +192,35 @@ def test_opt_in_fused_backward_gives_the_same_gradients():
             fused.FUSED_MLP_BWD = False
     for a, b in zip(out[False], out[True]):
         assert _rel(b, a) < 1e-2
+
+
+@pytest.mark.parametrize("M,K,bias,transposed", [(20000, 704, True, False), (205312, 1408, False, True), (40000 + 17, 832, False, True),
+                                                 (300, 256, True, False), (77, 512, False, False)])
+def test_deep_reduction_gemm(M, K, bias, transposed):
+    """vsde_linear_deep256_bf16 (y [M, 256] = x [M, K] W^T + b, the products the library ran until round 5) against the float32 product
+    of the same bf16 operands: fp32 accumulation, one rounding of the output (1e-2 of max is two bf16 ulps of the largest output);
+    weights as [256, K] and as the transposed view of a [K, 256] pack (the input-gradient GEMMs), ragged M, the shallowest K."""
+    from viforsdes_amd import _hip
+    from viforsdes_amd.primitives import fused
+    g = torch.Generator().manual_seed(K + M)
+    shape = (K, 256) if transposed else (256, K)
+    w = torch.nn.Parameter((torch.randn(*shape, generator=g) * K ** -0.5).to(DEV))
+    b = torch.nn.Parameter(torch.randn(256, generator=g).to(DEV)) if bias else None
+    pack = fused.plain_pack(w, b)
+    x = _rand(M, K, seed=3)
+    wide = _rand(M, K + 64, seed=4)
+    for xin in (x, wide[:, 32:32 + K]):   # a column range of a wider buffer: the row pitch is an argument
+        y = fused.deep256(xin, pack, transposed, pack.bias)
+        wb = pack.weight.float()
+        ref = xin.float() @ (wb if transposed else wb.t()) + (pack.bias.float() if bias else 0.0)
+        assert y.shape == (M, 256) and torch.isfinite(y).all()
+        assert _rel(y, ref) < 1e-2
+    # the image follows a refresh of the pack
+    with torch.no_grad():
+        w.mul_(0.5)
+    fused.note_parameters_changed()
+    fused.PackedWeight.refresh_all(force=True, params={id(w)})
+    y2 = fused.deep256(x, pack, transposed, pack.bias)
+    wb = pack.weight.float()
+    ref2 = x.float() @ (wb if transposed else wb.t()) + (pack.bias.float() if bias else 0.0)
+    assert _rel(y2, ref2) < 1e-2

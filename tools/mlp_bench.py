@@ -75,3 +75,14 @@ if M % 401 == 0 and C in (128, 256):
             ("block form", lambda: _hip.mlp_block_fwd(xs, attn, ga, sc, sh, gm, sn, hs, 1e-5, 1e-5, w1, w2, b1, b2o, H)),
             ("block form + out projection", lambda: _hip.mlp_attn_block_fwd(xs, attn, glog, oimg, bo, ga, sc, sh, gm, sn, hs, 1e-5, 1e-5, w1, w2, b1, b2o, H))):
         print(f"{name:40s} {timeit(fn):8.1f} us")
+
+# the deep-reduction GEMMs at width 256: library (torch.nn.functional.linear / matmul) against csrc/vsde_mlp.hip::deep256_kernel
+for name, K, tr in (("mlp out projection  [M,704] x [256,704]^T", 704, False), ("mlp input gradient  [M,1408] x [1408,256]", 1408, True),
+                    ("qkv input gradient  [M,832] x [832,256]", 832, True)):
+    wt = P(*((K, 256) if tr else (256, K)), sc=K ** -0.5)
+    pk = fused.plain_pack(wt, None)
+    xx = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    wb = pk.weight
+    t_lib = timeit(lambda: (xx @ wb) if tr else torch.nn.functional.linear(xx, wb))
+    t_own = timeit(lambda: fused.deep256(xx, pk, tr, None))
+    print(f"{name:46s} library {t_lib:7.1f} us   own {t_own:7.1f} us   ({2.0 * M * K * 256 / t_own / 1e6:5.0f} TF/s)")

@@ -61,7 +61,7 @@ EXPORTS = (
     "vsde_attention_fused_supported", "vsde_attention_fwd_gated_bf16", "vsde_gate_bwd_delta", "vsde_attention_bwd_fused_partials",
     "vsde_attention_bwd_fused_bf16",
     "vsde_euler_maruyama_fwd", "vsde_euler_maruyama_bwd", "vsde_sde_coefficients_fwd", "vsde_sde_coefficients_bwd", "vsde_linear_bf16_supported", "vsde_linear_bf16", "vsde_linear_qknorm_bf16", "vsde_linear_gated_bf16", "vsde_linear_gate_bwd_bf16",
-    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_attn_block_fwd_bf16", "vsde_mlp_debug_trace", "vsde_wgrad_debug_trace", "vsde_attn_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
+    "vsde_mlp_image_bytes", "vsde_mlp_fwd_bf16", "vsde_mlp_block_fwd_bf16", "vsde_mlp_attn_block_fwd_bf16", "vsde_linear_deep256_bf16", "vsde_mlp_debug_trace", "vsde_wgrad_debug_trace", "vsde_attn_debug_trace", "vsde_mlp_bwd_image_bytes", "vsde_mlp_bwd_bf16",
     "vsde_pack_tile_bytes", "vsde_pack_refresh", "vsde_optim_chunk_bytes", "vsde_optim_chunk_elems", "vsde_optim_step",
 )
 
@@ -920,6 +920,20 @@ def mlp_attn_block_fwd(x, attn, glog, wo_img, bo, ga, sc, sh, gm, sn, hs, eps: f
               _ptr(sh), _ptr(gm), _ptr(sn), _ptr(hs), _i64(mp), ctypes.c_int(N), ctypes.c_double(eps), ctypes.c_double(eps_next), _ptr(w1_img),
               _ptr(w2_img), _ptr(b1_img), _ptr(b2), _ptr(tok), _ptr(hnext), _i64(B * N), ctypes.c_int(C), ctypes.c_int(H), _stream(dev))
     return tok, hnext
+
+
+def linear_deep256(x: torch.Tensor, w_img: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y [M,256] = x [M,K] W^T (+ bias) for K % 64 == 0, K >= 256: ``w_img`` = W as K/16 k-step images [K/16, 2, 256, 8] bf16
+    (``fused.DeepImage``).  See include/vsde_hip.h."""
+    lib = load(); dev = _require_hip(x, w_img)
+    x, ldx = _rows2d(x)
+    M, K = x.shape
+    if w_img.dtype != torch.bfloat16 or w_img.numel() != 256 * K or not w_img.is_contiguous():
+        raise ValueError("linear_deep256: w_img must be a contiguous bf16 image of 256 x K elements")
+    y = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.device(dev):
+        _call(lib.vsde_linear_deep256_bf16, _ptr(x), _i64(ldx), _ptr(w_img), _ptr(bias), _ptr(y), _i64(256), _i64(M), ctypes.c_int(K), _stream(dev))
+    return y
 
 
 def mlp_bwd_image_bytes(C: int) -> int:

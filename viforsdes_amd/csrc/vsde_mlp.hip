@@ -910,6 +910,153 @@ static long long *g_mlp_trace = nullptr;
 // VSDE_MLP_DEBUG=16: device buffer of >= 8 (2 T + 2) 2 int64 that receives workgroup 0's phase stamps (tools/mlp_trace.py)
 extern "C" int vsde_mlp_debug_trace(void *buf) { g_mlp_trace = (long long *)buf; return 0; }
 
+// ===================================================================================================== deep reduction, 256 outputs
+// y [M][256] = x [M][K] W^T (+ bias), K a multiple of 64 and DEEP (704 / 832 / 1408 at the LV shapes): the SwiGLU output projection and
+// the two input-gradient GEMMs of a SiT block (primitives/mlp.py:54, and the backward of mlp.py:50 / attn.py:80-82) -- the three products
+// the library ran until round 5.  It is the G2 half of mlp_fwd_kernel on its own: a wave keeps its 32 rows' 32 x 256 output accumulators
+// (128 registers) for the whole reduction, the weight -- W as K / 16 k-step images [2 h][256 n][8 k] (the W2 image format) -- streams
+// through a ring of four LDS slots of FOUR k-steps (32 KB, 32 DMA pieces: four per wave and tile) three tiles ahead, one workgroup
+// barrier per tile (32 MFMAs per wave), the activation fragments (row r, k = 16 ks + 8 h .. + 7: 16 bytes per lane and k-step) come
+// straight from global memory one tile ahead.  Counted waits: per tile a wave issues [4 fragment loads | 4 DMA] in that order, so the
+// pieces of tile t + 1 have landed once at most the 16 younger instructions are in flight.
+namespace vsde {
+namespace mlp {
+struct DeepParams {
+    const uint16_t *X; int64_t ldx;
+    const uint16_t *WI;        // [T * 4 k-steps][2][256][8] bf16
+    const uint16_t *bias;      // [256] bf16 or nullptr
+    uint16_t *Y; int64_t ldy;
+    int64_t M; int T;          // T = tiles of 64 reduction indices
+    int rotate;
+};
+constexpr int DEEP_TILE = 4 * 32 * 256;   // bytes of one tile's images
+constexpr int DEEP_NSLOT = 4;
+
+__global__ void __launch_bounds__(512, 2) deep256_kernel(DeepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int64_t wg0 = (int64_t)blockIdx.x * 256, row0 = wg0 + wave * 32;
+    if (wg0 >= p.M) return;
+    const int T = p.T;
+    const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;   // workgroups start at different tiles: their L2 requests spread
+    auto issue = [&](int t, int slot) {   // this wave's four pieces of tile t (clamped: the last trips re-request the last tile into free slots)
+        const int tt = ((t < T ? t : T - 1) + rot) % T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const void *)((const char *)p.WI + (int64_t)tt * DEEP_TILE + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(lsm + slot * DEEP_TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
+    const uint16_t *xrow = p.X + m * p.ldx + 8 * h;
+    // The activation fragments travel TWO tiles ahead in two register sets, requested by inline asm: hipcc's own wait for a load that
+    // has LDS-DMA requests behind it is s_waitcnt vmcnt(0) (it drains the weight ring at every tile), so the loads are hidden from it
+    // and the waits below are counted by hand.  Per tile a wave issues [4 fragment loads | 4 DMA] in that order (loads return in order).
+    bf16x8 abuf[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) abuf[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_a = [&](int t, bf16x8 (&a)[4]) {
+        const int tt = ((t < T ? t : T - 1) + rot) % T;
+        const uint16_t *src = xrow + tt * 64;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(src) : "memory");   // "+v": IN PLACE -- an output the
+        // allocator is free to move would be copied (or reused, if dead) while the data is still on its way
+    };
+    f32x16 yacc[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
+    // request order of the steady state from the start: ... A(k - 1) D(k) ...
+    issue(0, 0);
+    load_a(0, abuf[0]); issue(1, 1);
+    load_a(1, abuf[1]); issue(2, 2);
+    // tile 0 has landed once at most [A0 | D1 | A1 | D2] = 16 younger requests are in flight
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    auto tile = [&](int t, bf16x8 (&acur)[4]) {
+        const char *slot = lsm + (t % DEEP_NSLOT) * DEEP_TILE + h * (16 * 256) + r * 16;
+        // A(t) (requested two tiles ago, in front of D(t + 1)) has landed once at most [D(t+1) | A(t+1) | D(t+2)] = 12 are in flight; the
+        // fragments are operands of the wait so that no MFMA below moves in front of it
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(acur[0]), "+v"(acur[1]), "+v"(acur[2]), "+v"(acur[3])::"memory");
+        bf16x8 wa[2][8];
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) wa[0][cb] = *(const bf16x8 *)(slot + cb * 512);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) wa[(ks + 1) & 1][cb] = *(const bf16x8 *)(slot + (ks + 1) * 8192 + cb * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) yacc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][cb], acur[ks], yacc[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the set just consumed takes tile t + 2; then the DMA of tile t + 3 into the slot of tile t - 1 (everyone left it at the barrier
+        // that ended that tile; issued BEHIND this tile's LDS reads: in front of them hipcc would order the reads after the DMA)
+        {   // (the MFMAs above must have READ acur before the loads overwrite it: they are in order on the wave; the asm's "+v" ties it)
+            asm volatile("" : "+v"(acur[0]), "+v"(acur[1]), "+v"(acur[2]), "+v"(acur[3]));
+            load_a(t + 2, acur);
+        }
+        issue(t + 3, (t + 3) % DEEP_NSLOT);
+        // tile t + 1's pieces (issued at tile t - 2) are followed by [A(t+1) | D(t+2) | A(t+2) | D(t+3)] = 16 requests
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    int t = 0;
+    for (; t + 1 < T; t += 2) { tile(t, abuf[0]); tile(t + 1, abuf[1]); }
+    if (t < T) tile(t, abuf[0]);
+    // the trailing requests must not outlive the tile slots' reuse below -- nor their destination registers' (kept alive up to here)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::"v"(abuf[0][0]), "v"(abuf[0][1]), "v"(abuf[0][2]), "v"(abuf[0][3]), "v"(abuf[1][0]), "v"(abuf[1][1]),
+                 "v"(abuf[1][2]), "v"(abuf[1][3]) : "memory");
+    // y = acc + bias, 64 columns at a time through this wave's staging rows (the tile slots are free now)
+    uint16_t *stage = (uint16_t *)lsm + wave * (32 * SLD);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x16 &a = yacc[2 * q + half];
+            uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 bb = make_uint2(0u, 0u);
+                if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + 64 * q + 32 * half + 8 * g + 4 * h);
+                *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                             pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+            }
+        }
+        wave_lds_fence();
+        flush64(stage, p.Y + 64 * q, p.ldy, row0, p.M, lane);
+        wave_lds_fence();
+    }
+}
+}  // namespace mlp
+}  // namespace vsde
+
+// y [M][256] = x [M][K] W^T (+ bias): w_img = W as K / 16 k-step images [2][256][8] bf16 (W[n][16 t + 8 h + 0..7]: the layout of w2_img),
+// K % 64 == 0, K >= 256.  Replaces the library GEMMs of primitives/mlp.py:54 (forward) and of the input gradients of mlp.py:50 /
+// attn.py:80-82 at the encoder's width 256.
+extern "C" int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *w_img, const void *bias, void *y, int64_t ldy, int64_t M, int K,
+                                        void *stream) {
+    VSDE_CHECK_ARG(x && w_img && y && M > 0, VSDE_E_BADARG, "bad linear_deep256 arguments");
+    VSDE_CHECK_ARG(K >= 256 && K % 64 == 0, VSDE_E_BADARG, "linear_deep256: the reduction length must be a multiple of 64, at least 256 (got %d)", K);
+    VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ldy >= 256 && ldy % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                   ((uintptr_t)w_img % 16) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), VSDE_E_BADARG,
+                   "linear_deep256 operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    mlp::DeepParams p = {};
+    p.X = (const uint16_t *)x; p.ldx = ldx; p.WI = (const uint16_t *)w_img; p.bias = (const uint16_t *)bias; p.Y = (uint16_t *)y; p.ldy = ldy;
+    p.M = M; p.T = K / 64;
+    { static int rot = -1; if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; } p.rotate = rot; }
+    const size_t lds = (size_t)mlp::DEEP_NSLOT * mlp::DEEP_TILE;
+    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mlp::deep256_kernel, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, (hipStream_t)stream, p);
+    VSDE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // Sizes (bytes) of the three weight images for width C per tile of 16 hidden units: what primitives/fused.py allocates
 extern "C" int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, int64_t *b1_tile) {
     VSDE_CHECK_ARG(C == 128 || C == 256, VSDE_E_BADARG, "fused SwiGLU MLP: width %d not built (128, 256)", C);

@@ -944,6 +944,57 @@ class OutProjImage:
         return self.img
 
 
+class DeepImage:
+    """A [256, K] weight (or, ``transposed``, the [K, 256] weight whose transpose is meant) as K / 16 k-step images [2 h][256][8]
+    (W[n, 16 t + 8 h + 0..7]): the operand of ``_hip.linear_deep256`` (csrc/vsde_mlp.hip::deep256_kernel), rebuilt whenever the pack
+    is refreshed."""
+
+    def __init__(self, pack: PackedWeight, transposed: bool) -> None:
+        K = pack.weight.shape[0] if transposed else pack.weight.shape[1]
+        self.img = torch.zeros(K // 16, 2, 256, 8, device=pack.weight.device, dtype=torch.bfloat16)
+        self.packs, self.K, self.transposed, self._key = (pack,), K, transposed, None
+        PackedWeight._derived.add(self)
+
+    @torch.no_grad()
+    def refresh_if_stale(self) -> None:
+        pack = self.packs[0]
+        key = tuple(pack._versions or ())
+        if key == self._key:
+            return
+        K = self.K
+        if self.transposed:   # weight [K, 256]: W^T[n, k] = weight[k, n]
+            self.img.copy_(pack.weight.view(K // 16, 2, 8, 256).permute(0, 1, 3, 2))
+        else:                 # weight [256, K]
+            self.img.copy_(pack.weight.view(256, K // 16, 2, 8).permute(1, 2, 0, 3))
+        self._key = key
+
+    def operand(self) -> Tensor:
+        self.packs[0].operands()
+        self.refresh_if_stale()
+        return self.img
+
+
+# the deep-reduction GEMMs at width 256 (SwiGLU output projection, the two input-gradient products of a block) on the own kernel
+# csrc/vsde_mlp.hip::deep256_kernel.  OPT-IN (VSDE_DEEP256=1): correct, and 30 % slower than the library's 256 x 224 macro tiles
+# (136 | 223 | 140 us against 96 | 170 | 111 us for K = 704 | 1408 | 832 at the LV shape) -- with a wave's 32 rows and all 256 output
+# columns stationary, every wave reads the whole weight tile out of LDS: 1 KB per MFMA, twice what the matrix pipe can be fed
+DEEP256 = os.environ.get("VSDE_DEEP256", "0") == "1"
+
+
+def deep256_usable(M: int, N: int, K: int) -> bool:
+    return ENABLED and OWN_GEMM and DEEP256 and N == 256 and K % 64 == 0 and K >= 512 and M >= BLOCK_MLP_MIN_ROWS
+
+
+def deep256(x2: Tensor, pack: PackedWeight, transposed: bool, bias: Optional[Tensor]) -> Tensor:
+    """x2 [M, K] @ W^T (+ bias) with W = pack.weight [256, K] (or its transpose when the pack holds [K, 256])."""
+    attr = "_deep_image_t" if transposed else "_deep_image"
+    img = getattr(pack, attr, None)
+    if img is None:
+        img = DeepImage(pack, transposed)
+        setattr(pack, attr, img)
+    return _hip.linear_deep256(x2, img.operand(), bias)
+
+
 class DeferredOutProjection:
     """What ``SelfAttention.forward_fused(defer_out=True)`` hands back instead of the projected branch output in no-grad calls:
     the merged attention output [B, N, C], the gate logits [B*N, 64] and the out projection's pack -- the block kernel applies
@@ -1051,7 +1102,7 @@ class _SwiGLUMLP(torch.autograd.Function):
             return y.reshape(*x.shape[:-1], w2.shape[0])
         # the pre-activation u is only kept for the backward: a no-grad call (posterior sampling) skips its [M, 2*width] write
         u, s_ = _hip.linear_swiglu_bf16(x2, w1, b1, want_u=train)
-        y = _mm_nt(s_, w2, b2)
+        y = deep256(s_, pout, False, b2) if deep256_usable(s_.shape[0], w2.shape[0], w2.shape[1]) else _mm_nt(s_, w2, b2)
         if train:
             ctx.save_for_backward(x2, u, s_, w1)
         ctx.packs = (pin, pout)
@@ -1074,7 +1125,9 @@ class _SwiGLUMLP(torch.autograd.Function):
             du, dx = _hip.mlp_bwd(dy2, u, img.operand(), pout.weight.shape[1])
         else:
             du = _hip.linear_swiglu_bwd_bf16(dy2, pout.transposed(), u)
-            if own_gemm(du.shape[0], w1.shape[1], w1.shape[0]):
+            if deep256_usable(du.shape[0], w1.shape[1], w1.shape[0]):
+                dx = deep256(du, pin, True, None)
+            elif own_gemm(du.shape[0], w1.shape[1], w1.shape[0]):
                 dx = _hip.linear_bf16(du, pin.transposed(), None)
             else:
                 dx = du @ w1
@@ -1181,7 +1234,10 @@ class _AttentionCore(torch.autograd.Function):
         wb = pack.weight
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = (_hip.linear_bf16(dy, pack.transposed(), None) if own_gemm(M, wb.shape[1], wb.shape[0]) else dy @ wb).view(B, N, K)
+            if deep256_usable(M, wb.shape[1], wb.shape[0]):
+                dx = deep256(dy, pack, True, None).view(B, N, K)
+            else:
+                dx = (_hip.linear_bf16(dy, pack.transposed(), None) if own_gemm(M, wb.shape[1], wb.shape[0]) else dy @ wb).view(B, N, K)
         return (dx, None, None, None, None, None, None, dv0, dlam, None, None, None, None, *_pack_weight_grads(dy, x2.contiguous(), pack), *ograds)
 
 
