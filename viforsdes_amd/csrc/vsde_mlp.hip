@@ -932,56 +932,80 @@ struct DeepParams {
 constexpr int DEEP_TILE = 4 * 32 * 256;   // bytes of one tile's images
 constexpr int DEEP_NSLOT = 4;
 
-__global__ void __launch_bounds__(512, 2) deep256_kernel(DeepParams p) {
+// RB = row blocks of 32 per wave.  RB = 1 (default): eight waves (two per SIMD, <= 256 registers) -- every wave reads the WHOLE weight tile
+// out of LDS for its 32 MFMAs: 1 KB of fragment per MFMA, 256 KB per tile and CU.  RB = 2 (VSDE_DEEP256_RB=2): FOUR waves, one per SIMD with
+// the whole register file (256 accumulators), every W fragment feeds two MFMAs: half the LDS traffic for the same MFMA work per SIMD --
+// and SLOWER (158 | 250 | 158 us against 138 | 237 | 143 us for K = 704 | 1408 | 832; the library: 96 | 170 | 111): as in the weight-gradient
+// kernel, one wave per SIMD loses more to exposed latencies than the halved LDS traffic returns.  Either way a tile takes ~5,300 cycles
+// for 1,984 cycles of MFMAs per SIMD; what fills the rest are the 64 vector-memory instructions per tile and CU (32 DMA pieces + 32
+// fragment loads of 32 rows x 32 bytes), the same per-CU intake that bounds the weight-gradient kernel (profiles/r05_wgrad.txt).
+template <int RB>
+__global__ void __launch_bounds__(512 / RB, RB == 1 ? 2 : 1) deep256_kernel(DeepParams p) {
+    constexpr int NWV = 8 / RB, PW = 32 / NWV, NA = 4 * RB;   // waves; DMA pieces per wave and tile; fragment loads per wave and tile
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-    const int64_t wg0 = (int64_t)blockIdx.x * 256, row0 = wg0 + wave * 32;
+    const int64_t wg0 = (int64_t)blockIdx.x * 256, row0 = wg0 + wave * (32 * RB);
     if (wg0 >= p.M) return;
     const int T = p.T;
     const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;   // workgroups start at different tiles: their L2 requests spread
-    auto issue = [&](int t, int slot) {   // this wave's four pieces of tile t (clamped: the last trips re-request the last tile into free slots)
+    auto issue = [&](int t, int slot) {   // this wave's pieces of tile t (clamped: the last trips re-request the last tile into free slots)
         const int tt = ((t < T ? t : T - 1) + rot) % T;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 8 * i;
+        for (int i = 0; i < PW; ++i) {
+            const int piece = wave + NWV * i;
             __builtin_amdgcn_global_load_lds((const void *)((const char *)p.WI + (int64_t)tt * DEEP_TILE + piece * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(lsm + slot * DEEP_TILE + piece * 1024), 16, 0, 0);
         }
     };
-    const int64_t m = row0 + r < p.M ? row0 + r : p.M - 1;   // rows past the end repeat the last one (never stored)
-    const uint16_t *xrow = p.X + m * p.ldx + 8 * h;
+    const uint16_t *xrow[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t m = row0 + 32 * rb + r < p.M ? row0 + 32 * rb + r : p.M - 1;   // rows past the end repeat the last one (never stored)
+        xrow[rb] = p.X + m * p.ldx + 8 * h;
+    }
     // The activation fragments travel TWO tiles ahead in two register sets, requested by inline asm: hipcc's own wait for a load that
     // has LDS-DMA requests behind it is s_waitcnt vmcnt(0) (it drains the weight ring at every tile), so the loads are hidden from it
-    // and the waits below are counted by hand.  Per tile a wave issues [4 fragment loads | 4 DMA] in that order (loads return in order).
-    bf16x8 abuf[2][4];
+    // and the waits below are counted by hand.  Per tile a wave issues [NA fragment loads | PW DMA] in that order (loads return in order).
+    bf16x8 abuf[2][RB][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) abuf[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_a = [&](int t, bf16x8 (&a)[4]) {
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) abuf[i][rb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_a = [&](int t, bf16x8 (&a)[RB][4]) {
         const int tt = ((t < T ? t : T - 1) + rot) % T;
-        const uint16_t *src = xrow + tt * 64;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(src) : "memory");   // "+v": IN PLACE -- an output the
-        // allocator is free to move would be copied (or reused, if dead) while the data is still on its way
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const uint16_t *src = xrow[rb] + tt * 64;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                         : "+v"(a[rb][0]), "+v"(a[rb][1]), "+v"(a[rb][2]), "+v"(a[rb][3]) : "v"(src) : "memory");   // "+v": IN PLACE -- an output the
+            // allocator is free to move would be copied (or reused, if dead) while the data is still on its way
+        }
     };
-    f32x16 yacc[8];
+    f32x16 yacc[RB][8];
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yacc[rb][cb][e] = 0.f;
     // request order of the steady state from the start: ... A(k - 1) D(k) ...
     issue(0, 0);
     load_a(0, abuf[0]); issue(1, 1);
     load_a(1, abuf[1]); issue(2, 2);
-    // tile 0 has landed once at most [A0 | D1 | A1 | D2] = 16 younger requests are in flight
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    auto tile = [&](int t, bf16x8 (&acur)[4]) {
+    // tile 0 has landed once at most [A0 | D1 | A1 | D2] younger requests are in flight
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NA + 2 * PW) : "memory");
+    auto tile = [&](int t, bf16x8 (&acur)[RB][4]) {
         const char *slot = lsm + (t % DEEP_NSLOT) * DEEP_TILE + h * (16 * 256) + r * 16;
-        // A(t) (requested two tiles ago, in front of D(t + 1)) has landed once at most [D(t+1) | A(t+1) | D(t+2)] = 12 are in flight; the
+        // A(t) (requested two tiles ago, in front of D(t + 1)) has landed once at most [D(t+1) | A(t+1) | D(t+2)] are in flight; the
         // fragments are operands of the wait so that no MFMA below moves in front of it
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(acur[0]), "+v"(acur[1]), "+v"(acur[2]), "+v"(acur[3])::"memory");
+        if constexpr (RB == 1)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(acur[0][0]), "+v"(acur[0][1]), "+v"(acur[0][2]), "+v"(acur[0][3]) : "n"(NA + 2 * PW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(acur[0][0]), "+v"(acur[0][1]), "+v"(acur[0][2]), "+v"(acur[0][3]), "+v"(acur[RB - 1][0]),
+                         "+v"(acur[RB - 1][1]), "+v"(acur[RB - 1][2]), "+v"(acur[RB - 1][3]) : "n"(NA + 2 * PW) : "memory");
         bf16x8 wa[2][8];
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) wa[0][cb] = *(const bf16x8 *)(slot + cb * 512);
@@ -993,45 +1017,56 @@ __global__ void __launch_bounds__(512, 2) deep256_kernel(DeepParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) yacc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][cb], acur[ks], yacc[cb], 0, 0, 0);
+            for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    yacc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][cb], acur[rb][ks], yacc[rb][cb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the set just consumed takes tile t + 2; then the DMA of tile t + 3 into the slot of tile t - 1 (everyone left it at the barrier
         // that ended that tile; issued BEHIND this tile's LDS reads: in front of them hipcc would order the reads after the DMA)
-        {   // (the MFMAs above must have READ acur before the loads overwrite it: they are in order on the wave; the asm's "+v" ties it)
-            asm volatile("" : "+v"(acur[0]), "+v"(acur[1]), "+v"(acur[2]), "+v"(acur[3]));
-            load_a(t + 2, acur);
-        }
+        load_a(t + 2, acur);
         issue(t + 3, (t + 3) % DEEP_NSLOT);
-        // tile t + 1's pieces (issued at tile t - 2) are followed by [A(t+1) | D(t+2) | A(t+2) | D(t+3)] = 16 requests
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // tile t + 1's pieces (issued at tile t - 2) are followed by [A(t+1) | D(t+2) | A(t+2) | D(t+3)]
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NA + 2 * PW) : "memory");
     };
     int t = 0;
     for (; t + 1 < T; t += 2) { tile(t, abuf[0]); tile(t + 1, abuf[1]); }
     if (t < T) tile(t, abuf[0]);
     // the trailing requests must not outlive the tile slots' reuse below -- nor their destination registers' (kept alive up to here)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::"v"(abuf[0][0]), "v"(abuf[0][1]), "v"(abuf[0][2]), "v"(abuf[0][3]), "v"(abuf[1][0]), "v"(abuf[1][1]),
-                 "v"(abuf[1][2]), "v"(abuf[1][3]) : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            asm volatile("" ::"v"(abuf[i][rb][0]), "v"(abuf[i][rb][1]), "v"(abuf[i][rb][2]), "v"(abuf[i][rb][3]));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            asm volatile("" ::"v"(abuf[i][rb][0]), "v"(abuf[i][rb][1]), "v"(abuf[i][rb][2]), "v"(abuf[i][rb][3]));
     // y = acc + bias, 64 columns at a time through this wave's staging rows (the tile slots are free now)
     uint16_t *stage = (uint16_t *)lsm + wave * (32 * SLD);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x16 &a = yacc[2 * q + half];
-            uint16_t *dst = stage + r * SLD + 32 * half;
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 bb = make_uint2(0u, 0u);
-                if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + 64 * q + 32 * half + 8 * g + 4 * h);
-                *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
-                                                             pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+            for (int half = 0; half < 2; ++half) {
+                const f32x16 &a = yacc[rb][2 * q + half];
+                uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 bb = make_uint2(0u, 0u);
+                    if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + 64 * q + 32 * half + 8 * g + 4 * h);
+                    *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                                 pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                }
             }
+            wave_lds_fence();
+            flush64(stage, p.Y + 64 * q, p.ldy, row0 + 32 * rb, p.M, lane);
+            wave_lds_fence();
         }
-        wave_lds_fence();
-        flush64(stage, p.Y + 64 * q, p.ldy, row0, p.M, lane);
-        wave_lds_fence();
-    }
 }
 }  // namespace mlp
 }  // namespace vsde
@@ -1051,8 +1086,15 @@ extern "C" int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *
     p.M = M; p.T = K / 64;
     { static int rot = -1; if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; } p.rotate = rot; }
     const size_t lds = (size_t)mlp::DEEP_NSLOT * mlp::DEEP_TILE;
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mlp::deep256_kernel, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, (hipStream_t)stream, p);
+    static int rb = -1;   // VSDE_DEEP256_RB=2: four waves x 64 rows (A/B runs); default: eight waves x 32 rows
+    if (rb < 0) { const char *e = getenv("VSDE_DEEP256_RB"); rb = (e && atoi(e) == 2) ? 2 : 1; }
+    if (rb == 1) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mlp::deep256_kernel<1>, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, (hipStream_t)stream, p);
+    } else {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mlp::deep256_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p);
+    }
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
