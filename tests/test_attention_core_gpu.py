@@ -244,6 +244,32 @@ def test_ring_forward_is_bit_identical_to_the_resident_forward(B, N, gated, monk
     assert torch.isfinite(o1.float()).all() and torch.equal(o0, o1) and torch.equal(l0, l1)
 
 
+@pytest.mark.parametrize("B,N,gated,boost", [(130, 401, True, 1.0), (130, 385, False, 1.0), (140, 416, True, 1.0), (130, 401, False, 2.5)])
+def test_eight_wave_forward_agrees_with_the_resident_forward(B, N, gated, boost, monkeypatch):
+    """The opt-in eight-wave persistent forward (VSDE_ATTN_FWD8=1, 385 .. 416 tokens: two waves per SIMD at 256 registers, K / V rows and
+    q fragments of the next pair requested by hand-counted asm loads under the tile loops, V row-major in LDS read through
+    ds_read_b64_tr_b16, the ragged 13th query block shared by four waves with fp32 partial tiles summed in fixed order) against the
+    default kernel: query blocks 0 .. 11 run the same arithmetic in the same order -- bit-identical rows; the shared block differs in
+    the order of its fp32 sums only.  boost > 1: scores past the range of the norm-bound softmax shift, i.e. the true-maximum pass."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(B + N)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV, torch.bfloat16)
+    q, k, v = (R(B, N, 4, 64).float() * boost).to(torch.bfloat16), (R(B, N, 4, 64).float() * boost).to(torch.bfloat16), R(B, N, 4, 64)
+    gate = torch.sigmoid(R(B * N, 64).float()).to(torch.bfloat16)
+    run = (lambda: _hip.attention_fwd_gated(q, k, v, gate, 0.125)) if gated else (lambda: _hip.attention_fwd(q, k, v, 0.125))
+    monkeypatch.delenv("VSDE_ATTN_RING", raising=False)
+    monkeypatch.delenv("VSDE_ATTN_FWD8", raising=False)
+    o0, l0 = run()
+    monkeypatch.setenv("VSDE_ATTN_FWD8", "1")
+    o1, l1 = run()
+    o2, l2 = run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2) and torch.equal(l1, l2)          # deterministic
+    assert torch.equal(o0[:, :384], o1[:, :384]) and torch.equal(l0[..., :384], l1[..., :384])
+    assert (o0[:, 384:].float() - o1[:, 384:].float()).abs().max().item() <= 2.0 ** -7 * max(1.0, o0[:, 384:].float().abs().max().item())
+    assert (l0[..., 384:] - l1[..., 384:]).abs().max().item() <= 1e-5 * max(1.0, l0.abs().max().item())
+
+
 def test_backward_kernel_variants_agree_on_every_output(tmp_path):
     """The fused attention backward with the ragged last block shared by four waves (default) against the same kernels with the lone
     second round (VSDE_ATTN_SPLIT=0): the variants differ only in the order of fp32 partial sums, so every output -- the one

@@ -54,6 +54,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *(uint32_t *)&r;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bfl(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfh(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -355,6 +357,391 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     }
 #undef VSDE_AT_STAMP
 #undef VSDE_FWD_STAGE
+}
+
+// (rare path of attn_fwd8_kernel) true row maxima of the scaled scores of a query block, as pass 1 of attn_fwd_kernel
+__device__ __forceinline__ float fwd8_true_max(const bf16x8 (&qf)[4], const uint16_t *Ks, int nkt, int N, bool ragged, int fr, int h2) {
+    float mx = -INFINITY;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uint16_t *krow = Ks + (kt * 32 + fr) * AT_KLD + h2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(krow + ks * 16), qf[ks], s, 0, 0, 0);
+        if (ragged && kt == nkt - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) s[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    }
+    const uint32_t u = __float_as_uint(mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the persistent forward on EIGHT waves for 385 .. 416 tokens (13 query blocks of 32: the benchmark's 401).  The phase stamps of
+// the twelve-wave kernel (tools/attn_trace.py, profiles/r05_attn_fwd_trace.txt) put 30 % of a pair into staging the next pair's K / V --
+// requested only when a wave is done, its HBM latency in front of everybody -- and 15 % into the blocks' q fragment loads; at 168
+// registers (three waves per SIMD) there is no room to request anything earlier.  Here a wave has 256 registers:
+//   * blocks: waves 0..3 own two query blocks (w, w + 8), waves 4..7 one (w) plus a QUARTER of the ragged 13th block's key tiles
+//     (partial O and row sums in spare LDS; the softmax shift is the Cauchy-Schwarz bound, the same for every sharer, so the partials
+//     just add) -- every SIMD runs 3.25 blocks;
+//   * a wave requests its share of the NEXT pair's K / V rows (7 + 8 x 16 bytes per lane) at the start of its LAST block and carries
+//     them through that block's tile loop; when the pair's barrier opens they have landed and go straight into LDS;
+//   * the q fragments of a wave's second block are requested under its first block's tile loop, those of the next pair's first block
+//     under the last one's;
+//   * the shared block's partials are summed (fixed order) by wave 4 between the two barriers of the pair boundary, its epilogue runs
+//     behind the second one.
+typedef short f8bf4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: within a 16-lane group, lane m supplies the address of 4 contiguous bf16 = row m / 4, columns 4 (m % 4) .. of a
+// [4][16] block, and lane i receives column i (rows 0..3)
+__device__ __forceinline__ uint2 f8_read_tr(const uint16_t *ptr) {
+    f8bf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f8bf4 *)ptr);
+    return *(uint2 *)&r;
+}
+
+template <bool TRACE>
+__global__ void __launch_bounds__(512, 1) attn_fwd8_kernel(AttnParams p) {
+    // TRACE (tools/attn_trace.py): per-wave cycle sums of workgroup 0: 0 = tile loops, 1 = block prologues (norms, requests),
+    // 2 = waits for requested rows, 3 = epilogues / partial sums, 4 = the pair's first barrier, 5 = LDS commit + second barrier
+    long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, last_ = 0, npairs_ = 0;   // (6 = issue of the staging requests)
+    if constexpr (TRACE) last_ = __builtin_readcyclecounter();
+#define VSDE_F8_STAMP(k_) do { if constexpr (TRACE) { const long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - last_; last_ = now_; } } while (0)
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
+    constexpr int NW = 8, PT = 512, KIT = (416 * 8 + PT - 1) / PT, NKT = 13;
+    uint16_t *Ks = asmem;                        // [npad][AT_KLD]
+    uint16_t *Vs = asmem + p.npad * AT_KLD;      // [npad][AT_KLD], row-major as in HBM: the PV product reads V^T with ds_read_b64_tr_b16
+    float *part = (float *)(asmem + 2 * p.npad * AT_KLD);   // [4 sharers][34][64]: 32 accumulator registers, row sum, shift
+    __shared__ float kred[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, npad = p.npad;
+    const int64_t ts = (int64_t)p.H * AT_D;
+    const uint32_t tsb = (uint32_t)ts * 2u;   // token stride in bytes
+    int fr = lane & 31, h2 = lane >> 5;
+    const bool ragged = (N & 31) != 0;
+    const float c2 = p.scale_log2e;
+    const int64_t nheads = p.pairs;
+    int64_t head = blockIdx.x;
+    // (batch, head) of the pair at hand, stepped by gridDim.x without a division per pair
+    int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
+    const int step_b = (int)(gridDim.x / p.H), step_h = (int)(gridDim.x - (unsigned)step_b * p.H);
+
+    // ---- one key-tile sweep of a query block: tiles kt0, kt0 + stride, ... (count of them), software-pipelined as in attn_fwd_kernel
+    // (hook(i): called in front of steps i = 0, 2, 4, ...: the first block's sweep requests the next pair's rows there, one K and one V
+    //  instruction per two steps -- 8 waves x 14 instructions at the top of the pair queue up in the memory pipeline and every wave
+    //  stalls at issue behind them)
+    auto sweep = [&](const bf16x8 (&qf)[4], float mc, int kt0, int stride, int count, f32x16 &o0, f32x16 &o1, float &lsum_out, auto &&hook) {
+        f32x2 lsum2v = {0.f, 0.f};
+        f32x16 sa = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sb = sa;
+        auto score = [&](int kt, f32x16 &s) {
+            const uint16_t *krow = Ks + (kt * 32 + fr) * AT_KLD + h2 * 8;
+            f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(krow + ks * 16), qf[ks], t, 0, 0, 0);
+            s = t;
+        };
+        auto step = [&](f32x16 &scur, f32x16 &snxt, int kt, int ktn) {
+            const uint16_t *krow = Ks + (ktn * 32 + fr) * AT_KLD + h2 * 8;
+            bf16x8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8 *)(krow + ks * 16);
+            // V^T fragments (row = channel dt * 32 + fr, k = the keys 4 h2 + {0..3, 8..11 | 16..19, 24..27} of the tile, the order of P's
+            // registers) out of the row-major tile by the transposing read: see accumulate_transposed below
+            uint2 vf[8];
+            const uint16_t *vsrc = Vs + (kt * 32 + 4 * h2 + ((fr & 15) >> 2)) * AT_KLD + ((fr >> 4) & 1) * 16 + (fr & 3) * 4;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) vf[dt * 4 + x] = f8_read_tr(vsrc + dt * 32 + x * 8 * AT_KLD);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ragged && kt == NKT - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) scur[r] = -INFINITY;
+            }
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {   // v_pk_fma_f32 / v_pk_add_f32: two scores per VALU instruction
+                const f32x2 arg = __builtin_elementwise_fma(f32x2{scur[r], scur[r + 1]}, f32x2{c2, c2}, f32x2{-mc, -mc});
+                pr[r] = fast_exp2(arg[0]); pr[r + 1] = fast_exp2(arg[1]);
+                lsum2v += f32x2{pr[r], pr[r + 1]};
+            }
+            uint4 pw0 = make_uint4(pack_bf16(pr[0], pr[1]), pack_bf16(pr[2], pr[3]), pack_bf16(pr[4], pr[5]), pack_bf16(pr[6], pr[7]));
+            uint4 pw1 = make_uint4(pack_bf16(pr[8], pr[9]), pack_bf16(pr[10], pr[11]), pack_bf16(pr[12], pr[13]), pack_bf16(pr[14], pr[15]));
+            const bf16x8 pb0 = *(bf16x8 *)&pw0, pb1 = *(bf16x8 *)&pw1;
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 t = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], t, 0, 0, 0);
+            snxt = t;
+            uint4 aw;
+            aw = make_uint4(vf[0].x, vf[0].y, vf[1].x, vf[1].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o0, 0, 0, 0);
+            aw = make_uint4(vf[4].x, vf[4].y, vf[5].x, vf[5].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb0, o1, 0, 0, 0);
+            aw = make_uint4(vf[2].x, vf[2].y, vf[3].x, vf[3].y); o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o0, 0, 0, 0);
+            aw = make_uint4(vf[6].x, vf[6].y, vf[7].x, vf[7].y); o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&aw, pb1, o1, 0, 0, 0);
+        };
+        score(kt0, sa);
+        for (int i = 0; i < count; i += 2) {
+            const int kt = kt0 + i * stride, k1 = kt + stride, k2 = k1 + stride;
+            hook(i);
+            step(sa, sb, kt, i + 1 < count ? k1 : kt);          // (the last step recomputes its own tile: result unused)
+            if (i + 1 < count) step(sb, sa, k1, i + 2 < count ? k2 : k1);
+        }
+        lsum_out = lsum2v[0] + lsum2v[1];
+    };
+    // q fragments of query block qblk of a pair (rows past N: zero).  asm loads, not counted by the compiler (see request_next below):
+    // the caller waits by hand (landed()) before the first use
+    auto load_q = [&](const uint16_t *qb, int qblk, bf16x8 (&qf)[4]) {
+        // no branch around an asm load: a phi behind it makes the compiler COPY the registers the load has not written yet.  Rows past
+        // N read row N - 1 (their results are never stored)
+        const uint32_t off = (uint32_t)min(qblk * 32 + fr, N - 1) * tsb + (uint32_t)h2 * 16u;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(qf[ks]) : "v"(off), "s"(qb), "n"(ks * 32) : "memory");
+        }
+    };
+    // (behind them in the queue: the 2 x KIT staging loads of request())
+    auto landed = [&](bf16x8 (&qf)[4]) { asm volatile("s_waitcnt vmcnt(14)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])); };
+    auto q_shift = [&](const bf16x8 (&qf)[4], float kmax) {   // |q| max|k| x 1.0001 >= every score of this query (softmax shift)
+        float qss = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 t = *(const uint4 *)&qf[ks];
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                qss = fmaf(lo, lo, fmaf(hi, hi, qss));
+            }
+        }
+        qss = sum_xor32(qss);
+        return sqrtf(qss) * kmax * 1.0001f;
+    };
+    // epilogue of one query block: gate, normalisation, head-merged store, log-sum-exp
+    auto finish = [&](int b, int hh, int64_t base, int qblk, f32x16 &o0, f32x16 &o1, float lsum, float mx) {
+        const int query = qblk * 32 + fr;
+        lsum = sum_xor32(lsum);
+        if (query < N) {
+            const float inv = 1.0f / lsum;
+            uint16_t *orow = p.o + base + query * ts;
+            if (p.gate != nullptr) {
+                const uint16_t *grow = p.gate + ((int64_t)b * N + query) * p.ldg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 8 * g + 4 * h2;
+                    const uint2 ga = *(const uint2 *)(grow + d0), gb = *(const uint2 *)(grow + 32 + d0);
+                    const float sa[4] = {bfl(ga.x), bfh(ga.x), bfl(ga.y), bfh(ga.y)};
+                    const float sb[4] = {bfl(gb.x), bfh(gb.x), bfl(gb.y), bfh(gb.y)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o0[4 * g + i] *= sa[i]; o1[4 * g + i] *= sb[i]; }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 8 * g + 4 * h2;
+                *(uint2 *)(orow + d0) = make_uint2(pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+                *(uint2 *)(orow + 32 + d0) = make_uint2(pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+            }
+            if (h2 == 0) p.lse[((int64_t)b * p.H + hh) * N + query] = mx * p.scale + __logf(lsum);
+        }
+    };
+
+    // ---- staging registers: K and V rows as 16-byte chunks (8 adjacent lanes = one 128-byte row), requested by asm loads the compiler
+    // does not count (its own wait for a load with a tile loop between request and use is vmcnt(0) in FRONT of the loop), kept in place
+    // until the hand-written wait (staged()).  No branch around an asm load: a phi behind it makes the compiler COPY registers the
+    // load has not written yet; rows past N read row N - 1 (masked keys, never-stored queries)
+    u32x4 kq[KIT], vq[KIT];
+    bf16x8 qnext[4];   // the q fragments of the wave's first block of the next pair
+    static_assert(KIT == 7, "the hand-written wait names the staging registers");
+    // (addresses: wave-uniform pair base in SGPRs + a 32-bit byte offset per lane -- the launcher checks that a pair's rows span < 2 GB)
+    auto request = [&](int64_t base_, int it) {   // instruction pair `it` of KIT: 16 bytes of a K row and of the same V row per lane
+        int pt = tid;
+        asm volatile("" : "+v"(pt));   // staging addresses are recomputed where they are used, not kept (spilled) across the tile loops
+        const uint16_t *kb = p.k + base_, *vb = p.v + base_;
+        const int i = pt + it * PT;
+        const uint32_t off = (uint32_t)min(i >> 3, N - 1) * tsb + (uint32_t)(i & 7) * 16u;
+#define VSDE_F8_REQ(IT_) case IT_: \
+            kq[IT_] = u32x4{0u, 0u, 0u, 0u}; vq[IT_] = u32x4{0u, 0u, 0u, 0u}; \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(kq[IT_]) : "v"(off), "s"(kb) : "memory"); \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(vq[IT_]) : "v"(off), "s"(vb) : "memory"); break;
+        switch (it) { VSDE_F8_REQ(0) VSDE_F8_REQ(1) VSDE_F8_REQ(2) VSDE_F8_REQ(3) VSDE_F8_REQ(4) VSDE_F8_REQ(5) VSDE_F8_REQ(6) default: break; }
+#undef VSDE_F8_REQ
+    };
+    auto staged = [&]() {   // behind the wave's last tile loop, in front of its stores (which a vmcnt wait would also cover)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(kq[0]), "+v"(kq[1]), "+v"(kq[2]), "+v"(kq[3]), "+v"(kq[4]), "+v"(kq[5]), "+v"(kq[6]));
+        asm volatile("" : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]));
+        asm volatile("" : "+v"(qnext[0]), "+v"(qnext[1]), "+v"(qnext[2]), "+v"(qnext[3]));
+    };
+    // ... and their way into LDS; the wave's maximum squared key norm goes to kred[wave] (the softmax shift needs max_j |k_j|)
+    auto commit = [&]() {
+        int pt = tid;
+        asm volatile("" : "+v"(pt));
+        float kss_max = 0.f;
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int i = pt + it * PT, n = i >> 3, c = i & 7;
+            if (i < npad * 8) {
+                *(u32x4 *)(Ks + n * AT_KLD + c * 8) = kq[it];
+                *(u32x4 *)(Vs + n * AT_KLD + c * 8) = vq[it];
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(kq[it][e] << 16), hi = __uint_as_float(kq[it][e] & 0xffff0000u);
+                ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+            }
+            ss += xor_lane<1>(ss); ss += xor_lane<2>(ss); ss += xor_lane<4>(ss);
+            kss_max = fmaxf(kss_max, ss);
+        }
+        kss_max = fmaxf(kss_max, xor_lane<8>(kss_max)); kss_max = fmaxf(kss_max, xor_lane<16>(kss_max));
+        const uint32_t u = __float_as_uint(kss_max);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        kss_max = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        if (lane == 0) kred[wave] = kss_max;
+    };
+    // ---- first pair
+    {
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) request(((int64_t)b * N * p.H + hh) * AT_D, it);
+        load_q(p.q + ((int64_t)b * N * p.H + hh) * AT_D, wave, qnext);
+        staged();
+        commit();
+        __syncthreads();
+    }
+    while (true) {
+        const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
+        const uint16_t *qb = p.q + base;
+        asm volatile("" : "+v"(fr), "+v"(h2));   // (see attn_fwd_kernel: keeps the tile loops' LDS addresses from being hoisted and spilled)
+        float kss_max = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) kss_max = fmaxf(kss_max, kred[w]);
+        const float kmax = sqrtf(kss_max);
+        const int64_t next = head + gridDim.x;
+        const bool has_next = next < nheads;
+        int nb = b + step_b, nh = hh + step_h;
+        if (nh >= p.H) { nh -= p.H; ++nb; }
+        const int64_t nbase = has_next ? ((int64_t)nb * N * p.H + nh) * AT_D : base;
+        // the next pair's K / V rows are requested at the TOP of the pair, by every wave, right behind the second block's q fragments
+        // (which are needed first: loads return in order) -- the CU takes in ~13 bytes per clock, 103 KB are 8 k cycles that have to
+        // run under the whole pair's tile loops, not under the last block's
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
+        const bool two = wave < 4;                           // waves 0..3: blocks w and w + 8; waves 4..7: block w and a quarter of block 12
+        f32x16 o0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, o1 = o0;
+        float lsum = 0.f;
+        if (two) {
+            // ---- first block; the second block's q fragments fly under its tile loop
+            float mx = q_shift(qf, kmax);
+            const bool exact = !__all(mx * c2 <= 40.0f);
+            load_q(qb, wave + 8, qnext);
+            VSDE_F8_STAMP(1);
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) request(nbase, it);
+            VSDE_F8_STAMP(6);
+            if (exact) mx = fwd8_true_max(qf, Ks, NKT, N, ragged, fr, h2);
+            VSDE_F8_STAMP(1);
+            sweep(qf, mx * c2, 0, 1, NKT, o0, o1, lsum, [](int) {});
+            VSDE_F8_STAMP(0);
+            landed(qnext);
+            VSDE_F8_STAMP(2);
+            finish(b, hh, base, wave, o0, o1, lsum, mx);
+            VSDE_F8_STAMP(3);
+            // ---- second (last) block: the next pair's K / V and first q fragments fly under its tile loop
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
+            load_q(p.q + nbase, wave, qnext);
+            mx = q_shift(qf, kmax);
+            const bool exact2 = !__all(mx * c2 <= 40.0f);
+            if (exact2) mx = fwd8_true_max(qf, Ks, NKT, N, ragged, fr, h2);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+            VSDE_F8_STAMP(1);
+            sweep(qf, mx * c2, 0, 1, NKT, o0, o1, lsum, [](int) {});
+            VSDE_F8_STAMP(0);
+            staged();
+            VSDE_F8_STAMP(2);
+            finish(b, hh, base, wave + 8, o0, o1, lsum, mx);
+        } else {
+            // ---- own block; the shared block's q fragments fly under its tile loop
+            float mx = q_shift(qf, kmax);
+            const bool exact = !__all(mx * c2 <= 40.0f);
+            bf16x8 qs[4];
+            load_q(qb, 12, qs);
+            VSDE_F8_STAMP(1);
+#pragma unroll
+            for (int it = 0; it < KIT; ++it) request(nbase, it);
+            VSDE_F8_STAMP(6);
+            if (exact) mx = fwd8_true_max(qf, Ks, NKT, N, ragged, fr, h2);
+            VSDE_F8_STAMP(1);
+            sweep(qf, mx * c2, 0, 1, NKT, o0, o1, lsum, [](int) {});
+            VSDE_F8_STAMP(0);
+            landed(qs);
+            VSDE_F8_STAMP(2);
+            finish(b, hh, base, wave, o0, o1, lsum, mx);
+            VSDE_F8_STAMP(3);
+            // ---- a quarter of the ragged block's key tiles (tiles w - 4, w, w + 4, ...): partial sums into LDS.  Last: the next pair's
+            // operands fly under it
+            load_q(p.q + nbase, wave, qnext);
+            float mxs = q_shift(qs, kmax);
+            const bool exacts = !__all(mxs * c2 <= 40.0f);   // (the same for every sharer: same rows, same kmax)
+            const int s4 = wave - 4;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+            float ls = 0.f;
+            if (exacts) {   // rare: one sharer takes the whole block with the true maxima, the others contribute zeros
+                if (s4 == 0) { mxs = fwd8_true_max(qs, Ks, NKT, N, ragged, fr, h2); VSDE_F8_STAMP(1); sweep(qs, mxs * c2, 0, 1, NKT, o0, o1, ls, [](int) {}); VSDE_F8_STAMP(0); }
+            } else {
+                VSDE_F8_STAMP(1);
+                sweep(qs, mxs * c2, s4, 4, (NKT - s4 + 3) / 4, o0, o1, ls, [](int) {});
+                VSDE_F8_STAMP(0);
+            }
+            staged();
+            VSDE_F8_STAMP(2);
+            float *pp = part + (s4 * 34) * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { pp[e * 64] = o0[e]; pp[(16 + e) * 64] = o1[e]; }
+            pp[32 * 64] = ls;
+            if (s4 == 0) pp[33 * 64] = mxs;
+        }
+        VSDE_F8_STAMP(3);
+        __syncthreads();   // everyone is done with this pair's K / V; the partials are complete
+        VSDE_F8_STAMP(4);
+        if (has_next) {
+            commit();
+            __syncthreads();
+        }
+        VSDE_F8_STAMP(5);
+        if (wave == 4) {   // fixed-order sum of the four partial tiles and the shared block's epilogue, behind the staging barrier (nobody
+                           // writes a partial tile again before the end of the next pair's tile loops)
+            f32x16 r0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r1 = r0;
+            float rl = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float *pp = part + (s4 * 34) * 64 + lane;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { r0[e] += pp[e * 64]; r1[e] += pp[(16 + e) * 64]; }
+                rl += pp[32 * 64];
+            }
+            finish(b, hh, base, 12, r0, r1, rl, part[33 * 64 + lane]);
+        }
+        if constexpr (TRACE) ++npairs_;
+        if (!has_next) break;
+        head = next; b = nb; hh = nh;
+    }
+    if constexpr (TRACE) {
+        VSDE_F8_STAMP(3);
+        if (blockIdx.x == 0 && lane == 0 && p.trace) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) p.trace[wave * 8 + k] = ph[k];
+            p.trace[wave * 8 + 7] = npairs_;
+        }
+    }
+#undef VSDE_F8_STAMP
 }
 
 // ===================================================================================== backward
@@ -1556,13 +1943,17 @@ static int attn_cus() {
 // forward launch: persistent workgroups (one per CU, next pair's operands requested behind the 13th query block) when a pair
 // has at most 13 query blocks and there are at least two pairs per CU; one workgroup per pair otherwise
 static long long *g_attn_trace = nullptr;
+static bool fwd8_enabled() {   // VSDE_ATTN_FWD8=1: the eight-wave persistent forward for 385 .. 416 tokens (read per launch: tests toggle it)
+    const char *e = getenv("VSDE_ATTN_FWD8");
+    return e != nullptr && e[0] == '1';
+}
 static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hipStream_t stream) {
     const int cus = attn_cus();
     const size_t lds = lds_kv, lds_p = lds_kv;
     AttnParams q = p;
     q.pairs = pairs;
     q.trace = g_attn_trace;
-    if (g_attn_trace && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // phase stamps (tools/attn_trace.py)
+    if (g_attn_trace && !(fwd8_enabled() && p.npad == 416) && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // phase stamps (tools/attn_trace.py)
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
         hipLaunchKernelGGL((attn_fwd_kernel<true, 16>), dim3((unsigned)cus), dim3(768), lds_p, stream, q);
         VSDE_CHECK_HIP(hipGetLastError());
@@ -1587,6 +1978,15 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hi
         const size_t ring = (size_t)2 * RG_SLOTS * RG_TILE * sizeof(uint16_t);
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring));
         hipLaunchKernelGGL(attn_fwd_ring_kernel, dim3((unsigned)cus), dim3(64 * RG_NW), ring, stream, q);
+    } else if (fwd8_enabled() && p.npad == 416 && (int64_t)p.N * p.H * AT_D * 2 < (1LL << 31) && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
+        const size_t lds8 = (size_t)2 * p.npad * AT_KLD * sizeof(uint16_t) + (size_t)4 * 34 * 64 * sizeof(float);
+        if (g_attn_trace) {
+            VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            hipLaunchKernelGGL(attn_fwd8_kernel<true>, dim3((unsigned)cus), dim3(512), lds8, stream, q);
+        } else {
+            VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            hipLaunchKernelGGL(attn_fwd8_kernel<false>, dim3((unsigned)cus), dim3(512), lds8, stream, q);
+        }
     } else if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds_p, stream, q);
