@@ -59,26 +59,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bfl(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfh(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// the staging loads of one (batch, head) pair into registers: K rows as 16-byte chunks (8 adjacent lanes = one 128-byte row), V
-// as 8 x 8 blocks (8 keys x 16 bytes per thread) for the in-register transpose; staging thread pt of PT
-template <int KIT, int VIT>
-__device__ __forceinline__ void fwd_request(uint4 (&kreg)[KIT], uint4 (&vreg)[VIT][8], const AttnParams &p, int64_t head, int pt, int PT,
+typedef short f8bf4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: within a 16-lane group, lane m supplies the address of 4 contiguous bf16 = row m / 4, columns 4 (m % 4) .. of a
+// [4][16] block, and lane i receives column i (rows 0..3)
+__device__ __forceinline__ uint2 f8_read_tr(const uint16_t *ptr) {
+    f8bf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f8bf4 *)ptr);
+    return *(uint2 *)&r;
+}
+
+// the staging loads of one (batch, head) pair into registers: K and V rows as 16-byte chunks (8 adjacent lanes = one 128-byte row);
+// staging thread pt of PT; base_ = element offset of the pair's first row
+template <int KIT>
+__device__ __forceinline__ void fwd_request(uint4 (&kreg)[KIT], uint4 (&vreg)[KIT], const AttnParams &p, int64_t base_, int pt, int PT,
                                             bool stager, int N, int npad, int64_t ts) {
-    const int64_t hb = head / p.H, base_ = (hb * N * p.H + (head - hb * p.H)) * AT_D;
     const uint16_t *kb = p.k + base_, *vb = p.v + base_;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int i = pt + it * PT, n = i >> 3, c = i & 7;
-        kreg[it] = (stager && i < npad * 8 && n < N) ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {  // (npad/8 key blocks) x (8 d-chunks); lanes c = 0..7 read one full 128-byte row
-        const int i = pt + it * PT, kblk = i >> 3, c = i & 7;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = kblk * 8 + j;
-            vreg[it][j] = (stager && i < npad && n < N) ? *(const uint4 *)(vb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
-        }
+        const bool ok = stager && i < npad * 8 && n < N;
+        kreg[it] = ok ? *(const uint4 *)(kb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
+        vreg[it] = ok ? *(const uint4 *)(vb + n * ts + c * 8) : make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -88,16 +88,20 @@ __device__ __forceinline__ void fwd_request(uint4 (&kreg)[KIT], uint4 (&vreg)[VI
 // been stored) and parks at the barrier; the wave that owns the 13th block is still computing then, so the HBM latency and part of
 // the transfer of the next pair's operands run behind it instead of in front of everybody.  Only the waves without a second
 // block stage (704 of 768 threads at N = 401).
-// ... and their way into LDS: K rows as they are ([key][AT_KLD]), V through the in-register 8 x 8 transpose as V^T [d][vld]; the
-// wave's maximum squared key norm goes to kred[wave] (the softmax shift needs max_j |k_j|)
-template <int KIT, int VIT>
-__device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vreg)[VIT][8], uint16_t *Ks, uint16_t *Vt, float *kred, int pt,
-                                           int PT, bool stager, int npad, int vld, int lane, int wave) {
+// ... and their way into LDS, both row-major as they are ([key][AT_KLD]; round 5: V used to go through an in-register 8 x 8 transpose
+// into a V^T image -- the PV product now reads its V^T fragments out of the row-major tile with ds_read_b64_tr_b16); the wave's
+// maximum squared key norm goes to kred[wave] (the softmax shift needs max_j |k_j|)
+template <int KIT>
+__device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], const uint4 (&vreg)[KIT], uint16_t *Ks, uint16_t *Vs, float *kred, int pt,
+                                           int PT, bool stager, int npad, int lane, int wave) {
     float kss_max = 0.f;  // max_j |k_j|^2 (8 adjacent lanes hold one key row)
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int i = pt + it * PT, n = i >> 3, c = i & 7;
-        if (stager && i < npad * 8) *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
+        if (stager && i < npad * 8) {
+            *(uint4 *)(Ks + n * AT_KLD + c * 8) = kreg[it];
+            *(uint4 *)(Vs + n * AT_KLD + c * 8) = vreg[it];
+        }
         const uint32_t w[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
         float ss = 0.f;
 #pragma unroll
@@ -115,20 +119,6 @@ __device__ __forceinline__ void fwd_commit(const uint4 (&kreg)[KIT], uint4 (&vre
         kss_max = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
     if (lane == 0) kred[wave] = kss_max;
-#pragma unroll
-    for (int it = 0; it < VIT; ++it) {
-        const int i = pt + it * PT, kblk = i >> 3, c = i & 7;
-        uint4 ct[8];
-        transpose8x8(vreg[it], ct);
-        if (stager && i < npad) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {  // row d = c*8+j holds keys kblk*8 .. +7; rows are only 8-byte aligned (vld = 4 mod 8)
-                uint2 *dst = (uint2 *)(Vt + (c * 8 + j) * vld + kblk * 8);
-                dst[0] = make_uint2(ct[j].x, ct[j].y);
-                dst[1] = make_uint2(ct[j].z, ct[j].w);
-            }
-        }
-    }
 }
 
 // ABL: timing-only ablations of the tile loop's VALU work (results are wrong): 1 = exponentials of the raw scores (no scale / shift
@@ -138,9 +128,9 @@ template <bool PERSIST, int ABL = 0, int NT = 768>
 __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     uint16_t *Ks = asmem;                      // [npad][AT_KLD]
-    uint16_t *Vt = asmem + p.npad * AT_KLD;    // [64][vld]
+    uint16_t *Vs = asmem + p.npad * AT_KLD;    // [npad][AT_KLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.N, npad = p.npad, vld = p.vld;
+    const int N = p.N, npad = p.npad;
     const int64_t ts = (int64_t)p.H * AT_D;    // token stride in elements
     constexpr int NW = NT / 64, MAXN = NT == 768 ? AT_MAXN : 128;
     static_assert(NT == 768 || !PERSIST, "the persistent form is built for 12-wave workgroups");
@@ -150,17 +140,16 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     const bool stager = pt >= 0;
     // ---- staging of K [key][d] and V^T [d][key]: every global load is issued before the first use; the staging registers live
     // only inside VSDE_FWD_STAGE (a loop-carried register set is spilled across the tile loop by hipcc)
-    constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (MAXN * 8 + NT - 1) / NT, VIT = PERSIST ? 1 : (MAXN + NT - 1) / NT;
+    constexpr int KIT = PERSIST ? (416 * 8 + 703) / 704 : (MAXN * 8 + NT - 1) / NT;
     __shared__ float kred[NW];
     // the wave's first query block of a pair: one dword of each of its 64-byte half rows is touched together with the pair's K / V
     // requests, so that the fragment loads after the barrier are served by the cache (the fragments themselves, requested here,
     // are spilled: 16 more registers do not fit beside the staging's)
     uint32_t qtouch = 0u;
-    auto touch_q = [&](int64_t head_) {
+    auto touch_q = [&](int64_t base_) {
         int ln = tid & 63;
         asm volatile("" : "+v"(ln));
         const int pq = wave * 32 + (ln & 31);
-        const int64_t hb = head_ / p.H, base_ = (hb * N * p.H + (head_ - hb * p.H)) * AT_D;
         qtouch = *(const uint32_t *)(p.q + base_ + (pq < N ? pq : N - 1) * ts + (ln >> 5) * 32);
     };
     // (Round 5, tools/attn_trace.py: per pair of ~36 k cycles the tile loops take 16 k, the staging 11 k, the blocks' prologues -- the
@@ -169,26 +158,28 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     //  registers do not fit anywhere around the tile loop.  Second form: the q rows by LDS-DMA into 4 KB per wave behind K and V^T (a
     //  swizzled [32][8 x 16 B] image, conflict-free fragment reads), requested when the wave is done with the previous pair: 19 spilled
     //  registers for its addressing, 203 vs 175 us.  The kernel sits at its 168-register cap; both dropped.)
-#define VSDE_FWD_STAGE(head_, first_)                                                                          \
+#define VSDE_FWD_STAGE(base_, first_)                                                                          \
     do {                                                                                                       \
-        uint4 kreg[KIT], vreg[VIT][8];                                                                         \
+        uint4 kreg[KIT], vreg[KIT];                                                                            \
         asm volatile("" : "+v"(pt));   /* staging addresses are recomputed per pair, not kept across the tile loop */ \
-        touch_q(head_);                                                                                        \
-        fwd_request<KIT, VIT>(kreg, vreg, p, (head_), pt, PT, stager, N, npad, ts);                            \
+        touch_q(base_);                                                                                        \
+        fwd_request<KIT>(kreg, vreg, p, (base_), pt, PT, stager, N, npad, ts);                                 \
         if (!(first_)) __syncthreads();   /* everyone is done with the previous pair's K / V */               \
-        fwd_commit<KIT, VIT>(kreg, vreg, Ks, Vt, kred, pt, PT, stager, npad, vld, lane, wave);                 \
+        fwd_commit<KIT>(kreg, vreg, Ks, Vs, kred, pt, PT, stager, npad, lane, wave);                           \
         __syncthreads();                                                                                       \
         asm volatile("" ::"v"(qtouch));                                                                        \
     } while (0)
     const int64_t nheads = p.pairs;              // total (batch, head) pairs
     int64_t head = blockIdx.x;
+    // (batch, head) of the pair at hand: stepped by gridDim.x, no 64-bit division per pair and wave
+    int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
+    const int step_b = PERSIST ? (int)(gridDim.x / p.H) : 0, step_h = PERSIST ? (int)(gridDim.x - (unsigned)step_b * p.H) : 0;
     long long ph[4] = {0, 0, 0, 0}, last_ = 0, npairs_ = 0;
     if constexpr ((ABL & 16) != 0) last_ = __builtin_readcyclecounter();
 #define VSDE_AT_STAMP(k_) do { if constexpr ((ABL & 16) != 0) { const long long now_ = __builtin_readcyclecounter(); ph[k_] += now_ - last_; last_ = now_; } } while (0)
-    VSDE_FWD_STAGE(head, true);
+    VSDE_FWD_STAGE(((int64_t)b * N * p.H + hh) * AT_D, true);
     VSDE_AT_STAMP(0);
   while (true) {
-    const int b = (int)(head / p.H), hh = (int)(head - (int64_t)b * p.H);
     const int64_t base = ((int64_t)b * N * p.H + hh) * AT_D;
     const uint16_t *qb = p.q + base;
     float kss_max = 0.f;
@@ -197,6 +188,8 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     const float kmax = sqrtf(kss_max);
     const int64_t next = head + gridDim.x;
     const bool has_next = PERSIST && next < nheads;
+    int nb = b + step_b, nh = hh + step_h;
+    if (nh >= p.H) { nh -= p.H; ++nb; }
 
     int fr = lane & 31, h2 = lane >> 5;
     // PERSIST: every LDS address of the tile loop below is invariant across the pair loop; hoisted out of it (LICM) they fill the
@@ -263,13 +256,14 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
             bf16x8 kf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8 *)(krow + ks * 16);
+            // V^T fragments (row = channel dt * 32 + fr, k = the keys 4 h2 + {0..3, 8..11 | 16..19, 24..27} of the tile, the order of P's
+            // registers) out of the row-major tile by the transposing read (see accumulate_transposed)
             uint2 vf[8];
+            const uint16_t *vsrc = Vs + (kt * 32 + 4 * h2 + ((fr & 15) >> 2)) * AT_KLD + ((fr >> 4) & 1) * 16 + (fr & 3) * 4;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const uint16_t *vrow = Vt + (dt * 32 + fr) * vld + kt * 32 + 4 * h2;
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) vf[dt * 4 + x] = *(const uint2 *)(vrow + 8 * x);
-            }
+                for (int x = 0; x < 4; ++x) vf[dt * 4 + x] = f8_read_tr(vsrc + dt * 32 + x * 8 * AT_KLD);
             __builtin_amdgcn_sched_barrier(0);
             if (ragged && kt == nkt - 1) {
 #pragma unroll
@@ -344,9 +338,9 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     if (!has_next) break;
     // this wave is done with the current pair: its share of the next pair's K / V is requested NOW (a wave with a second block
     // has pt < 0: no loads) and lands while the wave that owns the 13th block is still computing
-    VSDE_FWD_STAGE(next, false);
+    VSDE_FWD_STAGE(((int64_t)nb * N * p.H + nh) * AT_D, false);
     VSDE_AT_STAMP(0);
-    head = next;
+    head = next; b = nb; hh = nh;
   }
     if constexpr ((ABL & 16) != 0) {
         if (blockIdx.x == 0 && lane == 0 && p.trace) {
@@ -395,14 +389,6 @@ __device__ __forceinline__ float fwd8_true_max(const bf16x8 (&qf)[4], const uint
 //     under the last one's;
 //   * the shared block's partials are summed (fixed order) by wave 4 between the two barriers of the pair boundary, its epilogue runs
 //     behind the second one.
-typedef short f8bf4 __attribute__((ext_vector_type(4)));
-// ds_read_b64_tr_b16: within a 16-lane group, lane m supplies the address of 4 contiguous bf16 = row m / 4, columns 4 (m % 4) .. of a
-// [4][16] block, and lane i receives column i (rows 0..3)
-__device__ __forceinline__ uint2 f8_read_tr(const uint16_t *ptr) {
-    f8bf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f8bf4 *)ptr);
-    return *(uint2 *)&r;
-}
-
 template <bool TRACE>
 __global__ void __launch_bounds__(512, 1) attn_fwd8_kernel(AttnParams p) {
     // TRACE (tools/attn_trace.py): per-wave cycle sums of workgroup 0: 0 = tile loops, 1 = block prologues (norms, requests),
@@ -2014,7 +2000,7 @@ extern "C" int vsde_attention_fwd_bf16(const void *q, const void *k, const void 
     p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     p.gate = nullptr; p.ldg = 0;
-    const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * p.npad * AT_KLD * sizeof(uint16_t);   // K and V, row-major
     return launch_attn_fwd(p, B * H, lds, (hipStream_t)stream);
 }
 
@@ -2056,7 +2042,7 @@ extern "C" int vsde_attention_fwd_gated_bf16(const void *q, const void *k, const
     p.N = N; p.H = H; p.npad = (N + 31) & ~31; p.vld = p.npad + 4;
     p.scale = (float)scale; p.scale_log2e = (float)(scale * 1.4426950408889634);
     p.gate = (const uint16_t *)gate; p.ldg = ldg;
-    const size_t lds = ((size_t)p.npad * AT_KLD + (size_t)AT_D * p.vld) * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * p.npad * AT_KLD * sizeof(uint16_t);   // K and V, row-major
     return launch_attn_fwd(p, B * H, lds, (hipStream_t)stream);
 }
 
