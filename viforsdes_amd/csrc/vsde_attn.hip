@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(NT, 768 / NT) attn_fwd_kernel(AttnParams p) {
     //  the staging commit, in front of the barrier every wave waits at anyway, cost 26 spilled registers and 20 % of the kernel: the 16
     //  registers do not fit anywhere around the tile loop.  Second form: the q rows by LDS-DMA into 4 KB per wave behind K and V^T (a
     //  swizzled [32][8 x 16 B] image, conflict-free fragment reads), requested when the wave is done with the previous pair: 19 spilled
-    //  registers for its addressing, 203 vs 175 us.  The kernel sits at its 168-register cap; both dropped.)
+    //  registers for its addressing, 203 vs 175 us.  The kernel sits at its 168-register cap; both dropped.  Third attempt, after V
+    //  went row-major into LDS (40 staging registers instead of 52 + 32 for the transposes): fragments requested behind the commit and
+    //  carried into the block loop -- 14 spilled registers around the staging phase, 192 vs 168 us.)
 #define VSDE_FWD_STAGE(base_, first_)                                                                          \
     do {                                                                                                       \
         uint4 kreg[KIT], vreg[KIT];                                                                            \
