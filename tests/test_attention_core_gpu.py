@@ -270,6 +270,25 @@ def test_eight_wave_forward_agrees_with_the_resident_forward(B, N, gated, boost,
     assert (l0[..., 384:] - l1[..., 384:]).abs().max().item() <= 1e-5 * max(1.0, l0.abs().max().item())
 
 
+@pytest.mark.parametrize("B,N", [(40, 401), (24, 512), (40, 384), (30, 160)])
+def test_wide_dq_kernel_is_bit_identical_in_the_unfused_backward(B, N, monkeypatch):
+    """The opt-in dq kernel with 64 queries per wave (VSDE_ATTN_DQ_WIDE=1: eight waves, a key tile's fragments read once for two query
+    blocks) does the default kernel's arithmetic per element in the same order: dq, dk, dv must agree bit for bit (unfused API:
+    no shared ragged block on either side)."""
+    from viforsdes_amd import _hip
+    g = torch.Generator().manual_seed(B + N)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV, torch.bfloat16)
+    q, k, v, go = R(B, N, 4, 64), R(B, N, 4, 64), R(B, N, 4, 64), R(B, N, 4, 64)
+    o, lse = _hip.attention_fwd(q, k, v, 0.125)
+    monkeypatch.delenv("VSDE_ATTN_DQ_WIDE", raising=False)
+    ref = _hip.attention_bwd(go, q, k, v, o, lse, 0.125)
+    monkeypatch.setenv("VSDE_ATTN_DQ_WIDE", "1")
+    new = _hip.attention_bwd(go, q, k, v, o, lse, 0.125)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, new):
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+
+
 def test_backward_kernel_variants_agree_on_every_output(tmp_path):
     """The fused attention backward with the ragged last block shared by four waves (default) against the same kernels with the lone
     second round (VSDE_ATTN_SPLIT=0): the variants differ only in the order of fp32 partial sums, so every output -- the one

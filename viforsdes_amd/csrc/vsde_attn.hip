@@ -1645,6 +1645,128 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdPara
     }
 }
 
+// ---- Round 5 prototype (VSDE_ATTN_DQ_WIDE=1, the unfused API only): dq with 64 queries per wave.  Eight waves at 256 registers, wave w
+// owns the query blocks 2w and 2w + 1; a key tile's K rows, V rows and K^T fragments are read from LDS ONCE and feed the MFMAs of both
+// blocks -- 12 KB of LDS fragment reads per 24 MFMAs instead of per 12 (on this chip a SIMD's LDS-read, MFMA and VALU time add:
+// DESIGN 3.16).  No sharing of a ragged last unit, no fused epilogue: it exists to measure the tile loop of the wide form against
+// attn_bwd_dq_kernel<false> at token counts where both are balanced (512: 16 blocks = 8 units = 2 per SIMD either way).
+template <bool FUSED>
+__global__ void __launch_bounds__(512, 1) attn_bwd_dq_wide_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.x / p.H, hh = blockIdx.x - b * p.H, N = p.N, npad = p.ntile * 32;
+    uint16_t *Ks = asmem, *Vs = asmem + npad * AT_KLD;
+    const int64_t ts = (int64_t)p.H * AT_D, base = ((int64_t)b * N * p.H + hh) * AT_D;
+    const int64_t srow = ((int64_t)b * p.H + hh) * N;
+    bf16x8 qf[2][4], dof[2][4];
+    float lse2[2], dsum[2];
+    bool qok[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int qblk = 2 * wave + blk, query = qblk * 32 + fr;
+        qok[blk] = qblk < p.ntile && query < N;
+        load_bfrag(p.q + base, ts, query, qok[blk], h2, qf[blk]);
+        load_bfrag(p.dout + base, ts, query, qok[blk], h2, dof[blk]);
+        lse2[blk] = (qok[blk] ? p.lse[srow + query] : INFINITY) * 1.4426950408889634f;   // padded queries: P = 0
+        if constexpr (FUSED) {
+            dsum[blk] = qok[blk] ? p.delta[srow + query] : 0.f;   // D = <dO, O> from the gate backward
+        } else {
+            bf16x8 on[4];
+            load_bfrag(p.o + base, ts, query, qok[blk], h2, on);
+            float d = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    d = fmaf(__uint_as_float(((uint32_t)(uint16_t)dof[blk][ks][e]) << 16), __uint_as_float(((uint32_t)(uint16_t)on[ks][e]) << 16), d);
+            dsum[blk] = sum_xor32(d);
+            if (qok[blk] && h2 == 0) p.delta[srow + query] = dsum[blk];
+        }
+    }
+    stage_two<512, 512>(p.k + base, p.v + base, ts, N, npad, tid, Ks, Vs);
+    __syncthreads();
+    const float c2 = p.scale_log2e;
+    const bool ragged = (N & 31) != 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[blk][0][e] = 0.f; acc[blk][1][e] = 0.f; }
+    if (2 * wave < p.ntile) {
+        const int m = lane & 15;
+#pragma unroll 1
+        for (int kt = 0; kt < p.ntile; ++kt) {
+            const uint16_t *kt_ = Ks + kt * 32 * AT_KLD, *vt_ = Vs + kt * 32 * AT_KLD;
+            bf16x8 kr[4], vr[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kr[ks] = *(const bf16x8 *)(kt_ + fr * AT_KLD + h2 * 8 + ks * 16);
+                vr[ks] = *(const bf16x8 *)(vt_ + fr * AT_KLD + h2 * 8 + ks * 16);
+            }
+            // K^T fragments (see accumulate_transposed): rows = channels dt * 32 + fr, k = the tile's keys in the order of dS's registers
+            const uint16_t *src = kt_ + (4 * h2 + (m >> 2)) * AT_KLD + ((lane >> 4) & 1) * 16 + (m & 3) * 4;
+            uint4 kw[2][2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const uint2 a0 = lds_read_tr(src + dt * 32), a1 = lds_read_tr(src + dt * 32 + 8 * AT_KLD);
+                const uint2 a2 = lds_read_tr(src + dt * 32 + 16 * AT_KLD), a3 = lds_read_tr(src + dt * 32 + 24 * AT_KLD);
+                kw[dt][0] = make_uint4(a0.x, a0.y, a1.x, a1.y); kw[dt][1] = make_uint4(a2.x, a2.y, a3.x, a3.y);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f32x16 stl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dpt = stl;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) stl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[ks], qf[blk][ks], stl, 0, 0, 0);   // S^T  [key][query]
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[ks], dof[blk][ks], dpt, 0, 0, 0);  // dP^T [key][query]
+                float ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(fmaf(stl[r], c2, -lse2[blk])) * (dpt[r] - dsum[blk]);
+                if (ragged && kt == p.ntile - 1) {  // keys beyond N (zero rows of K: their P is not 0)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) ds[r] = 0.f;
+                }
+                bf16x8 b0, b1;
+                pack_tile(ds, b0, b1);
+                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&kw[0][0], b0, acc[blk][0], 0, 0, 0);   // dQ^T += K^T dS^T
+                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&kw[0][1], b1, acc[blk][0], 0, 0, 0);
+                acc[blk][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&kw[1][0], b0, acc[blk][1], 0, 0, 0);
+                acc[blk][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&kw[1][1], b1, acc[blk][1], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (!FUSED) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int query = (2 * wave + blk) * 32 + fr;
+            if (qok[blk]) store_transposed(p.dq + base + query * ts, h2, acc[blk][0], acc[blk][1], p.scale);
+        }
+    } else {
+        // the staged epilogue of attn_bwd_dq_kernel<true, true>, once per block: the q^ rows come from the fragments, the inverse RMS from
+        // memory (requested in front of the barrier), the result leaves as the q columns of dy (norm_rope_bwd through the wave's slice)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));   // the epilogue's addresses are computed here, not hoisted above the tile loop and spilled
+        NormRowsIn in[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+            if ((2 * wave + blk) * 32 < N) norm_rinv_request<0>(p.f, in[blk], (int64_t)b * N, (2 * wave + blk) * 32, N, hh, p.H, lane_e);
+        __syncthreads();   // every wave is done with K / V: their space becomes the waves' staging slices
+        float *slice = (float *)asmem + wave * AT_ESLICE;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int tok0 = (2 * wave + blk) * 32;
+            if (tok0 < N) {   // wave-uniform
+                norm_rows_from_frags(in[blk], (uint16_t *)slice, qf[blk], lane_e);
+                stage_acc_tile(slice, acc[blk][0], acc[blk][1], p.scale, lane_e);
+                wave_lds_fence();
+                staged_norm_rope_bwd<0>(p.f, slice, in[blk], (int64_t)b * N, tok0, N, hh, p.H, lane_e);
+                wave_lds_fence();
+            }
+        }
+    }
+}
+
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
 template <bool FUSED, bool ONE = false, int BT = AT_BT>
 __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dkv_kernel(AttnBwdParams p) {
@@ -2025,6 +2147,11 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
+    const char *wide = getenv("VSDE_ATTN_DQ_WIDE");
+    if (wide && wide[0] == '1' && p.ntile <= 16) {   // prototype: 64 queries per wave (read per call: tests toggle it)
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+        hipLaunchKernelGGL(attn_bwd_dq_wide_kernel<false>, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);
+    } else
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);   // also writes delta, read by the next kernel
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -2123,6 +2250,11 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
         VSDE_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    const char *wide = getenv("VSDE_ATTN_DQ_WIDE");   // read per call: tests toggle it
+    if (p.f.dbg == 0 && wide && wide[0] == '1' && p.ntile > 4 && p.ntile <= 16) {   // 64 queries per wave (attn_bwd_dq_wide_kernel)
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+        hipLaunchKernelGGL(attn_bwd_dq_wide_kernel<true>, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);
+    } else
     if (p.f.dbg == 0 && (p.ntile <= nwv || p.split_dq != 0)) {   // one block per wave: the lean instantiation
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);
