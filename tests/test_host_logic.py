@@ -269,3 +269,25 @@ def test_only_optimizers_that_own_packed_parameters_mark_packs_stale():
     w.grad = torch.ones(8, 8)
     o_own.step()
     assert pack.stale()
+
+
+def test_latent_start_cache_follows_the_tensor():
+    """sample_diffusion_paths remembers to_latent(x0) while x0 is the same unmodified memory (the start state is a constant of the
+    problem); an in-place edit, another tensor, or a tensor that carries a gradient must not see a stale value."""
+    import torch
+    from viforsdes_amd.inference.diffusion_path_sampler import _latent_start
+    from viforsdes_amd.inference.state_space import StateSpace
+    ss = StateSpace(2, [0, 1])
+    x0 = torch.tensor([[1.0, 2.0], [0.5, 3.0]])
+    a = _latent_start(ss, x0)
+    assert torch.equal(a, ss.to_latent(x0)) and _latent_start(ss, x0) is a                 # second call: the remembered tensor
+    assert _latent_start(ss, x0[:1].expand(4, -1)).shape == (4, 2)                          # another layout of the same memory
+    x0.mul_(2.0)                                                                            # in-place edit: version counter moves
+    b = _latent_start(ss, x0)
+    assert b is not a and torch.equal(b, ss.to_latent(x0))
+    y = torch.tensor([[1.0, 2.0], [0.5, 3.0]], requires_grad=True)
+    c = _latent_start(ss, y)
+    assert c.requires_grad and torch.equal(c.detach(), ss.to_latent(y.detach()))            # gradients flow: never cached
+    for k in range(8):                                                                      # fresh tensors: each gets its own value
+        z = torch.full((2, 2), 1.0 + k)
+        assert torch.equal(_latent_start(ss, z), ss.to_latent(z))

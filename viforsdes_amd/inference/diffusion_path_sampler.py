@@ -22,6 +22,25 @@ class HeadProtocol(Protocol):
                                time_step: float) -> tuple[Tensor, Tensor, Tensor]: ...
 
 
+def _latent_start(state_space: StateSpace, x0: Tensor) -> Tensor:
+    """``state_space.to_latent(x0)`` (reference line 61), remembered while ``x0`` stays the same tensor: the start state is a
+    constant of the problem (the trainer's ``x0_buffer``, the posterior's first observation), its inverse softplus seven small
+    launches per call.  Recomputed when the memory, its version counter (an in-place edit) or its layout changes, when it
+    carries a gradient, and inside a stream capture (a graph's private memory must not outlive it)."""
+    if x0.requires_grad or (x0.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return state_space.to_latent(x0)
+    key = (x0.data_ptr(), x0._version, tuple(x0.shape), tuple(x0.stride()), x0.dtype, x0.device)
+    cache = state_space.__dict__.setdefault("_latent_start_cache", {})
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) >= 4:
+            cache.clear()
+        with torch.no_grad():
+            # the entry keeps x0 (hence its storage) alive: the address in the key cannot be handed to another tensor meanwhile
+            hit = cache[key] = (x0, state_space.to_latent(x0))
+    return hit[1]
+
+
 def sample_diffusion_paths(encoder: EncoderProtocol, head: HeadProtocol, observations: Observations,
                            sde_parameters: Tensor, x0: Tensor, time_horizon: float, time_step: float,
                            state_space: StateSpace, noise: Optional[Tensor] = None) -> DiffusionPathSample:
@@ -36,7 +55,7 @@ def sample_diffusion_paths(encoder: EncoderProtocol, head: HeadProtocol, observa
         noise = torch.randn(B, n_steps, S, device=x0.device, dtype=x0.dtype)
     elif tuple(noise.shape) != (B, n_steps, S):
         raise ValueError(f"noise must have shape {(B, n_steps, S)}, got {tuple(noise.shape)}")
-    z0 = state_space.to_latent(x0)
+    z0 = _latent_start(state_space, x0)
     if getattr(head, "accepts_full_context", False):  # our head: reads the first T steps in place, gradient written in place
         paths, means, chol = head.sample_diffusion_paths(z0, context, sde_parameters, noise, time_step,
                                                          context_has_extra_step=True)

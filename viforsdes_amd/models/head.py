@@ -65,6 +65,8 @@ class DiffusionTransitionHead(nn.Module):
             return first + (w.new_empty(0, 3 * H, H), w.new_empty(0, 3 * H, H), w.new_empty(0, 3 * H),
                             w.new_empty(0, 3 * H))
         upper = range(1, self.num_layers)
+        if self.num_layers == 2:   # one upper layer: the stacked tensor is a view of the parameter (no copy, no copy-backward)
+            return first + tuple(getattr(g, f"{kind}_l1").unsqueeze(0) for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
         return first + tuple(torch.stack([getattr(g, f"{kind}_l{k}") for k in upper])
                              for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
 
