@@ -48,12 +48,23 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
+    # VSDE_TEST_RANK_ENV="<rank>:<NAME>=<value>[,...]": environment of ONE rank only (ranks that disagree on a switch)
+    for item in filter(None, os.environ.get("VSDE_TEST_RANK_ENV", "").split(",")):
+        r, kv = item.split(":", 1)
+        if int(r) == rank:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
     from oracle.torch_backend import OracleBackend
     from viforsdes_amd.kernels.backend import set_backend
     set_backend(OracleBackend())
     tr = _make_trainer(seed=77)
     ctx, model = tr.ctx, tr.ctx.model
     assert ctx.is_distributed and ctx.world_size == world and dist.get_backend() == "gloo"
+    if os.environ.get("VSDE_TEST_REVERSE_HOOKS") == str(rank):
+        # this rank's gradients "arrive" in the opposite order (what a rank-dependent graph or deferral would do)
+        gs = ctx.grad_sync
+        real = gs._propose_early
+        gs._propose_early = lambda: (setattr(gs, "_recording", list(reversed(gs._recording or []))), real())[1]
     flat0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     gathered = [torch.zeros_like(flat0) for _ in range(world)]
     dist.all_gather(gathered, flat0)
@@ -72,7 +83,14 @@ def _worker(rank, world, port, out_dir):
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     dist.all_gather(gathered, flat)
     assert all(torch.equal(gathered[0], g) for g in gathered), "parameters diverged across ranks"
-    torch.save({"final": flat, "early_launches": ctx.grad_sync.early_launches}, os.path.join(out_dir, f"final{rank}.pt"))
+    # a reduce() that follows an eager step WITHOUT a zero_grad() in between (the split-graph replay, trainer.capture_step_graph)
+    # must send every bucket again: fill the flat buffer with rank + 1, reduce, expect the mean everywhere
+    gs = ctx.grad_sync
+    gs.flat.fill_(float(rank + 1))
+    gs.reduce()
+    whole = bool(torch.all(gs.flat == (world + 1) / 2.0))
+    torch.save({"final": flat, "early_launches": gs.early_launches, "early": list(gs._early), "order_ok": whole,
+                "early_fraction": gs.early_fraction()}, os.path.join(out_dir, f"final{rank}.pt"))
     ctx.cleanup()
 
 
@@ -91,6 +109,34 @@ def test_early_bucket_overlap_is_bit_identical(tmp_path, monkeypatch):
         finals[mode] = torch.load(d / "final0.pt")
     assert finals["1"]["early_launches"] == 2 and finals["0"]["early_launches"] == 0
     assert torch.equal(finals["1"]["final"], finals["0"]["final"])
+
+
+@pytest.mark.timeout(600)
+def test_ranks_that_disagree_on_switches_and_arrival_order_share_rank0_layout(tmp_path, monkeypatch):
+    """the [early | late] layout of the flat gradient buffer used to be built from each rank's OWN hook
+    arrival order and environment.  Rank 1 here has the overlap switched off and reports its arrivals in reverse: both ranks must
+    end up with rank 0's early list (broadcast after the first step), identical parameters after three steps -- the same as a run
+    without any overlap -- and a reduce() issued without a zero_grad() in between must still average every bucket."""
+    monkeypatch.setenv("VSDE_DP_OVERLAP_MIN", "0")
+    d0 = tmp_path / "plain"; d0.mkdir()
+    monkeypatch.setenv("VSDE_DP_OVERLAP", "0")
+    mp.spawn(_worker, args=(2, _free_port(), str(d0)), nprocs=2, join=True)
+    monkeypatch.setenv("VSDE_DP_OVERLAP", "1")
+    monkeypatch.setenv("VSDE_TEST_RANK_ENV", "1:VSDE_DP_OVERLAP=0")
+    d1 = tmp_path / "mixed"; d1.mkdir()
+    mp.spawn(_worker, args=(2, _free_port(), str(d1)), nprocs=2, join=True)
+    monkeypatch.delenv("VSDE_TEST_RANK_ENV")
+    monkeypatch.setenv("VSDE_TEST_REVERSE_HOOKS", "1")
+    d2 = tmp_path / "reversed"; d2.mkdir()
+    mp.spawn(_worker, args=(2, _free_port(), str(d2)), nprocs=2, join=True)
+    plain = torch.load(d0 / "final0.pt")
+    for d in (d1, d2):
+        r0, r1 = torch.load(d / "final0.pt"), torch.load(d / "final1.pt")
+        assert r0["early"] and r0["early"] == r1["early"], (r0["early"], r1["early"])
+        assert 0.0 < r0["early_fraction"] < 1.0
+        assert r0["order_ok"] and r1["order_ok"]
+        assert torch.equal(r0["final"], r1["final"]) and torch.equal(r0["final"], plain["final"])
+    assert torch.load(d1 / "final0.pt")["early_launches"] == 2 and torch.load(d1 / "final1.pt")["early_launches"] == 0
 
 
 @pytest.mark.timeout(600)

@@ -266,6 +266,79 @@ def test_captured_step_refills_packs_that_an_ema_swap_rewrote():
     assert all(torch.equal(a, b) for a, b in zip(plain, swapped))
 
 
+def test_tile_images_built_after_a_capture_follow_the_replayed_optimizer_steps():
+    """the tile images of the no-grad block kernels (primitives/fused.py: MlpImages, OutProjImage) are built
+    lazily by the first no-grad forward.  Built AFTER the training step was captured they are not in the graph, and replays move the
+    parameters and packs on the device without touching a host counter: the images used to keep the weights of the moment they were
+    built.  Here: capture, sample once (builds the images), replay several steps at a large learning rate, then the block-form
+    forward must agree with the route that reads the packs directly -- eagerly and through a CapturedPathSampler replay."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_trainer
+    from viforsdes_amd.examples.sdes import lv_problem
+    from viforsdes_amd.inference.diffusion_path_sampler import CapturedPathSampler
+    from viforsdes_amd.primitives import fused
+    B = 96                                           # 96 x 401 tokens = 38,496 rows: the block kernels are taken (>= 32,768)
+    problem = lv_problem()
+    tr = build_trainer(problem, B, torch.device(DEV), True, seed=3, enc_hidden=128, enc_depth=2, heads=2)
+    for g in tr.ctx.optimizer.param_groups:
+        g["lr"] = 3e-3
+    ctx, model = tr.ctx, tr.ctx.model
+    with torch.no_grad():                            # identity blocks at init (zero modulators): make them do something
+        for n, p in model.encoder.named_parameters():
+            if p.requires_grad and p.abs().sum() == 0:
+                p.add_(torch.randn_like(p) * 0.05)
+    replay = tr.capture_step_graph(warmup=2)
+    assert replay is not None
+    horizon, dt = problem[4], problem[5]
+    theta = model.sde_parameter_posterior.rsample(B).detach()
+
+    def context(block):
+        old = fused.BLOCK_MLP
+        fused.BLOCK_MLP = block
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return model.encoder(ctx.observations.values, ctx.observations.times, theta, horizon, dt).float()
+        finally:
+            fused.BLOCK_MLP = old
+
+    model.eval()
+    c0 = context(True)                               # builds the images now, after the capture
+    assert any(isinstance(d, fused.MlpImages) for d in fused.PackedWeight._derived)
+    sampler = CapturedPathSampler(model, ctx.observations, horizon, dt, tr.state_space, B, autocast_dtype=torch.bfloat16)
+    model.train()
+    for _ in range(6):
+        replay()
+    torch.cuda.synchronize()
+    model.eval()
+    direct, blk = context(False), context(True)
+    err = float((blk - direct).abs().max() / direct.abs().max())
+    moved = float((direct - c0).abs().max() / c0.abs().max())
+    assert moved > 10 * err and moved > 2e-2, (moved, err)     # the six steps changed the encoder visibly ...
+    assert err < 2e-2, err                                       # ... and the block kernels saw the same weights as the packs
+    # the captured sampling call: same check through its replay (fixed draws: re-seed before both)
+    for _ in range(3):
+        model.train(); replay(); model.eval()
+    torch.cuda.synchronize()
+    torch.manual_seed(7); torch.cuda.manual_seed(7)
+    th_g, x_g, _ = sampler()
+    th_g, x_g = th_g.clone(), x_g.clone()
+    torch.manual_seed(7); torch.cuda.manual_seed(7)
+    from viforsdes_amd.inference.diffusion_path_sampler import sample_diffusion_paths
+    old = fused.BLOCK_MLP
+    fused.BLOCK_MLP = False
+    try:
+        with torch.no_grad():
+            th_e = model.sde_parameter_posterior.rsample(B)
+            x0 = ctx.observations.values[0].unsqueeze(0).expand(B, -1)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                s_e = sample_diffusion_paths(model.encoder, model.head, ctx.observations, th_e, x0, horizon, dt, tr.state_space)
+    finally:
+        fused.BLOCK_MLP = old
+    assert torch.equal(th_g, th_e)
+    assert float((x_g - s_e.x).abs().max() / s_e.x.abs().max()) < 5e-2
+
+
 def test_captured_step_with_the_multi_path_kernels_replays_like_eager_steps():
     """704 paths (OU, small encoder): forward AND reverse-time sweep take the multi-path MFMA kernels under the default dispatch; their
     launch sequence (fragment prep kernels, the max-abs pre-pass with its memset, the sweeps) must survive HIP-graph capture: a

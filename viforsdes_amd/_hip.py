@@ -66,10 +66,12 @@ EXPORTS = (
 )
 
 _lib: Optional[ctypes.CDLL] = None
+_loaded_path: Optional[str] = None
 
 
 def library_path() -> str:
-    return LIB_PATH
+    """The library file in use (the in-tree build unless VSDE_HIP_LIB names another one)."""
+    return _loaded_path or os.environ.get("VSDE_HIP_LIB") or LIB_PATH
 
 
 def load() -> ctypes.CDLL:
@@ -77,17 +79,20 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("VSDE_HIP_LIB") or LIB_PATH   # VSDE_HIP_LIB: an A/B build of the same sources (tools only)
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f"{LIB_PATH} is missing: build it with `python -m viforsdes_amd.build` "
+            f"{path} is missing: build it with `python -m viforsdes_amd.build` "
             "(there is no CPU fallback for the fused head / ELBO kernels)")
-    lib = ctypes.CDLL(os.environ.get("VSDE_HIP_LIB") or LIB_PATH)   # VSDE_HIP_LIB: an A/B build of the same sources (tools only)
+    lib = ctypes.CDLL(path)
     for name in EXPORTS:
         if not hasattr(lib, name):
-            raise HipLibraryError(f"{LIB_PATH} does not export {name}")
+            raise HipLibraryError(f"{path} does not export {name}")
+    global _loaded_path
+    _loaded_path = path
     lib.vsde_abi_version.restype = ctypes.c_int
     if lib.vsde_abi_version() != VSDE_ABI_VERSION:
-        raise HipLibraryError("libvsde_hip.so ABI version mismatch; rebuild it")
+        raise HipLibraryError(f"{path}: ABI version mismatch; rebuild it")
     lib.vsde_last_error.restype = ctypes.c_char_p
     lib.vsde_head_forward_workspace_bytes.restype = ctypes.c_size_t
     lib.vsde_head_backward_workspace_bytes.restype = ctypes.c_size_t

@@ -45,6 +45,16 @@ def init_process_group_if_needed(device_type: str) -> bool:
     return True
 
 
+def _deferred_ids(pending_only: bool) -> set:
+    """ids of the parameters whose weight gradients the encoder's deferred path writes at the end of the backward pass
+    (``pending_only``: only those with a product queued right now)."""
+    try:
+        from ..primitives import fused
+    except Exception:   # (the module is importable without the encoder's HIP operators)
+        return set()
+    return fused.deferred_parameter_ids(pending_only)
+
+
 class FlatGradientAllReduce:
     """Averages the gradients of ``params`` across ranks through ONE flat fp32 buffer.
 
@@ -130,6 +140,8 @@ class FlatGradientAllReduce:
 
     @torch.no_grad()
     def _send_early(self) -> None:
+        if _deferred_ids(pending_only=True) & {id(self.params[i]) for i in self._early}:
+            return   # a queued (deferred) weight-gradient product will still add to an early parameter at the end of the backward
         have = [(self._views[i], self.params[i].grad) for i in self._early
                 if self.params[i].grad is not None and self.params[i].grad is not self._views[i]]
         if len(have) + sum(1 for i in self._early if self.params[i].grad is self._views[i]) != len(self._early):
@@ -141,24 +153,58 @@ class FlatGradientAllReduce:
         self._early_sent = True
         self.early_launches += 1
 
-    def _finish_recording(self) -> None:
-        """First step done: lay the flat buffer out as [early | late] from the recorded arrival order."""
+    def _propose_early(self) -> list[int]:
+        """This rank's proposal for the early bucket from the arrival order it recorded (empty: no overlap)."""
         seen: set[int] = set()
         arrived = [i for i in (self._recording or []) if not (i in seen or seen.add(i))]
-        self._recording = None
-        self._laid_out = True
+        # parameters the deferred weight-gradient path (primitives/fused.py) has ever written are complete only at the END of the
+        # backward, whatever their hooks said earlier: never early
+        late_ids = _deferred_ids(pending_only=False)
+        arrived = [i for i in arrived if id(self.params[i]) not in late_ids]
         total = sum(p.numel() for p in self.params)
-        if total < self.overlap_min or len(arrived) < 2:
-            return
+        if not self.overlap or total < self.overlap_min or len(arrived) < 2:
+            return []
         early, acc = [], 0
         for i in arrived[:-1]:              # at least one arrival stays late: the hook of the last early one fires mid-backward
             early.append(i)
             acc += self.params[i].numel()
             if acc * 2 >= total:
                 break
+        return early
+
+    def _finish_recording(self) -> None:
+        """First step done: lay the flat buffer out as [early | late].  The layout is RANK 0's: every rank proposes from its own
+        arrival order and environment (VSDE_DP_OVERLAP*, deferred weight gradients), then rank 0's index list is broadcast and
+        adopted by all (what DDP does when it rebuilds its buckets) -- ranks whose order or switches differ would otherwise
+        all-reduce buffers whose elements belong to different parameters, silently.  A rank may still decline to SEND its early
+        bucket from inside the backward (overlap off locally, an absent gradient): it then issues the same two collectives in
+        the same order after the backward."""
+        early = self._propose_early()
+        self._recording = None
+        self._laid_out = True
+        if self.world_size > 1:
+            n = len(self.params)
+            plan = torch.full((n + 1,), -1, dtype=torch.int64)
+            plan[0] = len(early)
+            if early:
+                plan[1:1 + len(early)] = torch.tensor(early, dtype=torch.int64)
+            plan = plan.to(self.params[0].device)
+            dist.broadcast(plan, src=0)
+            vals = plan.tolist()
+            early = [int(v) for v in vals[1:1 + int(vals[0])]]
+            if any(not (0 <= i < n) for i in early) or len(set(early)) != len(early):   # a different model on rank 0
+                raise RuntimeError("data-parallel ranks disagree on the parameter list (early-bucket plan out of range)")
+        if not early:
+            return
         rest = [i for i in range(len(self.params)) if i not in set(early)]
         self._early, self._early_set = early, set(early)
         self._allocate(order=early + rest, n_early=len(early))
+
+    def early_fraction(self) -> float:
+        """Share of the payload that travels from inside the backward pass (0 until the [early | late] layout exists)."""
+        if not self._early or self.flat is None:
+            return 0.0
+        return float(self.buckets[0].numel()) / float(self.flat.numel())
 
     def flat_gradients(self) -> Tensor:
         """Copy of all gradients as one fp32 vector in parameter order (zeros where a gradient is absent)."""
@@ -170,8 +216,8 @@ class FlatGradientAllReduce:
         for p in self.params:
             p.grad = None
         self._arrived, self._early_sent, self._early_handle = 0, False, None
-        if self.active and self.overlap and not self._laid_out and self._recording is None:
-            self._recording = []
+        if self.active and not self._laid_out and self._recording is None and (self.overlap or self.world_size > 1):
+            self._recording = []   # (multi-rank: every rank takes part in the layout agreement, whatever its own switches say)
 
     @torch.no_grad()
     def pack(self) -> None:
@@ -197,6 +243,9 @@ class FlatGradientAllReduce:
             for h in handles:
                 h.wait()
             self.flat.mul_(1.0 / self.world_size)
+        # the early bucket of THIS backward is accounted for: a later reduce() without a zero_grad() in between (the split-graph
+        # replay calls reduce() directly) must send every bucket again
+        self._early_sent, self._early_handle, self._arrived = False, None, 0
 
     def attach(self) -> None:
         """Point ``p.grad`` at the views of the flat buffer (what unscale / clip / the optimizer read)."""

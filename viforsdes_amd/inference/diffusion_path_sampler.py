@@ -119,6 +119,9 @@ class CapturedPathSampler:
         # every pack stale: the per-pack copies of the unforced refresh would be ~50 launches)
         if any(pk.stale() for pk in self._packs._live if any(id(q) in self._ids for q in pk.params)):
             self._packs.refresh_all(force=True, params=self._ids)
+        # tile images derived from the packs: rebuilt here when dirty (a forced refresh, a replayed training step) -- the graph
+        # reads them in place
+        self._packs.refresh_dirty_derived(self._ids)
         self.graph.replay()
         return self._static
 

@@ -209,17 +209,25 @@ class VariationalInferenceTrainer:
             if any(pk.stale() for pk in PackedWeight._live if any(id(q) in ids for q in pk.params)):
                 PackedWeight.refresh_all(force=True, params=ids)
 
+        # The replayed optimizer step rewrites parameters and packs on the device; no host counter moves.  Operands DERIVED from the
+        # packs (the tile images of the no-grad block kernels) that were built after the capture are not in the graph: they are
+        # marked dirty after every replay, so the next no-grad forward (or captured sampler replay) rebuilds them from the packs.
+        def after_replay() -> None:
+            PackedWeight.invalidate_derived(ids)
+
         if not split:
             def replay() -> TrainStepResult:
                 refresh_if_stale()
                 graphs[0].replay()
+                after_replay()
                 return static
         else:
             def replay() -> TrainStepResult:
                 refresh_if_stale()
                 graphs[0].replay()
-                ctx.grad_sync.reduce()
+                ctx.grad_sync.reduce()   # sends every bucket: reduce() leaves no early-bucket state behind (an eager step in between)
                 graphs[1].replay()
+                after_replay()
                 return static
         return replay
 

@@ -617,7 +617,7 @@ class PackedWeight:
                     pk.mark_fresh()
                     if pk.weight_t is not None:
                         pk._t_versions = list(pk._versions)
-                PackedWeight._refresh_derived(live)
+                PackedWeight._refresh_derived(live, force=True)
                 return
         dst, src, packs = [], [], []
         for pk in live:
@@ -631,18 +631,42 @@ class PackedWeight:
                 if pk.weight_t is not None:
                     pk.weight_t.copy_(pk.weight.t())
                     pk._t_versions = list(pk._versions)
-        PackedWeight._refresh_derived(live)
+        PackedWeight._refresh_derived(live, force=force)
 
-    # operands derived from packs (tile images of the fused MLP kernels): objects with ``packs`` and ``refresh_if_stale()``; they
-    # follow every refresh of their packs, so that a captured training step (whose forward never checks staleness) replays with
-    # images of the parameters its captured optimizer step has just written
+    # operands derived from packs (tile images of the fused MLP kernels): objects with ``packs``, ``_key`` (None = dirty) and
+    # ``refresh_if_stale()``.  Inside a stream capture they are rebuilt with their packs, so that a captured training step (whose
+    # forward never checks staleness) replays with images of the parameters its captured optimizer step has just written.  Eagerly
+    # they are only MARKED dirty and rebuilt by the next ``operands()`` / ``refresh_dirty_derived()`` -- the training step never
+    # reads them, and five small launches per image and step are not free on a launch-bound step.
     _derived = weakref.WeakSet()
 
     @staticmethod
-    def _refresh_derived(live) -> None:
+    def _refresh_derived(live, force: bool = False) -> None:
         ids = {id(pk) for pk in live}
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         for d in sorted(PackedWeight._derived, key=id):
-            if any(id(pk) in ids for pk in d.packs):
+            if not any(id(pk) in ids for pk in d.packs):
+                continue
+            if force:
+                d._key = None      # the host-side version counters say nothing after a forced refresh (fused optimizer, graph replay)
+            if capturing:
+                d.refresh_if_stale()
+
+    @staticmethod
+    def invalidate_derived(params: Optional[set] = None) -> None:
+        """Mark the derived images (of the packs built from ``params``) dirty: their packs were rewritten on the device behind the
+        host counters' back (a replayed HIP graph of the training step)."""
+        for d in PackedWeight._derived:
+            if params is None or any(id(q) in params for pk in d.packs for q in pk.params):
+                d._key = None
+
+    @staticmethod
+    @torch.no_grad()
+    def refresh_dirty_derived(params: Optional[set] = None) -> None:
+        """Rebuild every dirty derived image now (what a captured sampling call needs before its replay: its graph reads the
+        images in place and never calls ``operands()``)."""
+        for d in sorted(PackedWeight._derived, key=id):
+            if params is None or any(id(q) in params for pk in d.packs for q in pk.params):
                 d.refresh_if_stale()
 
 
@@ -698,12 +722,24 @@ WGRAD_DEFER_MAX_ROWS = int(os.environ.get("VSDE_WGRAD_DEFER_MAX_ROWS", "65536"))
 WGRAD_DEFER_MAX_BYTES = int(os.environ.get("VSDE_WGRAD_DEFER_MAX_BYTES", str(1 << 30)))
 _wgrad_queue: Optional[list] = None
 _wgrad_queue_bytes = 0
+_deferred_ever: set = set()      # ids of every parameter a deferred product has been queued for (inference/data_parallel.py keeps
+                                 # them out of its early bucket: their gradient is complete only when the queue is flushed)
+
+
+def deferred_parameter_ids(pending_only: bool = False) -> set:
+    """ids of the parameters written by the deferred path; ``pending_only``: those with a product in the open queue right now."""
+    if not pending_only:
+        return set(_deferred_ever)
+    if not _wgrad_queue:
+        return set()
+    return {id(q) for item in _wgrad_queue for q in item[5].params}
 
 
 def _queue_weight_grads(item: tuple) -> None:
     """Append one (dy, x, ...) problem to the open queue; flush the queue when its operands exceed the byte budget."""
     global _wgrad_queue_bytes
     _wgrad_queue.append(item)
+    _deferred_ever.update(id(q) for q in item[5].params)
     _wgrad_queue_bytes += item[0].numel() * item[0].element_size() + item[1].numel() * item[1].element_size()
     if _wgrad_queue_bytes > WGRAD_DEFER_MAX_BYTES:
         queue = list(_wgrad_queue)
