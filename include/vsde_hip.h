@@ -56,6 +56,9 @@ extern "C" {
 #define VSDE_CTX_BF16 1
 
 int vsde_abi_version(void);
+/* 1: this library was built with -DVSDE_ABLATIONS (A/B switches read from the environment, losing kernel variants compiled in:
+   tools and their tests only); 0: the shipped library. */
+int vsde_build_ablations(void);
 const char *vsde_last_error(void);
 
 /* Problem dimensions shared by the head entry points (names as in SURVEY.md section 8). */

@@ -129,6 +129,7 @@ def test_pack_refresh_kernel_refills_every_pack_kind():
         assert not pk.stale()
 
 
+@pytest.mark.ablation_build
 @pytest.mark.gpu
 def test_persistent_deep_reduction_kernel():
     """lin_deep_kernel (persistent workgroups, both operands through LDS by global_load_lds, counted waits) is opt-in

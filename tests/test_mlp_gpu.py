@@ -144,6 +144,7 @@ def test_block_form_with_the_out_projection_in_front(B, N, C, H, hreal, last):
 
 @pytest.mark.parametrize("M,C,H,hreal", [(20000, 256, 704, 682), (4264, 128, 384, 341), (300, 128, 64, 64), (77, 256, 128, 100),
                                          (133000 + 5, 256, 704, 682), (205312, 256, 704, 682)])
+@pytest.mark.ablation_build
 def test_fused_mlp_backward(M, C, H, hreal):
     """vsde_mlp_bwd_bf16 against the two kernels it replaces (rows kernel with the SwiGLU derivative in its epilogue, then the dx
     GEMM over du) and against the fp32 formulas evaluated from the same bf16 u and dy: du to 2e-2 of its max (the derivative is
@@ -170,6 +171,7 @@ def test_fused_mlp_backward(M, C, H, hreal):
     assert _rel(dx, du_ref @ pin.weight.float()) < 1e-2
 
 
+@pytest.mark.ablation_build
 def test_opt_in_fused_backward_gives_the_same_gradients():
     """``fused.FUSED_MLP_BWD`` (VSDE_FUSED_MLP_BWD=1) swaps the two backward launches of ``_SwiGLUMLP`` for mlp_bwd_kernel: input and
     parameter gradients of the module-level op must agree with the default route (bf16 du: 1e-2 of each gradient's max)."""
@@ -196,6 +198,7 @@ def test_opt_in_fused_backward_gives_the_same_gradients():
 
 @pytest.mark.parametrize("M,K,bias,transposed", [(20000, 704, True, False), (205312, 1408, False, True), (40000 + 17, 832, False, True),
                                                  (300, 256, True, False), (77, 512, False, False)])
+@pytest.mark.ablation_build
 def test_deep_reduction_gemm(M, K, bias, transposed):
     """vsde_linear_deep256_bf16 (y [M, 256] = x [M, K] W^T + b, the products the library ran until round 5) against the float32 product
     of the same bf16 operands: fp32 accumulation, one rounding of the output (1e-2 of max is two bf16 ulps of the largest output);

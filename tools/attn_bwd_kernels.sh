@@ -1,4 +1,6 @@
 #!/bin/bash
+# (A/B switches exist only in the tools' library: python -m viforsdes_amd.build --ablations)
+export VSDE_HIP_LIB=${VSDE_HIP_LIB:-$GRAFT_REPO_ROOT/viforsdes_amd/libvsde_hip_abl.so}
 # per-kernel durations of the attention core (tools/attn_core_bench.py under rocprofv3).  A/B on ONE box:
 #   tools/attn_bwd_kernels.sh                      VSDE_ATTN_SPLIT = 0 and 1 with the tree's library
 #   tools/attn_bwd_kernels.sh base                 ... and first with viforsdes_amd/libvsde_hip_base.so (a library built from another commit) swapped in

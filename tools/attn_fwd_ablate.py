@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from viforsdes_amd import _hip

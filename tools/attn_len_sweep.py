@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Attention core at the LV width (512 x 4 pairs, head_dim 64) over sequence lengths around the benchmark's 401 tokens: what the ragged
 13th 32-token block costs each kernel (384 = twelve whole blocks, 416 = thirteen).   python tools/attn_len_sweep.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from viforsdes_amd import _hip

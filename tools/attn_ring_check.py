@@ -2,6 +2,7 @@
 """The ring forward (VSDE_ATTN_RING=1) against the LDS-resident forward: same arithmetic in the same order, so o and lse must be
 bit-identical.  Run once without the variable (writes gpurun_out/attn_ring_ref.npz), once with it (compares and times).
     python tools/attn_ring_check.py; VSDE_ATTN_RING=1 python tools/attn_ring_check.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys
 import numpy as np
 import torch

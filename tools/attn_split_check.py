@@ -3,6 +3,7 @@
 run once with VSDE_ATTN_SPLIT=0 (writes gpurun_out/attn_split_ref.npz) and once without (compares): the two differ only in the order
 of fp32 partial sums, so every output must agree to ~1e-6 of its scale before bf16 rounding, i.e. in all but a few bf16 ulps.
     VSDE_ATTN_SPLIT=0 python tools/attn_split_check.py; python tools/attn_split_check.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys
 import numpy as np
 import torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle sums of workgroup 0 of the persistent attention forward (csrc/vsde_attn.hip, vsde_attn_debug_trace), LV dims:
     python tools/attn_trace.py [N]          (VSDE_ATTN_FWD8=1: the eight-wave kernel)"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from viforsdes_amd import _hip

@@ -2,6 +2,7 @@
 """Prototype check: the dq kernel with 64 queries per wave (VSDE_ATTN_DQ_WIDE=1, csrc/vsde_attn.hip::attn_bwd_dq_wide_kernel, unfused API)
 against attn_bwd_dq_kernel<false>: bit identity of dq / dk / dv and the time of the whole backward (dq + dk/dv; the dk/dv launch is the
 same kernel on both sides, so the difference is the dq kernel's).    python tools/attn_wide_check.py [B]"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from viforsdes_amd import _hip

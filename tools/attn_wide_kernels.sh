@@ -1,4 +1,6 @@
 #!/bin/bash
+# (A/B switches exist only in the tools' library: python -m viforsdes_amd.build --ablations)
+export VSDE_HIP_LIB=${VSDE_HIP_LIB:-$GRAFT_REPO_ROOT/viforsdes_amd/libvsde_hip_abl.so}
 # per-kernel durations of the attention core (tools/attn_core_bench.py under rocprofv3) with the wide dq kernel off / on, one box
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

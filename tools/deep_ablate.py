@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Ablation of the persistent deep-reduction GEMM: VSDE_LIN_DEBUG = 0 full, 2 no activation DMA, 3 no weight DMA, 4 no DMA, 5 no MFMA."""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, subprocess, sys
 code = r'''
 import os, sys, torch

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GRU time-stepping kernels at the LV head dims, 512 paths, dispatcher defaults: training forward, sampling forward, reverse sweep (us).
 For same-box A/B of two library builds: tools/ab_lib.sh <other .so> python tools/head_ab.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viforsdes_amd import _hip

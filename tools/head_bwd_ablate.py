@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing-only ablations of the multi-path MFMA reverse-time sweep (VSDE_MP_BWD_ABL bits: 1 no stores, 2 no loads in the loop, 4 no split
 arithmetic, 8 no matrix products) at the LV head dims, B = 512, 4 paths per workgroup.  Results of the ablated variants are wrong."""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viforsdes_amd import _hip

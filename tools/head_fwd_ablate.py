@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing-only ablations of the multi-path MFMA forward (VSDE_MP_FWD_ABL bits: 1 = layer 0 does not store its saved activations, 2 = layer 1
 does not, 4 = no output stores) at the LV head dims; wrong results.   python tools/head_fwd_ablate.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viforsdes_amd import _hip

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (A/B switches exist only in the tools' library: python -m viforsdes_amd.build --ablations)
+export VSDE_HIP_LIB=${VSDE_HIP_LIB:-$GRAFT_REPO_ROOT/viforsdes_amd/libvsde_hip_abl.so}
 # In-step sweep of the launch-shape switches with the driver's bench command: tuning decisions taken in one round go
 # stale when the kernels change in the next.   usage (GPU box): tools/knob_sweep.sh [lv|ou] > gpurun_out/rNN/knobs.txt
 R=$GRAFT_REPO_ROOT; cd $R

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One shape of the encoder GEMM kernels, timed with HIP events (ablation / profiling driver).
     python tools/linear_probe.py N K [iters]"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os
 import sys
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) against the two-launch chain they replace, at the LV encoder's shape.
     python tools/mlp_bench.py [--m 205312]"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import argparse
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle sums of workgroup 0 of the fused MLP backward (csrc/vsde_mlp.hip::mlp_bwd_kernel, vsde_mlp_debug_trace):
     python tools/mlp_bwd_trace.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import ctypes
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launches the fused SwiGLU MLP kernels (csrc/vsde_mlp.hip) a few times at the LV shape -- the driver for tools/pmc.sh / rocprofv3:
     tools/pmc.sh mlp_ tools/mlp_probe.py [fwd|train|bwd] [M]"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os
 import sys
 

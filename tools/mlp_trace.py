@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle stamps of workgroup 0 of the fused MLP forward (VSDE_MLP_DEBUG=16 build of csrc/vsde_mlp.hip):
     VSDE_MLP_DEBUG=16 python tools/mlp_trace.py"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import ctypes
 import os
 import sys

@@ -19,7 +19,7 @@ for w in $WL; do
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o b -- python3 $R/bench.py $args --no-cpu-baseline --no-ou --no-pmc > $O/bench_prof_${w}_$TAG.log 2>&1
   python3 $R/tools/rocpd_stats.py $(find /tmp/prof_$w -name '*.db' | head -1) > $O/${ROUND}_bench_${w}_kernels_$TAG.txt 2>&1
   python3 $R/tools/rocpd_stats.py $(find /tmp/prof_$w -name '*.db' | head -1) busy >> $O/${ROUND}_bench_${w}_kernels_$TAG.txt 2>&1
-  (cd $R && python3 bench.py $args --no-cpu-baseline --no-ou > $O/bench_${ROUND}_${w}_$TAG.json 2> $O/bench_${ROUND}_${w}_$TAG.err)
+  (cd $R && python3 bench.py $args --no-cpu-baseline --no-ou --detail-out $O/bench_${ROUND}_${w}_$TAG.json > $O/bench_${ROUND}_${w}_${TAG}_headline.json 2> $O/bench_${ROUND}_${w}_$TAG.err)
   python3 -c "
 import json
 d=json.loads(open('$O/bench_${ROUND}_${w}_$TAG.json').read()); print('$w', round(d['ms_per_step'],3),'ms/step', round(d['value']), 'paths/s', round(d['sampled_paths_per_sec']), 'sampled/s, head only', round(d['sampled_paths_per_sec_head_only']))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Times vsde_linear_wgrad_bf16 on the LV encoder's four Linear shapes against its HBM floor (dy and x read once)."""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import os
 import sys
 

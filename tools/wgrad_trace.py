@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle sums of workgroup 0 of the weight-gradient kernel (csrc/vsde_wgrad.hip, eight-wave TN = 256 form; vsde_wgrad_debug_trace):
     python tools/wgrad_trace.py [N K]"""
+import os as _os; _os.environ.setdefault("VSDE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "viforsdes_amd", "libvsde_hip_abl.so"))  # the tools' library: A/B switches + variants (python -m viforsdes_amd.build --ablations)
 import ctypes
 import os
 import sys

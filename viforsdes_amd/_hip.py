@@ -48,7 +48,7 @@ class _Grads(ctypes.Structure):
 
 
 EXPORTS = (
-    "vsde_abi_version", "vsde_last_error",
+    "vsde_abi_version", "vsde_build_ablations", "vsde_last_error",
     "vsde_head_forward_workspace_bytes", "vsde_head_forward",
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
     "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd", "vsde_elbo_tail_fwd", "vsde_elbo_tail_bwd",
@@ -72,6 +72,15 @@ _loaded_path: Optional[str] = None
 def library_path() -> str:
     """The library file in use (the in-tree build unless VSDE_HIP_LIB names another one)."""
     return _loaded_path or os.environ.get("VSDE_HIP_LIB") or LIB_PATH
+
+
+def has_ablations() -> bool:
+    """Whether the loaded library is an ablation build (``python -m viforsdes_amd.build --ablations`` + VSDE_HIP_LIB): A/B switches are
+    read from the environment and the losing kernel variants exist.  The shipped library says False."""
+    return bool(load().vsde_build_ablations())
+
+
+ABL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libvsde_hip_abl.so")
 
 
 def load() -> ctypes.CDLL:

@@ -391,6 +391,7 @@ __device__ __forceinline__ float fwd8_true_max(const bf16x8 (&qf)[4], const uint
 //     under the last one's;
 //   * the shared block's partials are summed (fixed order) by wave 4 between the two barriers of the pair boundary, its epilogue runs
 //     behind the second one.
+#ifdef VSDE_ABLATIONS   // attn_fwd8_kernel: a measured, losing variant -- only in the tools' build (vsde_common.h)
 template <bool TRACE>
 __global__ void __launch_bounds__(512, 1) attn_fwd8_kernel(AttnParams p) {
     // TRACE (tools/attn_trace.py): per-wave cycle sums of workgroup 0: 0 = tile loops, 1 = block prologues (norms, requests),
@@ -731,6 +732,7 @@ __global__ void __launch_bounds__(512, 1) attn_fwd8_kernel(AttnParams p) {
     }
 #undef VSDE_F8_STAMP
 }
+#endif  // VSDE_ABLATIONS (attn_fwd8_kernel)
 
 // ===================================================================================== backward
 // Two kernels, each the mirror image of the other; both recompute the probabilities from q, k and the saved log-sum-exp.
@@ -846,6 +848,7 @@ __device__ __forceinline__ uint2 rg_read_tr(const uint16_t *ptr) {
     return *(uint2 *)&r;
 }
 
+#ifdef VSDE_ABLATIONS   // attn_fwd_ring_kernel: a measured, losing variant -- only in the tools' build (vsde_common.h)
 __global__ void __launch_bounds__(64 * RG_NW) attn_fwd_ring_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
     uint16_t *Kr = asmem, *Vr = asmem + RG_SLOTS * RG_TILE;
@@ -1119,6 +1122,7 @@ __global__ void __launch_bounds__(64 * RG_NW) attn_fwd_ring_kernel(AttnParams p)
         pbase += 13; pbase -= pbase >= RG_SLOTS ? RG_SLOTS : 0;
     }
 }
+#endif  // VSDE_ABLATIONS (attn_fwd_ring_kernel)
 
 __device__ __forceinline__ void pack_tile(const float (&x)[16], bf16x8 &b0, bf16x8 &b1) {
     uint4 w0 = make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
@@ -1650,6 +1654,7 @@ __global__ void __launch_bounds__(BT, AT_BT / BT) attn_bwd_dq_kernel(AttnBwdPara
 // blocks -- 12 KB of LDS fragment reads per 24 MFMAs instead of per 12 (on this chip a SIMD's LDS-read, MFMA and VALU time add:
 // DESIGN 3.16).  No sharing of a ragged last unit, no fused epilogue: it exists to measure the tile loop of the wide form against
 // attn_bwd_dq_kernel<false> at token counts where both are balanced (512: 16 blocks = 8 units = 2 per SIMD either way).
+#ifdef VSDE_ABLATIONS   // attn_bwd_dq_wide_kernel: a measured, losing variant -- only in the tools' build (vsde_common.h)
 template <bool FUSED>
 __global__ void __launch_bounds__(512, 1) attn_bwd_dq_wide_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t asmem[];
@@ -1766,6 +1771,7 @@ __global__ void __launch_bounds__(512, 1) attn_bwd_dq_wide_kernel(AttnBwdParams 
         }
     }
 }
+#endif  // VSDE_ABLATIONS (attn_bwd_dq_wide_kernel)
 
 // dk, dv: one workgroup per (batch, head); Q, dO, lse and delta resident in LDS, a wavefront owns 32 keys at a time.
 template <bool FUSED, bool ONE = false, int BT = AT_BT>
@@ -2017,27 +2023,29 @@ using namespace vsde;
 // VSDE_ATTN_STREAM=1: take the streamed kernels for every shape (A/B runs)
 static bool force_stream() {
     static int f = -1;
-    if (f < 0) { const char *e = getenv("VSDE_ATTN_STREAM"); f = e ? atoi(e) : 0; }
+    if (f < 0) f = (int)vsde_knob("VSDE_ATTN_STREAM", 0);
     return f != 0;
 }
 
 // VSDE_ATTN_PERSIST=0: one workgroup per (batch, head) pair for every shape (A/B runs)
 static bool persist_enabled() {
     static int f = -1;
-    if (f < 0) { const char *e = getenv("VSDE_ATTN_PERSIST"); f = e ? atoi(e) : 1; }
+    if (f < 0) f = (int)vsde_knob("VSDE_ATTN_PERSIST", 1);
     return f != 0;
 }
 // VSDE_ATTN_RING=1: forward with K / V streamed through the LDS ring by a producer wave (attn_fwd_ring_kernel) where it applies.
 // Opt-in (it is correct -- bit-identical to the resident kernel -- but slower: profiles/r04_attn_ring.txt); read at every launch so
 // that a test can switch it inside one process.
+#ifdef VSDE_ABLATIONS
 static bool ring_enabled() {
     const char *e = getenv("VSDE_ATTN_RING");
     return e != nullptr && atoi(e) != 0;
 }
+#endif
 // VSDE_ATTN_SMALL_WG=0: short sequences (N <= 128) on the 12-wave workgroups as before (A/B runs)
 static bool small_wg_enabled() {
     static int f = -1;
-    if (f < 0) { const char *e = getenv("VSDE_ATTN_SMALL_WG"); f = e ? atoi(e) : 1; }
+    if (f < 0) f = (int)vsde_knob("VSDE_ATTN_SMALL_WG", 1);
     return f != 0;
 }
 static int attn_cus() {
@@ -2053,16 +2061,23 @@ static int attn_cus() {
 // forward launch: persistent workgroups (one per CU, next pair's operands requested behind the 13th query block) when a pair
 // has at most 13 query blocks and there are at least two pairs per CU; one workgroup per pair otherwise
 static long long *g_attn_trace = nullptr;
+#ifdef VSDE_ABLATIONS
 static bool fwd8_enabled() {   // VSDE_ATTN_FWD8=1: the eight-wave persistent forward for 385 .. 416 tokens (read per launch: tests toggle it)
     const char *e = getenv("VSDE_ATTN_FWD8");
     return e != nullptr && e[0] == '1';
 }
+static bool dq_wide_enabled() {   // VSDE_ATTN_DQ_WIDE=1: the dq kernel with 64 queries per wave (read per call: tests toggle it)
+    const char *e = getenv("VSDE_ATTN_DQ_WIDE");
+    return e != nullptr && e[0] == '1';
+}
+#endif
 static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hipStream_t stream) {
     const int cus = attn_cus();
     const size_t lds = lds_kv, lds_p = lds_kv;
     AttnParams q = p;
     q.pairs = pairs;
     q.trace = g_attn_trace;
+#ifdef VSDE_ABLATIONS
     if (g_attn_trace && !(fwd8_enabled() && p.npad == 416) && persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus) {   // phase stamps (tools/attn_trace.py)
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
         hipLaunchKernelGGL((attn_fwd_kernel<true, 16>), dim3((unsigned)cus), dim3(768), lds_p, stream, q);
@@ -2080,9 +2095,12 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hi
     } while (0)
         if (abl == 1) VSDE_ABL_LAUNCH(1); else if (abl == 2) VSDE_ABL_LAUNCH(2); else if (abl == 3) VSDE_ABL_LAUNCH(3); else VSDE_ABL_LAUNCH(7);
 #undef VSDE_ABL_LAUNCH
-    } else if (small_wg_enabled() && p.npad <= 128) {
+    } else
+#endif
+    if (small_wg_enabled() && p.npad <= 128) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<false, 0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((attn_fwd_kernel<false, 0, 256>), dim3((unsigned)pairs), dim3(256), lds, stream, q);
+#ifdef VSDE_ABLATIONS
     } else if (ring_enabled() && p.npad >= 256 && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         // 8 .. 13 key tiles and query blocks (two sweeps of the seven consumer waves), at least two pairs per CU
         const size_t ring = (size_t)2 * RG_SLOTS * RG_TILE * sizeof(uint16_t);
@@ -2097,6 +2115,7 @@ static int launch_attn_fwd(const AttnParams &p, int64_t pairs, size_t lds_kv, hi
             VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
             hipLaunchKernelGGL(attn_fwd8_kernel<false>, dim3((unsigned)cus), dim3(512), lds8, stream, q);
         }
+#endif
     } else if (persist_enabled() && p.npad <= 416 && pairs >= 2 * (int64_t)cus && pairs < (1LL << 31)) {
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)cus), dim3(768), lds_p, stream, q);
@@ -2147,11 +2166,12 @@ extern "C" int vsde_attention_bwd_bf16(const void *dout, const void *q, const vo
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv));
     hipStream_t s = (hipStream_t)stream;
-    const char *wide = getenv("VSDE_ATTN_DQ_WIDE");
-    if (wide && wide[0] == '1' && p.ntile <= 16) {   // prototype: 64 queries per wave (read per call: tests toggle it)
+#ifdef VSDE_ABLATIONS
+    if (dq_wide_enabled() && p.ntile <= 16) {   // prototype: 64 queries per wave
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         hipLaunchKernelGGL(attn_bwd_dq_wide_kernel<false>, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);
     } else
+#endif
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);   // also writes delta, read by the next kernel
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3((unsigned)(B * H)), dim3(AT_BT), lds_dkv, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -2223,7 +2243,7 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
     {   // exactly one block more than waves (N = 385 .. 416): share it among four waves instead of a lone second round, if the
         // partial tiles fit behind the operands (VSDE_ATTN_SPLIT=0: the second round as before)
         static int on = -1;
-        if (on < 0) { const char *e = getenv("VSDE_ATTN_SPLIT"); on = e ? atoi(e) : 1; }
+        if (on < 0) on = (int)vsde_knob("VSDE_ATTN_SPLIT", 1);
         const int waves = AT_BT / 64;
         if (on && p.f.dbg == 0 && p.ntile == waves + 1) {
             p.nragged = N - waves * 32;
@@ -2250,11 +2270,12 @@ extern "C" int vsde_attention_bwd_fused_bf16(const void *dattn, const void *q, c
         VSDE_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    const char *wide = getenv("VSDE_ATTN_DQ_WIDE");   // read per call: tests toggle it
-    if (p.f.dbg == 0 && wide && wide[0] == '1' && p.ntile > 4 && p.ntile <= 16) {   // 64 queries per wave (attn_bwd_dq_wide_kernel)
+#ifdef VSDE_ABLATIONS
+    if (p.f.dbg == 0 && dq_wide_enabled() && p.ntile > 4 && p.ntile <= 16) {   // 64 queries per wave (attn_bwd_dq_wide_kernel)
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         hipLaunchKernelGGL(attn_bwd_dq_wide_kernel<true>, dim3((unsigned)(B * H)), dim3(512), lds_dq, s, p);
     } else
+#endif
     if (p.f.dbg == 0 && (p.ntile <= nwv || p.split_dq != 0)) {   // one block per wave: the lean instantiation
         VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)attn_bwd_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), dim3((unsigned)(B * H)), dim3(AT_BT), lds_dq, s, p);

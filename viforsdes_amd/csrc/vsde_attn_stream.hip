@@ -418,7 +418,7 @@ constexpr int AS_WIDE_TR = 128;   // streamed rows per stage of the 8-wave kerne
 // VSDE_ATTN_STREAM_NT=256: four-wave workgroups with 32-token stages (A/B runs)
 static bool as_wide() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("VSDE_ATTN_STREAM_NT"); v = e ? (atoi(e) == 512) : 1; }
+    if (v < 0) v = vsde_knob("VSDE_ATTN_STREAM_NT", 512) == 512 ? 1 : 0;
     return v != 0;
 }
 

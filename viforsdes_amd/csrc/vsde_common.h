@@ -16,14 +16,26 @@ constexpr int kMatF4 = kChunks * 3 * kHP;  // float4 elements of one packed 64x1
 
 void set_error(const char *fmt, ...);
 
-// Timing-only ablation switches (environment variables that make a kernel skip part of its work: RESULTS ARE WRONG) are read
-// through this: the first non-zero value is announced on stderr, so that a stray variable cannot corrupt a run silently.
+// A/B and ablation switches.  The SHIPPED library reads no environment variable: `vsde_knob(name, default)` is its default and the
+// losing kernel variants behind such switches are not compiled.  `python -m viforsdes_amd.build --ablations` builds
+// libvsde_hip_abl.so with -DVSDE_ABLATIONS (the tools load it through VSDE_HIP_LIB): there the knobs are read from the environment
+// (once per call site) and the variants exist.  Timing-only ablation switches (a kernel skips part of its work: RESULTS ARE WRONG) go
+// through `ablation_env`, which announces the first non-zero value on stderr.
+#ifdef VSDE_ABLATIONS
+static inline long long vsde_knob(const char *name, long long dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
 static inline int ablation_env(const char *name) {
     const char *e = getenv(name);
     const int v = e ? atoi(e) : 0;
     if (v != 0) fprintf(stderr, "libvsde_hip: %s=%d is a TIMING-ONLY ablation switch -- results of the affected kernels are WRONG\n", name, v);
     return v;
 }
+#else
+#define vsde_knob(name, dflt) ((long long)(dflt))
+#define ablation_env(name) (0)
+#endif
 
 #define VSDE_CHECK_ARG(cond, code, ...)          \
     do {                                         \

@@ -171,7 +171,7 @@ constexpr int kColsumChunksMax = 64;
 // with the chunk count: 4 chunks beat 8 by 5 % and 32 by 2x at B = 512), at least 8 tokens per chunk
 static int colsum_chunks(int64_t B, int N) {
     static int force = -1;   // VSDE_COLSUM_CHUNKS: token chunks per batch row (A/B runs)
-    if (force < 0) { const char *e = getenv("VSDE_COLSUM_CHUNKS"); force = e ? atoi(e) : 0; }
+    if (force < 0) force = (int)vsde_knob("VSDE_COLSUM_CHUNKS", 0);
     if (force > 0) return force > kColsumChunksMax ? kColsumChunksMax : (force > N ? (N > 0 ? N : 1) : force);
     int64_t c = (768 + B - 1) / B;   // ~768 workgroups (B = 128, 101 tokens: 12 | 8 | 6 | 4 | 2 chunks = 3.73 | 3.59 | 3.57 | 3.58 | 3.62 ms per OU step)
     if (c < 4) c = 4;
@@ -613,7 +613,7 @@ static inline int ew_grid(int64_t total, int per_block) {
 
 static int64_t ln_fwd_grid_cap() {   // resident workgroups of the grid-stride forward (VSDE_LN_GRID overrides, A/B runs)
     static int64_t v = 0;
-    if (!v) { const char *e = getenv("VSDE_LN_GRID"); v = e && atoll(e) > 0 ? atoll(e) : 4096; }
+    if (!v) { v = vsde_knob("VSDE_LN_GRID", 4096); if (v <= 0) v = 4096; }
     return v;
 }
 

@@ -339,7 +339,7 @@ static int tn_plan(const TnProblem *probs, int nprob, int M, TnKernelArgs &a) {
     // Whole rounds of resident workgroups (4 per CU: 36 KB of LDS each): all workgroups take the same time, so 2072 of them on
     // 1024 slots cost three rounds, 2044 cost two.
     static int target = -1;
-    if (target < 0) { const char *e = getenv("VSDE_TN_WGS"); target = e ? atoi(e) : 2048; }
+    if (target < 0) target = (int)vsde_knob("VSDE_TN_WGS", 2048);
     int want = tiles > 0 ? target / tiles : 1;
     int nsplit = want < 1 ? 1 : want;
     if (nsplit > chunks) nsplit = chunks;
@@ -366,7 +366,7 @@ int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace,
                        "grouped TN problem %d: both operands must share rows_per_batch", i);
     {
         static int generic_only = -1;   // VSDE_TN_GENERIC=1: A/B against the generic kernel
-        if (generic_only < 0) { const char *e = getenv("VSDE_TN_GENERIC"); generic_only = e ? atoi(e) : 0; }
+        if (generic_only < 0) generic_only = (int)vsde_knob("VSDE_TN_GENERIC", 0);
         const int rc = generic_only ? 0 : launch_tn_wide(probs, nprob, M, workspace, workspace_bytes, stream);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
@@ -387,3 +387,10 @@ int launch_tn_grouped(const TnProblem *probs, int nprob, int M, void *workspace,
 
 extern "C" const char *vsde_last_error(void) { return vsde::last_error(); }
 extern "C" int vsde_abi_version(void) { return VSDE_ABI_VERSION; }
+extern "C" int vsde_build_ablations(void) {
+#ifdef VSDE_ABLATIONS
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -1535,7 +1535,7 @@ static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // VSDE_PROJ_GENERIC=1: run the context projection / grad_context on the generic fp32-MFMA kernel (A/B against vsde_proj.hip)
 static bool proj_fast_path() {
     static int generic = -1;
-    if (generic < 0) { const char *e = getenv("VSDE_PROJ_GENERIC"); generic = e ? atoi(e) : 0; }
+    if (generic < 0) generic = (int)vsde_knob("VSDE_PROJ_GENERIC", 0);
     return generic == 0;
 }
 
@@ -1559,7 +1559,7 @@ static FwdLayout fwd_layout(const vsde_head_dims *d) {
 static int g_mp_mode = -1;   // -1 = environment / auto, 0 = never, 1 = whenever applicable; 4 / 8 / 16 = applicable + that many paths per group
 static int mp_env() {
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("VSDE_HEAD_MP"); mode = e ? atoi(e) : -1; }
+    if (mode == -2) mode = (int)vsde_knob("VSDE_HEAD_MP", -1);
     return mode;
 }
 static bool mp_auto(const vsde_head_dims *d, int save) {

@@ -1288,7 +1288,7 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     p.D4 = a.D4; p.DO = a.DO; p.g_x0 = a.g_x0; p.g_theta = a.g_theta;
     // groups of 2 (up to 512 paths) / 4 (up to 1024): the spread sweep (head_bwd_mps_kernel); VSDE_MP_BWD_SPREAD=0: round 4's kernel (A/B runs)
     static int spread = -1;
-    if (spread < 0) { const char *e = getenv("VSDE_MP_BWD_SPREAD"); spread = e ? atoi(e) : 1; }
+    if (spread < 0) spread = (int)vsde_knob("VSDE_MP_BWD_SPREAD", 1);
     int np = a.np == 2 || a.np == 4 || a.np == 8 ? a.np : (a.np == 16 ? 8 : (a.B <= 512 ? 2 : (a.B <= 1024 ? 4 : 8)));
     if (!spread && np == 2) np = 4;
     const dim3 grid((a.B + np - 1) / np), block(512);
@@ -1308,6 +1308,7 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
         VSDE_CHECK_HIP(hipGetLastError());
         return 0;
     }
+#ifdef VSDE_ABLATIONS
     static int abl = -1;
     if (abl < 0) abl = ablation_env("VSDE_MP_BWD_ABL");
     if (abl && a.S == 2 && np == 4) {
@@ -1325,6 +1326,10 @@ int launch_head_bwd_mp(const MpBwdLaunch &a, hipStream_t s, void (*mark)(int, in
     } else
     if (a.S == 1) { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<1, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<1, 8>), grid, block, 0, s, p); }
     else { if (np == 4) hipLaunchKernelGGL((head_bwd_mp_kernel<2, 4>), grid, block, 0, s, p); else hipLaunchKernelGGL((head_bwd_mp_kernel<2, 8>), grid, block, 0, s, p); }
+#else   // the shipped library: groups of 8 only get here (2 / 4 took the spread sweep above)
+    if (a.S == 1) hipLaunchKernelGGL((head_bwd_mp_kernel<1, 8>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((head_bwd_mp_kernel<2, 8>), grid, block, 0, s, p);
+#endif
     if (mark) mark(1, 1, s);
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1375,7 +1380,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     // the time of a launch is T x one step's latency whatever the group size, and ONE CU's vector-memory pipe would have to carry the
     // saved activations of all its paths (41 KB per step for 16 paths: +30 % at 512 paths, profiles/r04_head_mp.txt)
     static int spread = -1;   // VSDE_MP_SPREAD: see below
-    if (spread < 0) { const char *e = getenv("VSDE_MP_SPREAD"); spread = e ? atoi(e) : 1; }
+    if (spread < 0) spread = (int)vsde_knob("VSDE_MP_SPREAD", 1);
     int np = a.np;
     if (np != 2 && np != 4 && np != 8 && np != 16) np = (a.B <= 512 && spread) ? 2 : (a.B <= 1024 ? 4 : (a.B <= 2048 ? 8 : 16));
     const dim3 grid((a.B + np - 1) / np), block(256 * a.L);
@@ -1385,6 +1390,7 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
     // planes (842 vs 817 us at 2048 paths: a third more MFMAs for half the gate work) and stay as they were.
     // VSDE_MP_SPREAD=0: the side-by-side planes of round 4 everywhere, =2: the spread form for groups of 8 as well (A/B runs)
 #define VSDE_MP_LAUNCH_(LL, SV, SS, NN, UU) hipLaunchKernelGGL((head_fwd_mp_kernel<LL, SV, SS, NN, UU>), grid, block, 0, s, p)
+#ifdef VSDE_ABLATIONS
 #define VSDE_MP_LAUNCH(LL, SV, SS)                                  \
     do {                                                            \
         if (np == 2) VSDE_MP_LAUNCH_(LL, SV, SS, 2, 1);             \
@@ -1395,6 +1401,15 @@ int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, 
         else if (np == 8) VSDE_MP_LAUNCH_(LL, SV, SS, 8, 4);        \
         else VSDE_MP_LAUNCH_(LL, SV, SS, 16, 4);                    \
     } while (0)
+#else   // the shipped library: the forms the dispatcher takes (spread for groups of 2 / 4, side-by-side planes for 8 / 16)
+#define VSDE_MP_LAUNCH(LL, SV, SS)                                  \
+    do {                                                            \
+        if (np == 2) VSDE_MP_LAUNCH_(LL, SV, SS, 2, 1);             \
+        else if (np == 4) VSDE_MP_LAUNCH_(LL, SV, SS, 4, 1);        \
+        else if (np == 8) VSDE_MP_LAUNCH_(LL, SV, SS, 8, 4);        \
+        else VSDE_MP_LAUNCH_(LL, SV, SS, 16, 4);                    \
+    } while (0)
+#endif
     if (a.L == 1) {
         if (a.save) { if (a.S == 1) VSDE_MP_LAUNCH(1, true, 1); else VSDE_MP_LAUNCH(1, true, 2); }
         else { if (a.S == 1) VSDE_MP_LAUNCH(1, false, 1); else VSDE_MP_LAUNCH(1, false, 2); }

@@ -747,6 +747,7 @@ constexpr int DP_LDS_BYTES = (DP_ASTAGES + DP_WSTAGES) * DP_HALF;   // 160 KB
 // are requested before the eight MFMAs of k-step s, hand-counted lgkmcnt).  The two operand streams have their own rings: the
 // activations (HBM: latency-bound with one chunk in flight, 3.4 TB/s) THREE stages = two chunks in flight, loaded by waves 0..3;
 // the weight chunks (L2 hits) two stages, loaded by waves 4..7 -- 160 KB of LDS, each wave counts only its own stream.
+#ifdef VSDE_ABLATIONS   // lin_deep_kernel: 30 % behind the tuned library solutions (profiles/r03_deep_gemm_ablation.txt): tools' build only
 __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char dlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -877,10 +878,11 @@ __global__ void __launch_bounds__(DP_THREADS, 2) lin_deep_kernel(LinParams p, in
         }
     }
 }
+#endif  // VSDE_ABLATIONS (lin_deep_kernel)
 
 static int rows_xstage() {   // VSDE_ROWS_XSTAGE=0: fragment-shaped activation loads in the rows kernel (A/B runs)
     static int v = -1;
-    if (v < 0) { const char *e = getenv("VSDE_ROWS_XSTAGE"); v = e ? atoi(e) : 1; }
+    if (v < 0) v = (int)vsde_knob("VSDE_ROWS_XSTAGE", 1);
     return v;
 }
 
@@ -917,7 +919,7 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
     }
     {
         static int big = -1;   // VSDE_ROWS_CHUNKS: chunks at large M (A/B runs; 0 = the default below)
-        if (big < 0) { const char *e = getenv("VSDE_ROWS_CHUNKS"); big = e ? atoi(e) : 0; }
+        if (big < 0) big = (int)vsde_knob("VSDE_ROWS_CHUNKS", 0);
         // measured at M = 205 k: SwiGLU forward 290 | 277 | 272 | 307 us and backward 303 | 287 | 295 | 305 us for 1 | 2 | 4 | 8
         // chunks (every chunk reloads the stripe's rows and restarts the tile pipeline); the plain epilogue does not gain
         const bool uneven_ok = EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD;   // a shorter last chunk is fine for these epilogues
@@ -946,7 +948,7 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
     int64_t tail_groups = 0; int tail_chunks = chunks;
     {
         static int on = -1;   // VSDE_ROWS_TAIL=0: no finer chunks for the last round (A/B runs)
-        if (on < 0) { const char *e = getenv("VSDE_ROWS_TAIL"); on = e ? atoi(e) : 1; }
+        if (on < 0) on = (int)vsde_knob("VSDE_ROWS_TAIL", 1);
         const int64_t full = wg_main / resident * resident, rest = wg_main - full;   // workgroups of the partly filled last round
         const bool can_chunk = EPI != EPI_GATE_BWD && (EPI == EPI_SWIGLU || EPI == EPI_SWIGLU_BWD || EPI == EPI_QKNORM || EPI == EPI_PLAIN);
         if (on && can_chunk && full > 0 && rest >= 8 * (int64_t)chunks && rest * 2 <= resident) {   // (at least one stripe group in the last round)
@@ -968,7 +970,7 @@ static int launch_rows_nw(const LinParams &p, hipStream_t s) {
 
 static int rows_wide_wg() {   // VSDE_ROWS_NW=4: four-wave workgroups for every epilogue (A/B runs)
     static int v = -1;
-    if (v < 0) { const char *e = getenv("VSDE_ROWS_NW"); v = e ? atoi(e) : 8; }
+    if (v < 0) v = (int)vsde_knob("VSDE_ROWS_NW", 8);
     return v;
 }
 template <int KC, int EPI, int NKH = 1>
@@ -1005,6 +1007,7 @@ static int launch_cols(const LinParams &p, hipStream_t s) {
     return 0;
 }
 
+#ifdef VSDE_ABLATIONS
 static int launch_deep(const LinParams &p, hipStream_t s) {
     static int cus = 0;
     if (!cus) {
@@ -1023,24 +1026,29 @@ static int launch_deep(const LinParams &p, hipStream_t s) {
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
 }
+#endif
 
 // EPI_QKNORM: K = 256 (the LV / OU encoder width) and K = 128 (the width of the reference-generated parity fixtures)
 static int launch_qknorm(const LinParams &p, hipStream_t s) {
     return p.K == 128 ? launch_rows<128, EPI_QKNORM>(p, s) : launch_rows<256, EPI_QKNORM>(p, s);
 }
 
+#ifdef VSDE_ABLATIONS
 static bool deep_enabled() {
     static int v = -1;
     // off by default: 137 / 260 us at K = 768 / 1536 (M = 205 k) against 102 / 179 us of the tuned library solutions
     // (profiles/r03_deep_gemm_ablation.txt); VSDE_DEEP_GEMM=1 routes the deep reductions here (tests, A/B runs)
-    if (v < 0) { const char *e = getenv("VSDE_DEEP_GEMM"); v = e ? atoi(e) : 0; }
+    if (v < 0) v = (int)vsde_knob("VSDE_DEEP_GEMM", 0);
     return v != 0;
 }
+#endif
 
 // 1 = rows kernel, 2 = cols kernel, 3 = deep kernel (persistent, both operands through LDS), 0 = shape not covered
 static int lin_variant(int64_t M, int N, int K, int epilogue) {
     // deep reductions with a narrow output at sizes that fill the chip (>= 128 rows per CU): the persistent kernel
+#ifdef VSDE_ABLATIONS
     if (epilogue == EPI_PLAIN && deep_enabled() && K >= 512 && K % 64 == 0 && N % 256 == 0 && N <= K && M >= 32768) return 3;
+#endif
     const bool rows_ok = (K == 128 || K == 256 || K == 512) && N % 64 == 0;   // K = 512: two k-halves per output tile
     const bool cols_ok = K % 64 == 0 && N % 128 == 0 && epilogue == EPI_PLAIN;
     if (epilogue != EPI_PLAIN) return rows_ok ? 1 : 0;
@@ -1075,7 +1083,9 @@ extern "C" int vsde_linear_bf16(const void *x, int64_t ldx, const void *w, const
     if (epilogue == EPI_PLAIN) {
         VSDE_CHECK_ARG(y && ldy >= N && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0, VSDE_E_BADARG, "bad linear output");
         if (variant == 1) return launch_rows_k<EPI_PLAIN>(p, st);
+#ifdef VSDE_ABLATIONS
         if (variant == 3) return launch_deep(p, st);
+#endif
         return N % 256 == 0 ? launch_cols<8>(p, st) : launch_cols<4>(p, st);
     }
     if (epilogue == EPI_SWIGLU) {

@@ -696,6 +696,7 @@ struct BwdParams {
     long long *trace;                    // debugging (vsde_mlp_debug_trace): per-wave phase cycle sums of workgroup 0, [4 waves][8]
 };
 
+#ifdef VSDE_ABLATIONS   // mlp_bwd_kernel: measured 470-490 us against 435 us for rows kernel + library GEMM (profiles/r05_mlp_bwd.txt)
 template <int C, int VAR = 3, bool TRACE = false>
 __global__ void __launch_bounds__(256, 1) mlp_bwd_kernel(BwdParams p) {
     using G = bwd::Geo<C>;
@@ -901,6 +902,7 @@ static int launch_bwd(const BwdParams &p, hipStream_t s) {
     return 0;
 }
 
+#endif  // VSDE_ABLATIONS (mlp_bwd_kernel)
 }  // namespace mlp
 }  // namespace vsde
 
@@ -911,14 +913,21 @@ static long long *g_mlp_trace = nullptr;
 extern "C" int vsde_mlp_debug_trace(void *buf) { g_mlp_trace = (long long *)buf; return 0; }
 
 // ===================================================================================================== deep reduction, 256 outputs
+// (tools' build only -- VSDE_ABLATIONS: measured 10-15 % behind hipBLASLt at the LV shapes, profiles/r06_deep256_ablation.txt; the
+// shipped library answers vsde_linear_deep256_bf16 with an error and primitives/fused.py never routes to it)
+#ifdef VSDE_ABLATIONS
 // y [M][256] = x [M][K] W^T (+ bias), K a multiple of 64 and DEEP (704 / 832 / 1408 at the LV shapes): the SwiGLU output projection and
 // the two input-gradient GEMMs of a SiT block (primitives/mlp.py:54, and the backward of mlp.py:50 / attn.py:80-82) -- the three products
-// the library ran until round 5.  It is the G2 half of mlp_fwd_kernel on its own: a wave keeps its 32 rows' 32 x 256 output accumulators
-// (128 registers) for the whole reduction, the weight -- W as K / 16 k-step images [2 h][256 n][8 k] (the W2 image format) -- streams
-// through a ring of four LDS slots of FOUR k-steps (32 KB, 32 DMA pieces: four per wave and tile) three tiles ahead, one workgroup
-// barrier per tile (32 MFMAs per wave), the activation fragments (row r, k = 16 ks + 8 h .. + 7: 16 bytes per lane and k-step) come
-// straight from global memory one tile ahead.  Counted waits: per tile a wave issues [4 fragment loads | 4 DMA] in that order, so the
-// pieces of tile t + 1 have landed once at most the 16 younger instructions are in flight.
+// the library runs.  The weight is an IMAGE: K / 16 k-step images [2 h][256 n][8 k] (the W2 image format), 32 KB per tile of 64 reduction
+// indices.  History (profiles/r06_deep256_ablation.txt; K = 704 | 1408 | 832, hipBLASLt 96 | 167 | 113 us):
+//   round 5   deep256_kernel: a wave's 32 rows x all 256 columns stationary, fragment-shaped activation loads, tile-synchronous: 125 | 223 | 144
+//   round 6   the same with the activations as full 128-byte row segments through per-wave staging rows:                      118 | 200 | 129
+//             deep256p_kernel (below): operands requested one k-step ahead through the tile barrier, 64-row tail launch:         113 | 196 | 129
+//             deep256q_kernel (below): 64 x 128 per wave, both operands by LDS-DMA:                                             112 | 193 | 126
+// Three schedules, one result: with the MFMAs removed the memory / LDS pipeline alone takes as long as hipBLASLt's whole kernel (the
+// activation stream then runs at the HBM rate), with only the MFMAs left the loop takes half of that -- and together they ADD (one
+// tile-synchronous workgroup per CU: whoever waits for memory holds the matrix pipe's only two waves per SIMD).  The strip-read probe
+// (tools/probes/strip_read_probe.hip) says the access pattern itself streams at 6.2 TB/s.
 namespace vsde {
 namespace mlp {
 struct DeepParams {
@@ -928,28 +937,42 @@ struct DeepParams {
     uint16_t *Y; int64_t ldy;
     int64_t M; int T;          // T = tiles of 64 reduction indices
     int rotate;
+    int64_t row_begin;         // pipelined form: first row of this launch
 };
 constexpr int DEEP_TILE = 4 * 32 * 256;   // bytes of one tile's images
 constexpr int DEEP_NSLOT = 4;
 
-// RB = row blocks of 32 per wave.  RB = 1 (default): eight waves (two per SIMD, <= 256 registers) -- every wave reads the WHOLE weight tile
-// out of LDS for its 32 MFMAs: 1 KB of fragment per MFMA, 256 KB per tile and CU.  RB = 2 (VSDE_DEEP256_RB=2): FOUR waves, one per SIMD with
-// the whole register file (256 accumulators), every W fragment feeds two MFMAs: half the LDS traffic for the same MFMA work per SIMD --
-// and SLOWER (158 | 250 | 158 us against 138 | 237 | 143 us for K = 704 | 1408 | 832; the library: 96 | 170 | 111): as in the weight-gradient
-// kernel, one wave per SIMD loses more to exposed latencies than the halved LDS traffic returns.  Either way a tile takes ~5,300 cycles
-// for 1,984 cycles of MFMAs per SIMD; what fills the rest are the 64 vector-memory instructions per tile and CU (32 DMA pieces + 32
-// fragment loads of 32 rows x 32 bytes), the same per-CU intake that bounds the weight-gradient kernel (profiles/r05_wgrad.txt).
-template <int RB>
-__global__ void __launch_bounds__(512 / RB, RB == 1 ? 2 : 1) deep256_kernel(DeepParams p) {
-    constexpr int NWV = 8 / RB, PW = 32 / NWV, NA = 4 * RB;   // waves; DMA pieces per wave and tile; fragment loads per wave and tile
+// ---------------------------------------------------------------------------------------------------------------- round 6: pipelined form
+// deep256p_kernel<NWV>: the same product, software-pipelined ACROSS the tile boundary.  What held the first form at ~4,800 cycles per tile
+// for 2,048 cycles of MFMAs per SIMD was its schedule: behind every tile barrier all eight waves issued their whole LDS burst (the first
+// sixteen weight fragments + the activation shuffle: 24 KB per wave) and waited for all of it with the matrix pipe idle, and once more in
+// the middle of the tile.  Here a k-step's operands are requested one k-step ahead THROUGH the barrier:
+//   * k-step g = 4 t + ks computes on wa[g & 1] / af[g & 1] while the nine reads of k-step g + 1 (8 weight fragments + 1 activation
+//     fragment) are in flight -- for ks = 3 those are the first operands of tile t + 1, whose DMA pieces are guaranteed one tile earlier
+//     than before (the barrier that ends tile t guarantees tile t + 2);
+//   * the activations arrive as full 128-byte row segments two tiles ahead in two register sets; a set is written to the wave's staging
+//     rows at ks = 3 of the tile BEFORE its use (in-order LDS: the last fragment read of the current tile was issued at ks = 2), read from
+//     there one fragment per k-step, and re-requested at once for three tiles later;
+//   * the tile's DMA (into the slot of the tile that has just ended) is issued behind the barrier, as the last thing of the loop body.
+// Vector-memory stream per wave: ... A(t+2) D(t+3) | A(t+3) D(t+4) | ...  (A = NA row-segment loads, D = PW DMA pieces), loads return in
+// order: the set A(t+1) has landed once at most [D(t+2) A(t+2) D(t+3)] are in flight, the pieces D(t+2) once at most [A(t+2) D(t+3) A(t+3)].
+// NWV = 8: 256-row workgroups (the bulk of a launch); NWV = 2: 64-row workgroups for the rows of the last, partly filled round of
+// workgroups (802 stripes on 256 CUs are 3.13 rounds: the 34 stripes of the fourth round run as 136 small workgroups on otherwise idle CUs).
+// ABL (timing-only ablations, VSDE_DEEP256_ABL, results wrong): 1 no MFMAs, 2 no activation loads, 4 no weight DMA, 8 no weight fragment
+// reads, 16 no activation staging / fragment reads
+template <int NWV, int ABL = 0>
+__global__ void __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) deep256p_kernel(DeepParams p) {
+    constexpr int PW = 32 / NWV, NA = 4;
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-    const int64_t wg0 = (int64_t)blockIdx.x * 256, row0 = wg0 + wave * (32 * RB);
+    const int64_t wg0 = p.row_begin + (int64_t)blockIdx.x * (32 * NWV), row0 = wg0 + wave * 32;
     if (wg0 >= p.M) return;
     const int T = p.T;
-    const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;   // workgroups start at different tiles: their L2 requests spread
-    auto issue = [&](int t, int slot) {   // this wave's pieces of tile t (clamped: the last trips re-request the last tile into free slots)
-        const int tt = ((t < T ? t : T - 1) + rot) % T;
+    const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;
+    auto tile_of = [&](int t) { return ((t < T ? t : T - 1) + rot) % T; };   // (trips past the end re-request the last tile)
+    auto issue = [&](int t, int slot) {
+        const int tt = tile_of(t);
+        if constexpr ((ABL & 4) != 0) { if (t > 3) return; }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int piece = wave + NWV * i;
@@ -957,119 +980,276 @@ __global__ void __launch_bounds__(512 / RB, RB == 1 ? 2 : 1) deep256_kernel(Deep
                                              (__attribute__((address_space(3))) void *)(lsm + slot * DEEP_TILE + piece * 1024), 16, 0, 0);
         }
     };
-    const uint16_t *xrow[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int64_t m = row0 + 32 * rb + r < p.M ? row0 + 32 * rb + r : p.M - 1;   // rows past the end repeat the last one (never stored)
-        xrow[rb] = p.X + m * p.ldx + 8 * h;
-    }
-    // The activation fragments travel TWO tiles ahead in two register sets, requested by inline asm: hipcc's own wait for a load that
-    // has LDS-DMA requests behind it is s_waitcnt vmcnt(0) (it drains the weight ring at every tile), so the loads are hidden from it
-    // and the waits below are counted by hand.  Per tile a wave issues [NA fragment loads | PW DMA] in that order (loads return in order).
-    bf16x8 abuf[2][RB][4];
+    // row segments: load i covers rows 8 i .. 8 i + 7 of the wave's 32, lane -> (row 8 i + lane / 8, k-chunk lane % 8); offsets held at the
+    // operand's last row for rows past the end (never stored)
+    const uint32_t voff0 = (uint32_t)((lane >> 3) * p.ldx * 2 + (lane & 7) * 16), step8 = (uint32_t)(8 * p.ldx * 2);
+    const int64_t rbase = row0 < p.M ? row0 : p.M - 1;
+    const int64_t left = p.M - 1 - rbase;
+    const uint32_t vlast = (uint32_t)((left < 31 ? left : 31) * p.ldx * 2 + (lane & 7) * 16);
+    const char *xwave = (const char *)p.X + rbase * p.ldx * 2;
+    char *stg = lsm + DEEP_NSLOT * DEEP_TILE + wave * 4096;   // staging rows [32][128 bytes]: chunk c of row q at slot c ^ ((q >> 1) & 7)
+    bf16x8 araw[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) abuf[i][rb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    auto load_a = [&](int t, bf16x8 (&a)[RB][4]) {
-        const int tt = ((t < T ? t : T - 1) + rot) % T;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const uint16_t *src = xrow[rb] + tt * 64;
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                         : "+v"(a[rb][0]), "+v"(a[rb][1]), "+v"(a[rb][2]), "+v"(a[rb][3]) : "v"(src) : "memory");   // "+v": IN PLACE -- an output the
-            // allocator is free to move would be copied (or reused, if dead) while the data is still on its way
-        }
+        for (int k = 0; k < 4; ++k) araw[i][k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_a = [&](int t, bf16x8 (&a)[4]) {
+        if constexpr ((ABL & 2) != 0) { if (t > 2) return; }
+        const char *base = xwave + tile_of(t) * 128;
+        const uint32_t v1 = min(voff0 + step8, vlast), v2 = min(voff0 + 2 * step8, vlast), v3 = min(voff0 + 3 * step8, vlast);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\t"
+                     "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(min(voff0, vlast)), "v"(v1), "v"(v2), "v"(v3), "s"(base) : "memory");
     };
-    f32x16 yacc[RB][8];
+    auto stage_a = [&](const bf16x8 (&a)[4]) {
+        if constexpr ((ABL & 16) != 0) return;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+        for (int i = 0; i < 4; ++i) {
+            const int q = 8 * i + (lane >> 3);
+            *(bf16x8 *)(stg + q * 128 + (((lane & 7) ^ ((q >> 1) & 7)) << 4)) = a[i];
+        }
+        wave_lds_fence();
+    };
+    const char *afrag = stg + r * 128;
+    const int asw = (r >> 1) & 7;
+    auto read_af = [&](int ks) { return *(const bf16x8 *)(afrag + (((2 * ks + h) ^ asw) << 4)); };
+    f32x16 yacc[8];
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) yacc[rb][cb][e] = 0.f;
-    // request order of the steady state from the start: ... A(k - 1) D(k) ...
+        for (int e = 0; e < 16; ++e) yacc[cb][e] = 0.f;
+    // prologue: D(0) A(0) D(1) A(1) D(2); tile 0 and 1, set 0 landed -> barrier; set 0 -> staging; first operands; A(2) D(3)
     issue(0, 0);
-    load_a(0, abuf[0]); issue(1, 1);
-    load_a(1, abuf[1]); issue(2, 2);
-    // tile 0 has landed once at most [A0 | D1 | A1 | D2] younger requests are in flight
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NA + 2 * PW) : "memory");
-    auto tile = [&](int t, bf16x8 (&acur)[RB][4]) {
-        const char *slot = lsm + (t % DEEP_NSLOT) * DEEP_TILE + h * (16 * 256) + r * 16;
-        // A(t) (requested two tiles ago, in front of D(t + 1)) has landed once at most [D(t+1) | A(t+1) | D(t+2)] are in flight; the
-        // fragments are operands of the wait so that no MFMA below moves in front of it
-        if constexpr (RB == 1)
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(acur[0][0]), "+v"(acur[0][1]), "+v"(acur[0][2]), "+v"(acur[0][3]) : "n"(NA + 2 * PW) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(acur[0][0]), "+v"(acur[0][1]), "+v"(acur[0][2]), "+v"(acur[0][3]), "+v"(acur[RB - 1][0]),
-                         "+v"(acur[RB - 1][1]), "+v"(acur[RB - 1][2]), "+v"(acur[RB - 1][3]) : "n"(NA + 2 * PW) : "memory");
-        bf16x8 wa[2][8];
+    load_a(0, araw[0]); issue(1, 1);
+    load_a(1, araw[1]); issue(2, 2);
+    asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(araw[0][0]), "+v"(araw[0][1]), "+v"(araw[0][2]), "+v"(araw[0][3]) : "n"(NA + PW) : "memory");
+    stage_a(araw[0]);
+    bf16x8 wa[2][8], af[2];
+    {
+        const char *s0 = lsm + h * (16 * 256) + r * 16;
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) wa[0][cb] = *(const bf16x8 *)(slot + cb * 512);
+        for (int cb = 0; cb < 8; ++cb) wa[0][cb] = *(const bf16x8 *)(s0 + cb * 512);
+        af[0] = read_af(0);
+    }
+    load_a(2, araw[0]);
+    issue(3, 3);
+    // tile t; `nxt`: the register set that holds A(t + 1) (requested two tiles ago) and takes A(t + 3)
+    auto tile = [&](int t, bf16x8 (&nxt)[4]) {
+        const char *slot = lsm + (t % DEEP_NSLOT) * DEEP_TILE + h * (16 * 256) + r * 16;
+        const char *slot1 = lsm + ((t + 1) % DEEP_NSLOT) * DEEP_TILE + h * (16 * 256) + r * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
+            const int cur = ks & 1, nb = cur ^ 1;
+            if (ks < 3) {
+                if constexpr ((ABL & 8) == 0) {
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) wa[(ks + 1) & 1][cb] = *(const bf16x8 *)(slot + (ks + 1) * 8192 + cb * 512);
+                    for (int cb = 0; cb < 8; ++cb) wa[nb][cb] = *(const bf16x8 *)(slot + (ks + 1) * 8192 + cb * 512);
+                }
+                if constexpr ((ABL & 16) == 0) af[nb] = read_af(ks + 1);
+            } else {
+                // A(t + 1) has landed once at most [D(t+2) A(t+2) D(t+3)] are in flight; the set is an operand of the wait so that nothing
+                // below moves in front of it
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]) : "n"(NA + 2 * PW) : "memory");
+                stage_a(nxt);
+                if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+                    for (int cb = 0; cb < 8; ++cb) wa[nb][cb] = *(const bf16x8 *)(slot1 + cb * 512);
+                }
+                if constexpr ((ABL & 16) == 0) af[nb] = read_af(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 1) == 0) {
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb)
+                for (int cb = 0; cb < 8; ++cb) yacc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][cb], af[cur], yacc[cb], 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    yacc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks & 1][cb], acur[rb][ks], yacc[rb][cb], 0, 0, 0);
+                for (int cb = 0; cb < 8; ++cb) asm volatile("" ::"v"(wa[cur][cb]), "v"(af[cur]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the set just consumed takes tile t + 2; then the DMA of tile t + 3 into the slot of tile t - 1 (everyone left it at the barrier
-        // that ended that tile; issued BEHIND this tile's LDS reads: in front of them hipcc would order the reads after the DMA)
-        load_a(t + 2, acur);
-        issue(t + 3, (t + 3) % DEEP_NSLOT);
-        // tile t + 1's pieces (issued at tile t - 2) are followed by [A(t+1) | D(t+2) | A(t+2) | D(t+3)]
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NA + 2 * PW) : "memory");
+        load_a(t + 3, nxt);
+        // D(t + 2) (issued behind the barrier of tile t - 2) has landed once at most [A(t+2) D(t+3) A(t+3)] are in flight
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NA + PW) : "memory");
+        issue(t + 4, t % DEEP_NSLOT);   // the slot everyone has just left
     };
     int t = 0;
-    for (; t + 1 < T; t += 2) { tile(t, abuf[0]); tile(t + 1, abuf[1]); }
-    if (t < T) tile(t, abuf[0]);
+    for (; t + 1 < T; t += 2) { tile(t, araw[1]); tile(t + 1, araw[0]); }
+    if (t < T) tile(t, araw[1]);
     // the trailing requests must not outlive the tile slots' reuse below -- nor their destination registers' (kept alive up to here)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(araw[i][0]), "v"(araw[i][1]), "v"(araw[i][2]), "v"(araw[i][3]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            asm volatile("" ::"v"(abuf[i][rb][0]), "v"(abuf[i][rb][1]), "v"(abuf[i][rb][2]), "v"(abuf[i][rb][3]));
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            asm volatile("" ::"v"(abuf[i][rb][0]), "v"(abuf[i][rb][1]), "v"(abuf[i][rb][2]), "v"(abuf[i][rb][3]));
+    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(araw[i][0]), "v"(araw[i][1]), "v"(araw[i][2]), "v"(araw[i][3]));
+    mfma_result_guard();
     // y = acc + bias, 64 columns at a time through this wave's staging rows (the tile slots are free now)
     uint16_t *stage = (uint16_t *)lsm + wave * (32 * SLD);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int half = 0; half < 2; ++half) {
+            const f32x16 &a = yacc[2 * q + half];
+            uint16_t *dst = stage + r * SLD + 32 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 bb = make_uint2(0u, 0u);
+                if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + 64 * q + 32 * half + 8 * g + 4 * h);
+                *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                             pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+            }
+        }
+        wave_lds_fence();
+        flush64(stage, p.Y + 64 * q, p.ldy, row0, p.M, lane);
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- round 6: two-dimensional form
+// deep256q_kernel: the bulk kernel of the deep reductions.  The ablations of deep256p_kernel (profiles/r06_deep256_ablation.txt) say that
+// its matrix pipe (2,048 cycles per tile and SIMD) and its LDS / memory pipeline (~2,600 cycles per tile with the MFMAs removed) run one
+// AFTER the other, and that the LDS is the busiest unit: every wave reads the whole 32 KB weight tile (1 KB of fragment per MFMA) and
+// shuffles its activation rows through staging rows on top.  Here the workgroup's 256 x 256 output block is cut in TWO dimensions --
+// wave (wr, wc) owns rows 64 wr .. + 63 and columns 128 wc .. + 127 (2 x 4 accumulator blocks, 128 registers as before) -- so that a k-step
+// is 2 activation + 4 weight fragment reads for 8 MFMAs (0.75 KB per MFMA), and BOTH operands arrive by LDS-DMA: no staging registers, no
+// staging writes.  Activation tiles [256 rows][128 bytes] are row-major with the 16-byte chunks of row q XOR-ed by (q >> 1) & 7 -- applied
+// to the SOURCE address of the lane-linear DMA and to the fragment reads (conflict-free ds_read_b128) -- in a ring of three slots, two
+// tiles ahead (HBM); weight tiles (the W2 image format) in a ring of two slots, one tile ahead (L2).  160 KB of LDS, one workgroup per CU.
+// Vector-memory stream per wave (4 + 4 pieces per tile): the group [W(t+2) A(t+3)] is issued behind the barrier that ends tile t; the
+// barrier that ends tile t + 1 is preceded by vmcnt(4): everything but A(t+3) has landed, i.e. W(t+2) and A(t+2).
+constexpr int DQ_ASLOT = 256 * 128, DQ_NA = 3, DQ_NW = 2;
+template <int ABL = 0>
+__global__ void __launch_bounds__(512, 2) deep256q_kernel(DeepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t wg0 = p.row_begin + (int64_t)blockIdx.x * 256;
+    if (wg0 >= p.M) return;
+    const int T = p.T;
+    const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;
+    auto tile_of = [&](int t) { return ((t < T ? t : T - 1) + rot) % T; };
+    char *aring = lsm, *wring = lsm + DQ_NA * DQ_ASLOT;
+    // activation pieces of this wave: piece j = wave + 8 i covers rows 8 j .. 8 j + 7; lane -> row 8 j + lane / 8, LDS chunk position lane % 8,
+    // source chunk (lane % 8) ^ ((row >> 1) & 7).  Rows past the end read the last row (never stored).
+    const char *asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 8 * (wave + 8 * i) + (lane >> 3);
+        int64_t m = wg0 + q;
+        m = m < p.M ? m : p.M - 1;
+        asrc[i] = (const char *)p.X + m * p.ldx * 2 + ((((lane & 7) ^ ((q >> 1) & 7))) << 4);
+    }
+    auto issue_w = [&](int t, int slot) {
+        if constexpr ((ABL & 4) != 0) { if (t > 1) return; }
+        const int tt = tile_of(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const void *)((const char *)p.WI + (int64_t)tt * DEEP_TILE + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(wring + slot * DEEP_TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_a = [&](int t, int slot) {
+        if constexpr ((ABL & 2) != 0) { if (t > 2) return; }
+        const int tt = tile_of(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const void *)(asrc[i] + tt * 128),
+                                             (__attribute__((address_space(3))) void *)(aring + slot * DQ_ASLOT + piece * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 yacc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yacc[rb][cb][e] = 0.f;
+    // fragment addresses inside a slot: weight (k-step ks, column block 4 wc + cb) at ks * 8192 + h * 4096 + (32 (4 wc + cb) + r) * 16;
+    // activation (row block rb, k-step ks): row q = 64 wr + 32 rb + r, chunk (2 ks + h) ^ ((q >> 1) & 7)
+    const int woff = h * 4096 + (128 * wc + r) * 16;
+    int aoff[2], asw[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) { const int q = 64 * wr + 32 * rb + r; aoff[rb] = q * 128; asw[rb] = (q >> 1) & 7; }
+    // prologue: W(0) A(0) A(1) | W(1) A(2); tile 0 needs the first two groups: at most [A(1) W(1) A(2)] stay in flight
+    issue_w(0, 0); issue_a(0, 0); issue_a(1, 1);
+    issue_w(1, 1); issue_a(2, 2);
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    for (int t = 0; t < T; ++t) {
+        const char *ws = wring + (t % DQ_NW) * DEEP_TILE + woff;
+        const char *as = aring + (t % DQ_NA) * DQ_ASLOT;
+        bf16x8 wa[2][4], af[2][2];
+        auto fetch = [&](int ks, int b) {
+            if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[b][cb] = *(const bf16x8 *)(ws + ks * 8192 + cb * 512);
+            }
+            if constexpr ((ABL & 16) == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) af[b][rb] = *(const bf16x8 *)(as + aoff[rb] + (((2 * ks + h) ^ asw[rb]) << 4));
+            }
+        };
+        if constexpr ((ABL & 24) != 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[b][cb] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+                af[b][0] = af[b][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+            }
+        }
+        fetch(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks < 3) fetch(ks + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 1) == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        yacc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][cb], af[cur][rb], yacc[rb][cb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) asm volatile("" ::"v"(wa[cur][cb]), "v"(af[cur][0]), "v"(af[cur][1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // W(t+1) and A(t+1) (and A(t+2)'s older pieces) have landed once only the four pieces of A(t+2)... see the header: vmcnt(4)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_w(t + 2, t % DQ_NW);
+        issue_a(t + 3, t % DQ_NA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    mfma_result_guard();
+    // y = acc + bias, 64 columns at a time through this wave's staging rows (the rings are free now)
+    uint16_t *stage = (uint16_t *)lsm + wave * (32 * SLD);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const f32x16 &a = yacc[rb][2 * q + half];
                 uint16_t *dst = stage + r * SLD + 32 * half;
+                const int col0 = 128 * wc + 64 * q + 32 * half;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 bb = make_uint2(0u, 0u);
-                    if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + 64 * q + 32 * half + 8 * g + 4 * h);
+                    if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + col0 + 8 * g + 4 * h);
                     *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
                                                                  pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
                 }
             }
             wave_lds_fence();
-            flush64(stage, p.Y + 64 * q, p.ldy, row0 + 32 * rb, p.M, lane);
+            flush64(stage, p.Y + 128 * wc + 64 * q, p.ldy, wg0 + 64 * wr + 32 * rb, p.M, lane);
             wave_lds_fence();
         }
 }
 }  // namespace mlp
 }  // namespace vsde
+
+#endif  // VSDE_ABLATIONS (deep reduction kernels)
 
 // y [M][256] = x [M][K] W^T (+ bias): w_img = W as K / 16 k-step images [2][256][8] bf16 (W[n][16 t + 8 h + 0..7]: the layout of w2_img),
 // K % 64 == 0, K >= 256.  Replaces the library GEMMs of primitives/mlp.py:54 (forward) and of the input gradients of mlp.py:50 /
@@ -1081,22 +1261,55 @@ extern "C" int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *
     VSDE_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ldy >= 256 && ldy % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                    ((uintptr_t)w_img % 16) == 0 && (!bias || ((uintptr_t)bias % 8) == 0), VSDE_E_BADARG,
                    "linear_deep256 operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+#ifndef VSDE_ABLATIONS
+    vsde::set_error("vsde_linear_deep256_bf16: the own deep-reduction GEMM is only built into the tools' library (python -m viforsdes_amd.build "
+                    "--ablations, VSDE_HIP_LIB): it is 10-15 %% slower than hipBLASLt at the shapes it was written for");
+    return VSDE_E_BADARG;
+#else
     mlp::DeepParams p = {};
     p.X = (const uint16_t *)x; p.ldx = ldx; p.WI = (const uint16_t *)w_img; p.bias = (const uint16_t *)bias; p.Y = (uint16_t *)y; p.ldy = ldy;
     p.M = M; p.T = K / 64;
-    { static int rot = -1; if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; } p.rotate = rot; }
-    const size_t lds = (size_t)mlp::DEEP_NSLOT * mlp::DEEP_TILE;
-    static int rb = -1;   // VSDE_DEEP256_RB=2: four waves x 64 rows (A/B runs); default: eight waves x 32 rows
-    if (rb < 0) { const char *e = getenv("VSDE_DEEP256_RB"); rb = (e && atoi(e) == 2) ? 2 : 1; }
-    if (rb == 1) {
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mlp::deep256_kernel<1>, dim3((unsigned)((M + 255) / 256)), dim3(512), lds, (hipStream_t)stream, p);
+    { static int rot = -1; if (rot < 0) rot = (int)vsde_knob("VSDE_MLP_ROTATE", 1); p.rotate = rot; }
+    // VSDE_DEEP256_Q=0: the bulk on deep256p_kernel<8> (one-dimensional wave tiling); VSDE_DEEP256_TAIL=0: one launch of 256-row
+    // workgroups also when the last round is mostly empty; VSDE_DEEP256_ABL: timing-only ablations (bits in the kernels' headers)
+    static int qk = -1, tail = -1, abl = -1;
+    if (qk < 0) qk = (int)vsde_knob("VSDE_DEEP256_Q", 1);
+    if (tail < 0) tail = (int)vsde_knob("VSDE_DEEP256_TAIL", 1);
+    if (abl < 0) abl = ablation_env("VSDE_DEEP256_ABL");
+    const size_t ring = (size_t)mlp::DEEP_NSLOT * mlp::DEEP_TILE;
+    const int64_t stripes = (M + 255) / 256;
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipDeviceProp_t pr; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    const int64_t rem = stripes % cus;
+    // the last round of 256-row workgroups fills at most half of the CUs: its rows run as 64-row workgroups instead (four times as many,
+    // a quarter of the work each)
+    const int64_t bulk = (tail && stripes > cus && rem > 0 && 2 * rem <= cus) ? stripes - rem : stripes;
+    const size_t lds8 = ring + 8 * 4096, lds2 = ring + 2 * 4096;
+    const size_t ldsq = (size_t)mlp::DQ_NA * mlp::DQ_ASLOT + (size_t)mlp::DQ_NW * mlp::DEEP_TILE;
+    p.row_begin = 0;
+    mlp::DeepParams pb = p;
+    if (bulk < stripes) pb.M = bulk * 256;
+    hipStream_t st = (hipStream_t)stream;
+#define VSDE_DEEP_P(A) case A: VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256p_kernel<8, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8)); \
+        hipLaunchKernelGGL((mlp::deep256p_kernel<8, A>), dim3((unsigned)bulk), dim3(512), lds8, st, pb); break;
+#define VSDE_DEEP_Q(A) case A: VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256q_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq)); \
+        hipLaunchKernelGGL((mlp::deep256q_kernel<A>), dim3((unsigned)bulk), dim3(512), ldsq, st, pb); break;
+    if (qk) {
+        switch (abl) { VSDE_DEEP_Q(1) VSDE_DEEP_Q(6) VSDE_DEEP_Q(24) VSDE_DEEP_Q(30) VSDE_DEEP_Q(31) default: VSDE_DEEP_Q(0) }
     } else {
-        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mlp::deep256_kernel<2>, dim3((unsigned)((M + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p);
+        switch (abl) { VSDE_DEEP_P(1) VSDE_DEEP_P(2) VSDE_DEEP_P(4) VSDE_DEEP_P(8) VSDE_DEEP_P(16) VSDE_DEEP_P(6) VSDE_DEEP_P(24) VSDE_DEEP_P(30) VSDE_DEEP_P(31)
+                       default: VSDE_DEEP_P(0) }
+    }
+#undef VSDE_DEEP_P
+#undef VSDE_DEEP_Q
+    if (bulk < stripes) {
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        p.row_begin = bulk * 256;
+        hipLaunchKernelGGL((mlp::deep256p_kernel<2>), dim3((unsigned)((M - p.row_begin + 63) / 64)), dim3(128), lds2, st, p);
     }
     VSDE_CHECK_HIP(hipGetLastError());
     return 0;
+#endif
 }
 
 // Sizes (bytes) of the three weight images for width C per tile of 16 hidden units: what primitives/fused.py allocates
@@ -1109,8 +1322,8 @@ extern "C" int vsde_mlp_image_bytes(int C, int64_t *w1_tile, int64_t *w2_tile, i
 
 static void mlp_env(mlp::FwdParams &p) {
     static int anti = -1, rot = -1;   // VSDE_MLP_ANTIPHASE (see FwdParams), VSDE_MLP_ROTATE=0: every workgroup walks the tiles in the same order
-    if (anti < 0) { const char *e = getenv("VSDE_MLP_ANTIPHASE"); anti = e ? atoi(e) : 2; }
-    if (rot < 0) { const char *e = getenv("VSDE_MLP_ROTATE"); rot = e ? atoi(e) : 1; }
+    if (anti < 0) anti = (int)vsde_knob("VSDE_MLP_ANTIPHASE", 2);
+    if (rot < 0) rot = (int)vsde_knob("VSDE_MLP_ROTATE", 1);
     p.antiphase = anti; p.rotate = rot; p.trace = g_mlp_trace;
 }
 
@@ -1179,6 +1392,7 @@ extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img,
     if (dbg < 0) dbg = ablation_env("VSDE_MLP_DEBUG");
     mlp_env(p);
     hipStream_t st = (hipStream_t)stream;
+#ifdef VSDE_ABLATIONS
     if (C == 256 && dbg && !s_out) {
         switch (dbg) {
             case 2: return mlp::launch_fwd<256, 0, 2>(p, st);
@@ -1189,6 +1403,9 @@ extern "C" int vsde_mlp_fwd_bf16(const void *x, int64_t ldx, const void *w1_img,
             default: break;
         }
     }
+#else
+    (void)dbg;
+#endif
     if (C == 256) return s_out ? mlp::launch_fwd<256, 1>(p, st) : mlp::launch_fwd<256, 0>(p, st);
     return s_out ? mlp::launch_fwd<128, 1>(p, st) : mlp::launch_fwd<128, 0>(p, st);
 }
@@ -1205,12 +1422,17 @@ extern "C" int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, in
     VSDE_CHECK_ARG(lddy >= C && lddx >= C && ldu >= 2 * H && lddu >= 2 * H && lddy % 8 == 0 && lddx % 8 == 0 && ldu % 8 == 0 && lddu % 8 == 0 &&
                    ((uintptr_t)dy % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)img % 16) == 0 && ((uintptr_t)du % 16) == 0 &&
                    ((uintptr_t)dx % 16) == 0, VSDE_E_BADARG, "mlp_bwd operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+#ifndef VSDE_ABLATIONS
+    vsde::set_error("vsde_mlp_bwd_bf16: the fused SwiGLU backward is only built into the tools' library (python -m viforsdes_amd.build --ablations, "
+                    "VSDE_HIP_LIB): it is slower than the two launches the training step uses");
+    return VSDE_E_BADARG;
+#else
     mlp::BwdParams p = {};
     p.DY = (const uint16_t *)dy; p.lddy = lddy; p.U = (const uint16_t *)u; p.ldu = ldu; p.IMG = (const char *)img;
     p.DU = (uint16_t *)du; p.lddu = lddu; p.DX = (uint16_t *)dx; p.lddx = lddx; p.M = M; p.TP = H / 32;
     p.trace = g_mlp_trace;
     static int var = -1;   // VSDE_MLP_BWD_VAR: bit 0 = tile staging right after the barrier, bit 1 = grouped fragment prefetch in the dx product (A/B runs)
-    if (var < 0) { const char *e = getenv("VSDE_MLP_BWD_VAR"); var = e ? atoi(e) : 3; }
+    if (var < 0) var = (int)vsde_knob("VSDE_MLP_BWD_VAR", 3);
     if (C == 256 && g_mlp_trace != nullptr) return mlp::launch_bwd<256, 3, true>(p, (hipStream_t)stream);   // tools/mlp_bwd_trace.py
     if (C == 256) {
         switch (var & 3) {
@@ -1221,4 +1443,5 @@ extern "C" int vsde_mlp_bwd_bf16(const void *dy, int64_t lddy, const void *u, in
         }
     }
     return mlp::launch_bwd<128>(p, (hipStream_t)stream);
+#endif
 }

@@ -315,7 +315,7 @@ static bool tw_plan_shapes(const TnProblem *probs, int nprob, int &tiles) {
 static void tw_splits(const int *kinds, int nt, int64_t chunks, int *nsplit) {
     const float w[3] = {1.0f, 0.35f, 0.2f};
     static int wgs = -1;
-    if (wgs < 0) { const char *e = getenv("VSDE_TW_WGS"); wgs = e ? atoi(e) : 1536; }
+    if (wgs < 0) wgs = (int)vsde_knob("VSDE_TW_WGS", 1536);
     float tot = 0.f;
     for (int i = 0; i < nt; ++i) tot += w[kinds[i]];
     for (int i = 0; i < nt; ++i) {

@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_reduce_group_kernel(Wgrad2Group 
 // their partial-tile traffic (131 KB per workgroup) is otherwise as large as the operands.
 static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
     static int force_tn = -1;
-    if (force_tn < 0) { const char *e = getenv("VSDE_WGRAD_TN"); force_tn = e ? atoi(e) : 0; }
+    if (force_tn < 0) force_tn = (int)vsde_knob("VSDE_WGRAD_TN", 0);
     p.M = M; p.N = N; p.K = K;
     p.tn = force_tn ? force_tn : (((N + 255) / 256) * ((K + W2_TK - 1) / W2_TK) >= 3 ? 256 : 128);
     p.tiles_n = (N + p.tn - 1) / p.tn; p.tiles_k = (K + W2_TK - 1) / W2_TK; p.tiles = p.tiles_n * p.tiles_k;
@@ -459,7 +459,7 @@ static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
     // One round of workgroups can leave the chip badly filled when the tile count does not divide it (dW[2816, 512]: 22 tiles x 8
     // splits = 176 workgroups on 256 CUs).  Then finer splits in several rounds: rounds x (rows per split), plus the partial
     // tiles' share of the traffic (each workgroup writes, and the reduction reads, one fp32 tile against (TN + 256) x 2 bytes per row).
-    if (p.tiles >= 3 && p.tiles * nsplit < (wgs * 85) / 100 && !getenv("VSDE_WGRAD_ONE_ROUND")) {
+    if (p.tiles >= 3 && p.tiles * nsplit < (wgs * 85) / 100 && !vsde_knob("VSDE_WGRAD_ONE_ROUND", 0)) {
         double best = 1e30; int64_t pick = nsplit;
         for (int64_t ns = 8; ns <= 64 && ns <= chunks; ns += 8) {
             const double rounds = (double)((p.tiles * ns + wgs - 1) / wgs);
@@ -480,7 +480,7 @@ static void wgrad2_plan(int64_t M, int N, int K, Wgrad2Params &p) {
     }
     {
         static int force_ns = -1;   // VSDE_WGRAD_NSPLIT: split count for every problem (A/B runs)
-        if (force_ns < 0) { const char *e = getenv("VSDE_WGRAD_NSPLIT"); force_ns = e ? atoi(e) : 0; }
+        if (force_ns < 0) force_ns = (int)vsde_knob("VSDE_WGRAD_NSPLIT", 0);
         if (force_ns > 0) { nsplit = force_ns; if (nsplit > chunks) nsplit = chunks; }
     }
     p.nsplit = (int)nsplit; p.chunks = chunks;
@@ -492,24 +492,36 @@ static size_t wgrad2_workspace(const Wgrad2Params &p) {
 // TN = 256: eight waves with 64 x 128 blocks (default), or four with 128 x 128 (VSDE_WGRAD_WAVES=4; A/B runs).  Measured, round 5, LV
 // shapes, one box: four waves 194 | 275 | 143 us against 166 | 234 | 133 us for dW[832,256] | [1408,256] | [256,704] -- a third fewer LDS
 // bytes per MFMA does not pay for one wave per SIMD having nobody to hide its LDS latency behind.
+#ifdef VSDE_ABLATIONS
 static bool wgrad2_four_waves() {
     static int w = -1;
-    if (w < 0) { const char *e = getenv("VSDE_WGRAD_WAVES"); w = (e && atoi(e) == 4) ? 4 : 8; }
+    if (w < 0) w = vsde_knob("VSDE_WGRAD_WAVES", 8) == 4 ? 4 : 8;
     return w == 4;
 }
+#define VSDE_FOUR_WAVES() wgrad2_four_waves()
+#define VSDE_FOUR_WAVES_GROUP(G_, n_, s_) wgrad2_launch_group<256, 256>(G_, n_, s_)
+#else
+#define VSDE_FOUR_WAVES() false
+#define VSDE_FOUR_WAVES_GROUP(G_, n_, s_) 0
+#endif
 static long long *g_wgrad_trace = nullptr;
 template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &p_, hipStream_t s) {
     using C = W2<TN, TH>;
     const size_t lds = (size_t)2 * C::BUF * sizeof(uint16_t);
     Wgrad2Params p = p_;
     p.trace = g_wgrad_trace;
+#ifdef VSDE_ABLATIONS
     auto kern = (g_wgrad_trace && TN == 256 && TH == 512) ? wgrad_tr_kernel<TN, TH, (TN == 256 && TH == 512)> : wgrad_tr_kernel<TN, TH>;
+#else
+    auto kern = wgrad_tr_kernel<TN, TH>;
+#endif
     // VSDE_WGRAD_DMA=1: the LDS-DMA form (wgrad_dma_kernel; A/B runs).  Opt-in: measured 184 | 251 | 143 us against 169 | 232 | 131 us for
     // dW[832,256] | [1408,256] | [256,704] -- the ~1,000 cycles per step the register form spends storing to LDS are not what bounds
     // it: with them gone the step waits as long for its data (36 KB per CU and step arrive at ~13 B/clk either way, three or four steps
     // ahead make no difference: profiles/r05_wgrad.txt)
+#ifdef VSDE_ABLATIONS
     static int use_dma = -1;
-    if (use_dma < 0) { const char *e = getenv("VSDE_WGRAD_DMA"); use_dma = (e && e[0] == '1') ? 1 : 0; }
+    if (use_dma < 0) use_dma = vsde_knob("VSDE_WGRAD_DMA", 0) == 1 ? 1 : 0;
     if constexpr (TN == 256 && TH == 512) {
         if (use_dma && !g_wgrad_trace && p.M % W2_BM == 0) {   // whole 32-row blocks only (rows past M cannot be zeroed on the way in)
             const size_t dlds = (size_t)4 * C::BUF * sizeof(uint16_t) + 1024;
@@ -521,6 +533,7 @@ template <int TN, int TH = 2 * TN> static int wgrad2_launch(const Wgrad2Params &
             return 0;
         }
     }
+#endif
     VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(((p.nsplit + 7) / 8) * 8 * p.tiles)), dim3(C::THREADS), lds, s, p);
     VSDE_CHECK_HIP(hipGetLastError());
@@ -619,7 +632,7 @@ extern "C" int vsde_linear_wgrad_group_bf16(int n, const void *items_, int group
                 w += bytes;
             }
             if (flush && G.n > 0) {
-                const int rc = tn == 256 ? (wgrad2_four_waves() ? wgrad2_launch_group<256, 256>(G, G.first[G.n], (hipStream_t)stream)
+                const int rc = tn == 256 ? (VSDE_FOUR_WAVES() ? VSDE_FOUR_WAVES_GROUP(G, G.first[G.n], (hipStream_t)stream)
                                                                 : wgrad2_launch_group<256>(G, G.first[G.n], (hipStream_t)stream))
                                          : wgrad2_launch_group<128>(G, G.first[G.n], (hipStream_t)stream);
                 if (rc != 0) return rc;
@@ -656,6 +669,9 @@ extern "C" int vsde_linear_wgrad_bf16_rows(const void *dy, const void *x, int64_
     const size_t need = wgrad2_workspace(p);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "linear_wgrad workspace too small: %zu < %zu", workspace_bytes, need);
     p.dy = (const uint16_t *)dy; p.x = (const uint16_t *)x; p.partial = (float *)workspace; p.dW = dW; p.db = db; p.row_map = row_map;
-    if (p.tn == 256) return wgrad2_four_waves() ? wgrad2_launch<256, 256>(p, (hipStream_t)stream) : wgrad2_launch<256>(p, (hipStream_t)stream);
+#ifdef VSDE_ABLATIONS
+    if (p.tn == 256 && wgrad2_four_waves()) return wgrad2_launch<256, 256>(p, (hipStream_t)stream);
+#endif
+    if (p.tn == 256) return wgrad2_launch<256>(p, (hipStream_t)stream);
     return wgrad2_launch<128>(p, (hipStream_t)stream);
 }

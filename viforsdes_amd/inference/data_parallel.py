@@ -92,11 +92,17 @@ class FlatGradientAllReduce:
         self._early_handle = None
         self._early_sent = False
         self._laid_out = False
+        self._hooks: list = []
         if self.active:
             self._allocate()
             if self.overlap:
-                for p in self.params:
-                    p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def close(self) -> None:
+        """Remove the gradient hooks (an instance that is dropped while its parameters live on: tools, the bench's probe)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def _allocate(self, order: Optional[list[int]] = None, n_early: int = 0) -> None:
         """Flat buffer and the per-parameter views in ``order`` (default: parameter order); with ``n_early`` > 0 the first

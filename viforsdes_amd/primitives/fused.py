@@ -1010,15 +1010,16 @@ class DeepImage:
         return self.img
 
 
-# the deep-reduction GEMMs at width 256 (SwiGLU output projection, the two input-gradient products of a block) on the own kernel
-# csrc/vsde_mlp.hip::deep256_kernel.  OPT-IN (VSDE_DEEP256=1): correct, and 30 % slower than the library's 256 x 224 macro tiles
-# (136 | 223 | 140 us against 96 | 170 | 111 us for K = 704 | 1408 | 832 at the LV shape) -- with a wave's 32 rows and all 256 output
-# columns stationary, every wave reads the whole weight tile out of LDS: 1 KB per MFMA, twice what the matrix pipe can be fed
+# the deep-reduction GEMMs at width 256 (SwiGLU output projection, the two input-gradient products of a block) on the own kernels
+# csrc/vsde_mlp.hip::deep256q_kernel / deep256p_kernel.  OPT-IN (VSDE_DEEP256=1) and only with the tools' library (VSDE_HIP_LIB =
+# libvsde_hip_abl.so): correct, and 10-15 % slower than the library's 256 x 224 macro tiles (112 | 193 | 126 us against 96 | 167 | 113 us
+# for K = 704 | 1408 | 832 at the LV shape; three schedules measured, profiles/r06_deep256_ablation.txt)
 DEEP256 = os.environ.get("VSDE_DEEP256", "0") == "1"
 
 
 def deep256_usable(M: int, N: int, K: int) -> bool:
-    return ENABLED and OWN_GEMM and DEEP256 and N == 256 and K % 64 == 0 and K >= 512 and M >= BLOCK_MLP_MIN_ROWS
+    return (ENABLED and OWN_GEMM and DEEP256 and N == 256 and K % 64 == 0 and K >= 512 and M >= BLOCK_MLP_MIN_ROWS
+            and _hip.has_ablations())   # the kernels exist only in the tools' library (csrc/vsde_common.h)
 
 
 def deep256(x2: Tensor, pack: PackedWeight, transposed: bool, bias: Optional[Tensor]) -> Tensor:
@@ -1152,7 +1153,7 @@ class _SwiGLUMLP(torch.autograd.Function):
         pin, pout = ctx.packs
         dy2 = dy.to(torch.bfloat16).reshape(-1, dy.shape[-1]).contiguous()
         if (FUSED_MLP_BWD and pin.grad_rows is not None and dy2.shape[1] in (128, 256) and pout.weight.shape[1] % 64 == 0
-                and dy2.shape[0] >= BLOCK_MLP_MIN_ROWS):
+                and dy2.shape[0] >= BLOCK_MLP_MIN_ROWS and _hip.has_ablations()):
             # one kernel for du AND dx (csrc/vsde_mlp.hip::mlp_bwd_kernel): du is never re-read.  Opt-in: at the LV shape it measures
             # 470-480 us against 435 us for the two launches below (profiles/r05_mlp_bwd.txt says why)
             img = getattr(pin, "_mlp_bwd_images", None)
