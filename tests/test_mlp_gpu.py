@@ -74,10 +74,36 @@ def test_images_follow_a_pack_refresh():
         for q in params:
             q.mul_(0.5)
     fused.note_parameters_changed()
-    fused.PackedWeight.refresh_all(force=True, params={id(q) for q in params})
-    y1, _ = _hip.mlp_fwd(x, img.w1, img.w2, img.b1, pout.bias, 704)   # no operands() call: what a captured step replays
+    ids = {id(q) for q in params}
+    fused.PackedWeight.refresh_all(force=True, params=ids)
+    # an EAGER forced refresh only marks the derived images dirty (the training step never reads them: no launches for them per step);
+    # whoever reads them without going through operands() -- a captured sampling call before its replay -- rebuilds the dirty ones first
+    assert img._key is None
+    fused.PackedWeight.refresh_dirty_derived(ids)
+    assert img._key is not None
+    y1, _ = _hip.mlp_fwd(x, img.w1, img.w2, img.b1, pout.bias, 704)   # no operands() call: what a captured sampling call replays
     _, y_ref = _reference(x, *[q.detach() for q in params])
     assert _rel(y1, y_ref) < 1e-2 and _rel(y0, y_ref) > 0.1
+    # inside a stream capture the forced refresh rebuilds them itself (the captured optimizer step's tail): replaying that graph after
+    # another parameter change brings packs AND images up to date on the device
+    with torch.no_grad():
+        for q in params:
+            q.mul_(2.0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fused.PackedWeight.refresh_all(force=True, params=ids)   # (the refresh table is built outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fused.PackedWeight.refresh_all(force=True, params=ids)
+    with torch.no_grad():
+        for q in params:
+            q.mul_(0.25)
+    g.replay()
+    y2, _ = _hip.mlp_fwd(x, img.w1, img.w2, img.b1, pout.bias, 704)
+    _, y_ref2 = _reference(x, *[q.detach() for q in params])
+    assert _rel(y2, y_ref2) < 1e-2
 
 
 @pytest.mark.parametrize("B,N,C,H,hreal,last", [(40, 401, 256, 704, 682, False), (40, 401, 256, 704, 682, True), (33, 129, 128, 384, 341, False), (128, 101, 256, 704, 682, False),
