@@ -16,7 +16,8 @@
 //   12 chain of dependent v_mfma_f32_16x16x32_bf16 (4 accumulator registers)
 //   13 VALU: v_mov_b32 between 8 registers (no arithmetic, one source operand)
 //   14 / 15 / 16 ONE wave: INDEPENDENT 32x32x16 bf16 MFMAs (4 accumulators, round robin) with 2 / 4 / 6 v_fma in every gap
-//   17 ONE wave: the same with 4 v_mov_b32 in every gap
+//   17 ONE wave: the same with 4 v_mov_b32 in every gap;  18: 4 v_cvt_pk_bf16_f32;  19: 2 v_exp_f32
+//   (the fillers of the one-wave roles are asm volatile statements between sched_barriers: they stay in their gap)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +26,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// fillers that stay where they are written: the compiler clumps plain fmaf() calls of several gaps together (and SLP-packs them into
+// v_pk_fma_f32); an asm volatile statement keeps its place between the sched_barriers
+__device__ __forceinline__ void fill_fma(float &v, float c) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v) : "v"(c)); }
+__device__ __forceinline__ void fill_exp(float &v) { asm volatile("v_exp_f32 %0, %0" : "+v"(v)); }
+__device__ __forceinline__ void fill_rcp(float &v) { asm volatile("v_rcp_f32 %0, %0" : "+v"(v)); }
+__device__ __forceinline__ void fill_cvt(uint32_t &d, float a, float b) { asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
 
 template <int ROLE>
 __device__ __forceinline__ float run_role(int iters, float seed, char *lds) {
@@ -129,21 +137,21 @@ __device__ __forceinline__ float run_role(int iters, float seed, char *lds) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
                 if constexpr (ROLE == 6) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) v[i] = __builtin_fmaf(v[i], 0.999f, 0.001f);
+                    for (int i = 0; i < 6; ++i) fill_fma(v[i], 0.999f);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) v[i] = __builtin_amdgcn_exp2f(-0.5f * v[i]);
+                    for (int i = 0; i < 2; ++i) fill_exp(v[i]);
 #pragma unroll
-                    for (int i = 2; i < 4; ++i) v[i] = __builtin_amdgcn_rcpf(1.0f + v[i]);
+                    for (int i = 2; i < 4; ++i) fill_rcp(v[i]);
 #pragma unroll
-                    for (int i = 4; i < 8; ++i) v[i] = __builtin_fmaf(v[i], 0.999f, 0.001f);
+                    for (int i = 4; i < 8; ++i) fill_fma(v[i], 0.999f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         out = acc[0] + acc[7];
         for (int i = 0; i < 8; ++i) out += v[i];
-    } else if constexpr (ROLE >= 14 && ROLE <= 17) {
+    } else if constexpr (ROLE >= 14 && ROLE <= 19) {
         f32x16 acc[4] = {{0}, {0}, {0}, {0}};
         bf16x8 a, b;
         for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + i); b[i] = (short)(0x3c00 + i); }
@@ -155,8 +163,16 @@ __device__ __forceinline__ float run_role(int iters, float seed, char *lds) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NF; ++i) v[i] = __builtin_fmaf(v[i], 0.999f, 0.001f);
+                for (int i = 0; i < NF; ++i) fill_fma(v[i], 0.999f);
+                if constexpr (ROLE == 18) {   // 4 v_cvt_pk_bf16_f32
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fill_cvt(u[i], v[i], v[i + 4]);
+                }
+                if constexpr (ROLE == 19) {   // 2 v_exp_f32
+                    fill_exp(v[0]); fill_exp(v[1]);
+                }
                 if constexpr (ROLE == 17) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(u[i + 4]));
@@ -262,6 +278,8 @@ int main(int argc, char **argv) {
     line<15, 0>("32x32x16 bf16 (4 independent acc) with 4 v_fma per gap", out, 16, 0, 0);
     line<16, 0>("32x32x16 bf16 (4 independent acc) with 6 v_fma per gap", out, 16, 0, 0);
     line<17, 0>("32x32x16 bf16 (4 independent acc) with 4 v_mov per gap", out, 16, 0, 0);
+    line<18, 0>("32x32x16 bf16 (4 independent acc) with 4 v_cvt_pk per gap", out, 16, 0, 0);
+    line<19, 0>("32x32x16 bf16 (4 independent acc) with 2 v_exp per gap", out, 16, 0, 0);
     line<15, 15>("both waves: 4 independent acc + 4 v_fma per gap each", out, 16, 0, 0);
     return 0;
 }
