@@ -108,13 +108,16 @@ __device__ __forceinline__ void flush_rows32(const uint16_t *stage, uint16_t *ds
 }
 
 // acc (one 32x32 MFMA block: this lane holds row r, columns 8 g + 4 h + i) + bias -> bf16 into the staging row
+// (all four bias reads first: bias row and staging row are both LDS, the compiler must assume they alias and would otherwise wait for
+//  every read behind the previous store -- four LDS round trips per block instead of one)
 __device__ __forceinline__ void stage_block(const f32x16 &acc, const uint16_t *bias32, uint16_t *dst_row, int h) {
+    uint2 bb[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
-        *(uint2 *)(dst_row + 8 * g + 4 * h) = make_uint2(pack_bf16x2(acc[4 * g + 0] + bf_lo(bb.x), acc[4 * g + 1] + bf_hi(bb.x)),
-                                                        pack_bf16x2(acc[4 * g + 2] + bf_lo(bb.y), acc[4 * g + 3] + bf_hi(bb.y)));
-    }
+    for (int g = 0; g < 4; ++g) bb[g] = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *(uint2 *)(dst_row + 8 * g + 4 * h) = make_uint2(pack_bf16x2(acc[4 * g + 0] + bf_lo(bb[g].x), acc[4 * g + 1] + bf_hi(bb[g].x)),
+                                                        pack_bf16x2(acc[4 * g + 2] + bf_lo(bb[g].y), acc[4 * g + 3] + bf_hi(bb[g].y)));
 }
 
 // weight tile [ROWS][KW] (row pitch ldw in global memory) <-> registers <-> LDS rows of LDB elements, THREADS threads
@@ -162,9 +165,12 @@ __device__ __forceinline__ void swiglu_quads(const f32x16 &acc, const uint16_t *
 // epilogue is the longer phase of this kernel, profiles/r04_pmc_linear_swiglu.txt: 4.5 -> 2 v_cvt_pk_bf16_f32 and 4 -> 3 adds per pair).
 __device__ __forceinline__ void swiglu_stage(const f32x16 &acc, const uint16_t *bias32, uint16_t *dst_row, int h, uint32_t (&out)[4]) {
     uint32_t uw[4][2];
+    uint2 bbv[4];   // all four bias reads in front of the first staging store (see stage_block)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bbv[g] = *(const uint2 *)(bias32 + 8 * g + 4 * h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const uint2 bb = *(const uint2 *)(bias32 + 8 * g + 4 * h);
+        const uint2 bb = bbv[g];
         uw[g][0] = pack_bf16x2(acc[4 * g + 0] + bf_lo(bb.x), acc[4 * g + 1] + bf_hi(bb.x));
         uw[g][1] = pack_bf16x2(acc[4 * g + 2] + bf_lo(bb.y), acc[4 * g + 3] + bf_hi(bb.y));
         *(uint2 *)(dst_row + 8 * g + 4 * h) = make_uint2(uw[g][0], uw[g][1]);
@@ -374,11 +380,19 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
         }
         wave_lds_fence();
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            // the row's eight u quads first, then the stores (read-after-store through LDS pointers the compiler cannot tell apart:
+            // one round trip per row block instead of four)
+            uint2 uav[4], ubv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint16_t *pa = stage + (rb * 32 + r) * SLD + 32 * (g >> 1) + 8 * (g & 1) + 4 * h;
+                uav[g] = *(const uint2 *)pa; ubv[g] = *(const uint2 *)(pa + 16);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {   // ds column 8 g + 4 h + i  <->  u columns 32 (g / 2) + 8 (g % 2) + 4 h + i (a), + 16 (b)
                 uint16_t *pa = stage + (rb * 32 + r) * SLD + 32 * (g >> 1) + 8 * (g & 1) + 4 * h, *pb = pa + 16;
-                const uint2 ua = *(const uint2 *)pa, ub = *(const uint2 *)pb;
+                const uint2 ua = uav[g], ub = ubv[g];
                 const float a[4] = {bf_lo(ua.x), bf_hi(ua.x), bf_lo(ua.y), bf_hi(ua.y)};
                 const float b[4] = {bf_lo(ub.x), bf_hi(ub.x), bf_lo(ub.y), bf_hi(ub.y)};
                 float da[4], db[4];
@@ -391,6 +405,7 @@ __device__ __forceinline__ void rows_epilogue(const LinParams &p, f32x16 (&acc)[
                 *(uint2 *)pa = make_uint2(pack_bf16x2(da[0], da[1]), pack_bf16x2(da[2], da[3]));
                 *(uint2 *)pb = make_uint2(pack_bf16x2(db[0], db[1]), pack_bf16x2(db[2], db[3]));
             }
+        }
         wave_lds_fence();
         flush_rows64<SLD, R>(stage, p.C + 2 * n0, p.ldc, row0, p.M, lane);
         wave_lds_fence();
