@@ -24,6 +24,7 @@
 // Training additionally writes s [M, H] (natural unit order) for the weight gradient of W_out; u is NOT kept: the backward
 // recomputes it from x with the same products in the same order (bit-identical), see mlp_bwd_kernel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "vsde_common.h"
 
@@ -1246,6 +1247,158 @@ __global__ void __launch_bounds__(512, 2) deep256q_kernel(DeepParams p) {
             wave_lds_fence();
         }
 }
+
+// ----------------------------------------------------------------------------------------------- round 6: two resident workgroups per CU
+// deep256r_kernel.  The ablations of the forms above say it plainly: a tile-synchronous workgroup that owns its CU runs its memory / LDS
+// pipeline and its MFMAs one after the other (116 + 79 -> 163 us).  The rows kernels of csrc/vsde_linear.hip never had that problem --
+// two independent four-wave workgroups per CU drift apart and cover each other's waits.  The same here: a workgroup is FOUR waves
+// (2 x 2: a wave owns 64 rows x 128 columns, 2 x 4 accumulator blocks as in deep256q_kernel) = 128 rows, 80 KB of LDS:
+//   activation tiles [128 rows][128 bytes] (K = 64), chunks XOR-swizzled as in deep256q_kernel: ring of TWO slots (32 KB);
+//   weight HALF tiles (K = 32: two k-step images, 16 KB): ring of THREE slots (48 KB); one barrier per half tile (16 MFMAs per wave).
+// Every request has two half tiles of flight.  Stream per wave (4 pieces each): behind the barrier that ends half tile j the group
+// [W(j+3)] is issued, for odd j = 2 t + 1 also A(t+2) (tile t has just been left); the barrier that ends half tile j is preceded
+// by vmcnt(4) for odd j (only W(j+2) may still fly) and vmcnt(8) for even j ([W(j+2) A(..)]): W(j+1) -- and for odd j the tile A((j+1)/2)
+// that starts behind it -- have landed.  Each workgroup streams the whole weight: twice the L2 -> LDS weight traffic per CU, which is
+// what the second workgroup costs.  Measured (profiles/r06_deep256_ablation.txt, section 6): 104 | 192 | 119 us (hipBLASLt 99 | 168 | 113) --
+// the closest of the four forms, MFMAs alone 65 us -- but its memory pipeline alone (no MFMAs) takes 156 us: 1,604 workgroups x 720 KB of
+// weight images + the activations = 1.7 GB through L2 -> LDS at ~11 TB/s, the same aggregate rate the one-workgroup form reaches with
+// 1.2 GB.  The bound of every form is that LDS-DMA intake, not the schedule around it.
+constexpr int DR_ASLOT = 128 * 128, DR_WSLOT = 2 * 32 * 256, DR_NA = 2, DR_NW = 3;
+template <int ABL = 0>
+__global__ void __launch_bounds__(256, 2) deep256r_kernel(DeepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t wg0 = p.row_begin + (int64_t)blockIdx.x * 128;
+    if (wg0 >= p.M) return;
+    const int T = p.T, G = 2 * T;
+    const int rot = p.rotate ? (int)((blockIdx.x * 5u) % (unsigned)T) : 0;
+    auto tile_of = [&](int t) { return ((t < T ? t : T - 1) + rot) % T; };
+    char *aring = lsm, *wring = lsm + DR_NA * DR_ASLOT;
+    const char *asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 8 * (wave + 4 * i) + (lane >> 3);
+        int64_t m = wg0 + q;
+        m = m < p.M ? m : p.M - 1;
+        asrc[i] = (const char *)p.X + m * p.ldx * 2 + ((((lane & 7) ^ ((q >> 1) & 7))) << 4);
+    }
+    auto issue_w = [&](int g, int slot) {   // half tile g = 2 t + u: bytes [u * 16 KB, ..) of tile t's image
+        if constexpr ((ABL & 4) != 0) { if (g > 2) return; }
+        const int gg = g < G ? g : G - 1;
+        const int64_t off = (int64_t)tile_of(gg >> 1) * DEEP_TILE + (gg & 1) * DR_WSLOT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const void *)((const char *)p.WI + off + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(wring + slot * DR_WSLOT + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_a = [&](int t, int slot) {
+        if constexpr ((ABL & 2) != 0) { if (t > 1) return; }
+        const int tt = tile_of(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((const void *)(asrc[i] + tt * 128),
+                                             (__attribute__((address_space(3))) void *)(aring + slot * DR_ASLOT + piece * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 yacc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yacc[rb][cb][e] = 0.f;
+    const int woff = h * 4096 + (128 * wc + r) * 16;
+    int aoff[2], asw[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) { const int q = 64 * wr + 32 * rb + r; aoff[rb] = q * 128; asw[rb] = (q >> 1) & 7; }
+    // prologue = the groups of the barriers "-3, -2, -1": [W(0) A(0)] [W(1)] [W(2) A(1)]; half tile 0 needs the first
+    issue_w(0, 0); issue_a(0, 0);
+    issue_w(1, 1);
+    issue_w(2, 2); issue_a(1, 1);
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    auto half = [&](int g, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
+        const char *ws = wring + (g % DR_NW) * DR_WSLOT + woff;
+        const char *as = aring + ((g >> 1) % DR_NA) * DR_ASLOT;
+        bf16x8 wa[2][4], af[2][2];
+        if constexpr ((ABL & 24) != 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[b][cb] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+                af[b][0] = af[b][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+            }
+        }
+        auto fetch = [&](int ksl, int b) {
+            if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[b][cb] = *(const bf16x8 *)(ws + ksl * 8192 + cb * 512);
+            }
+            if constexpr ((ABL & 16) == 0) {
+                const int ks = (ODD ? 2 : 0) + ksl;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) af[b][rb] = *(const bf16x8 *)(as + aoff[rb] + (((2 * ks + h) ^ asw[rb]) << 4));
+            }
+        };
+        fetch(0, 0);
+        fetch(1, 1);
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 1) == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        yacc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ksl][cb], af[ksl][rb], yacc[rb][cb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) asm volatile("" ::"v"(wa[ksl][cb]), "v"(af[ksl][0]), "v"(af[ksl][1]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ODD) {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_w(g + 3, g % DR_NW);
+            issue_a((g >> 1) + 2, ((g >> 1) + 2) % DR_NA);   // tile (g >> 1) has just been left: its slot takes tile + 2
+        } else {
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_w(g + 3, g % DR_NW);
+        }
+    };
+    for (int t = 0; t < T; ++t) {
+        half(2 * t, std::false_type{});
+        half(2 * t + 1, std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    mfma_result_guard();
+    uint16_t *stage = (uint16_t *)lsm + wave * (32 * SLD);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int half_ = 0; half_ < 2; ++half_) {
+                const f32x16 &a = yacc[rb][2 * q + half_];
+                uint16_t *dst = stage + r * SLD + 32 * half_;
+                const int col0 = 128 * wc + 64 * q + 32 * half_;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 bb = make_uint2(0u, 0u);
+                    if (p.bias != nullptr) bb = *(const uint2 *)(p.bias + col0 + 8 * g + 4 * h);
+                    *(uint2 *)(dst + 8 * g + 4 * h) = make_uint2(pack2(a[4 * g + 0] + bf_lo(bb.x), a[4 * g + 1] + bf_hi(bb.x)),
+                                                                 pack2(a[4 * g + 2] + bf_lo(bb.y), a[4 * g + 3] + bf_hi(bb.y)));
+                }
+            }
+            wave_lds_fence();
+            flush64(stage, p.Y + 128 * wc + 64 * q, p.ldy, wg0 + 64 * wr + 32 * rb, p.M, lane);
+            wave_lds_fence();
+        }
+}
 }  // namespace mlp
 }  // namespace vsde
 
@@ -1272,7 +1425,8 @@ extern "C" int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *
     { static int rot = -1; if (rot < 0) rot = (int)vsde_knob("VSDE_MLP_ROTATE", 1); p.rotate = rot; }
     // VSDE_DEEP256_Q=0: the bulk on deep256p_kernel<8> (one-dimensional wave tiling); VSDE_DEEP256_TAIL=0: one launch of 256-row
     // workgroups also when the last round is mostly empty; VSDE_DEEP256_ABL: timing-only ablations (bits in the kernels' headers)
-    static int qk = -1, tail = -1, abl = -1;
+    static int qk = -1, tail = -1, abl = -1, rk = -1;
+    if (rk < 0) rk = (int)vsde_knob("VSDE_DEEP256_R", 1);   // 1: the bulk on deep256r_kernel (two four-wave workgroups per CU)
     if (qk < 0) qk = (int)vsde_knob("VSDE_DEEP256_Q", 1);
     if (tail < 0) tail = (int)vsde_knob("VSDE_DEEP256_TAIL", 1);
     if (abl < 0) abl = ablation_env("VSDE_DEEP256_ABL");
@@ -1294,6 +1448,27 @@ extern "C" int vsde_linear_deep256_bf16(const void *x, int64_t ldx, const void *
         hipLaunchKernelGGL((mlp::deep256p_kernel<8, A>), dim3((unsigned)bulk), dim3(512), lds8, st, pb); break;
 #define VSDE_DEEP_Q(A) case A: VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256q_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq)); \
         hipLaunchKernelGGL((mlp::deep256q_kernel<A>), dim3((unsigned)bulk), dim3(512), ldsq, st, pb); break;
+    if (rk) {
+        // 128-row workgroups, two per CU: the rows of the last, at most half filled round of (2 x CUs) workgroups go to the tail launch
+        const int64_t s128 = (M + 127) / 128, slots = 2 * (int64_t)cus, rem128 = s128 % slots;
+        // (VSDE_DEEP256_TAIL=2 only: with two workgroups per CU the rounds overlap and the second launch costs more than the ragged
+        //  round -- 110 | 196 | 127 us with it, 104 | 192 | 119 without)
+        const int64_t bulk128 = (tail == 2 && s128 > slots && rem128 > 0 && 2 * rem128 <= slots) ? s128 - rem128 : s128;
+        const size_t ldsr = (size_t)mlp::DR_NA * mlp::DR_ASLOT + (size_t)mlp::DR_NW * mlp::DR_WSLOT;
+        mlp::DeepParams pr = p;
+        if (bulk128 < s128) pr.M = bulk128 * 128;
+#define VSDE_DEEP_R(A) case A: VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256r_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr)); \
+        hipLaunchKernelGGL((mlp::deep256r_kernel<A>), dim3((unsigned)bulk128), dim3(256), ldsr, st, pr); break;
+        switch (abl) { VSDE_DEEP_R(1) VSDE_DEEP_R(6) VSDE_DEEP_R(24) VSDE_DEEP_R(30) VSDE_DEEP_R(31) default: VSDE_DEEP_R(0) }
+#undef VSDE_DEEP_R
+        if (bulk128 < s128) {
+            VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)mlp::deep256p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            p.row_begin = bulk128 * 128;
+            hipLaunchKernelGGL((mlp::deep256p_kernel<2>), dim3((unsigned)((M - p.row_begin + 63) / 64)), dim3(128), lds2, st, p);
+        }
+        VSDE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (qk) {
         switch (abl) { VSDE_DEEP_Q(1) VSDE_DEEP_Q(6) VSDE_DEEP_Q(24) VSDE_DEEP_Q(30) VSDE_DEEP_Q(31) default: VSDE_DEEP_Q(0) }
     } else {
