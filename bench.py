@@ -70,7 +70,7 @@ def build_trainer(problem, batch, device, mixed_precision, seed, enc_hidden=256,
     return tr
 
 
-PMC_FILE = "profiles/r05_pmc_head_lv.txt"
+PMC_FILE = "profiles/r06_pmc_head_lv.txt"
 
 
 FWD_KERNELS = ("head_fwd_mp_kernel<2, true", "head_fwd_v2_kernel<2, true")

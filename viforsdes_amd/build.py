@@ -17,10 +17,10 @@ HEADERS = ["vsde_common.h", os.path.join("..", "..", "include", "vsde_hip.h")]
 ARCH = "gfx950"
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _stale(lib_path: str = LIB_PATH) -> bool:
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib_path)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -33,6 +33,8 @@ def build_library(force: bool = False, verbose: bool = False, ablations: bool = 
     header changed) and link them into one shared library.  ``ablations``: the tools' build (-DVSDE_ABLATIONS ->
     libvsde_hip_abl.so: A/B switches read from the environment, losing kernel variants compiled in; load it with VSDE_HIP_LIB)."""
     if ablations:
+        if not force and not _stale(ABL_LIB_PATH):
+            return ABL_LIB_PATH
         return _build(force, verbose, ABL_LIB_PATH, ".obj_abl", ["-DVSDE_ABLATIONS"])
     if not force and not _stale():
         return LIB_PATH
