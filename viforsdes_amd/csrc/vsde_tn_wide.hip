@@ -15,6 +15,7 @@
 //   * the tiles of one row split sit on one XCD, so the X rows the four context tiles share come out of that XCD's L2.
 // Splits are summed in a fixed order by the reduce kernels (deterministic).  Reference: kernels/backward.py:108-139,575-590
 // (the global fp32 atomics these reductions replace).
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "vsde_common.h"
@@ -49,17 +50,58 @@ struct TwTile {
 struct TwArgs {
     TwTile tile[TW_MAXTILES];
     int ntiles, nlocal, M, T;
+    int dbg;                 // ablation build only (VSDE_TW_DBG): 16 | 32 | 64 = only the narrow | 192 x 64 | context tiles run
+    int n0, local0;          // the 192 x 64 tiles (tile[0 .. n0), equal splits) and the `local` indices they share split-major: tw_locate
     int64_t chunks;
     float *partial;
 };
 
+#ifdef VSDE_ABLATIONS
+#define TW_DBG(bit_) ((a.dbg & (bit_)) != 0)
+#else
+#define TW_DBG(bit_) false
+#endif
 __device__ float tw_zeros[8];   // never written: the source of masked Y rows
 
 __device__ __forceinline__ void tw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- round 6: the 192 x 64 tiles on the bf16 matrix instruction with SPLIT operands ------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the VALU's rate (32 cycles per instruction) and nothing overlaps with it on its SIMD
+// (profiles/r06_mfma_valu_overlap.txt): the fp32 tiles held the matrix pipe 63 % busy at 404 us (profiles/r06_pmc_head_lv.txt).  Here an
+// fp32 operand value is cut into three bf16 pieces by TRUNCATION -- x = h + m + l exactly (8 + 8 + 8 significant bits) -- when its
+// rows go to LDS, and a 16 x 16 block over 32 rows is hh + hm + mh + mm + hl + lh: six v_mfma_f32_16x16x32_bf16 of 16 cycles instead of
+// eight fp32 instructions of 32 (the dropped products ml, lm, ll are <= 2^-24 of the term: fp32 round-off class); with a bf16 context
+// operand (exact in one piece) three.  Two 16-row blocks of the split are staged per step (K = 32).  The pieces sit in LDS as row-major
+// bf16 planes [32 rows][cols], the MFMA operands (8 consecutive ROWS of one column per lane) come out of them through the transposing
+// read ds_read_b64_tr_b16; row pitch 416 / 160 bytes and +128 bytes per octet of rows: the eight 32-byte row pieces a half-wave touches
+// fall on disjoint banks.  Column sums of X (the bias gradients) are one more product against a block of ones.
+typedef short twbf8 __attribute__((ext_vector_type(8)));
+typedef short twbf4 __attribute__((ext_vector_type(4)));
+constexpr int TS_SX = 416, TS_OSX = 8 * TS_SX + 128, TS_XP = 4 * TS_OSX;   // X planes: row pitch, octet pitch, plane size (bytes)
+constexpr int TS_SY = 160, TS_OSY = 8 * TS_SY + 128, TS_YP = 4 * TS_OSY;   // Y planes
+constexpr int TS_LDS = 3 * TS_XP + 3 * TS_YP;                              // 58,368 bytes: two workgroups per CU
+
+// two fp32 values (bit patterns) -> their three bf16 pieces, packed (value 0 in the low half)
+__device__ __forceinline__ void tw_split2(uint32_t v0, uint32_t v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    const float r0 = __uint_as_float(v0) - __uint_as_float(v0 & 0xffff0000u), r1 = __uint_as_float(v1) - __uint_as_float(v1 & 0xffff0000u);
+    const uint32_t q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(q0 & 0xffff0000u), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+    // v_perm_b32: the upper halves of (second, first) -> (low, high)
+    h = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ twbf8 tw_tr_frag(const char *p0, const char *p1) {   // rows +0..3 and +4..7 of this lane's column
+    const twbf4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) twbf4 *)p0);
+    const twbf4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) twbf4 *)p1);
+    return (twbf8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 // NB: 16-column blocks of X per wave (3: X is 192 wide, 1: 64 wide); NARROW: Y has at most 16 columns (one block, scalar loads)
-template <int NB, bool NARROW>
+// SPLIT (NB = 3, wide Y only): the bf16 split form above; YBF: Y is a bf16 operand (one piece)
+template <int NB, bool NARROW, bool SPLIT = false, bool YBF = false>
 __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *tws, int split) {
+    static_assert(!SPLIT || (NB == 3 && !NARROW), "split form: 192 x 64 tiles");
     constexpr int NX = 64 * NB, LDX = NX + 16, JB = NARROW ? 1 : 4, LDY = NARROW ? 48 : TW_LDY;
     constexpr int XI = NX * TW_BM / 4 / 256;          // 16-byte X chunks per thread and step (6 | 2)
     constexpr int XCH = NX / 4;                        // chunks per X row
@@ -104,8 +146,8 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
     const int64_t y_adv_b = y_adv * yesz, y_wrap_b = y_wrap * yesz;
     const char *ybase = (const char *)P.y;
     const char *zeros = (const char *)tw_zeros;
-    twu4 rx[2][XI], ry[2][TW_YI];
-    int fetched = 0;   // blocks requested so far; the offsets only move on while another block of this split exists, so the two
+    twu4 rx[SPLIT ? 4 : 2][XI], ry[SPLIT ? 4 : 2][TW_YI];   // split form: two 32-row steps (of two 16-row blocks) in flight
+    int fetched = 0;   // blocks requested so far; the offsets only move on while another block of this split exists, so the
                        // requests past the end re-read the last block instead of running off the operands
 #define TW_FETCH(set_)                                                                                                  \
     do {                                                                                                                \
@@ -143,6 +185,111 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
             }                                                                                                           \
         }                                                                                                               \
     } while (0)
+    if constexpr (SPLIT) {
+        char *lds = (char *)tws;
+        constexpr int NYP = YBF ? 1 : 3;
+        const int fr_ = lane & 15, fq_ = lane >> 4;
+        // commit of one 16-row block (register set set_) into rows 16 hf_ .. of the planes; zero_: the block does not exist
+#define TW_COMMIT_S(set_, hf_, zero_)                                                                                   \
+        do {                                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                            \
+                const int m_ = 16 * (hf_) + xr[i], c4_ = ((tid + 256 * i) % XCH) * 4;                                   \
+                char *d_ = lds + (m_ >> 3) * TS_OSX + (m_ & 7) * TS_SX + c4_ * 2;                                       \
+                twu4 v_ = rx[set_][i];                                                                                  \
+                if (zero_) v_ = (twu4){0u, 0u, 0u, 0u};                                                                 \
+                uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                                  \
+                tw_split2(v_.x, v_.y, h0_, m0_, l0_); tw_split2(v_.z, v_.w, h1_, m1_, l1_);                             \
+                *(twu2 *)d_ = (twu2){h0_, h1_}; *(twu2 *)(d_ + TS_XP) = (twu2){m0_, m1_}; *(twu2 *)(d_ + 2 * TS_XP) = (twu2){l0_, l1_}; \
+            }                                                                                                           \
+            {                                                                                                           \
+                const int m_ = 16 * (hf_) + yr[0];                                                                      \
+                char *d_ = lds + 3 * TS_XP + (m_ >> 3) * TS_OSY + (m_ & 7) * TS_SY + yc[0] * 2;                         \
+                twu4 v_ = ry[set_][0];                                                                                  \
+                if (zero_) v_ = (twu4){0u, 0u, 0u, 0u};                                                                 \
+                if constexpr (YBF) {                                                                                    \
+                    *(twu2 *)d_ = (twu2){v_.x, v_.y};                                                                   \
+                } else {                                                                                                \
+                    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                              \
+                    tw_split2(v_.x, v_.y, h0_, m0_, l0_); tw_split2(v_.z, v_.w, h1_, m1_, l1_);                         \
+                    *(twu2 *)d_ = (twu2){h0_, h1_}; *(twu2 *)(d_ + TS_YP) = (twu2){m0_, m1_}; *(twu2 *)(d_ + 2 * TS_YP) = (twu2){l0_, l1_}; \
+                }                                                                                                       \
+            }                                                                                                           \
+        } while (0)
+        f32x4 sacc[3][4], bacc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const twbf8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+        const bool want_bias = P.bias_out != nullptr;
+        // this lane's address inside a plane for the transposing reads: octet fq_, row (fr_ >> 2) (+ 4 for the second read), columns 4 (fr_ & 3)
+        const int xlane = fq_ * TS_OSX + (fr_ >> 2) * TS_SX + (fr_ & 3) * 8, ylane = fq_ * TS_OSY + (fr_ >> 2) * TS_SY + (fr_ & 3) * 8;
+        // one 32-row step out of the register sets (sa_, sb_) = the blocks s2_, s2_ + 1 of this split; the sets are refilled with the
+        // blocks of the step after next as soon as they are in LDS: a request has two whole steps to come back from memory
+#define TW_STEP_S(sa_, sb_, s2_)                                                                                        \
+        do {                                                                                                            \
+            const bool second = (s2_) + 1 < nsteps;                                                                     \
+            TW_COMMIT_S(sa_, 0, false);                                                                                 \
+            TW_COMMIT_S(sb_, 1, !second);                                                                               \
+            tw_barrier();                                                                                               \
+            TW_FETCH(sa_); TW_FETCH(sb_);                                                                               \
+            twbf8 yb[NYP][4];                                                                                           \
+            _Pragma("unroll") for (int pl = 0; pl < NYP; ++pl)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+                    const char *q_ = lds + 3 * TS_XP + pl * TS_YP + ylane + 32 * j;                                     \
+                    yb[pl][j] = tw_tr_frag(q_, q_ + 4 * TS_SY);                                                         \
+                }                                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                             \
+                twbf8 xa[3];                                                                                            \
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                      \
+                    const char *q_ = lds + pl * TS_XP + xlane + 32 * (3 * wave + i);                                    \
+                    xa[pl] = tw_tr_frag(q_, q_ + 4 * TS_SX);                                                            \
+                }                                                                                                       \
+                /* smallest products first; neighbours in the issue order write different accumulators */              \
+                _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+                        sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[YBF ? QX[p % 3] : PX[p]], yb[YBF ? 0 : PY[p]][j], \
+                                                                             sacc[i][j], 0, 0, 0);                      \
+                if (want_bias) {   /* workgroup-uniform */                                                              \
+                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[2], ones, bacc[i], 0, 0, 0);                   \
+                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[1], ones, bacc[i], 0, 0, 0);                   \
+                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[0], ones, bacc[i], 0, 0, 0);                   \
+                }                                                                                                       \
+            }                                                                                                           \
+            tw_barrier();   /* everyone is done with the planes */                                                      \
+        } while (0)
+        constexpr int NP = YBF ? 3 : 6;
+        constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PY[6] = {0, 2, 1, 0, 1, 0};   // l h, h l, m m, m h, h m, h h
+        constexpr int QX[3] = {2, 1, 0};
+        if (nsteps > 0) { TW_FETCH(0); TW_FETCH(1); TW_FETCH(2); TW_FETCH(3); }
+        // straight-line pairs of steps (a conditional second step would make hipcc merge the two orders in which the sets can be
+        // outstanding at the top of the loop and wait with vmcnt(0) there)
+        int s2 = 0;
+        for (; s2 + 2 < nsteps; s2 += 4) {
+            TW_STEP_S(0, 1, s2);
+            TW_STEP_S(2, 3, s2 + 2);
+        }
+        if (s2 < nsteps) TW_STEP_S(0, 1, s2);
+#undef TW_STEP_S
+#undef TW_COMMIT_S
+        float *dst = a.partial + P.part_off + (int64_t)split * TW_PART;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(48 * wave + 16 * i + 4 * fq_ + r) * TW_K + 16 * j + fr_] = sacc[i][j][r];
+        // column sums: every column of the ones product holds them; column 0 writes
+        if (fr_ == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[TW_N * TW_K + 48 * wave + 16 * i + 4 * fq_ + r] = bacc[i][r];
+        }
+        return;
+    }
     f32x4 acc[NB][JB];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -208,19 +355,51 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
     if (P.kind == 2 && wave == 0 && fq == 0) dst[TW_N * TW_K + fr] = ysum;
 }
 
+// Workgroup id = 8 * local + xcd -> (tile, split).  Split s of every tile runs on XCD s % 8.  The 192 x 64 tiles take the first
+// `local0` locals SPLIT-MAJOR (local = group of 8 splits * n0 + tile): the tiles of one split -- which walk the same rows in the same
+// order, four of them (the context tiles) at the same speed -- are dispatched back to back on one XCD and find the X rows one of them
+// fetched in that XCD's L2 (tile-major order, round 2-5: the tiles of a split started a whole wave of workgroups apart and every one
+// of them read X from memory: 1.33 GB fetched for 0.63 GB of operands).  The narrow tiles follow tile-major, [local_begin, + nsplit / 8).
+// The tile descriptor is read with a computed offset straight out of the kernel-argument segment (TwArgs is the only argument: offset 0;
+// scalar loads from constant memory) -- indexing the by-value argument itself would make hipcc copy all 3 KB of it to scratch.
+__device__ __forceinline__ bool tw_locate(const TwArgs &a, TwTile &P, int &split) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const bool shared = local < a.local0;
+    const int q = shared ? local / a.n0 : 0;
+    int w = shared ? local - q * a.n0 : 0;
+    if (!shared) {
+#pragma unroll
+        for (int i = 1; i < TW_MAXTILES; ++i)
+            if (i < a.ntiles && a.tile[i].local_begin >= 0 && local >= a.tile[i].local_begin) w = i;
+    }
+    typedef __attribute__((address_space(4))) const char kchar;
+    kchar *ka = (kchar *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TwArgs, tile) + (size_t)w * sizeof(TwTile);
+    __builtin_memcpy(&P, ka, sizeof(TwTile));
+    split = shared ? q * 8 + xcd : (local - P.local_begin) * 8 + xcd;
+    return split < P.nsplit;
+}
+
 __global__ void __launch_bounds__(256, 3) tn_wide_kernel(TwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tws[];
-    // id = 8 * local + xcd; a tile owns the locals [local_begin, local_begin + nsplit / 8), split = 8 * (local - begin) + xcd:
-    // split s of every tile runs on XCD s % 8, so tiles that read the same rows (the context tiles) share them through that L2
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    TwTile P = a.tile[0];
-#pragma unroll
-    for (int i = 1; i < TW_MAXTILES; ++i)
-        if (i < a.ntiles && local >= a.tile[i].local_begin) P = a.tile[i];
-    const int split = (local - P.local_begin) * 8 + xcd;
-    if (split >= P.nsplit) return;
+    TwTile P; int split;
+    if (!tw_locate(a, P, split)) return;
     if (P.kind == 0) tw_run<3, false>(a, P, tws, split);
     else if (P.kind == 1) tw_run<3, true>(a, P, tws, split);
+    else tw_run<1, true>(a, P, tws, split);
+}
+
+// the same launch with the 192 x 64 tiles in the split bf16 form (58 KB of LDS, two workgroups per CU)
+__global__ void __launch_bounds__(256, 2) tn_wide_split_kernel(TwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tws[];
+    TwTile P; int split;
+    if (!tw_locate(a, P, split)) return;
+    if (TW_DBG(16) && P.kind == 0) return;   // narrow tiles alone
+    if (TW_DBG(32) && P.kind != 0) return;   // 192 x 64 tiles alone
+    if (TW_DBG(64) && !(P.kind == 0 && P.y_bf16)) return;   // context tiles alone
+    if (P.kind == 0) {
+        if (P.y_bf16) tw_run<3, false, true, true>(a, P, tws, split);
+        else tw_run<3, false, true, false>(a, P, tws, split);
+    } else if (P.kind == 1) tw_run<3, true>(a, P, tws, split);
     else tw_run<1, true>(a, P, tws, split);
 }
 
@@ -309,17 +488,37 @@ static bool tw_plan_shapes(const TnProblem *probs, int nprob, int &tiles) {
     }
     return any_wide && tiles <= TW_MAXTILES;
 }
-// Row splits per tile: 1536 workgroups (two rounds of three per CU; measured 488 | 447 | 429 us for 768 | 1024 | 1536 at LV,
-// VSDE_TW_WGS overrides) shared out by MFMA work per row -- a 192 x 64 tile issues 4x the MFMAs of a 192 x 16 tile, the
-// swapped 64 x 16 tile a twelfth, all stage the same rows -- in multiples of 8 (one split per XCD and `local`).
+static bool tw_split_form() {
+    static int on = -1;
+    if (on < 0) on = (int)vsde_knob("VSDE_TW_SPLIT", 1);
+    return on != 0;
+}
+// Row splits per tile, in multiples of 8 (one split per XCD and `local`), adding up to EXACTLY `wgs` workgroups = whole rounds of the
+// resident set (fp32 form: three workgroups per CU, 1536 = two rounds; measured 488 | 447 | 429 us for 768 | 1024 | 1536 at LV.  Split
+// form: two per CU, 1024 = two rounds -- the proportional rounding of rounds 2-5 would give 1032, i.e. a third round for 8 workgroups).
+// The 192 x 64 tiles get equal splits (tw_locate relies on it); the narrow tiles share what is left by their time per row relative
+// to a 192 x 64 tile (w1 | w2 per cent: a 192 x 16 tile issues a quarter of the MFMAs, the swapped 64 x 16 tile a twelfth, all
+// stage the same rows).  VSDE_TW_WGS / _W1 / _W2 override (ablation build).
 static void tw_splits(const int *kinds, int nt, int64_t chunks, int *nsplit) {
-    const float w[3] = {1.0f, 0.35f, 0.2f};
-    static int wgs = -1;
-    if (wgs < 0) wgs = (int)vsde_knob("VSDE_TW_WGS", 1536);
-    float tot = 0.f;
-    for (int i = 0; i < nt; ++i) tot += w[kinds[i]];
+    static int wgs = -1, w1 = -1, w2 = -1;
+    if (wgs < 0) {
+        wgs = (int)vsde_knob("VSDE_TW_WGS", tw_split_form() ? 1024 : 1536);
+        w1 = (int)vsde_knob("VSDE_TW_W1", tw_split_form() ? 70 : 35);
+        w2 = (int)vsde_knob("VSDE_TW_W2", tw_split_form() ? 40 : 20);
+    }
+    const float w[3] = {1.0f, 0.01f * w1, 0.01f * w2};
+    float tot = 0.f, narrow = 0.f;
+    int nwide = 0;
+    for (int i = 0; i < nt; ++i) { tot += w[kinds[i]]; if (kinds[i] == 0) ++nwide; else narrow += w[kinds[i]]; }
+    const int wide_n = nwide ? ((int)(wgs / tot)) & ~7 : 0;
+    int left = wgs - nwide * wide_n;           // for the narrow tiles, handed out in order; the last one takes the remainder
+    int last_narrow = -1;
+    for (int i = 0; i < nt; ++i) if (kinds[i] != 0) last_narrow = i;
     for (int i = 0; i < nt; ++i) {
-        int n = ((int)(wgs * w[kinds[i]] / tot + 4.f)) & ~7;
+        int n;
+        if (kinds[i] == 0) n = wide_n;
+        else if (i == last_narrow) n = left & ~7;
+        else { n = ((int)(left * w[kinds[i]] / narrow + 4.f)) & ~7; left -= n; narrow -= w[kinds[i]]; }
         if (n < 8) n = 8;
         if (n > chunks) n = (int)chunks;
         nsplit[i] = n;
@@ -387,22 +586,49 @@ int launch_tn_wide(const TnProblem *probs, int nprob, int M, void *workspace, si
         }
     }
     a.ntiles = nt; a.M = M; a.T = T; a.chunks = ((int64_t)M + TW_BM - 1) / TW_BM;
+    // the 192 x 64 tiles (equal splits: tw_splits) come first and share the first locals split-major, the others follow tile-major
+    static int interleave = -1;
+    if (interleave < 0) interleave = (int)vsde_knob("VSDE_TW_INTERLEAVE", 1);
+    int n0 = 0;
+    if (interleave) {
+        TwTile sorted[TW_MAXTILES];
+        int k = 0;
+        for (int i = 0; i < nt; ++i)
+            if (a.tile[i].kind == 0) sorted[k++] = a.tile[i];
+        n0 = k;
+        for (int i = 0; i < nt; ++i)
+            if (a.tile[i].kind != 0) sorted[k++] = a.tile[i];
+        for (int i = 0; i < nt; ++i) a.tile[i] = sorted[i];
+    }
     int kinds[TW_MAXTILES], nsplit[TW_MAXTILES];
-    tw_tile_kinds(probs, nprob, kinds);
+    for (int i = 0; i < nt; ++i) kinds[i] = a.tile[i].kind;
     tw_splits(kinds, nt, a.chunks, nsplit);
-    int local = 0;
+    int local = n0 > 0 ? n0 * ((nsplit[0] + 7) / 8) : 0;
     int64_t part = 0;
+    a.n0 = n0; a.local0 = local;
+#ifdef VSDE_ABLATIONS
+    a.dbg = (int)vsde_knob("VSDE_TW_DBG", 0);
+#endif
     for (int i = 0; i < nt; ++i) {
-        a.tile[i].nsplit = nsplit[i]; a.tile[i].local_begin = local; a.tile[i].part_off = part;
-        local += (nsplit[i] + 7) / 8; part += (int64_t)nsplit[i] * TW_PART;
+        a.tile[i].nsplit = nsplit[i]; a.tile[i].part_off = part;
+        part += (int64_t)nsplit[i] * TW_PART;
+        if (i < n0) { a.tile[i].local_begin = -1; continue; }
+        a.tile[i].local_begin = local;
+        local += (nsplit[i] + 7) / 8;
     }
     a.nlocal = local;
     const size_t need = (size_t)part * sizeof(float);
     VSDE_CHECK_ARG(workspace_bytes >= need, VSDE_E_WORKSPACE, "TN workspace too small: %zu < %zu", workspace_bytes, need);
     a.partial = (float *)workspace;
-    const size_t lds = (size_t)2 * TW_BUF * sizeof(float);
-    VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tn_wide_kernel, dim3((unsigned)(a.nlocal * 8)), dim3(256), lds, stream, a);
+    if (tw_split_form()) {
+        static_assert(TS_LDS >= 2 * TW_BUF * (int)sizeof(float), "the narrow tiles of the launch use the fp32 buffers");
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)tn_wide_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS));
+        hipLaunchKernelGGL(tn_wide_split_kernel, dim3((unsigned)(a.nlocal * 8)), dim3(256), TS_LDS, stream, a);
+    } else {
+        const size_t lds = (size_t)2 * TW_BUF * sizeof(float);
+        VSDE_CHECK_HIP(hipFuncSetAttribute((const void *)tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tn_wide_kernel, dim3((unsigned)(a.nlocal * 8)), dim3(256), lds, stream, a);
+    }
     VSDE_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(tn_wide_reduce_kernel, dim3(TW_N * TW_K / 4 / 64 + 1, nt), dim3(256), 0, stream, a);
     VSDE_CHECK_HIP(hipGetLastError());
