@@ -126,3 +126,19 @@ def test_head_full_size_vs_f64_oracle(name, forward_kernel):
     for k, v in errs.items():
         tol = (TF_FWD_TOL if "grad" not in k else TF_BWD_TOL) if k.startswith("tf_") else (fr_fwd if "grad" not in k else fr_bwd)
         assert v < tol, (k, v, tol)
+
+
+@pytest.mark.ablation_build
+def test_weight_gradient_forms_of_the_head_agree_at_full_size():
+    """The split-operand bf16 tiles (default), the fp32-MFMA tiles and both workgroup orders of vsde_tn_wide.hip, each in its own process
+    on the ablation library (the switches are read once per process): all 13 gradients of the LV-size reverse pass within fp32
+    round-off of the fp32-MFMA form (the measured figure is 1e-6 of the peak gradient; profiles/r06_tn_wide_split.txt)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tn_wide_check.py")], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("VSDE_TW_SPLIT")]
+    assert r.returncode == 0 and len(lines) == 4, r.stdout + r.stderr
+    for ln in lines:
+        mt = re.search(r": ok, max relative-to-peak difference from the first form ([0-9.e+-]+)", ln)
+        assert mt, ln
+        assert float(mt.group(1)) <= (0.0 if "SPLIT=0" in ln else 5e-6), ln

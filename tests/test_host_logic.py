@@ -291,3 +291,37 @@ def test_latent_start_cache_follows_the_tensor():
     for k in range(8):                                                                      # fresh tensors: each gets its own value
         z = torch.full((2, 2), 1.0 + k)
         assert torch.equal(_latent_start(ss, z), ss.to_latent(z))
+
+
+def test_three_bf16_pieces_reproduce_an_fp32_value_and_six_products_its_product():
+    """The operand split of the head's weight-gradient tiles (vsde_tn_wide.hip::tw_split2), restated in numpy: x = h + m + l exactly
+    with every piece a bf16 (round to nearest even of what is left), and hh + hm + mh + mm + hl + lh within 2^-23 of x y."""
+    rng = np.random.default_rng(11)
+    # exact while the smallest piece stays a normal number and the largest does not round up to infinity
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 20000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.38e38, 2.0 ** -109, 65504.0, 1 + 2.0 ** -23, 1 - 2.0 ** -24, 1 + 2.0 ** -8], np.float32)])
+
+    def bf16(v):   # round to nearest even, result as fp32
+        u = v.view(np.uint32).astype(np.uint64)
+        u = (u + np.uint64(0x7fff) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xffff0000)
+        return u.astype(np.uint32).view(np.float32)
+
+    def split(v):
+        hi = bf16(v)
+        r = v - hi
+        mid = bf16(r)
+        s_ = r - mid
+        lo = bf16(s_)
+        return hi, mid, lo
+
+    h, m, l = split(x)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), x.astype(np.float64))
+    nz = x != 0
+    assert (np.abs(m[nz]) <= np.abs(x[nz]) * 2.0 ** -8).all() and (np.abs(l[nz]) <= np.abs(x[nz]) * 2.0 ** -16).all()
+    y = rng.standard_normal(x.size).astype(np.float32)
+    yh, ym, yl = split(y)
+    f = lambda a: a.astype(np.float64)
+    six = f(h) * f(yh) + f(h) * f(ym) + f(m) * f(yh) + f(m) * f(ym) + f(h) * f(yl) + f(l) * f(yh)
+    exact = f(x) * f(y)
+    ok = np.abs(exact) > 1e-300
+    assert np.max(np.abs(six[ok] - exact[ok]) / np.abs(exact[ok])) < 2.0 ** -23

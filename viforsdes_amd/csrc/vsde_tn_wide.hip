@@ -68,28 +68,39 @@ __device__ __forceinline__ void tw_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // ---- round 6: the 192 x 64 tiles on the bf16 matrix instruction with SPLIT operands ------------------------------------------------
 // v_mfma_f32_16x16x4_f32 runs at the VALU's rate (32 cycles per instruction) and nothing overlaps with it on its SIMD
 // (profiles/r06_mfma_valu_overlap.txt): the fp32 tiles held the matrix pipe 63 % busy at 404 us (profiles/r06_pmc_head_lv.txt).  Here an
-// fp32 operand value is cut into three bf16 pieces by TRUNCATION -- x = h + m + l exactly (8 + 8 + 8 significant bits) -- when its
-// rows go to LDS, and a 16 x 16 block over 32 rows is hh + hm + mh + mm + hl + lh: six v_mfma_f32_16x16x32_bf16 of 16 cycles instead of
-// eight fp32 instructions of 32 (the dropped products ml, lm, ll are <= 2^-24 of the term: fp32 round-off class); with a bf16 context
-// operand (exact in one piece) three.  Two 16-row blocks of the split are staged per step (K = 32).  The pieces sit in LDS as row-major
-// bf16 planes [32 rows][cols], the MFMA operands (8 consecutive ROWS of one column per lane) come out of them through the transposing
-// read ds_read_b64_tr_b16; row pitch 416 / 160 bytes and +128 bytes per octet of rows: the eight 32-byte row pieces a half-wave touches
-// fall on disjoint banks.  Column sums of X (the bias gradients) are one more product against a block of ones.
+// fp32 operand value is cut into three bf16 pieces -- x = h + m + l exactly (8 + 8 + 8 significant bits, tw_split2) -- when its
+// rows go to LDS, and a 32 x 32 block over 16 rows is hh + hm + mh + mm + hl + lh: six v_mfma_f32_32x32x16_bf16 (32 cycles each) for
+// what took sixteen fp32 instructions of 32 cycles (the dropped products ml, lm, ll are <= 2^-23 of the term: fp32 round-off class);
+// with a bf16 context operand (exact in one piece) three.  The pieces sit in LDS as row-major bf16 planes [16 rows][cols]; the MFMA
+// operands (8 consecutive ROWS of one column per lane) come out of them through the transposing read ds_read_b64_tr_b16; row pitch =
+// row + 64 bytes (64 past a multiple of 256: the 4 rows x 64 bytes a half-wave's read touches fall on disjoint banks).  Two plane
+// sets: while the waves multiply block s out of one, they split block s + 1 into the other -- plain VALU work issues in the shadow of
+// the bf16 MFMAs (the same profile) -- and one barrier per block separates the two roles.  A wave owns 96 x 32 of the tile.
 typedef short twbf8 __attribute__((ext_vector_type(8)));
 typedef short twbf4 __attribute__((ext_vector_type(4)));
-constexpr int TS_SX = 416, TS_OSX = 8 * TS_SX + 128, TS_XP = 4 * TS_OSX;   // X planes: row pitch, octet pitch, plane size (bytes)
-constexpr int TS_SY = 160, TS_OSY = 8 * TS_SY + 128, TS_YP = 4 * TS_OSY;   // Y planes
-constexpr int TS_LDS = 3 * TS_XP + 3 * TS_YP;                              // 58,368 bytes: two workgroups per CU
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TS_SX = 2 * TW_N + 64, TS_XP = TW_BM * TS_SX;   // X planes: row pitch, plane size (bytes)
+constexpr int TS_SY = 2 * TW_K + 64, TS_YP = TW_BM * TS_SY;   // Y planes
+constexpr int TS_BUF = 3 * TS_XP + 3 * TS_YP;                 // one set of planes: 30,720 bytes
+constexpr int TS_LDS = 2 * TS_BUF;                            // 61,440 bytes: two workgroups per CU
 
-// two fp32 values (bit patterns) -> their three bf16 pieces, packed (value 0 in the low half)
+// two fp32 values (bit patterns) -> their three bf16 pieces, packed (value 0 in the low half).  Each piece is the value rounded to
+// nearest-even bf16 (v_cvt_pk_bf16_f32, two values per instruction), the next one splits what is left: both remainders are exact in
+// fp32 and the third (<= 8 significant bits) is exact in bf16: h + m + l == x bit for bit for |x| in [2^-110, 3.38e38]; |m| <= 2^-8 |x|,
+// |l| <= 2^-16 |x| with signs of their own, so the dropped products m l + l m + l l are <= 2^-23 |x y| and do not pile up one-sided
+// (truncated pieces would all carry the sign of x: 2^-21 and biased).  11 VALU instructions per pair.
+typedef float twf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 twb2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t tw_pack(float a, float b) {
+    const twb2 r = __builtin_convertvector((twf2){a, b}, twb2);
+    return *(const uint32_t *)&r;
+}
 __device__ __forceinline__ void tw_split2(uint32_t v0, uint32_t v1, uint32_t &h, uint32_t &m, uint32_t &l) {
-    const float r0 = __uint_as_float(v0) - __uint_as_float(v0 & 0xffff0000u), r1 = __uint_as_float(v1) - __uint_as_float(v1 & 0xffff0000u);
-    const uint32_t q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(q0 & 0xffff0000u), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
-    // v_perm_b32: the upper halves of (second, first) -> (low, high)
-    h = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    m = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    h = tw_pack(__uint_as_float(v0), __uint_as_float(v1));
+    const float r0 = __uint_as_float(v0) - __uint_as_float(h << 16), r1 = __uint_as_float(v1) - __uint_as_float(h & 0xffff0000u);
+    m = tw_pack(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = tw_pack(s0, s1);
 }
 __device__ __forceinline__ twbf8 tw_tr_frag(const char *p0, const char *p1) {   // rows +0..3 and +4..7 of this lane's column
     const twbf4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) twbf4 *)p0);
@@ -98,8 +109,8 @@ __device__ __forceinline__ twbf8 tw_tr_frag(const char *p0, const char *p1) {   
 }
 
 // NB: 16-column blocks of X per wave (3: X is 192 wide, 1: 64 wide); NARROW: Y has at most 16 columns (one block, scalar loads)
-// SPLIT (NB = 3, wide Y only): the bf16 split form above; YBF: Y is a bf16 operand (one piece)
-template <int NB, bool NARROW, bool SPLIT = false, bool YBF = false>
+// SPLIT (NB = 3, wide Y only): the bf16 split form above; YBF: Y is a bf16 operand (one piece); BIAS: the column sums of X are wanted
+template <int NB, bool NARROW, bool SPLIT = false, bool YBF = false, bool BIAS = false>
 __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *tws, int split) {
     static_assert(!SPLIT || (NB == 3 && !NARROW), "split form: 192 x 64 tiles");
     constexpr int NX = 64 * NB, LDX = NX + 16, JB = NARROW ? 1 : 4, LDY = NARROW ? 48 : TW_LDY;
@@ -146,7 +157,8 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
     const int64_t y_adv_b = y_adv * yesz, y_wrap_b = y_wrap * yesz;
     const char *ybase = (const char *)P.y;
     const char *zeros = (const char *)tw_zeros;
-    twu4 rx[SPLIT ? 4 : 2][XI], ry[SPLIT ? 4 : 2][TW_YI];   // split form: two 32-row steps (of two 16-row blocks) in flight
+    constexpr int NSET = SPLIT ? 4 : 2;   // blocks in flight
+    twu4 rx[NSET][XI], ry[NSET][TW_YI];
     int fetched = 0;   // blocks requested so far; the offsets only move on while another block of this split exists, so the
                        // requests past the end re-read the last block instead of running off the operands
 #define TW_FETCH(set_)                                                                                                  \
@@ -187,25 +199,32 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
     } while (0)
     if constexpr (SPLIT) {
         char *lds = (char *)tws;
-        constexpr int NYP = YBF ? 1 : 3;
-        const int fr_ = lane & 15, fq_ = lane >> 4;
-        // commit of one 16-row block (register set set_) into rows 16 hf_ .. of the planes; zero_: the block does not exist
-#define TW_COMMIT_S(set_, hf_, zero_)                                                                                   \
+        constexpr int NYP = YBF ? 1 : 3, NP = YBF ? 3 : 6;
+        constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PY[6] = {0, 2, 1, 0, 1, 0};   // l h, h l, m m, m h, h m, h h: smallest products first
+        constexpr int QX[3] = {2, 1, 0};
+        const int wn = wave & 1, wk = wave >> 1;   // the wave's 96 rows (n) x 32 columns (k) of the tile
+        float bsum[XI][4];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) bsum[i][0] = bsum[i][1] = bsum[i][2] = bsum[i][3] = 0.f;
+        // one 16-row block out of register set set_ into plane set buf_ (+ the column sums of X for the bias gradient: a thread's
+        // chunks keep their columns from block to block); MASK_: the block may lie past the end of the split (live_ = 0: it is zeros)
+#define TW_COMMIT_S(set_, buf_, MASK_, live_)                                                                                \
         do {                                                                                                            \
+            char *b_ = lds + (buf_) * TS_BUF;                                                                           \
             _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                            \
-                const int m_ = 16 * (hf_) + xr[i], c4_ = ((tid + 256 * i) % XCH) * 4;                                   \
-                char *d_ = lds + (m_ >> 3) * TS_OSX + (m_ & 7) * TS_SX + c4_ * 2;                                       \
-                twu4 v_ = rx[set_][i];                                                                                  \
-                if (zero_) v_ = (twu4){0u, 0u, 0u, 0u};                                                                 \
+                char *d_ = b_ + xr[i] * TS_SX + ((tid + 256 * i) % XCH) * 8;                                            \
+                const twu4 v_ = (MASK_) ? rx[set_][i] & (live_) : rx[set_][i];                                          \
+                if constexpr (BIAS) {                                                                                   \
+                    bsum[i][0] += __uint_as_float(v_.x); bsum[i][1] += __uint_as_float(v_.y);                           \
+                    bsum[i][2] += __uint_as_float(v_.z); bsum[i][3] += __uint_as_float(v_.w);                           \
+                }                                                                                                       \
                 uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                                  \
                 tw_split2(v_.x, v_.y, h0_, m0_, l0_); tw_split2(v_.z, v_.w, h1_, m1_, l1_);                             \
                 *(twu2 *)d_ = (twu2){h0_, h1_}; *(twu2 *)(d_ + TS_XP) = (twu2){m0_, m1_}; *(twu2 *)(d_ + 2 * TS_XP) = (twu2){l0_, l1_}; \
             }                                                                                                           \
             {                                                                                                           \
-                const int m_ = 16 * (hf_) + yr[0];                                                                      \
-                char *d_ = lds + 3 * TS_XP + (m_ >> 3) * TS_OSY + (m_ & 7) * TS_SY + yc[0] * 2;                         \
-                twu4 v_ = ry[set_][0];                                                                                  \
-                if (zero_) v_ = (twu4){0u, 0u, 0u, 0u};                                                                 \
+                char *d_ = b_ + 3 * TS_XP + yr[0] * TS_SY + yc[0] * 2;                                                  \
+                const twu4 v_ = (MASK_) ? ry[set_][0] & (live_) : ry[set_][0];                                          \
                 if constexpr (YBF) {                                                                                    \
                     *(twu2 *)d_ = (twu2){v_.x, v_.y};                                                                   \
                 } else {                                                                                                \
@@ -215,78 +234,83 @@ __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *
                 }                                                                                                       \
             }                                                                                                           \
         } while (0)
-        f32x4 sacc[3][4], bacc[3];
+        f32x16 sacc[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const twbf8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-        const bool want_bias = P.bias_out != nullptr;
-        // this lane's address inside a plane for the transposing reads: octet fq_, row (fr_ >> 2) (+ 4 for the second read), columns 4 (fr_ & 3)
-        const int xlane = fq_ * TS_OSX + (fr_ >> 2) * TS_SX + (fr_ & 3) * 8, ylane = fq_ * TS_OSY + (fr_ >> 2) * TS_SY + (fr_ & 3) * 8;
-        // one 32-row step out of the register sets (sa_, sb_) = the blocks s2_, s2_ + 1 of this split; the sets are refilled with the
-        // blocks of the step after next as soon as they are in LDS: a request has two whole steps to come back from memory
-#define TW_STEP_S(sa_, sb_, s2_)                                                                                        \
+            for (int r = 0; r < 16; ++r) sacc[i][r] = 0.f;
+        // Transposing reads of a 32-column operand block: the 16-lane group (lane >> 4) covers columns 16 ((lane >> 4) & 1) .. of rows
+        // 8 (lane >> 5) + {0..3 | 4..7}; lane m of the group supplies row m / 4, columns 4 (m % 4) .. and receives column m.
+        const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const int xlane = lrow * TS_SX + lcol * 2 + 64 * 3 * wn, ylane = 3 * TS_XP + lrow * TS_SY + lcol * 2 + 64 * wk;
+        // Block s_ (plane set k_ & 1): its operands are read first, then its products issue interleaved with the splitting of block
+        // s_ + 1 (register set (k_ + 1) % NSET) into the other plane set and with the requests that refill those registers: the reads
+        // stand before the writes in program order, so nothing orders the VALU work behind the MFMAs
+#define TW_IT_S(k_, s_, MASK_)                                                                                              \
         do {                                                                                                            \
-            const bool second = (s2_) + 1 < nsteps;                                                                     \
-            TW_COMMIT_S(sa_, 0, false);                                                                                 \
-            TW_COMMIT_S(sb_, 1, !second);                                                                               \
-            tw_barrier();                                                                                               \
-            TW_FETCH(sa_); TW_FETCH(sb_);                                                                               \
-            twbf8 yb[NYP][4];                                                                                           \
-            _Pragma("unroll") for (int pl = 0; pl < NYP; ++pl)                                                          \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-                    const char *q_ = lds + 3 * TS_XP + pl * TS_YP + ylane + 32 * j;                                     \
-                    yb[pl][j] = tw_tr_frag(q_, q_ + 4 * TS_SY);                                                         \
-                }                                                                                                       \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                             \
-                twbf8 xa[3];                                                                                            \
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                      \
-                    const char *q_ = lds + pl * TS_XP + xlane + 32 * (3 * wave + i);                                    \
-                    xa[pl] = tw_tr_frag(q_, q_ + 4 * TS_SX);                                                            \
-                }                                                                                                       \
-                /* smallest products first; neighbours in the issue order write different accumulators */              \
-                _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                          \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-                        sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[YBF ? QX[p % 3] : PX[p]], yb[YBF ? 0 : PY[p]][j], \
-                                                                             sacc[i][j], 0, 0, 0);                      \
-                if (want_bias) {   /* workgroup-uniform */                                                              \
-                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[2], ones, bacc[i], 0, 0, 0);                   \
-                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[1], ones, bacc[i], 0, 0, 0);                   \
-                    bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[0], ones, bacc[i], 0, 0, 0);                   \
-                }                                                                                                       \
+            const char *b_ = lds + ((k_) & 1) * TS_BUF;                                                                 \
+            twbf8 yb[NYP], xa[3][3];                                                                                    \
+            _Pragma("unroll") for (int pl = 0; pl < NYP; ++pl) {                                                        \
+                const char *q_ = b_ + pl * TS_YP + ylane;                                                               \
+                yb[pl] = tw_tr_frag(q_, q_ + 4 * TS_SY);                                                                \
             }                                                                                                           \
-            tw_barrier();   /* everyone is done with the planes */                                                      \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                         \
+                    const char *q_ = b_ + pl * TS_XP + xlane + 64 * i;                                                  \
+                    xa[i][pl] = tw_tr_frag(q_, q_ + 4 * TS_SX);                                                         \
+                }                                                                                                       \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                              \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                           \
+                    sacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i][YBF ? QX[p % 3] : PX[p]], yb[YBF ? 0 : PY[p]], sacc[i], 0, 0, 0); \
+            const uint32_t live_ = (s_) + 1 < nsteps ? 0xffffffffu : 0u;                                                \
+            TW_COMMIT_S(((k_) + 1) % NSET, ((k_) + 1) & 1, MASK_, live_);                                               \
+            TW_FETCH(((k_) + 1) % NSET);                                                                                \
+            _Pragma("unroll") for (int g = 0; g < 3 * NP; ++g) {                                                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  /* one MFMA */                      \
+                __builtin_amdgcn_sched_group_barrier(0x002, YBF ? 14 : 8, 0);       /* VALU in its shadow */            \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  /* an LDS write */                  \
+                if (g % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, YBF ? 2 : 1, 0);   /* a memory request */   \
+            }                                                                                                           \
+            tw_barrier();                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);   /* one scheduling region per block */                                  \
         } while (0)
-        constexpr int NP = YBF ? 3 : 6;
-        constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PY[6] = {0, 2, 1, 0, 1, 0};   // l h, h l, m m, m h, h m, h h
-        constexpr int QX[3] = {2, 1, 0};
-        if (nsteps > 0) { TW_FETCH(0); TW_FETCH(1); TW_FETCH(2); TW_FETCH(3); }
-        // straight-line pairs of steps (a conditional second step would make hipcc merge the two orders in which the sets can be
-        // outstanding at the top of the loop and wait with vmcnt(0) there)
-        int s2 = 0;
-        for (; s2 + 2 < nsteps; s2 += 4) {
-            TW_STEP_S(0, 1, s2);
-            TW_STEP_S(2, 3, s2 + 2);
+        if (nsteps > 0) {
+            static_assert(NSET == 4, "the groups below are written out for four register sets");
+            TW_FETCH(0); TW_FETCH(1); TW_FETCH(2); TW_FETCH(3);
+            TW_COMMIT_S(0, 0, false, 0u);
+            TW_FETCH(0);
+            tw_barrier();
+            // whole groups of blocks, straight-line (a conditional block inside the body would make hipcc merge the orders in which the
+            // register sets can be outstanding and wait with vmcnt(0); leaving the loop from its middle makes it copy the accumulators):
+            // in the last group a block past the end of the split is split as zeros
+            int s = 0;
+            for (; s + NSET < nsteps; s += NSET) {
+                TW_IT_S(0, s, false); TW_IT_S(1, s + 1, false); TW_IT_S(2, s + 2, false); TW_IT_S(3, s + 3, false);
+            }
+            TW_IT_S(0, s, true); TW_IT_S(1, s + 1, true); TW_IT_S(2, s + 2, true); TW_IT_S(3, s + 3, true);
         }
-        if (s2 < nsteps) TW_STEP_S(0, 1, s2);
-#undef TW_STEP_S
+#undef TW_IT_S
 #undef TW_COMMIT_S
+        // C/D layout of the 32x32 MFMA: column (k) = lane & 31, rows (n) 8 (r / 4) + 4 (lane >> 5) + r % 4
         float *dst = a.partial + P.part_off + (int64_t)split * TW_PART;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < 16; ++r)
+                dst[(96 * wn + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * TW_K + 32 * wk + (lane & 31)] = sacc[i][r];
+        if constexpr (BIAS) {   // the 16 threads that hold the rows of one column chunk meet in LDS
+            float *sc = (float *)lds;
+            tw_barrier();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(48 * wave + 16 * i + 4 * fq_ + r) * TW_K + 16 * j + fr_] = sacc[i][j][r];
-        // column sums: every column of the ones product holds them; column 0 writes
-        if (fr_ == 0) {
+            for (int i = 0; i < XI; ++i)
+                *(float4 *)(sc + xr[i] * TW_N + ((tid + 256 * i) % XCH) * 4) = make_float4(bsum[i][0], bsum[i][1], bsum[i][2], bsum[i][3]);
+            tw_barrier();
+            if (tid < TW_N) {
+                float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[TW_N * TW_K + 48 * wave + 16 * i + 4 * fq_ + r] = bacc[i][r];
+                for (int r = 0; r < TW_BM; ++r) t += sc[r * TW_N + tid];
+                dst[TW_N * TW_K + tid] = t;
+            }
         }
         return;
     }
@@ -397,8 +421,9 @@ __global__ void __launch_bounds__(256, 2) tn_wide_split_kernel(TwArgs a) {
     if (TW_DBG(32) && P.kind != 0) return;   // 192 x 64 tiles alone
     if (TW_DBG(64) && !(P.kind == 0 && P.y_bf16)) return;   // context tiles alone
     if (P.kind == 0) {
-        if (P.y_bf16) tw_run<3, false, true, true>(a, P, tws, split);
-        else tw_run<3, false, true, false>(a, P, tws, split);
+        const bool bias = P.bias_out != nullptr;
+        if (P.y_bf16) { if (bias) tw_run<3, false, true, true, true>(a, P, tws, split); else tw_run<3, false, true, true, false>(a, P, tws, split); }
+        else { if (bias) tw_run<3, false, true, false, true>(a, P, tws, split); else tw_run<3, false, true, false, false>(a, P, tws, split); }
     } else if (P.kind == 1) tw_run<3, true>(a, P, tws, split);
     else tw_run<1, true>(a, P, tws, split);
 }
@@ -494,15 +519,16 @@ static bool tw_split_form() {
     return on != 0;
 }
 // Row splits per tile, in multiples of 8 (one split per XCD and `local`), adding up to EXACTLY `wgs` workgroups = whole rounds of the
-// resident set (fp32 form: three workgroups per CU, 1536 = two rounds; measured 488 | 447 | 429 us for 768 | 1024 | 1536 at LV.  Split
-// form: two per CU, 1024 = two rounds -- the proportional rounding of rounds 2-5 would give 1032, i.e. a third round for 8 workgroups).
-// The 192 x 64 tiles get equal splits (tw_locate relies on it); the narrow tiles share what is left by their time per row relative
-// to a 192 x 64 tile (w1 | w2 per cent: a 192 x 16 tile issues a quarter of the MFMAs, the swapped 64 x 16 tile a twelfth, all
-// stage the same rows).  VSDE_TW_WGS / _W1 / _W2 override (ablation build).
+// resident set.  fp32 form: three workgroups per CU, 1536 = two rounds (measured 488 | 447 | 429 us for 768 | 1024 | 1536 at LV).  Split
+// form: two per CU, 512 = one round (225 + 8 us with the reduction against 238 + 17 for two rounds: profiles/r06_tn_wide_split.txt; the
+// proportional rounding of rounds 2-5 would have given 520 workgroups, i.e. a second round for 8 of them).  The 192 x 64 tiles get
+// equal splits (tw_locate relies on it); the narrow tiles share what is left by their time per row relative to a 192 x 64 tile (w1 |
+// w2 per cent: a 192 x 16 tile issues a quarter of the MFMAs, the swapped 64 x 16 tile a twelfth, all stage the same rows; in the
+// split form they still run on the fp32 instruction).  VSDE_TW_WGS / _W1 / _W2 override (ablation build).
 static void tw_splits(const int *kinds, int nt, int64_t chunks, int *nsplit) {
     static int wgs = -1, w1 = -1, w2 = -1;
     if (wgs < 0) {
-        wgs = (int)vsde_knob("VSDE_TW_WGS", tw_split_form() ? 1024 : 1536);
+        wgs = (int)vsde_knob("VSDE_TW_WGS", tw_split_form() ? 512 : 1536);
         w1 = (int)vsde_knob("VSDE_TW_W1", tw_split_form() ? 70 : 35);
         w2 = (int)vsde_knob("VSDE_TW_W2", tw_split_form() ? 40 : 20);
     }
