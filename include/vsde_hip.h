@@ -451,6 +451,12 @@ int vsde_debug_force_v1(int on);
  * mode 1 = the multi-path MFMA kernel (16 paths per workgroup, csrc/vsde_head_mp.hip) whenever applicable, 0 = never (the
  * four-waves-per-path kernel), < 0 = default (environment VSDE_HEAD_MP, else by batch size). */
 int vsde_debug_head_mp(int mode);
+/* 1 once a GRU head weight has left the f16 range of the multi-path MFMA kernels (|W| > 2.2e4; the weight preparation of every such
+ * launch checks): the launch that found it returns NON-FINITE paths (never silently wrong ones), and every later launch of the process
+ * takes the fp32 four-waves-per-path kernels.  The flag lives in host-mapped memory and is written in stream order: a caller that
+ * REPLAYS a captured graph (whose kernel choice was fixed at capture) polls it after a replay and re-captures / steps eagerly.
+ * mode > 0 clears the flag (tests).  No reference counterpart (the reference's Triton kernels are fp32 throughout). */
+int vsde_head_mfma_range_exceeded(int clear);
 int vsde_profile_elapsed_ms(int which, float *ms);
 
 #ifdef __cplusplus

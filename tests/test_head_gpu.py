@@ -358,3 +358,36 @@ def test_a_non_finite_path_does_not_contaminate_its_group(forward_kernel):
     assert torch.equal(out[0][6, :5], clean[0][6, :5]) and torch.isnan(out[0][6, 5, 1]) and torch.isnan(out[0][6, 6:]).all()
     assert torch.isnan(out[1][6, 5:]).all()              # the NaN state feeds the next step's GRU input: means are NaN from step 5 on
     assert torch.equal(out[0][13, :8], clean[0][13, :8]) and not torch.isfinite(out[0][13, 8:]).any()
+
+
+def test_a_weight_beyond_the_f16_range_is_loud_then_served_by_the_fp32_kernels():
+    """A recurrent weight above 2.2e4 cannot be a pair of f16 MFMA operands.  Contract (include/vsde_hip.h:
+    vsde_head_mfma_range_exceeded): the launch that meets it returns non-finite paths -- never silently wrong ones -- and raises the
+    sticky flag; every later launch takes the fp32 kernels and matches the float64 oracle again.  The flag is cleared at the end (it is
+    process-wide)."""
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, T, S, C, P, H, L = 64, 24, 2, 256, 3, 64, 2
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    ws = [rn(3 * H, S + C + P, sc=0.08), rn(3 * H, H, sc=0.12), rn(3 * H, sc=0.1), rn(3 * H, sc=0.1),
+          rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, H, sc=0.12), rn(L - 1, 3 * H, sc=0.1), rn(L - 1, 3 * H, sc=0.1),
+          rn(S + 3, H, sc=0.1), torch.tensor([0.0, 0.0, 1.0, 0.0, 1.0])]
+    ws[1][5, 7] = 5.0e4   # W_hh of layer 0
+    x0, ctx, theta, eps = rn(B, S), rn(B, T + 1, C), rn(B, P).abs(), rn(B, T, S)
+    d_ = lambda t: t.to(dev)
+    wd = [d_(w) for w in ws]
+    assert not _hip.head_mfma_range_exceeded()
+    try:
+        first = _hip.head_forward(d_(x0), d_(ctx)[:, :-1], d_(theta), d_(eps), wd, 0.1, False)
+        torch.cuda.synchronize()
+        assert _hip.head_mfma_range_exceeded(), "the weight preparation did not flag the weight"
+        assert not bool(torch.isfinite(first[0]).all()), "the MFMA launch must not return finite paths for an operand it cannot hold"
+        again = _hip.head_forward(d_(x0), d_(ctx)[:, :-1], d_(theta), d_(eps), wd, 0.1, False)
+        w = vo.HeadWeights(*[t.numpy() for t in ws])
+        f = vo.head_forward(x0.numpy(), ctx.numpy()[:, :-1], theta.numpy(), eps.numpy(), w, 0.1, False, np.float64)
+        assert rel_err(again[0].cpu().numpy(), f.paths) < FWD_TOL and rel_err(again[2].cpu().numpy(), f.chol) < FWD_TOL
+    finally:
+        _hip.head_mfma_range_exceeded(clear=True)
+    assert not _hip.head_mfma_range_exceeded()

@@ -52,7 +52,7 @@ EXPORTS = (
     "vsde_head_forward_workspace_bytes", "vsde_head_forward",
     "vsde_head_backward_workspace_bytes", "vsde_head_backward",
     "vsde_elbo_path_terms", "vsde_elbo_path_terms_bwd", "vsde_elbo_tail_fwd", "vsde_elbo_tail_bwd",
-    "vsde_profile_enable", "vsde_profile_elapsed_ms", "vsde_debug_force_v1", "vsde_debug_head_mp",
+    "vsde_profile_enable", "vsde_profile_elapsed_ms", "vsde_debug_force_v1", "vsde_debug_head_mp", "vsde_head_mfma_range_exceeded",
     "vsde_ln_modulate_fwd", "vsde_ln_modulate_bwd", "vsde_gated_residual_fwd", "vsde_gated_residual_bwd",
     "vsde_swiglu_fwd", "vsde_swiglu_bwd", "vsde_gate_merge_fwd", "vsde_gate_merge_bwd",
     "vsde_qk_norm_rope_fwd", "vsde_qk_norm_rope_bwd_partials", "vsde_qk_norm_rope_bwd",
@@ -456,6 +456,13 @@ def debug_head_mp(mode: int) -> None:
     """Forward time-stepping kernel for hidden_dim 64 / L <= 2 / state_dim <= 2: 1 = the multi-path MFMA kernel whenever
     applicable, 0 = the four-waves-per-path kernel, -1 = default (VSDE_HEAD_MP, else by batch size)."""
     load().vsde_debug_head_mp(ctypes.c_int(mode))
+
+
+def head_mfma_range_exceeded(clear: bool = False) -> bool:
+    """True once a GRU head weight has left the f16 range of the multi-path MFMA kernels (|W| > 2.2e4): the launch that found it returned
+    non-finite paths and every later launch takes the fp32 kernels.  Host-mapped flag written in stream order, no synchronisation: callers
+    that replay captured graphs poll it after a replay.  ``clear=True`` resets it (tests)."""
+    return bool(load().vsde_head_mfma_range_exceeded(ctypes.c_int(1 if clear else 0)))
 
 
 # ---------------------------------------------------------------------------------------------

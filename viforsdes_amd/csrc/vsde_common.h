@@ -203,6 +203,7 @@ struct MpLaunch {
 };
 bool mp_applicable(int H, int L, int S);
 bool mp_weights_overflowed();   // sticky: a weight left the f16 range of the multi-path kernels (no device synchronisation)
+void mp_clear_overflow();        // tests: forget it
 size_t mp_frag_bytes(int L, int S);
 // mark: the profile-event hook of vsde_head.hip (slot 0 = the time-stepping kernel), may be nullptr
 int launch_head_fwd_mp(const MpLaunch &a, hipStream_t s, void (*mark)(int, int, hipStream_t));

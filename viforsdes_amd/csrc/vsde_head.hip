@@ -1654,6 +1654,11 @@ extern "C" int vsde_debug_head_mp(int mode) {
     return 0;
 }
 
+extern "C" int vsde_head_mfma_range_exceeded(int clear) {
+    if (clear > 0) { mp_clear_overflow(); return 0; }
+    return mp_weights_overflowed() ? 1 : 0;
+}
+
 extern "C" int vsde_profile_enable(int on) {
     g_prof_on = on != 0;
     for (int i = 0; i < kProfSlots; ++i) g_prof_valid[i] = false;

@@ -1348,6 +1348,9 @@ static int *mp_overflow_flag() {
     }
     return g_mp_overflow;
 }
+void mp_clear_overflow() {
+    if (g_mp_overflow) *(volatile int *)g_mp_overflow = 0;
+}
 bool mp_weights_overflowed() {
     static bool told = false;
     const bool o = g_mp_overflow != nullptr && *(volatile int *)g_mp_overflow != 0;

@@ -125,6 +125,14 @@ class CapturedPathSampler:
         self.graph.replay()
         return self._static
 
+    @staticmethod
+    def kernel_choice_outdated() -> bool:
+        """The captured call keeps the GRU kernels it was captured with.  Once a head weight has left the f16 range of the multi-path
+        MFMA kernels (sticky flag, ``_hip.head_mfma_range_exceeded``) a sampler captured before that must be re-captured: eager
+        launches already take the fp32 kernels."""
+        from .. import _hip
+        return _hip.head_mfma_range_exceeded()
+
 
 # VSDE_SAMPLE_GRAPH=0: VariationalPosterior.sample never replays a captured call (A/B runs, debugging)
 SAMPLE_GRAPH = os.environ.get("VSDE_SAMPLE_GRAPH", "1") != "0"

@@ -53,6 +53,16 @@ class TrainStepResult:
     grad_norm: Tensor  # 0-dim tensor on the training device (call .item() to sync)
 
 
+
+def _head_range_exceeded() -> bool:
+    """The sticky f16-range flag of the GRU head's MFMA kernels (``_hip.head_mfma_range_exceeded``); False without the GPU library."""
+    try:
+        from .. import _hip
+        return _hip.head_mfma_range_exceeded()
+    except Exception:
+        return False
+
+
 class VariationalInferenceTrainer:
     def __init__(self, sde: SDE, observations: Observations, observation_likelihood: ObservationLikelihood,
                  prior: Prior, time_horizon: float, config: TrainingConfig, encoder_config: EncoderConfig,
@@ -284,6 +294,12 @@ class VariationalInferenceTrainer:
                 if replay is not None:
                     last = replay()
                     pending.append(last.elbo_result.evidence_lower_bound.detach().clone())  # static output tensor
+                    if _head_range_exceeded():
+                        # the captured step keeps the multi-path MFMA kernels it was captured with; a GRU weight has left their f16
+                        # range (that step's ELBO is non-finite): eager steps from here on take the fp32 kernels
+                        replay = None
+                        self.console.config_panel("a GRU head weight left the f16 range of the MFMA kernels: HIP graph dropped, "
+                                                  "stepping eagerly on the fp32 kernels")
                 else:
                     last = self._train_step(model)
                     ctx.ema.update()

@@ -112,6 +112,9 @@ class VariationalPosterior:
     def _replayable(self, n: int, amp: Optional[torch.dtype] = None) -> Optional[CapturedPathSampler]:
         if self.device.type != "cuda" or not _sampler.SAMPLE_GRAPH:
             return None
+        if self._captured and not getattr(self, "_range_flag_seen", False) and CapturedPathSampler.kernel_choice_outdated():
+            self._range_flag_seen = True   # captured with the MFMA GRU kernels, which a weight has outgrown: capture again (fp32 kernels)
+            self._captured.clear()
         key = (n, amp)
         self._calls[key] = self._calls.get(key, 0) + 1
         if self._calls[key] < 2:
