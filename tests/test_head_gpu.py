@@ -391,3 +391,39 @@ def test_a_weight_beyond_the_f16_range_is_loud_then_served_by_the_fp32_kernels()
     finally:
         _hip.head_mfma_range_exceeded(clear=True)
     assert not _hip.head_mfma_range_exceeded()
+
+
+@pytest.mark.parametrize("ctx_dtype", [torch.float32, torch.bfloat16], ids=["ctx32", "ctx16"])
+@pytest.mark.parametrize("B,T,S", [(1, 16, 2), (2, 16, 2), (3, 16, 1), (5, 16, 2), (16, 17, 2), (16, 31, 3), (48, 25, 2), (7, 64, 2), (9, 48, 1),
+                                   (64, 18, 2)])
+def test_weight_gradient_tiles_on_split_operands_at_every_block_count(B, T, S, ctx_dtype):
+    """Shapes the fast weight-gradient path takes (hidden 64, B T a multiple of 16, T >= 16; csrc/vsde_tn_wide.hip): 1, 2, 3, 5 ... 16-row
+    blocks per split (the last group of four blocks is masked), blocks that straddle two batch rows (T = 17, 25, 31, 18), fp32 and bf16
+    context operands (six / three products per block): all 13 gradients against the float64 oracle, twice with equal bits."""
+    from oracle import vsde_oracle as vo
+    from viforsdes_amd import _hip
+    dev = _dev()
+    C, P, H, L = 256, 3, 64, 2
+    NO = S + S * (S + 1) // 2
+    g = np.random.default_rng(7000 + 100 * B + T + S)
+    rn = lambda *s, sc=1.0: (g.standard_normal(s) * sc).astype(np.float32)
+    ws = [rn(3 * H, S + C + P, sc=.08), rn(3 * H, H, sc=.12), rn(3 * H, sc=.1), rn(3 * H, sc=.1), rn(L - 1, 3 * H, H, sc=.12),
+          rn(L - 1, 3 * H, H, sc=.12), rn(L - 1, 3 * H, sc=.1), rn(L - 1, 3 * H, sc=.1), rn(NO, H, sc=.1), rn(NO, sc=.3)]
+    ctx = torch.from_numpy(rn(B, T + 1, C)).to(ctx_dtype)
+    x0, theta, eps = rn(B, S), np.abs(rn(B, P)), rn(B, T, S)
+    gp, gm, gl = rn(B, T + 1, S), rn(B, T, S), rn(B, T, S, S)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tws, cd = [t(w) for w in ws], ctx.to(dev)
+    out = _hip.head_forward(t(x0), cd[:, :-1], t(theta), t(eps), tws, 0.05, True)
+    run = lambda: _hip.head_backward(t(gp), t(gm), t(gl), cd[:, :-1], t(theta), t(eps), out[0], out[3], out[4], tws, 0.05)
+    grads, again = run(), run()
+    for a, b_ in zip(grads, again):
+        assert torch.equal(a, b_)
+    c64 = ctx.float().numpy().astype(np.float64)
+    w64 = vo.HeadWeights(*[w.astype(np.float64) for w in ws])
+    f64 = lambda a: a.astype(np.float64)
+    f = vo.head_forward(f64(x0), c64[:, :-1], f64(theta), f64(eps), w64, 0.05, True, dtype=np.float64)
+    gref = vo.head_backward(f64(gp), f64(gm), f64(gl), c64[:, :-1], f64(theta), f64(eps), f, w64, 0.05, dtype=np.float64)
+    for name, a, b_ in zip(G_NAMES, grads, gref):
+        if b_.size and name != "context":
+            assert rel_err(a.float().cpu().numpy(), b_) < BWD_TOL, name
