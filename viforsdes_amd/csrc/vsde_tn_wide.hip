@@ -12,7 +12,11 @@
 //     forward by constants (no division or 64-bit multiply in the loop), masked Y rows (h_{t-1} at t = 0) come from a zero buffer;
 //   * the narrow operands (the state / theta columns of W_ih0: NY <= 16; the emission rows of out_proj: NX <= 16, computed as
 //     out^T with the roles swapped) run in the same launch as 192 x 16 / 64 x 16 tiles with one column block of MFMAs;
-//   * the tiles of one row split sit on one XCD, so the X rows the four context tiles share come out of that XCD's L2.
+//   * the tiles of one row split sit on one XCD, so the X rows the four context tiles share come out of that XCD's L2;
+//   * round 6: the 192 x 64 tiles run on the bf16 matrix instruction with operands split exactly into three bf16 pieces on their way
+//     into LDS (tn_wide_split_kernel, the default; section "round 6" below), take their workgroups split-major, and all splits add up
+//     to whole rounds of resident workgroups.  The fp32 form (tn_wide_kernel) is what the narrow tiles still use and what
+//     VSDE_TW_SPLIT=0 runs in the ablation build.
 // Splits are summed in a fixed order by the reduce kernels (deterministic).  Reference: kernels/backward.py:108-139,575-590
 // (the global fp32 atomics these reductions replace).
 #include <stddef.h>
@@ -114,7 +118,7 @@ template <int NB, bool NARROW, bool SPLIT = false, bool YBF = false, bool BIAS =
 __device__ __forceinline__ void tw_run(const TwArgs &a, const TwTile &P, float *tws, int split) {
     static_assert(!SPLIT || (NB == 3 && !NARROW), "split form: 192 x 64 tiles");
     constexpr int NX = 64 * NB, LDX = NX + 16, JB = NARROW ? 1 : 4, LDY = NARROW ? 48 : TW_LDY;
-    constexpr int XI = NX * TW_BM / 4 / 256;          // 16-byte X chunks per thread and step (6 | 2)
+    constexpr int XI = NX * TW_BM / 4 / 256;          // 16-byte X chunks per thread and step (3 | 1)
     constexpr int XCH = NX / 4;                        // chunks per X row
     constexpr int BUF = TW_BM * (LDX + LDY);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
