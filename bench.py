@@ -29,6 +29,7 @@ head, the VariationalPosterior.sample path) are extra fields.
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import socket
@@ -553,7 +554,15 @@ def measure(workload, batch, args, device, distributed, world):
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            # under a torchrun agent (one rank) TORCHELASTIC_USE_AGENT_STORE makes every tcp:// rendezvous a CLIENT of the agent's
+            # store: against this private port it would wait for a server that never comes
+            agent_store = os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            try:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                        timeout=datetime.timedelta(seconds=120))
+            finally:
+                if agent_store is not None:
+                    os.environ["TORCHELASTIC_USE_AGENT_STORE"] = agent_store
             for b in gs.buckets:
                 dist.all_reduce(b)
             sync(device); e0.record()
